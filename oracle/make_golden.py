@@ -1,0 +1,363 @@
+"""Generate tests/golden/*.npz by importing the REFERENCE (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+Needs /root/reference (read-only); it never travels to the GPU box -- only the .npz outputs do.
+
+How the reference is imported: the reference's own hot-path modules
+(ViewTransformerLSSVoxel.py, ViewTransformerLSSBEVDepth.py, attention.py, resnet3d.py,
+second_fpn_3d.py, occhead.py, utils/semkitti.py, utils/ssc_metric.py) are executed unmodified.
+Their *third-party* imports that are absent from this image (mmcv, mmdet, mmdet3d, torchmetrics,
+...) are satisfied by in-memory stand-ins created below:
+  * registries / BaseModule / force_fp32: pure plumbing;
+  * build_norm_layer / build_conv_layer / build_upsample_layer: map to torch.nn layers;
+  * bev_pool, DCN, mmdet BasicBlock: third-party arithmetic -> provided from oracle.path_ref
+    (so fixtures do NOT pin those three; "parity unpinned", see oracle/__init__.py).
+The only patch applied to reference behaviour is the `torch` name inside VT: a proxy that drops
+`device='cuda'` from arange (VT:139-144 hard-codes CUDA) and presents a chosen `__version__`
+string so both branches of VT:151-154 can be exercised.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import path_ref as O  # noqa: E402
+from stereoscene_amd import synthetic as S  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-ins for absent third-party packages
+# ---------------------------------------------------------------------------------------------
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path=None):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    sys.modules[name] = m
+    return m
+
+
+class _Registry:
+    def __init__(self, name):
+        self.name, self.table = name, {}
+
+    def register_module(self, *a, **k):
+        def deco(cls):
+            self.table[cls.__name__] = cls
+            return cls
+        return deco
+
+
+class _BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+
+def _identity_decorator(*a, **k):
+    def deco(fn):
+        return fn
+    return deco
+
+
+def _build_norm_layer(cfg, num_features, postfix=""):
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    rg = cfg.pop("requires_grad", True)
+    if t == "GN":
+        layer = nn.GroupNorm(cfg["num_groups"], num_features)
+        name = "gn"
+    elif t in ("BN", "BN2d"):
+        layer, name = nn.BatchNorm2d(num_features), "bn"
+    elif t == "BN3d":
+        layer, name = nn.BatchNorm3d(num_features), "bn"
+    else:
+        raise KeyError(t)
+    for p in layer.parameters():
+        p.requires_grad = rg
+    return name + str(postfix), layer
+
+
+class _DCN(nn.Module):
+    """Stand-in with mmcv DeformConv2dPack's parameters; arithmetic from the oracle restatement."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, groups=1, im2col_step=128, **k):
+        super().__init__()
+        self.groups = groups
+        self.weight = nn.Parameter(torch.zeros(out_channels, in_channels // groups, kernel_size, kernel_size))
+        self.conv_offset = nn.Conv2d(in_channels, 2 * kernel_size * kernel_size, 3, 1, 1)
+
+    def forward(self, x):
+        return O.deform_conv2d(x, self.conv_offset(x), self.weight, 1, 1, 1, self.groups, 1)
+
+
+def _build_conv_layer(cfg, *args, **kwargs):
+    cfg = dict(cfg or dict(type="Conv2d"))
+    t = cfg.pop("type")
+    kwargs = {**cfg, **kwargs}
+    if t == "DCN":
+        return _DCN(*args, **kwargs)
+    return {"Conv2d": nn.Conv2d, "Conv3d": nn.Conv3d, "Conv": nn.Conv2d}[t](*args, **kwargs)
+
+
+def _build_upsample_layer(cfg, *args, **kwargs):
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    kwargs = {**cfg, **kwargs}
+    return {"deconv": nn.ConvTranspose2d, "deconv3d": nn.ConvTranspose3d}[t](*args, **kwargs)
+
+
+class _BasicBlock(nn.Module):
+    """Parameter container for mmdet BasicBlock; forward from the oracle restatement (third-party)."""
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        return F.relu(self.bn2(self.conv2(y)) + x)
+
+
+_POOL_LOG = []
+
+
+def _bev_pool(feats, coords, B, D, H, W):
+    _POOL_LOG.append(coords.clone())
+    return O.bev_pool(feats.detach(), coords, int(B), int(D), int(H), int(W))
+
+
+class _Metric(nn.Module):
+    def __init__(self, compute_on_step=False):
+        super().__init__()
+
+    def add_state(self, name, default, dist_reduce_fx=None):
+        self.register_buffer(name, default)
+
+
+def install_shims():
+    NECKS, BACKBONES, HEADS, DETECTORS = (_Registry(n) for n in ("necks", "backbones", "heads", "detectors"))
+    _pkg("mmcv")
+    _mod("mmcv.runner", BaseModule=_BaseModule, force_fp32=_identity_decorator, auto_fp16=_identity_decorator,
+         get_dist_info=lambda: (0, 1), init_dist=None, load_checkpoint=None, save_checkpoint=None,
+         wrap_fp16_model=None)
+    _mod("mmcv.cnn", build_norm_layer=_build_norm_layer, build_conv_layer=_build_conv_layer,
+         build_upsample_layer=_build_upsample_layer)
+    sys.modules["mmcv"].runner = sys.modules["mmcv.runner"]
+    sys.modules["mmcv"].cnn = sys.modules["mmcv.cnn"]
+    _pkg("mmdet3d"); _pkg("mmdet3d.models"); _pkg("mmdet3d.ops")
+    _mod("mmdet3d.models.builder", NECKS=NECKS, BACKBONES=BACKBONES, HEADS=HEADS, DETECTORS=DETECTORS)
+    _mod("mmdet3d.ops.bev_pool", bev_pool=_bev_pool)
+    _mod("mmdet3d.ops.voxel_pooling", voxel_pooling=None)
+    _pkg("mmdet"); _pkg("mmdet.models.backbones")
+    _mod("mmdet.models", NECKS=NECKS, HEADS=HEADS, BACKBONES=BACKBONES)
+    _mod("mmdet.models.backbones.resnet", BasicBlock=_BasicBlock)
+    _pkg("torchmetrics")
+    _mod("torchmetrics.metric", Metric=_Metric)
+    # reference namespace packages (their heavy __init__ files never run)
+    base = os.path.join(REF, "projects", "mmdet3d_plugin")
+    _pkg("projects", os.path.join(REF, "projects"))
+    _pkg("projects.mmdet3d_plugin", base)
+    _pkg("projects.mmdet3d_plugin.occupancy", os.path.join(base, "occupancy"))
+    for sub in ("image2bev", "backbones", "necks", "dense_heads"):
+        _pkg(f"projects.mmdet3d_plugin.occupancy.{sub}", os.path.join(base, "occupancy", sub))
+    u = _pkg("projects.mmdet3d_plugin.utils", os.path.join(base, "utils"))
+    for n in ("cm_to_ious", "query_points_from_voxels", "per_class_iu", "fast_hist_crop",
+              "SoftDiceLossWithProb", "PositionAwareLoss"):
+        setattr(u, n, None)
+    sk = importlib.import_module("projects.mmdet3d_plugin.utils.semkitti")
+    _mod("projects.mmdet3d_plugin.occupancy.dense_heads.bevocc_head_kitti", CE_ssc_loss=sk.CE_ssc_loss,
+         sem_scal_loss=sk.sem_scal_loss, geo_scal_loss=sk.geo_scal_loss)
+    _mod("projects.mmdet3d_plugin.occupancy.dense_heads.lovasz_softmax", lovasz_softmax=None)
+    return sk
+
+
+class _TorchProxy:
+    """`torch` as seen by the reference VT module: CPU arange, selectable version string."""
+
+    def __init__(self, version):
+        self.__version__ = version
+
+    def arange(self, *a, **k):
+        k.pop("device", None)
+        return torch.arange(*a, **k)
+
+    def __getattr__(self, n):
+        return getattr(torch, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------
+
+def sd_np(module):
+    return {k: v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1e3:.1f} kB)")
+
+
+def sample_every(t, step=7):
+    return t.detach().reshape(-1)[::step].clone()
+
+
+def main():
+    sk = install_shims()
+    VT = importlib.import_module("projects.mmdet3d_plugin.occupancy.image2bev.ViewTransformerLSSVoxel")
+    ATT = importlib.import_module("projects.mmdet3d_plugin.occupancy.image2bev.attention")
+    R3D = importlib.import_module("projects.mmdet3d_plugin.occupancy.backbones.resnet3d")
+    FPN = importlib.import_module("projects.mmdet3d_plugin.occupancy.necks.second_fpn_3d")
+    OCC = importlib.import_module("projects.mmdet3d_plugin.occupancy.dense_heads.occhead")
+    SSC = importlib.import_module("projects.mmdet3d_plugin.utils.ssc_metric")
+    torch.manual_seed(0)
+
+    # ---- (1) gwc volume + warp, both grid_sample modes -------------------------------------
+    print("gwc_warp")
+    B, C, H, W, D = 2, 64, 3, 32, 20
+    L = S.hash_normal("gwc/L", (B, C, H, W))
+    R = S.hash_normal("gwc/R", (B, C, H, W))
+    calib = torch.tensor([96.0, 61.7])
+    vol = VT.build_gwc_volume(L, R, D, 32)
+    outs = {}
+    for ver, tag in (("2.1.0", "ac1"), ("1.10.1", "ac0")):
+        VT.torch = _TorchProxy(ver)
+        outs[tag] = VT.warp(vol, calib, down=1, maxdepth=D)
+    VT.torch = _TorchProxy("2.1.0")
+    save("gwc_warp", left=L, right=R, calib=calib, ndisp=D, volume_sample=sample_every(vol, 5), warped_ac1=outs["ac1"], warped_ac0=outs["ac0"])
+
+    # ---- (2) hourglass (train + eval BN) ---------------------------------------------------
+    print("hourglass")
+    hg = VT.hourglass(8)
+    S.fill_state_dict_(hg, "hg.")
+    x = S.hash_normal("hg/x", (2, 8, 8, 8, 12))
+    hg.train()
+    y_tr = hg(x)
+    rm = {k: v.clone() for k, v in hg.state_dict().items() if "running" in k}
+    S.fill_state_dict_(hg, "hg.")
+    hg.eval()
+    y_ev = hg(x)
+    save("hourglass", x=x, y_train=y_tr, y_eval=y_ev, **{"stat:" + k: v for k, v in rm.items()},
+         **{"shape:" + k: np.array(v.shape) for k, v in hg.state_dict().items()})
+
+    # ---- (3) BRI attention + (4) volume_interaction ----------------------------------------
+    print("attention / volume_interaction")
+    Dv, Hv, Wv = 16, 8, 12
+    q = F.softmax(S.hash_normal("att/q", (2, 1, Dv, Hv, Wv), 2.0), dim=2)
+    kv = F.softmax(S.hash_normal("att/kv", (2, 1, Dv, Hv, Wv), 2.0), dim=2)
+    att = ATT.attention(in_dim=1)
+    S.fill_state_dict_(att, "att.")
+    save("attention", q=q, kv=kv, out=att(q, kv), **{"w:" + k: v for k, v in sd_np(att).items()})
+    vi = VT.volume_interaction()
+    S.fill_state_dict_(vi, "vi.")
+    vi.eval()
+    out_ev = vi(q[:, 0], kv[:, 0])
+    vi.train()
+    out_tr = vi(q[:, 0], kv[:, 0])
+    save("volume_interaction", stereo=q[:, 0], lss=kv[:, 0], out_eval=out_ev, out_train=out_tr,
+         **{"shape:" + k: np.array(v.shape) for k, v in vi.state_dict().items()})
+
+    # ---- (5) full view transformer at the small config (fill-by-key weights) ---------------
+    print("view transformer (cfg small_d48)")
+    cfg = S.CFG_S
+    gc = S.grid_config(cfg)
+    vt = VT.ViewTransformerLiftSplatShootVoxel(
+        downsample=8, numC_input=640, cam_channels=30, semkitti=False, loss_depth_weight=1.0,
+        grid_config=gc, data_config={"input_size": cfg["input_size"]}, numC_Trans=128, vp_megvii=False)
+    S.fill_state_dict_(vt, "img_view_transformer.")
+    smp = S.synthetic_sample(cfg, B=2, tag="vtS")
+    mlp_l = vt.get_mlp_input(*smp["geo_l"])
+    mlp_r = vt.get_mlp_input(*smp["geo_r"])
+    inputs = [smp["x_l"], *smp["geo_l"], mlp_l, smp["x_r"], *smp["geo_r"], mlp_r, smp["calib"]]
+    manifest = {"shape:" + k: np.array(v.shape) for k, v in vt.state_dict().items()}
+    res = {}
+    for mode, ver in (("ac1", "2.1.0"), ("ac0", "1.10.1")):
+        VT.torch = _TorchProxy(ver)
+        vt.eval()
+        _POOL_LOG.clear()
+        with torch.no_grad():
+            bev, dp = vt(inputs)
+        res[mode] = (bev, dp)
+    VT.torch = _TorchProxy("2.1.0")
+    coords = _POOL_LOG[-1]
+    geom = vt.get_geometry(*smp["geo_l"])
+    save("vt_small", mlp_input_l=mlp_l, mlp_input_r=mlp_r,
+         geom=geom, pool_coords=coords.to(torch.int32),
+         depth_prob_ac1=res["ac1"][1], depth_prob_ac0=res["ac0"][1],
+         bev_sample_ac1=sample_every(res["ac1"][0]), bev_sample_ac0=sample_every(res["ac0"][0]),
+         bev_abs_sum_ac1=res["ac1"][0].abs().double().sum(), bev_abs_sum_ac0=res["ac0"][0].abs().double().sum(),
+         dx=vt.dx, bx=vt.bx, nx=vt.nx, frustum_sample=sample_every(vt.frustum, 97), **manifest)
+
+    # depth loss on the same depth_prob
+    gtd = smp["gt_depths"]
+    ld = vt.get_depth_loss(gtd, res["ac1"][1])
+    save("depth_loss", depth_prob=res["ac1"][1], gt_depths_nz_idx=torch.nonzero(gtd.reshape(-1)).reshape(-1).to(torch.int32),
+         gt_depths_nz_val=gtd.reshape(-1)[gtd.reshape(-1) != 0], gt_shape=np.array(gtd.shape), loss=ld)
+
+    # ---- (6) 3-D encoder / neck / head on a small voxel grid --------------------------------
+    print("encoder / neck / head")
+    norm_cfg = dict(type="GN", num_groups=32, requires_grad=True)
+    bb = R3D.CustomResNet3D(depth=18, num_stage=3, n_input_channels=128, block_inplanes=[128, 256, 512],
+                            out_indices=(0, 1, 2), norm_cfg=norm_cfg)
+    nk = FPN.SECONDFPN3D(norm_cfg=norm_cfg, in_channels=[128, 256, 512], upsample_strides=[1, 2, 4],
+                         out_channels=[128, 128, 128])
+    hd = OCC.OccHead(num_level=1, in_channels=[384], out_channel=20, semantic_kitti=True,
+                     point_cloud_range=list(cfg["pc_range"]), supervise_points=False, sampling_img_feats=True,
+                     in_img_channels=640, soft_weights=True,
+                     semkitti_loss_weight_cfg={"voxel_ce": 1.0, "voxel_sem_scal": 1.0, "voxel_geo_scal": 1.0,
+                                               "voxel_ohem": 0.0, "voxel_lovasz": 0.0, "frustum_dist": 0.0})
+    S.fill_state_dict_(bb, "img_bev_encoder_backbone.")
+    S.fill_state_dict_(nk, "img_bev_encoder_neck.")
+    S.fill_state_dict_(hd, "pts_bbox_head.")
+    xv = S.hash_normal("enc/x", (1, 128, 16, 16, 8))
+    with torch.no_grad():
+        feats = bb(xv)
+        neck = nk(feats)
+        logits = hd(voxel_feats=neck)["output_voxels"][0]
+    man = {}
+    for pfx, m in (("img_bev_encoder_backbone.", bb), ("img_bev_encoder_neck.", nk), ("pts_bbox_head.", hd)):
+        man.update({"shape:" + pfx + k: np.array(v.shape) for k, v in m.state_dict().items()})
+    save("encoder_head", x=xv, feat0_sample=sample_every(feats[0]), feat1_sample=sample_every(feats[1]),
+         feat2_sample=sample_every(feats[2]), neck_sample=sample_every(neck[0]), logits=logits, **man)
+
+    # ---- (7) losses + grads, (8) SSC metric -------------------------------------------------
+    print("losses / metric")
+    lg = S.hash_normal("loss/logits", (2, 20, 8, 8, 4), 2.0).requires_grad_(True)
+    gt = S.synthetic_sample(dict(S.CFG_T, occ_size=(16, 16, 8)), B=2, tag="loss")["gt_occ"]
+    losses = hd.loss(output_voxels=[lg], target_voxels=gt)
+    total = sum(v for k, v in losses.items() if k.startswith("loss"))
+    total.backward()
+    save("occ_losses", logits=lg, gt_occ=gt.to(torch.int16), grad_logits=lg.grad,
+         **{k: v.detach() for k, v in losses.items()})
+    met = SSC.SSCMetrics(sk.kitti_class_names)
+    pred = S.hash_uniform("ssc/pred", (2, 16, 16, 8), 0, 20).long().clamp_(0, 19)
+    tup = met.compute_single(pred.clone(), gt.clone())
+    save("ssc_metric", pred=pred.to(torch.int16), gt=gt.to(torch.int16), tp=tup[0], fp=tup[1], fn=tup[2],
+         tp_c=tup[3], fp_c=tup[4], fn_c=tup[5])
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""The CPU oracle (oracle/path_ref.py) against fixtures produced by the imported reference
+(oracle/make_golden.py).  CPU only; this is what pins the oracle."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, state_dict_from_manifest
+from oracle import path_ref as O
+from stereoscene_amd import synthetic as S
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol):
+    a, b = T(a).double(), T(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= tol, f"max-abs {err:.3e} > {tol}"
+
+
+def test_gwc_volume_and_warp_both_modes():
+    g = load_golden("gwc_warp")
+    L, R, calib, D = T(g["left"]), T(g["right"]), T(g["calib"]), int(g["ndisp"])
+    vol = O.gwc_volume(L, R, D, 32)
+    close(vol.reshape(-1)[::5], g["volume_sample"], 0.0)
+    close(O.warp_volume(vol, calib, 1, True), g["warped_ac1"], 2e-6)
+    close(O.warp_volume(vol, calib, 1, False), g["warped_ac0"], 2e-6)
+    # the two grid_sample conventions differ materially
+    assert np.abs(g["warped_ac1"] - g["warped_ac0"]).max() > 1e-2
+
+
+def _hg_sd(g):
+    sd = state_dict_from_manifest(g)
+    return {k: v for k, v in sd.items()}
+
+
+def test_hourglass_eval_and_train_bn():
+    g = load_golden("hourglass")
+    sd = _hg_sd(g)
+    sd = {"hg." + k if not k.startswith("hg.") else k: v for k, v in sd.items()}
+    # manifest keys are un-prefixed; weights were filled with the 'hg.' prefix
+    sd = {}
+    for k, shp in g.items():
+        if k.startswith("shape:"):
+            key = k[6:]
+            t = torch.zeros(tuple(int(v) for v in shp), dtype=torch.int64 if key.endswith("tracked") else torch.float32)
+            v = S.fill_value_for("hg." + key, t)
+            sd["hg." + key] = t if v is None else v.to(t.dtype)
+    x = T(g["x"])
+    close(O.hourglass(sd, "hg", x, train=False), g["y_eval"], 2e-5)
+    stats = {}
+    close(O.hourglass(sd, "hg", x, train=True, stats_out=stats), g["y_train"], 2e-5)
+    for k, v in g.items():
+        if k.startswith("stat:"):
+            close(stats["hg." + k[5:]], v, 1e-6)
+
+
+def test_bri_attention():
+    g = load_golden("attention")
+    sd = {"att." + k[2:]: T(v) for k, v in g.items() if k.startswith("w:")}
+    close(O.bri_attention(sd, "att", T(g["q"]), T(g["kv"])), g["out"], 1e-6)
+
+
+def test_volume_interaction():
+    g = load_golden("volume_interaction")
+    sd = {}
+    for k, shp in g.items():
+        if k.startswith("shape:"):
+            key = k[6:]
+            t = torch.zeros(tuple(int(v) for v in shp), dtype=torch.int64 if key.endswith("tracked") else torch.float32)
+            v = S.fill_value_for("vi." + key, t)
+            sd["vi." + key] = t if v is None else v.to(t.dtype)
+    close(O.volume_interaction(sd, "vi", T(g["stereo"]), T(g["lss"]), train=False), g["out_eval"], 2e-6)
+    close(O.volume_interaction(sd, "vi", T(g["stereo"]), T(g["lss"]), train=True), g["out_train"], 2e-6)
+
+
+def _vt_state(g):
+    cfg = S.CFG_S
+    gc = S.grid_config(cfg)
+    sd = {}
+    for k, shp in g.items():
+        if k.startswith("shape:"):
+            key = k[6:]
+            t = torch.zeros(tuple(int(v) for v in shp), dtype=torch.int64 if key.endswith("tracked") else torch.float32)
+            v = S.fill_value_for("img_view_transformer." + key, t)
+            sd["img_view_transformer." + key] = t if v is None else v.to(t.dtype)
+    dx, bx, nx = O.gen_dx_bx(gc["xbound"], gc["ybound"], gc["zbound"])
+    sd["img_view_transformer.dx"], sd["img_view_transformer.bx"], sd["img_view_transformer.nx"] = dx, bx, nx
+    sd["img_view_transformer.frustum"] = O.create_frustum(cfg["input_size"], cfg["downsample"], gc["dbound"])
+    return sd, cfg, gc
+
+
+def test_view_transformer_small_config_both_modes():
+    g = load_golden("vt_small")
+    sd, cfg, gc = _vt_state(g)
+    close(sd["img_view_transformer.dx"], g["dx"], 0.0)
+    close(sd["img_view_transformer.bx"], g["bx"], 0.0)
+    close(sd["img_view_transformer.nx"], g["nx"], 0.0)
+    close(sd["img_view_transformer.frustum"].reshape(-1)[::97], g["frustum_sample"], 0.0)
+    smp = S.synthetic_sample(cfg, B=2, tag="vtS")
+    mlp_l = O.get_mlp_input(*smp["geo_l"])
+    mlp_r = O.get_mlp_input(*smp["geo_r"])
+    close(mlp_l, g["mlp_input_l"], 0.0)
+    close(mlp_r, g["mlp_input_r"], 0.0)
+    inputs = [smp["x_l"], *smp["geo_l"], mlp_l, smp["x_r"], *smp["geo_r"], mlp_r, smp["calib"]]
+    D = sd["img_view_transformer.frustum"].shape[0]
+    for mode, ac in (("ac1", True), ("ac0", False)):
+        taps = {}
+        with torch.no_grad():
+            bev, dp = O.view_transformer(sd, "img_view_transformer", inputs,
+                                         dict(D=D, numC_Trans=128, warp_align_corners=ac), taps=taps)
+        close(dp, g["depth_prob_" + mode], 5e-6)
+        close(bev.reshape(-1)[::7], g["bev_sample_" + mode], 2e-4)
+        assert abs(bev.abs().double().sum().item() - float(g["bev_abs_sum_" + mode])) <= 1e-5 * float(g["bev_abs_sum_" + mode])
+        if ac:
+            close(taps["geom"], g["geom"], 1e-4)
+            idx, kept = O.voxel_index(T(g["geom"]), sd["img_view_transformer.dx"], sd["img_view_transformer.bx"],
+                                      sd["img_view_transformer.nx"])
+            per = idx.shape[0] // 2
+            coords = torch.cat((idx, torch.arange(2).repeat_interleave(per)[:, None]), 1)[kept]
+            assert torch.equal(coords.to(torch.int32), T(g["pool_coords"]))  # bit-exact integer indices
+
+
+def test_depth_bce_loss():
+    g = load_golden("depth_loss")
+    shape = tuple(int(v) for v in g["gt_shape"])
+    gt = torch.zeros(int(np.prod(shape)))
+    gt[T(g["gt_depths_nz_idx"]).long()] = T(g["gt_depths_nz_val"])
+    cfg = S.CFG_S
+    loss = O.depth_bce_loss(gt.view(shape), T(g["depth_prob"]), cfg["downsample"], cfg["dbound"], 48)
+    close(loss, g["loss"], 1e-5)
+
+
+def test_encoder_neck_head():
+    g = load_golden("encoder_head")
+    sd = {}
+    for k, shp in g.items():
+        if k.startswith("shape:"):
+            key = k[6:]
+            t = torch.zeros(tuple(int(v) for v in shp))
+            sd[key] = S.fill_value_for(key, t)
+    x = T(g["x"])
+    with torch.no_grad():
+        feats = O.resnet3d(sd, "img_bev_encoder_backbone", x)
+        neck = O.second_fpn3d(sd, "img_bev_encoder_neck", feats)
+        logits = O.occ_head(sd, "pts_bbox_head", neck)[0]
+    for i in range(3):
+        close(feats[i].reshape(-1)[::7], g[f"feat{i}_sample"], 5e-5)
+    close(neck[0].reshape(-1)[::7], g["neck_sample"], 5e-5)
+    close(logits, g["logits"], 1e-4)
+
+
+def test_occ_losses_and_grads():
+    g = load_golden("occ_losses")
+    lg = T(g["logits"]).clone().requires_grad_(True)
+    gt = T(g["gt_occ"]).long()
+    losses = O.occ_losses(lg, gt)
+    for k in ("loss_voxel_ce_0", "loss_voxel_sem_scal_0", "loss_voxel_geo_scal_0"):
+        close(losses[k].detach(), g[k], 2e-6)
+    sum(losses.values()).backward()
+    close(lg.grad, g["grad_logits"], 1e-7)
+    # the train-time metric of the reference (sc_iou_0 / ssc_miou_0, OCC:345-359)
+    up = O.upsample_logits(lg.detach(), gt.shape[-3:]).argmax(1)
+    tp, fp, fn, tpc, fpc, fnc = O.ssc_counts(up.numpy(), gt.numpy())
+    sc, miou, _ = O.ssc_scores(tp, fp, fn, tpc, fpc, fnc)
+    assert abs(sc - float(g["sc_iou_0"])) < 1e-6 and abs(miou - float(g["ssc_miou_0"])) < 1e-6
+
+
+def test_ssc_metric_counts_are_exact():
+    g = load_golden("ssc_metric")
+    tp, fp, fn, tpc, fpc, fnc = O.ssc_counts(g["pred"], g["gt"], recompute_mask=True)
+    assert (tp, fp, fn) == (int(g["tp"]), int(g["fp"]), int(g["fn"]))
+    assert np.array_equal(tpc, g["tp_c"]) and np.array_equal(fpc, g["fp_c"]) and np.array_equal(fnc, g["fn_c"])
