@@ -1,0 +1,102 @@
+"""ctypes binding of libssbev_hip.so (include/ssbev.h).  PyTorch only supplies device memory and
+streams; every argument that crosses this boundary is a raw pointer, an int or a POD struct.
+
+There is NO fallback: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libssbev_hip.so")
+
+OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
+_ERR = {EINVAL: "SSBEV_EINVAL (bad dims / null pointer / unsupported configuration)",
+        EWORKSPACE: "SSBEV_EWORKSPACE (workspace too small)",
+        ELAUNCH: "SSBEV_ELAUNCH (HIP launch failure)"}
+
+
+class SsbevError(RuntimeError):
+    pass
+
+
+class PoolDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("P", C.c_int), ("C", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("origin", C.c_float * 3), ("dx", C.c_float * 3)]
+
+
+class LiftDims(C.Structure):
+    _fields_ = [("N", C.c_int), ("D", C.c_int), ("HW", C.c_int)]
+
+
+class GwcDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("G", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("down", C.c_float), ("align_corners", C.c_int)]
+
+
+class ConvDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "B", "Cin", "Cout", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "kd", "kh", "kw", "sd", "sh", "sw",
+        "pd", "ph", "pw", "dd", "dh", "dw", "transposed", "relu", "accumulate")]
+
+
+_P = C.c_void_p
+# name -> (restype, argtypes); this table is checked against include/ssbev.h by tests/test_capi_symbols.py
+SIGNATURES = {
+    "ssbev_version": (C.c_int, []),
+    "ssbev_build_arch": (C.c_char_p, []),
+    "ssbev_voxel_index": (C.c_int, [_P, _P, _P, C.POINTER(PoolDims), _P]),
+    "ssbev_coords_to_vox": (C.c_int, [_P, C.c_int, _P, C.POINTER(PoolDims), _P]),
+    "ssbev_pool_prepare_workspace": (C.c_size_t, [C.c_int, C.POINTER(PoolDims)]),
+    "ssbev_pool_prepare": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(PoolDims), _P, C.c_size_t, _P]),
+    "ssbev_bev_pool_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(PoolDims), _P]),
+    "ssbev_bev_pool_bwd": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(PoolDims), _P]),
+    "ssbev_lift_splat_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
+    "ssbev_lift_splat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
+    "ssbev_gwc_warp_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(GwcDims), _P]),
+    "ssbev_gwc_warp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P]),
+    "ssbev_conv_packed_weight_elems": (C.c_size_t, [C.POINTER(ConvDims)]),
+    "ssbev_conv_pack_weight": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),
+    "ssbev_conv_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), _P]),
+    "ssbev_conv_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),
+    "ssbev_conv_bwd_weight_workspace": (C.c_size_t, [C.POINTER(ConvDims)]),
+    "ssbev_conv_bwd_weight": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (built by ``stereoscene_amd.build`` / ``__graft_entry__.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SsbevError(f"{LIB_PATH} is missing: run `python -m stereoscene_amd.build` "
+                             "(there is no CPU / PyTorch fallback for the HIP operators)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export what the header declares
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != OK:
+        raise SsbevError(f"{what}: {_ERR.get(code, code)}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous GPU tensor (or NULL for None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SsbevError("ssbev operators run on the MI355X only: got a CPU tensor (no CPU fallback exists)")
+    if not t.is_contiguous():
+        raise SsbevError("ssbev operators need contiguous buffers")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,443 @@
+// Dense N-d convolution family as im2col-free implicit GEMM on the gfx950 matrix cores.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate, 157 TF/s chip peak).
+// Layout: channels-last activations [B, D, H, W, C]; GEMM rows M = output voxels, columns N =
+// output channels, reduction K = taps x input channels.
+//
+//   A operand (32 voxels x 2 k):  lane (i = lane&31, kh = lane>>5) reads ONE float4 =
+//       x[voxel_i + tap][8q + 4kh .. +3] straight from global/L2 (a voxel's channel vector is
+//       contiguous, so the pair of lanes (i,0),(i,1) consumes a full 32-B sector and a wave a
+//       set of whole 128-B lines); the 4 components feed 4 consecutive MFMAs.  No LDS, no
+//       im2col buffer: the "patch matrix" only ever exists as addresses.
+//   B operand (2 k x 32 couts):   weights are pre-packed so that lane (j, kh) reads one float4
+//       Wp[tap][q][kh][j][0..3] = W[cout j][cin 8q+4kh+0..3][tap]  (512 B contiguous per half wave,
+//       shared by every wave on the chip -> L1/L2 resident).
+//   C/D: lane holds column j (one output channel) and 16 rows; a store instruction writes
+//       32 consecutive floats (128 B) per voxel.
+//
+// Two gather forms cover every forward and data-gradient problem of the path:
+//   form 0 (conv):    in = o*stride - pad + k*dil
+//   form 1 (deconv):  in = (o + pad - k*dil)/stride   -- outputs are enumerated per PARITY CLASS
+//                     (o mod stride) so that the valid taps are uniform over a tile: no wasted
+//                     MFMAs on transposed convolutions (stride-2 k3: 27 taps spread over 8 classes;
+//                     k=s deconvs of the FPN: one 1x1x1 GEMM per class).
+// The weight gradient is a third kernel (reduction over voxels, split-K with a deterministic
+// two-stage reduction).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvGeom {
+  int B, Cin, Cout, CinPad, CoutPad;   // channel roles of THIS gather (K = Cin, N = Cout)
+  int Di, Hi, Wi, Do, Ho, Wo;          // source grid (i) and destination grid (o) of THIS gather
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int form;                            // 0 conv gather, 1 deconv gather
+  int relu, accumulate;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// One wave computes an (MT*32 voxels) x (NT*32 channels) tile.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256)
+conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                   float* __restrict__ y, ConvGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+
+  // ---- parity class (form 1) --------------------------------------------------------------
+  int par_d = 0, par_h = 0, par_w = 0;
+  int Dc = g.Do, Hc = g.Ho, Wc = g.Wo;   // extent of the enumerated (per-class) output grid
+  if (g.form == 1) {
+    int cls = blockIdx.z;
+    par_w = cls % g.sw; cls /= g.sw;
+    par_h = cls % g.sh; cls /= g.sh;
+    par_d = cls;
+    Dc = g.Do / g.sd; Hc = g.Ho / g.sh; Wc = g.Wo / g.sw;
+  }
+  const long Mtot = (long)g.B * Dc * Hc * Wc;
+  const long m_wave = ((long)blockIdx.x * 4 + wave) * (MT * 32);
+  if (m_wave >= Mtot) return;
+  const int n0 = blockIdx.y * (NT * 32);
+
+  // ---- decode this lane's voxel for every M sub-tile ----------------------------------------
+  int ob[MT], od[MT], oh[MT], ow[MT];
+  bool mok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long m = m_wave + mt * 32 + li;
+    mok[mt] = m < Mtot;
+    if (!mok[mt]) m = 0;
+    ow[mt] = (int)(m % Wc); m /= Wc;
+    oh[mt] = (int)(m % Hc); m /= Hc;
+    od[mt] = (int)(m % Dc);
+    ob[mt] = (int)(m / Dc);
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  const int Q = g.CinPad >> 3;
+  const size_t w_tap_stride = (size_t)Q * 2 * g.CoutPad * 4;
+  const float* wlane = wp + ((size_t)lk * g.CoutPad + n0 + li) * 4;
+
+  // tap ranges: form 0 walks all taps; form 1 only those congruent with the parity class
+  int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
+  if (g.form == 1) {
+    kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
+    kds = g.sd; khs = g.sh; kws = g.sw;
+  }
+  for (int a = kd0; a < g.kd; a += kds)
+    for (int bq = kh0; bq < g.kh; bq += khs)
+      for (int c = kw0; c < g.kw; c += kws) {
+        const int tap = (a * g.kh + bq) * g.kw + c;
+        const float* ap[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int id, ih, iw;
+          if (g.form == 0) {
+            id = od[mt] * g.sd - g.pd + a * g.dd;
+            ih = oh[mt] * g.sh - g.ph + bq * g.dh;
+            iw = ow[mt] * g.sw - g.pw + c * g.dw;
+          } else {  // exact divisions by construction of the class / tap walk (dil == 1 when s > 1)
+            id = od[mt] + (par_d + g.pd - a * g.dd) / g.sd;
+            ih = oh[mt] + (par_h + g.ph - bq * g.dh) / g.sh;
+            iw = ow[mt] + (par_w + g.pw - c * g.dw) / g.sw;
+          }
+          const bool ok = mok[mt] && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+          ap[mt] = ok ? x + ((((size_t)ob[mt] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.Cin + 4 * lk : nullptr;
+        }
+        const float* wt = wlane + (size_t)tap * w_tap_stride;
+        for (int q = 0; q < Q; ++q) {
+          float4 av[MT], bv[NT];
+          const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            av[mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bv[nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = mfma32(av[mt].x, bv[nt].x, acc[mt][nt]);
+              acc[mt][nt] = mfma32(av[mt].y, bv[nt].y, acc[mt][nt]);
+              acc[mt][nt] = mfma32(av[mt].z, bv[nt].z, acc[mt][nt]);
+              acc[mt][nt] = mfma32(av[mt].w, bv[nt].w, acc[mt][nt]);
+            }
+        }
+      }
+
+  // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lk, col = li ---------------------------
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      // voxel coordinates of `row` live in lane `row` (any lk): fetch them with a shuffle
+      const int rb = __shfl(ob[mt], row, 64), rd = __shfl(od[mt], row, 64);
+      const int rh = __shfl(oh[mt], row, 64), rw = __shfl(ow[mt], row, 64);
+      const bool rok = __shfl((int)mok[mt], row, 64) != 0;
+      size_t vox;
+      if (g.form == 0)
+        vox = (((size_t)rb * g.Do + rd) * g.Ho + rh) * g.Wo + rw;
+      else
+        vox = (((size_t)rb * g.Do + (rd * g.sd + par_d)) * g.Ho + (rh * g.sh + par_h)) * g.Wo + (rw * g.sw + par_w);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + nt * 32 + li;
+        if (rok && co < g.Cout) {
+          float v = acc[mt][nt][r];
+          if (bias) v += bias[co];
+          float* dst = y + vox * g.Cout + co;
+          if (g.accumulate) v += *dst;
+          if (g.relu) v = fmaxf(v, 0.0f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight packing
+// dst[tap][q][kh][n][t] = W[k_ch = 8q+4kh+t][n_ch = n][tap]   (zero beyond Cin / Cout)
+// src index depends on the torch layout and on which tensor axis plays K / N:
+//   layout 0: [A0, A1, taps] with K = A1, N = A0   (conv fwd: [Cout,Cin,k])
+//   layout 1: [A0, A1, taps] with K = A0, N = A1   (deconv fwd: [Cin,Cout,k]; conv bwd-data: [Cout,Cin,k])
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int N, int KPad,
+                                   int NPad, int taps, int layout, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long r = i;
+  const int t = (int)(r & 3); r >>= 2;
+  const int n = (int)(r % NPad); r /= NPad;
+  const int kh = (int)(r & 1); r >>= 1;
+  const int Q = KPad >> 3;
+  const int q = (int)(r % Q);
+  const int tap = (int)(r / Q);
+  const int k = 8 * q + 4 * kh + t;
+  float v = 0.0f;
+  if (k < K && n < N) {
+    const size_t a0 = layout == 0 ? n : k, a1 = layout == 0 ? k : n;
+    const size_t A1 = layout == 0 ? K : N;
+    v = src[(a0 * A1 + a1) * taps + tap];
+  }
+  dst[i] = v;
+}
+
+// ---------------------------------------------------------------- weight gradient
+// T[tap][qc][pc] = sum_m Qt[pos(m, tap)][qc] * Pt[m][pc]     (m over the "small" grid)
+//   conv  : Pt = gy [B,Do,Ho,Wo,Cout] (small), Qt = x  [B,Di,Hi,Wi,Cin] sampled at m*s - p + k*dil
+//   deconv: Pt = x  [B,Di,Hi,Wi,Cin ] (small), Qt = gy [B,Do,Ho,Wo,Cout] sampled at m*s - p + k
+// MFMA roles: rows i = q-channel, cols j = p-channel, k = 2 voxels per instruction.
+// One wave: (32*MQ q-channels) x (32 p-channels) x TW taps along the innermost kernel axis, over one
+// chunk of voxels.  Partials go to ws[chunk][...]; wgrad_reduce_kernel sums them in chunk order.
+struct WgradGeom {
+  int B, Cp, Cq;                 // channels of the small-grid tensor (P) and the sampled tensor (Q)
+  int Ds, Hs, Ws;                // small grid
+  int Dq, Hq, Wq;                // sampled grid
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int chunk;                     // voxels per chunk (multiple of 2)
+  int nchunks;
+};
+
+template <int TW>
+__global__ void __launch_bounds__(256)
+wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Qt, float* __restrict__ ws, WgradGeom g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  // block -> (chunk, q-tile, p-tile, tap group); the 4 waves of a block take 4 consecutive chunks
+  const int chunk_id = blockIdx.x * 4 + wave;
+  if (chunk_id >= g.nchunks) return;
+  const int qt = blockIdx.y % ((g.Cq + 31) / 32), pt = blockIdx.y / ((g.Cq + 31) / 32);
+  const int kw_groups = (g.kw + TW - 1) / TW;
+  const int tg = blockIdx.z;
+  const int kwg = tg % kw_groups;
+  const int khi = (tg / kw_groups) % g.kh;
+  const int kdi = tg / (kw_groups * g.kh);
+  const int qc = qt * 32 + li, pc = pt * 32 + li;
+  const bool qok = qc < g.Cq, pok = pc < g.Cp;
+
+  f32x16 acc[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
+  const long m_begin = (long)chunk_id * g.chunk;
+  const long m_end = min(Mtot, m_begin + g.chunk);
+  for (long m2 = m_begin; m2 < m_end; m2 += 2) {
+    const long m = m2 + lk;           // this half-wave's voxel
+    const bool mok = m < m_end;
+    long r = mok ? m : 0;
+    const int w = (int)(r % g.Ws); r /= g.Ws;
+    const int h = (int)(r % g.Hs); r /= g.Hs;
+    const int d = (int)(r % g.Ds);
+    const int b = (int)(r / g.Ds);
+    const float pv = (mok && pok) ? P[(size_t)m * g.Cp + pc] : 0.0f;
+    const int id = d * g.sd - g.pd + kdi * g.dd;
+    const int ih = h * g.sh - g.ph + khi * g.dh;
+    const bool rowok = mok && qok && id >= 0 && id < g.Dq && ih >= 0 && ih < g.Hq;
+    const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const int kwi = kwg * TW + t;
+      const int iw = w * g.sw - g.pw + kwi * g.dw;
+      const bool ok = rowok && kwi < g.kw && iw >= 0 && iw < g.Wq;
+      const float qv = ok ? Qt[(rowbase + iw) * g.Cq + qc] : 0.0f;
+      acc[t] = mfma32(qv, pv, acc[t]);
+    }
+  }
+  // partial tile -> ws[chunk][tap][q-channel][p-channel]
+  const int taps = g.kd * g.kh * g.kw;
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    const int kwi = kwg * TW + t;
+    if (kwi >= g.kw) continue;
+    const int tap = (kdi * g.kh + khi) * g.kw + kwi;
+    float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < g.Cq && pok) dst[(size_t)row * g.Cp + pc] = acc[t][r];
+    }
+  }
+}
+
+// gw (torch layout) = sum over chunks, in chunk order (deterministic).
+//   conv  : gw[co = p][ci = q][tap];  deconv: gw[ci = p][co = q][tap]   -> both are [p][q][tap]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps,
+                                    int Cq, int Cp, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // i over ws-slab order [tap][q][p]
+  if (i >= total) return;
+  float s = 0.0f;
+  for (int c = 0; c < nchunks; ++c) s += ws[(size_t)c * total + i];
+  const int p = (int)(i % Cp);
+  const int q = (int)((i / Cp) % Cq);
+  const int tap = (int)(i / ((long)Cp * Cq));
+  gw[((size_t)p * Cq + q) * taps + tap] = s;
+}
+
+// ---------------------------------------------------------------- host side
+bool conv_dims_ok(const ssbev_conv_dims* d) {
+  if (!d) return false;
+  if (d->B <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
+  if (d->Di <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
+  if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || d->sd <= 0 || d->sh <= 0 || d->sw <= 0) return false;
+  if (d->dd <= 0 || d->dh <= 0 || d->dw <= 0 || d->pd < 0 || d->ph < 0 || d->pw < 0) return false;
+  const bool strided = d->sd > 1 || d->sh > 1 || d->sw > 1;
+  const bool dilated = d->dd > 1 || d->dh > 1 || d->dw > 1;
+  if (strided && dilated) return false;
+  if (d->transposed) {
+    if (d->Do % d->sd || d->Ho % d->sh || d->Wo % d->sw) return false;
+  }
+  return true;
+}
+
+int pad8(int c) { return (c + 7) & ~7; }
+int pad32(int c) { return (c + 31) & ~31; }
+
+template <int MT, int NT>
+int launch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  int classes = 1;
+  if (g.form == 1) {
+    classes = g.sd * g.sh * g.sw;
+    Mtot /= classes;
+  }
+  dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
+  hipLaunchKernelGGL((conv_gather_kernel<MT, NT>), grid, block, 0, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
+int dispatch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+  if (g.Cin % 4 != 0) return SSBEV_EINVAL;
+  if (g.Cout <= 32) return launch_gather<4, 1>(x, wp, bias, y, g, st);
+  if (g.Cout <= 64) return launch_gather<2, 2>(x, wp, bias, y, g, st);
+  return launch_gather<2, 4>(x, wp, bias, y, g, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
+  if (!conv_dims_ok(d)) return 0;
+  // big enough for either role assignment (forward or data-gradient operand)
+  const size_t taps = (size_t)d->kd * d->kh * d->kw;
+  const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
+  return taps * (a > b ? a : b);
+}
+
+int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
+                           ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  const int taps = d->kd * d->kh * d->kw;
+  // forward: K = Cin, N = Cout; data gradient: K = Cout, N = Cin
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  // torch layout: conv [Cout,Cin,k], deconv [Cin,Cout,k]
+  //   fwd conv  : K=A1 (layout 0)   fwd deconv: K=A0 (layout 1)
+  //   bwd conv  : K=A0 (layout 1)   bwd deconv: K=A1 (layout 0)
+  const int layout = (mode == 0) == (d->transposed == 0) ? 0 : 1;
+  const int KPad = pad8(K), NPad = pad32(N);
+  const long total = (long)taps * KPad * NPad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, K,
+                     N, KPad, NPad, taps, layout, total);
+  return ssbev_launch_status();
+}
+
+int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                   const ssbev_conv_dims* d, ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
+  if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
+  ConvGeom g;
+  g.B = d->B; g.Cin = d->Cin; g.Cout = d->Cout; g.CinPad = pad8(d->Cin); g.CoutPad = pad32(d->Cout);
+  g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo;
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate;
+  return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
+}
+
+int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
+                        const ssbev_conv_dims* d, ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin
+  g.B = d->B; g.Cin = d->Cout; g.Cout = d->Cin; g.CinPad = pad8(d->Cout); g.CoutPad = pad32(d->Cin);
+  g.Di = d->Do; g.Hi = d->Ho; g.Wi = d->Wo; g.Do = d->Di; g.Ho = d->Hi; g.Wo = d->Wi;
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
+  g.relu = 0; g.accumulate = d->accumulate;
+  if (g.form == 1 && (g.Do % g.sd || g.Ho % g.sh || g.Wo % g.sw)) return SSBEV_EINVAL;
+  if (g.Cin % 4 != 0) return SSBEV_EINVAL;
+  return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
+}
+
+static WgradGeom make_wgrad_geom(const ssbev_conv_dims* d) {
+  WgradGeom g;
+  g.B = d->B;
+  if (!d->transposed) {
+    g.Cp = d->Cout; g.Cq = d->Cin;
+    g.Ds = d->Do; g.Hs = d->Ho; g.Ws = d->Wo; g.Dq = d->Di; g.Hq = d->Hi; g.Wq = d->Wi;
+  } else {
+    g.Cp = d->Cin; g.Cq = d->Cout;
+    g.Ds = d->Di; g.Hs = d->Hi; g.Ws = d->Wi; g.Dq = d->Do; g.Hq = d->Ho; g.Wq = d->Wo;
+  }
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
+  // aim for ~2048 wave-tasks in total, chunks of at least 512 voxels
+  const long tiles = (long)((g.Cp + 31) / 32) * ((g.Cq + 31) / 32) * g.kd * g.kh * ((g.kw + 2) / 3);
+  long want = 4096 / (tiles > 0 ? tiles : 1);
+  if (want < 1) want = 1;
+  long chunk = (Mtot + want - 1) / want;
+  if (chunk < 512) chunk = 512;
+  chunk = (chunk + 1) & ~1L;
+  g.chunk = (int)chunk;
+  g.nchunks = (int)((Mtot + chunk - 1) / chunk);
+  return g;
+}
+
+size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
+  if (!conv_dims_ok(d)) return 0;
+  const WgradGeom g = make_wgrad_geom(d);
+  return (size_t)g.nchunks * d->kd * d->kh * d->kw * g.Cp * g.Cq * sizeof(float);
+}
+
+int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_conv_dims* d,
+                          void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  const WgradGeom g = make_wgrad_geom(d);
+  const float* P = d->transposed ? x : gy;
+  const float* Qt = d->transposed ? gy : x;
+  hipStream_t st = as_stream(stream);
+  const int taps = g.kd * g.kh * g.kw;
+  const int ytiles = ((g.Cq + 31) / 32) * ((g.Cp + 31) / 32);
+  if (g.kw >= 3) {
+    dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * g.kh * ((g.kw + 2) / 3));
+    hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, P, Qt, static_cast<float*>(ws), g);
+  } else {
+    dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * g.kh * g.kw);
+    hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, P, Qt, static_cast<float*>(ws), g);
+  }
+  const long total = (long)taps * g.Cq * g.Cp;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
+                     g.nchunks, taps, g.Cq, g.Cp, total);
+  return ssbev_launch_status();
+}
+
+}  // extern "C"

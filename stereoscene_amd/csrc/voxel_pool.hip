@@ -1,0 +1,432 @@
+// Frustum -> voxel scatter for the LSS "splat" (SURVEY a9-a11), gfx950.
+//
+// Design (MI355X-first, not a translation of BEVFusion's bev_pool CUDA op):
+//   * the scatter is turned into a GATHER over a CSR table (voxel -> ascending point list) that
+//     is built on the device with a histogram / scan / fill / per-segment canonicalisation;
+//     no float atomics anywhere, sums are sequential fp32 in a fixed order => bit-reproducible
+//     and bit-identical to the CPU oracle;
+//   * one wavefront owns one voxel and streams its C channels with 8-byte lanes (C=128 ->
+//     one 512-B line per point, one 512-B store per voxel): the kernel is bound by the
+//     [B,nx,ny,nz,C] output write (134 MB at the KITTI config), everything else stays in L2;
+//   * Lift (depth x feature outer product, 755 MB at D=192) is fused in: never materialised.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- voxel index (VT:441-451)
+__global__ void voxel_index_kernel(const float* __restrict__ geom, int32_t* __restrict__ vox,
+                                   int32_t* __restrict__ idx3, long total, int P, int nx, int ny, int nz,
+                                   float ox, float oy, float oz, float dx, float dy, float dz) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const float gx = geom[3 * p + 0], gy = geom[3 * p + 1], gz = geom[3 * p + 2];
+  // fp32 subtract, IEEE divide, no contraction: identical to the torch CPU sequence.
+  const float fx = __fdiv_rn(__fsub_rn(gx, ox), dx);
+  const float fy = __fdiv_rn(__fsub_rn(gy, oy), dy);
+  const float fz = __fdiv_rn(__fsub_rn(gz, oz), dz);
+  // trunc-toward-zero then 0 <= i < n  <=>  -1 < f < n  (NaN fails both, as INT64_MIN does).
+  const bool kept = (fx > -1.0f) && (fx < (float)nx) && (fy > -1.0f) && (fy < (float)ny) &&
+                    (fz > -1.0f) && (fz < (float)nz);
+  int v = -1;
+  if (kept) {
+    const int b = (int)(p / P);
+    v = ((b * nx + (int)fx) * ny + (int)fy) * nz + (int)fz;
+  }
+  vox[p] = v;
+  if (idx3) {
+    auto sat = [](float f) -> int32_t {
+      if (!(f == f)) return INT32_MIN;
+      if (f >= 2147483648.0f) return INT32_MAX;
+      if (f <= -2147483648.0f) return INT32_MIN;
+      return (int32_t)f;
+    };
+    idx3[3 * p + 0] = sat(fx);
+    idx3[3 * p + 1] = sat(fy);
+    idx3[3 * p + 2] = sat(fz);
+  }
+}
+
+__global__ void coords_to_vox_kernel(const int32_t* __restrict__ coords, int n, int32_t* __restrict__ vox,
+                                     int B, int nx, int ny, int nz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ix = coords[4 * i], iy = coords[4 * i + 1], iz = coords[4 * i + 2], b = coords[4 * i + 3];
+  const bool ok = ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz && b >= 0 && b < B;
+  vox[i] = ok ? ((b * nx + ix) * ny + iy) * nz + iz : -1;
+}
+
+// ---------------------------------------------------------------- CSR build
+__global__ void histogram_kernel(const int32_t* __restrict__ vox, int n, int32_t* __restrict__ counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = vox[i];
+  if (v >= 0) atomicAdd(&counts[v], 1);
+}
+
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+// exclusive scan of one tile inside a block; returns the tile total through *total
+__device__ int block_exclusive_scan(int thread_sum, int* lds, int* total) {
+  const int t = threadIdx.x;
+  lds[t] = thread_sum;
+  __syncthreads();
+#pragma unroll
+  for (int off = 1; off < SCAN_T; off <<= 1) {
+    int v = (t >= off) ? lds[t - off] : 0;
+    __syncthreads();
+    lds[t] += v;
+    __syncthreads();
+  }
+  const int incl = lds[t];
+  *total = lds[SCAN_T - 1];
+  __syncthreads();
+  return incl - thread_sum;
+}
+
+__global__ void scan_tile_sums_kernel(const int32_t* __restrict__ counts, int nv, int32_t* __restrict__ tile_sums) {
+  __shared__ int lds[SCAN_T];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) s += (base + j < nv) ? counts[base + j] : 0;
+  int total;
+  block_exclusive_scan(s, lds, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the tile sums in place (ntiles is small: NV/1024)
+__global__ void scan_tile_offsets_kernel(int32_t* __restrict__ tile_sums, int ntiles) {
+  __shared__ int lds[SCAN_T];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += SCAN_T) {
+    const int i = base + threadIdx.x;
+    const int v = (i < ntiles) ? tile_sums[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, &total);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+}
+
+__global__ void scan_write_kernel(const int32_t* __restrict__ counts, int nv, const int32_t* __restrict__ tile_off,
+                                  int32_t* __restrict__ starts, int n_total_slot) {
+  __shared__ int lds[SCAN_T];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int c[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    c[j] = (base + j < nv) ? counts[base + j] : 0;
+    s += c[j];
+  }
+  int total;
+  int ex = block_exclusive_scan(s, lds, &total) + tile_off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < nv) starts[base + j] = ex;
+    ex += c[j];
+    if (base + j == nv - 1) starts[nv] = ex;  // grand total in the sentinel slot
+  }
+  (void)n_total_slot;
+}
+
+__global__ void fill_kernel(const int32_t* __restrict__ vox, int n, const int32_t* __restrict__ starts,
+                            int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = vox[i];
+  if (v < 0) return;
+  const int pos = atomicAdd(&cursor[v], 1);
+  tmp[starts[v] + pos] = i;
+}
+
+// Put every voxel's point list into ascending order (the atomic fill order is arbitrary).
+// One wave per 64 voxels: short lists by a per-lane insertion sort, long ones by a wave-wide
+// rank sort (point ids are unique, so rank = number of smaller ids).
+constexpr int SHORT_SEG = 12;
+__global__ void canonicalise_kernel(const int32_t* __restrict__ starts, const int32_t* __restrict__ tmp,
+                                    int32_t* __restrict__ order, int nv) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int v = wave * 64 + lane;
+  int s = 0, n = 0;
+  if (v < nv) {
+    s = starts[v];
+    n = starts[v + 1] - s;
+  }
+  if (n > 0 && n <= SHORT_SEG) {
+    int e[SHORT_SEG];
+#pragma unroll
+    for (int i = 0; i < SHORT_SEG; ++i) e[i] = (i < n) ? tmp[s + i] : INT32_MAX;
+    // odd-even transposition network on a fixed-size register array (no dynamic indexing)
+#pragma unroll
+    for (int r = 0; r < SHORT_SEG; ++r) {
+#pragma unroll
+      for (int i = (r & 1); i + 1 < SHORT_SEG; i += 2) {
+        const int a = e[i], b = e[i + 1];
+        e[i] = min(a, b);
+        e[i + 1] = max(a, b);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SHORT_SEG; ++i)
+      if (i < n) order[s + i] = e[i];
+  }
+  unsigned long long longs = __ballot(n > SHORT_SEG);
+  while (longs) {
+    const int src = __ffsll((long long)longs) - 1;
+    longs &= longs - 1;
+    const int ls = __shfl(s, src, 64), ln = __shfl(n, src, 64);
+    for (int i = lane; i < ln; i += 64) {
+      const int e = tmp[ls + i];
+      int r = 0;
+      for (int j = 0; j < ln; ++j) r += (tmp[ls + j] < e) ? 1 : 0;
+      order[ls + r] = e;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- gather-sum kernels
+// FUSED = true : acc += fp32(depth[p] * feat[row(p), c])   (lift + splat)
+// FUSED = false: acc += feats[p, c]                          (bev_pool drop-in)
+template <bool FUSED, int VEC>
+__global__ void __launch_bounds__(256)
+pool_gather_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                   const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                   float* __restrict__ out, int nv, int C, int P, int vox_per_batch, int N, int D, int HW) {
+  const int lane = threadIdx.x & 63;
+  const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (v >= nv) return;
+  const int s = starts[v], e = starts[v + 1];
+  const int b = v / vox_per_batch;
+  for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    for (int j = s; j < e; ++j) {
+      const int p = order[j];
+      size_t row;
+      float w = 1.0f;
+      if (FUSED) {
+        const int q = p - b * P;              // point index inside the batch element
+        const int n = q / (D * HW);
+        row = (size_t)(b * N + n) * HW + (q % HW);
+        w = depth[p];
+      } else {
+        row = (size_t)p;
+      }
+      const float* src = feat + row * C + c0;
+      float f[VEC];
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        f[0] = t.x; f[1 % VEC] = t.y; f[2 % VEC] = t.z; f[3 % VEC] = t.w;
+      } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        f[0] = t.x; f[1 % VEC] = t.y;
+      } else {
+        f[0] = src[0];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = __fadd_rn(acc[k], FUSED ? __fmul_rn(w, f[k]) : f[k]);
+    }
+    float* dst = out + (size_t)v * C + c0;
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+    } else if (VEC == 2) {
+      *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1 % VEC]);
+    } else {
+      dst[0] = acc[0];
+    }
+  }
+}
+
+// grad_feats[n,:] = grad_out[vox[n],:]
+__global__ void bev_pool_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ vox,
+                                    float* __restrict__ gfeat, long total, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long n = i / C;
+  const int c = (int)(i - n * C);
+  const int v = vox[n];
+  gfeat[i] = v >= 0 ? gout[(size_t)v * C + c] : 0.0f;
+}
+
+// Backward of the fused lift-splat.  One wave per feature row (b, n, pixel); the wave walks the D
+// depth planes four at a time (16 lanes x float4 cover a 64-channel slab of one voxel row):
+//   grad_depth[p]   = <grad_out[vox[p], :], feat[row, :]>
+//   grad_feat[row]  = sum_d depth[p] * grad_out[vox[p], :]
+// Every output element is written exactly once: no atomics, deterministic.
+__global__ void __launch_bounds__(256)
+lift_splat_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ depth,
+                      const float* __restrict__ feat, const int32_t* __restrict__ vox,
+                      float* __restrict__ gdepth, float* __restrict__ gfeat, int rows, int C, int P, int N,
+                      int D, int HW) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int slot = lane >> 4, l16 = lane & 15;
+  const int bn = row / HW, pix = row - bn * HW;
+  const int b = bn / N, n = bn - b * N;
+  const size_t pbase = (size_t)b * P + (size_t)n * D * HW + pix;
+  const float* frow = feat + (size_t)row * C;
+  for (int cb = 0; cb < C; cb += 64) {   // 64-channel slabs (C=128 -> 2 passes over the planes)
+    const int c = cb + l16 * 4;
+    const bool cok = c < C;
+    float4 f = cok ? *reinterpret_cast<const float4*>(frow + c) : make_float4(0, 0, 0, 0);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int d0 = 0; d0 < D; d0 += 4) {
+      const int d = d0 + slot;
+      float dot = 0.0f;
+      size_t p = 0;
+      if (d < D) {
+        p = pbase + (size_t)d * HW;
+        const int v = vox[p];
+        if (v >= 0 && cok) {
+          const float4 g = *reinterpret_cast<const float4*>(gout + (size_t)v * C + c);
+          const float w = depth[p];
+          dot = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
+          acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+      if (d < D && l16 == 0) {
+        if (cb == 0) gdepth[p] = dot; else gdepth[p] += dot;
+      }
+    }
+    // fold the four depth slots together
+    acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+    acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+    acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+    acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+    if (slot == 0 && cok) *reinterpret_cast<float4*>(gfeat + (size_t)row * C + c) = acc;
+  }
+}
+
+bool pool_dims_ok(const ssbev_pool_dims* d) {
+  return d && d->B > 0 && d->P >= 0 && d->C > 0 && d->nx > 0 && d->ny > 0 && d->nz > 0 &&
+         (long)d->B * d->nx * d->ny * d->nz < (1L << 31) && (long)d->B * d->P < (1L << 31);
+}
+
+template <bool FUSED>
+int launch_gather(const float* depth, const float* feat, const int32_t* starts, const int32_t* order, float* out,
+                  const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st) {
+  const int nv = d->B * d->nx * d->ny * d->nz;
+  const int vpb = d->nx * d->ny * d->nz;
+  dim3 grid(cdiv((size_t)nv * 64, 256)), block(256);
+  if (d->C % 256 == 0)
+    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 4>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+                       d->P, vpb, N, D, HW);
+  else if (d->C % 2 == 0)
+    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 2>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+                       d->P, vpb, N, D, HW);
+  else
+    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 1>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+                       d->P, vpb, N, D, HW);
+  return ssbev_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssbev_voxel_index(const float* geom, int32_t* vox, int32_t* idx3, const ssbev_pool_dims* d,
+                      ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || !geom || !vox) return SSBEV_EINVAL;
+  const long total = (long)d->B * d->P;
+  if (total == 0) return SSBEV_OK;
+  hipLaunchKernelGGL(voxel_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), geom, vox, idx3,
+                     total, d->P, d->nx, d->ny, d->nz, d->origin[0], d->origin[1], d->origin[2], d->dx[0], d->dx[1],
+                     d->dx[2]);
+  return ssbev_launch_status();
+}
+
+int ssbev_coords_to_vox(const int32_t* coords, int n, int32_t* vox, const ssbev_pool_dims* d,
+                        ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || n < 0 || (n && (!coords || !vox))) return SSBEV_EINVAL;
+  if (n == 0) return SSBEV_OK;
+  hipLaunchKernelGGL(coords_to_vox_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords, n, vox, d->B,
+                     d->nx, d->ny, d->nz);
+  return ssbev_launch_status();
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d) {
+  if (!pool_dims_ok(d) || n_points < 0) return 0;
+  const size_t nv = (size_t)d->B * d->nx * d->ny * d->nz;
+  const size_t ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
+  // counts[nv] | cursor[nv] | tile_sums[ntiles] | tmp[n_points]
+  return align256(nv * 4) * 2 + align256(ntiles * 4) + align256((size_t)n_points * 4 + 4);
+}
+
+int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
+                       const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || n_points < 0 || !starts || !ws || (n_points && (!vox || !order))) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_pool_prepare_workspace(n_points, d)) return SSBEV_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int nv = d->B * d->nx * d->ny * d->nz;
+  const int ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
+  char* base = static_cast<char*>(ws);
+  int32_t* counts = reinterpret_cast<int32_t*>(base);
+  int32_t* cursor = reinterpret_cast<int32_t*>(base + align256((size_t)nv * 4));
+  int32_t* tiles = reinterpret_cast<int32_t*>(base + 2 * align256((size_t)nv * 4));
+  int32_t* tmp = reinterpret_cast<int32_t*>(base + 2 * align256((size_t)nv * 4) + align256((size_t)ntiles * 4));
+  if (hipMemsetAsync(base, 0, 2 * align256((size_t)nv * 4), st) != hipSuccess) return SSBEV_ELAUNCH;
+  if (n_points)
+    hipLaunchKernelGGL(histogram_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, counts);
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_T), 0, st, tiles, ntiles);
+  hipLaunchKernelGGL(scan_write_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles, starts, nv);
+  if (n_points) {
+    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, starts, cursor, tmp);
+    hipLaunchKernelGGL(canonicalise_kernel, dim3(cdiv((size_t)nv, 256)), dim3(256), 0, st, starts, tmp, order, nv);
+  }
+  return ssbev_launch_status();
+}
+
+int ssbev_bev_pool_fwd(const float* feats, const int32_t* starts, const int32_t* order, float* out,
+                       const ssbev_pool_dims* d, ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || !starts || !out) return SSBEV_EINVAL;
+  return launch_gather<false>(nullptr, feats, starts, order, out, d, 1, 1, 1, as_stream(stream));
+}
+
+int ssbev_bev_pool_bwd(const float* grad_out, const int32_t* vox, int n_points, float* grad_feats,
+                       const ssbev_pool_dims* d, ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || n_points < 0) return SSBEV_EINVAL;
+  if (n_points == 0) return SSBEV_OK;
+  if (!grad_out || !vox || !grad_feats) return SSBEV_EINVAL;
+  const long total = (long)n_points * d->C;
+  hipLaunchKernelGGL(bev_pool_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), grad_out, vox,
+                     grad_feats, total, d->C);
+  return ssbev_launch_status();
+}
+
+int ssbev_lift_splat_fwd(const float* depth, const float* feat, const int32_t* starts,
+                         const int32_t* order, float* out, const ssbev_pool_dims* d,
+                         const ssbev_lift_dims* l, ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || !l || !depth || !feat || !starts || !out) return SSBEV_EINVAL;
+  if (l->N <= 0 || l->D <= 0 || l->HW <= 0 || (long)l->N * l->D * l->HW != d->P) return SSBEV_EINVAL;
+  return launch_gather<true>(depth, feat, starts, order, out, d, l->N, l->D, l->HW, as_stream(stream));
+}
+
+int ssbev_lift_splat_bwd(const float* grad_out, const float* depth, const float* feat,
+                         const int32_t* vox, float* grad_depth, float* grad_feat,
+                         const ssbev_pool_dims* d, const ssbev_lift_dims* l, ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || !l || !grad_out || !depth || !feat || !vox || !grad_depth || !grad_feat)
+    return SSBEV_EINVAL;
+  if (l->N <= 0 || l->D <= 0 || l->HW <= 0 || (long)l->N * l->D * l->HW != d->P || d->C % 4 != 0)
+    return SSBEV_EINVAL;
+  const int rows = d->B * l->N * l->HW;
+  hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3(cdiv((size_t)rows * 64, 256)), dim3(256), 0, as_stream(stream),
+                     grad_out, depth, feat, vox, grad_depth, grad_feat, rows, d->C, d->P, l->N, l->D, l->HW);
+  return ssbev_launch_status();
+}
+
+}  // extern "C"

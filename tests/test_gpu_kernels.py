@@ -1,0 +1,206 @@
+"""GPU parity of every HIP kernel against the CPU oracle, through the C ABI (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import load_golden
+from oracle import path_ref as O
+from stereoscene_amd import functional as F
+from stereoscene_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------ scatter
+def _geometry(cfg, B):
+    gc = S.grid_config(cfg)
+    dx, bx, nx = O.gen_dx_bx(gc["xbound"], gc["ybound"], gc["zbound"])
+    fr = O.create_frustum(cfg["input_size"], cfg["downsample"], gc["dbound"])
+    geo = S.kitti_calibration(B, cfg["input_size"][1])
+    geom = O.get_geometry(fr, *geo[:6])
+    return geom, dx, bx, nx
+
+
+@pytest.mark.parametrize("cfgname,B", [("small_d48", 2), ("kitti_d112", 1)])
+def test_voxel_index_bit_exact(cfgname, B):
+    geom, dx, bx, nx = _geometry(S.CONFIGS[cfgname], B)
+    # add hostile values: exact boundaries, (-1,0) truncation zone, NaN/inf, huge
+    g = geom.clone().reshape(-1, 3)
+    g[0] = torch.tensor([float("nan"), 0.0, 0.0])
+    g[1] = torch.tensor([float("inf"), 1.0, 1.0])
+    g[2] = torch.tensor([-1e30, 1.0, 1.0])
+    g[3] = (bx - dx / 2) - 0.5 * dx          # idx = -0.5 -> truncates to 0 -> kept
+    g[4] = (bx - dx / 2) - 1.0 * dx          # idx = -1 exactly -> dropped
+    g[5] = (bx - dx / 2) + nx * dx           # idx = n exactly -> dropped
+    g = g.view_as(geom)
+    idx, kept = O.voxel_index(g, dx, bx, nx)
+    vox, idx3 = F.voxel_index(g.to(DEV), bx, dx, nx, return_idx=True)
+    n = [int(v) for v in nx.tolist()]
+    P = idx.shape[0] // B
+    b = torch.arange(B).repeat_interleave(P)
+    want = torch.where(kept, ((b * n[0] + idx[:, 0]) * n[1] + idx[:, 1]) * n[2] + idx[:, 2], torch.full_like(b, -1))
+    assert torch.equal(vox.cpu().long(), want)
+    fin = kept | ((idx.abs() < 2 ** 31 - 1).all(1))
+    assert torch.equal(idx3.cpu().long()[fin], idx[fin])
+    assert bool(kept[3]) and not bool(kept[4]) and not bool(kept[5])
+
+
+@pytest.mark.parametrize("cfgname,B,C", [("small_d48", 2, 128), ("tiny_d16", 1, 6), ("kitti_d112", 1, 128)])
+def test_lift_splat_bit_exact_and_grads(cfgname, B, C):
+    cfg = S.CONFIGS[cfgname]
+    geom, dx, bx, nx = _geometry(cfg, B)
+    _, N, D, H, W, _ = geom.shape
+    depth = torch.softmax(S.hash_normal("ls/depth", (B * N, D, H, W), 2.0), 1)
+    feat = S.hash_normal("ls/feat", (B * N, C, H, W))
+    want = O.lift_splat(depth, feat, geom, dx, bx, nx)
+    dg = depth.to(DEV).requires_grad_(True)
+    fg = feat.to(DEV).requires_grad_(True)
+    got = F.lift_splat(dg, fg, geom.to(DEV), bx, dx, nx)
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu(), want), f"max diff {maxdiff(got, want)}"   # bit-exact sums
+    # gradients against autograd through the materialised reference formulation
+    go = S.hash_normal("ls/go", tuple(want.shape))
+    got.backward(go.to(DEV))
+    dc = depth.clone().requires_grad_(True)
+    fc = feat.clone().requires_grad_(True)
+    idx, kept = O.voxel_index(geom, dx, bx, nx)
+    n = [int(v) for v in nx.tolist()]
+    P = idx.shape[0] // B
+    lin = ((torch.arange(B).repeat_interleave(P) * n[0] + idx[:, 0]) * n[1] + idx[:, 1]) * n[2] + idx[:, 2]
+    vol = (dc.unsqueeze(1) * fc.unsqueeze(2)).view(B, N, C, D, H, W).permute(0, 1, 3, 4, 5, 2).reshape(-1, C)
+    flat = torch.zeros(B * n[0] * n[1] * n[2], C).index_add(0, lin[kept], vol[kept])
+    (flat.view(B, n[0], n[1], n[2], C).permute(0, 4, 1, 2, 3) * go).sum().backward()
+    assert maxdiff(dg.grad, dc.grad) < 2e-4 * max(1.0, dc.grad.abs().max().item())
+    assert maxdiff(fg.grad, fc.grad) < 2e-4 * max(1.0, fc.grad.abs().max().item())
+
+
+def test_bev_pool_dropin_matches_oracle_and_golden_coords():
+    g = load_golden("vt_small")
+    coords = torch.from_numpy(g["pool_coords"]).long()
+    n = coords.shape[0]
+    feats = S.hash_normal("bp/feats", (n, 128))
+    want = O.bev_pool(feats, coords, 2, 8, 32, 32)
+    fg = feats.to(DEV).requires_grad_(True)
+    got = F.bev_pool(fg, coords.to(DEV), 2, 8, 32, 32)
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    go = S.hash_normal("bp/go", tuple(want.shape))
+    got.backward(go.to(DEV))
+    ref = go.permute(0, 2, 3, 4, 1)[coords[:, 3], coords[:, 2], coords[:, 0], coords[:, 1]]
+    assert torch.equal(fg.grad.cpu(), ref)
+    # empty input (edge case of the upstream op's assert path)
+    e = F.bev_pool(torch.zeros(0, 16, device=DEV), torch.zeros(0, 4, dtype=torch.long, device=DEV), 1, 2, 4, 4)
+    assert e.shape == (1, 16, 2, 4, 4) and float(e.abs().sum()) == 0.0
+
+
+def test_pool_is_deterministic_run_to_run():
+    cfg = S.CONFIGS["small_d48"]
+    geom, dx, bx, nx = _geometry(cfg, 2)
+    _, N, D, H, W, _ = geom.shape
+    depth = torch.softmax(S.hash_normal("det/depth", (2, D, H, W), 2.0), 1).to(DEV)
+    feat = S.hash_normal("det/feat", (2, 128, H, W)).to(DEV)
+    a = F.lift_splat(depth, feat, geom.to(DEV), bx, dx, nx)
+    for _ in range(3):
+        assert torch.equal(a, F.lift_splat(depth, feat, geom.to(DEV), bx, dx, nx))
+
+
+# ------------------------------------------------------------------------------------ cost volume
+@pytest.mark.parametrize("ac", [True, False])
+def test_gwc_warp_golden(ac):
+    g = load_golden("gwc_warp")
+    L, R, calib = (torch.from_numpy(g[k]) for k in ("left", "right", "calib"))
+    got = F.gwc_warp(L.to(DEV), R.to(DEV), calib.to(DEV), int(g["ndisp"]), 32, ac)
+    assert maxdiff(got, torch.from_numpy(g["warped_ac1" if ac else "warped_ac0"])) < 5e-6
+
+
+@pytest.mark.parametrize("ac", [True, False])
+@pytest.mark.parametrize("B,C,G,H,W,D", [(2, 64, 32, 3, 40, 48), (1, 64, 32, 2, 160, 192), (1, 32, 8, 2, 24, 16)])
+def test_gwc_warp_fwd_bwd_vs_oracle(ac, B, C, G, H, W, D):
+    L = S.hash_normal("gw/L", (B, C, H, W))
+    R = S.hash_normal("gw/R", (B, C, H, W))
+    calib = torch.tensor([383.0, 97.3])[:B] * (W / 160.0)
+    Lc, Rc = L.clone().requires_grad_(True), R.clone().requires_grad_(True)
+    cpg = C // G
+    vol = O.gwc_volume(Lc, Rc, D, G) if cpg == 2 or True else None
+    want = O.warp_volume(vol, calib, 1, ac)
+    Lg, Rg = L.to(DEV).requires_grad_(True), R.to(DEV).requires_grad_(True)
+    got = F.gwc_warp(Lg, Rg, calib.to(DEV), D, G, ac)
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 1e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal("gw/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    s = max(1.0, Lc.grad.abs().max().item())
+    assert maxdiff(Lg.grad, Lc.grad) < 2e-5 * s
+    assert maxdiff(Rg.grad, Rc.grad) < 2e-5 * s
+
+
+# ------------------------------------------------------------------------------------ convolutions
+CONV_CASES = [
+    # (B, Cin, Cout, D, H, W, k, s, p, dil, transposed, out_pad, bias)
+    (1, 32, 32, 6, 7, 9, 3, 1, 1, 1, False, 0, False),
+    (2, 32, 64, 8, 6, 10, 3, 2, 1, 1, False, 0, False),
+    (1, 64, 128, 5, 6, 7, 3, 2, 1, 1, False, 0, True),
+    (1, 128, 64, 3, 4, 5, 3, 2, 1, 1, True, 1, False),
+    (1, 64, 32, 4, 3, 5, 3, 2, 1, 1, True, 1, False),
+    (1, 32, 32, 4, 5, 6, 1, 1, 0, 1, False, 0, False),
+    (1, 128, 256, 6, 6, 4, 1, 2, 0, 1, False, 0, False),
+    (1, 256, 128, 3, 3, 2, 2, 2, 0, 1, True, 0, False),
+    (1, 512, 128, 2, 2, 1, 4, 4, 0, 1, True, 0, False),
+    (1, 128, 128, 4, 4, 4, 1, 1, 0, 1, True, 0, False),
+    (1, 2, 32, 4, 5, 6, 3, 1, 1, 1, False, 0, True),
+    (1, 32, 1, 4, 5, 6, 3, 1, 1, 1, False, 0, True),
+    (1, 192, 20, 4, 4, 4, 1, 1, 0, 1, False, 0, False),
+    (1, 384, 192, 3, 4, 4, 3, 1, 1, 1, False, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_family_fwd_bwd(case):
+    B, Cin, Cout, D, H, W, k, s, p, dil, tr, op, has_bias = case
+    x = S.hash_normal(f"cv/x{case}", (B, Cin, D, H, W))
+    wshape = (Cin, Cout, k, k, k) if tr else (Cout, Cin, k, k, k)
+    w = S.hash_uniform(f"cv/w{case}", wshape, -1, 1) * (3.0 / (Cin * k ** 3)) ** 0.5
+    b = S.hash_uniform(f"cv/b{case}", (Cout,), -0.5, 0.5) if has_bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bc = b.clone().requires_grad_(True) if has_bias else None
+    if tr:
+        want = TF.conv_transpose3d(xc, wc, bc, s, p, op)
+    else:
+        want = TF.conv3d(xc, wc, bc, s, p, dil)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if has_bias else None
+    got = F.conv_transpose3d(xg, wg, bg, s, p, op) if tr else F.conv3d(xg, wg, bg, s, p, dil)
+    assert got.shape == want.shape
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(got, want) < tol
+    go = S.hash_normal(f"cv/go{case}", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    if has_bias:
+        assert maxdiff(bg.grad, bc.grad) < 5e-5 * max(1.0, bc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout,k,p,dil,bias", [(640, 128, 3, 1, 1, True), (128, 64, 1, 0, 1, True),
+                                                  (64, 64, 3, 6, 6, False), (64, 64, 3, 18, 18, False)])
+def test_conv2d_incl_dilation(Cin, Cout, k, p, dil, bias):
+    x = S.hash_normal("c2/x", (2, Cin, 12, 40))
+    w = S.hash_uniform("c2/w", (Cout, Cin, k, k), -1, 1) * (3.0 / (Cin * k * k)) ** 0.5
+    b = S.hash_uniform("c2/b", (Cout,), -0.5, 0.5) if bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv2d(xc, wc, b, 1, p, dil)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    got = F.conv2d(xg, wg, b.to(DEV) if bias else None, 1, p, dil)
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal("c2/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
