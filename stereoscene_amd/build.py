@@ -12,6 +12,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+# Kernels whose results must be BIT-identical to the CPU oracle are built without FMA contraction
+# (hipcc's __fmul_rn/__fadd_rn are plain * and + and would otherwise fuse).
+PER_FILE_FLAGS = {"voxel_pool.hip": ["-ffp-contract=off"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -34,7 +39,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -58,7 +58,8 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     par_w = cls % g.sw; cls /= g.sw;
     par_h = cls % g.sh; cls /= g.sh;
     par_d = cls;
-    Dc = g.Do / g.sd; Hc = g.Ho / g.sh; Wc = g.Wo / g.sw;
+    // class extent = number of o in [0, Do) with o % s == par
+    Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
   }
   const long Mtot = (long)g.B * Dc * Hc * Wc;
   const long m_wave = ((long)blockIdx.x * 4 + wave) * (MT * 32);
@@ -300,9 +301,6 @@ bool conv_dims_ok(const ssbev_conv_dims* d) {
   const bool strided = d->sd > 1 || d->sh > 1 || d->sw > 1;
   const bool dilated = d->dd > 1 || d->dh > 1 || d->dw > 1;
   if (strided && dilated) return false;
-  if (d->transposed) {
-    if (d->Do % d->sd || d->Ho % d->sh || d->Wo % d->sw) return false;
-  }
   return true;
 }
 
@@ -313,9 +311,9 @@ template <int MT, int NT>
 int launch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
   int classes = 1;
-  if (g.form == 1) {
+  if (g.form == 1) {   // grid sized for the largest parity class (parity 0)
     classes = g.sd * g.sh * g.sw;
-    Mtot /= classes;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
   }
   dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
   hipLaunchKernelGGL((conv_gather_kernel<MT, NT>), grid, block, 0, st, x, wp, bias, y, g);
@@ -381,7 +379,6 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
   g.relu = 0; g.accumulate = d->accumulate;
-  if (g.form == 1 && (g.Do % g.sd || g.Ho % g.sh || g.Wo % g.sw)) return SSBEV_EINVAL;
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }

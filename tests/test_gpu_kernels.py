@@ -46,12 +46,12 @@ def test_voxel_index_bit_exact(cfgname, B):
     b = torch.arange(B).repeat_interleave(P)
     want = torch.where(kept, ((b * n[0] + idx[:, 0]) * n[1] + idx[:, 1]) * n[2] + idx[:, 2], torch.full_like(b, -1))
     assert torch.equal(vox.cpu().long(), want)
-    fin = kept | ((idx.abs() < 2 ** 31 - 1).all(1))
+    fin = ((idx > -2 ** 31) & (idx < 2 ** 31 - 1)).all(1)   # int32-representable rows (idx3 saturates)
     assert torch.equal(idx3.cpu().long()[fin], idx[fin])
     assert bool(kept[3]) and not bool(kept[4]) and not bool(kept[5])
 
 
-@pytest.mark.parametrize("cfgname,B,C", [("small_d48", 2, 128), ("tiny_d16", 1, 6), ("kitti_d112", 1, 128)])
+@pytest.mark.parametrize("cfgname,B,C", [("small_d48", 2, 128), ("tiny_d16", 1, 12), ("kitti_d112", 1, 128)])
 def test_lift_splat_bit_exact_and_grads(cfgname, B, C):
     cfg = S.CONFIGS[cfgname]
     geom, dx, bx, nx = _geometry(cfg, B)
