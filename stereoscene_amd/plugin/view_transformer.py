@@ -1,0 +1,450 @@
+"""Stereo-geometry view transformer: host-side mirror of the reference's
+``ViewTransformerLiftSplatShootVoxel`` (VT:273-526) with its ancestors folded in
+(``ViewTransformerLSSBEVDepth`` BD:577-767, ``ViewTransformerLiftSplatShoot`` BD:70-309).
+
+Same registry name, constructor kwargs, forward signature and state-dict keys as the reference;
+the arithmetic runs on the ssbev HIP kernels:
+
+    a2+a3  build_gwc_volume + warp        -> functional.gwc_warp (one fused kernel)
+    a4/a8  conv3d / deconv3d stacks       -> MFMA implicit-GEMM kernels (layers.Conv3d, ...)
+    a9+a11 lift + voxel_pooling/bev_pool  -> functional.lift_splat (CSR gather, deterministic)
+
+VT = projects/mmdet3d_plugin/occupancy/image2bev/ViewTransformerLSSVoxel.py
+BD = .../image2bev/ViewTransformerLSSBEVDepth.py, ATT = .../image2bev/attention.py
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from .. import functional as F
+from ..layers import Conv2d, Conv3d, ConvTranspose3d, build_conv_layer, build_norm_layer
+from ..registry import NECKS
+
+GN2 = dict(type="GN", num_groups=2, requires_grad=True)
+
+
+# ------------------------------------------------------------------------------- small blocks
+class Mlp(nn.Module):
+    """fc1 -> ReLU -> fc2 (BD:417-439; both dropouts are p=0)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(torch.relu(self.fc1(x)))
+
+
+class SELayer(nn.Module):
+    """Camera-aware squeeze-excite gate (BD:442-454).  The 1x1 convs act on a [B,C,1,1] vector."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1, bias=True)
+        self.conv_expand = nn.Conv2d(channels, channels, 1, bias=True)
+
+    def forward(self, x, x_se):
+        w, b = self.conv_reduce.weight.flatten(1), self.conv_reduce.bias
+        s = torch.relu(TF.linear(x_se.flatten(1), w, b))
+        s = TF.linear(s, self.conv_expand.weight.flatten(1), self.conv_expand.bias)
+        return x * torch.sigmoid(s)[..., None, None]
+
+
+class BasicBlock2d(nn.Module):
+    """mmdet ResNet BasicBlock (third-party, BD:486-488): conv3x3-BN-ReLU-conv3x3-BN, +x, ReLU."""
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        return torch.relu(self.bn2(self.conv2(y)) + x)
+
+
+class _ASPPModule(nn.Module):
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation):
+        super().__init__()
+        self.atrous_conv = Conv2d(inplanes, planes, kernel_size, 1, padding, dilation, bias=False)
+        self.bn = nn.BatchNorm2d(planes)
+        nn.init.kaiming_normal_(self.atrous_conv.weight)
+
+    def forward(self, x):
+        return torch.relu(self.bn(self.atrous_conv(x)))
+
+
+class ASPP(nn.Module):
+    """Atrous pyramid, dilations 1/6/12/18 + image-level branch (BD:343-414)."""
+
+    def __init__(self, inplanes, mid_channels=256):
+        super().__init__()
+        self.aspp1 = _ASPPModule(inplanes, mid_channels, 1, 0, 1)
+        self.aspp2 = _ASPPModule(inplanes, mid_channels, 3, 6, 6)
+        self.aspp3 = _ASPPModule(inplanes, mid_channels, 3, 12, 12)
+        self.aspp4 = _ASPPModule(inplanes, mid_channels, 3, 18, 18)
+        self.global_avg_pool = nn.Sequential(
+            nn.AdaptiveAvgPool2d((1, 1)),
+            nn.Conv2d(inplanes, mid_channels, 1, stride=1, bias=False),
+            build_norm_layer(GN2, mid_channels)[1],
+            nn.ReLU())
+        self.conv1 = Conv2d(int(mid_channels * 5), mid_channels, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid_channels)
+        self.dropout = nn.Dropout(0.5)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, Conv2d)):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        g = x.mean(dim=(2, 3))                                       # AdaptiveAvgPool2d((1,1))
+        g = TF.linear(g, self.global_avg_pool[1].weight.flatten(1))  # 1x1 conv on a 1x1 map
+        g = torch.relu(self.global_avg_pool[2](g))[..., None, None]
+        g = g.expand(-1, -1, x.shape[2], x.shape[3])                 # bilinear(align_corners) of a 1x1 map
+        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), dim=1)
+        return self.dropout(torch.relu(self.bn1(self.conv1(y))))
+
+
+class DepthNet(nn.Module):
+    """Camera-aware monocular depth logits || context features (BD:457-517)."""
+
+    def __init__(self, in_channels, mid_channels, context_channels, depth_channels, cam_channels=27):
+        super().__init__()
+        self.reduce_conv = nn.Sequential(
+            Conv2d(in_channels, mid_channels, 3, 1, 1), build_norm_layer(GN2, mid_channels)[1], nn.ReLU(inplace=True))
+        self.context_conv = Conv2d(mid_channels, context_channels, 1)
+        self.bn = build_norm_layer(GN2, cam_channels)[1]
+        self.depth_mlp = Mlp(cam_channels, mid_channels, mid_channels)
+        self.depth_se = SELayer(mid_channels)
+        self.context_mlp = Mlp(cam_channels, mid_channels, mid_channels)
+        self.context_se = SELayer(mid_channels)
+        self.depth_conv = nn.Sequential(
+            BasicBlock2d(mid_channels, mid_channels),
+            BasicBlock2d(mid_channels, mid_channels),
+            BasicBlock2d(mid_channels, mid_channels),
+            ASPP(mid_channels, mid_channels),
+            build_conv_layer(dict(type="DCN", in_channels=mid_channels, out_channels=mid_channels, kernel_size=3,
+                                  padding=1, groups=4, im2col_step=128)),
+            Conv2d(mid_channels, depth_channels, 1))
+
+    def forward(self, x, mlp_input):
+        cam = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
+        x = self.reduce_conv(x)
+        context = self.context_conv(self.context_se(x, self.context_mlp(cam)[..., None, None]))
+        depth = self.depth_conv(self.depth_se(x, self.depth_mlp(cam)[..., None, None]))
+        return torch.cat([depth, context], dim=1)
+
+
+# ------------------------------------------------------------------------------- stereo branch
+class stereofeature_net(nn.Module):
+    """Matching features of one view (VT:32-65): conv3x3+GN+ReLU, camera SE gate, conv1x1."""
+
+    def __init__(self, in_channels, mid_channels, depth_channels, cam_channels):
+        super().__init__()
+        self.reduce_conv = nn.Sequential(
+            Conv2d(in_channels, mid_channels, 3, 1, 1), build_norm_layer(GN2, mid_channels)[1], nn.ReLU())
+        self.bn = nn.Identity()
+        self.depth_mlp = Mlp(cam_channels, mid_channels, mid_channels)
+        self.depth_se = SELayer(mid_channels)
+        self.depth_conv = nn.Sequential(Conv2d(mid_channels, depth_channels, 1, 1, 0))
+
+    def forward(self, x, mlp_input):
+        cam = mlp_input.reshape(-1, mlp_input.shape[-1])
+        x = self.reduce_conv(x)
+        return self.depth_conv(self.depth_se(x, self.depth_mlp(cam)[..., None, None]))
+
+
+def convbn_3d(cin, cout, kernel_size, stride, pad):
+    """Bias-free conv3d + GN(2) (VT:66-69)."""
+    return nn.Sequential(Conv3d(cin, cout, kernel_size, stride, pad, bias=False), build_norm_layer(GN2, cout)[1])
+
+
+class hourglass(nn.Module):
+    """3-D encoder/decoder with BatchNorm3d after the transposed convs (VT:70-96)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Sequential(convbn_3d(c, c * 2, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(convbn_3d(c * 2, c * 2, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv3 = nn.Sequential(convbn_3d(c * 2, c * 4, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(convbn_3d(c * 4, c * 4, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv5 = nn.Sequential(ConvTranspose3d(c * 4, c * 2, 3, 2, 1, 1, bias=False), nn.BatchNorm3d(c * 2))
+        self.conv6 = nn.Sequential(ConvTranspose3d(c * 2, c, 3, 2, 1, 1, bias=False), nn.BatchNorm3d(c))
+        self.redir1 = convbn_3d(c, c, 1, 1, 0)
+        self.redir2 = convbn_3d(c * 2, c * 2, 1, 1, 0)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c4 = self.conv4(self.conv3(c2))
+        c5 = torch.relu(self.conv5(c4) + self.redir2(c2))
+        return torch.relu(self.conv6(c5) + self.redir1(x))
+
+
+class GwcNet_volume_encoder(nn.Module):
+    """Stereo cost-volume branch (VT:158-224)."""
+
+    def __init__(self, maxdisp, out_c, warp_align_corners=True):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.num_groups = 32
+        self.warp_align_corners = warp_align_corners
+        self.feature_withcam = stereofeature_net(640, 128, 64, 30)
+        self.dres0 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True))
+        self.dres1 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True), convbn_3d(32, 32, 3, 1, 1))
+        self.dres2 = hourglass(32)
+        self.dres3 = hourglass(32)
+        self.dres4 = hourglass(32)
+        self.classif3_1 = nn.Sequential(convbn_3d(32, out_c, 3, 1, 1), nn.ReLU(inplace=True))
+        self.classif3_2 = nn.Sequential(Conv3d(out_c, 1, 3, 1, 1, bias=False))
+        for m in self.modules():                          # He-normal re-initialisation (VT:189-203)
+            if isinstance(m, (Conv2d, Conv3d)):
+                n = math.prod(m.kernel_size) * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.Linear):
+                m.bias.data.zero_()
+
+    def forward(self, features_left, features_right, mlp_input_left, mlp_input_right, calib):
+        B = features_left.shape[0]
+        fea = self.feature_withcam(torch.cat([features_left, features_right], 0),
+                                   torch.cat([mlp_input_left, mlp_input_right], 0))
+        volume = F.gwc_warp(fea[:B], fea[B:], calib, self.maxdisp, self.num_groups, self.warp_align_corners)
+        cost0 = self.dres0(volume)
+        cost0 = self.dres1(cost0) + cost0
+        out3 = self.dres4(self.dres3(self.dres2(cost0)))
+        cost3_1 = self.classif3_1(out3)
+        pred3 = torch.softmax(self.classif3_2(cost3_1).squeeze(1), dim=1)
+        return {"multi_channel": cost3_1, "single_channel": pred3}
+
+
+# ------------------------------------------------------------------------------- MIE
+class attention(nn.Module):
+    """BRI cross attention over [B,1,D,H,W] volumes (ATT:45-86): tokens = pixels, head dim = D.
+    The 1x1x1 single-channel convs are scalar affine maps."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        assert in_dim == 1
+        self.chanel_in = in_dim
+        self.query_conv = nn.Conv3d(in_dim, in_dim, 1)
+        self.key_conv = nn.Conv3d(in_dim, in_dim, 1)
+        self.value_conv = nn.Conv3d(in_dim, in_dim, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    @staticmethod
+    def _affine(conv, x):
+        return x * conv.weight.view(()) + conv.bias.view(())
+
+    def forward(self, q, kv):
+        B, C, D, H, W = kv.shape
+        hw = H * W
+        conf = torch.softmax(q, dim=2).amax(dim=2).view(B, 1, hw)             # [B,1,HW]
+        Q = self._affine(self.query_conv, q).view(B, D, hw).transpose(1, 2)   # [B,HW,D]
+        K = self._affine(self.key_conv, kv).view(B, D, hw)
+        V = self._affine(self.value_conv, kv).view(B, D, hw)
+        att = torch.softmax(torch.bmm(Q, K), dim=-1) * conf                   # key-side re-weight, no renorm
+        out = torch.bmm(V, att.transpose(1, 2)).view(B, C, D, H, W)
+        return self.gamma * out + kv
+
+
+class CA3D(nn.Module):
+    """DVE channel recalibration (ATT:90-120)."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.conv1 = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), nn.GroupNorm(1, channel))
+        self.conv2 = nn.Sequential(nn.Conv3d(channel, channel // 8, 1), nn.GELU(),
+                                   nn.Conv3d(channel // 8, channel, 1), nn.GELU())
+        self.conv = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), nn.GroupNorm(1, channel))
+
+    def forward(self, x):
+        data = self.conv1(x)
+        pool = data.mean(dim=(2, 3, 4))
+        s = TF.gelu(TF.linear(pool, self.conv2[0].weight.flatten(1), self.conv2[0].bias))
+        s = TF.gelu(TF.linear(s, self.conv2[2].weight.flatten(1), self.conv2[2].bias))
+        return self.conv(torch.sigmoid(s)[..., None, None, None] * data)
+
+
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+        self.alpha = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return self.alpha * self.fn(x) + x
+
+
+class volume_interaction(nn.Module):
+    """Mutual Interactive Ensemble: BRI both ways + DVE (VT:236-268)."""
+
+    def __init__(self, out_channels=1):
+        super().__init__()
+        self.redir1 = Conv3d(2, 32, 3, 1, 1)
+        self.dres1 = hourglass(32)
+        self.redir2 = Conv3d(32, out_channels, 3, 1, 1)
+        self.lss2stereo = attention(in_dim=1)
+        self.stereo2lss = attention(in_dim=1)
+        self.CA3D = Residual(CA3D(32))
+
+    def forward(self, stereo_volume, lss_volume):
+        s, m = stereo_volume.unsqueeze(1), lss_volume.unsqueeze(1)
+        a = self.lss2stereo(q=s, kv=m)
+        b = self.stereo2lss(q=m, kv=s)
+        x = torch.relu(self.redir1(torch.cat((a, b), dim=1)))
+        x = self.CA3D(self.dres1(x))
+        x = torch.relu(self.redir2(x)).squeeze(1)
+        return torch.softmax(x, dim=1)
+
+
+# ------------------------------------------------------------------------------- the transformer
+def gen_dx_bx(xbound, ybound, zbound):
+    rows = (xbound, ybound, zbound)
+    dx = torch.tensor([r[2] for r in rows], dtype=torch.float64).float()
+    bx = torch.tensor([r[0] + r[2] / 2.0 for r in rows], dtype=torch.float64).float()
+    nx = torch.tensor([(r[1] - r[0]) / r[2] for r in rows], dtype=torch.float64).float()
+    return dx, bx, nx
+
+
+@NECKS.register_module()
+class ViewTransformerLiftSplatShootVoxel(nn.Module):
+    """Registry-compatible stand-in for the reference class of the same name (VT:273-526).
+
+    Extra kwarg ``warp_align_corners`` selects the grid_sample convention of ``warp`` (VT:151-154):
+    True = literal behaviour on torch >= 1.3, False = what torch 1.10.1 (README pin) executed.
+    """
+
+    def __init__(self, loss_depth_weight, semkitti=False, imgseg=False, imgseg_class=20, lift_with_imgseg=False,
+                 point_cloud_range=None, loss_seg_weight=1.0, loss_depth_type="bce", point_xyz_channel=0,
+                 point_xyz_mode="cat", cam_channels=27, loss_depth_reg_weight=0.0, use_voxel_net=False,
+                 grid_config=None, data_config=None, numC_input=512, numC_Trans=64, downsample=16,
+                 accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False,
+                 warp_align_corners=True, **kwargs):
+        super().__init__()
+        if imgseg or point_xyz_channel or use_voxel_net or vp_megvii:
+            raise NotImplementedError("options unused by projects/configs/.../stereoscene.py are not built")
+        self.grid_config, self.data_config = grid_config, data_config
+        dx, bx, nx = gen_dx_bx(grid_config["xbound"], grid_config["ybound"], grid_config["zbound"])
+        self.dx = nn.Parameter(dx, requires_grad=False)
+        self.bx = nn.Parameter(bx, requires_grad=False)
+        self.nx = nn.Parameter(nx, requires_grad=False)
+        self.downsample = downsample
+        self.frustum = self.create_frustum()
+        self.D = self.frustum.shape[0]
+        self.numC_input, self.numC_Trans, self.cam_channels = numC_input, numC_Trans, cam_channels
+        self.loss_depth_weight, self.loss_depth_type = loss_depth_weight, loss_depth_type
+        self.imgseg, self.semkitti = False, semkitti
+        self.depth_net = DepthNet(numC_input, numC_input, numC_Trans, self.D, cam_channels=cam_channels)
+        self.stereo_volume_net = GwcNet_volume_encoder(self.D, 32, warp_align_corners)
+        self.volume_interaction = volume_interaction()
+        self.cam_depth_range = grid_config["dbound"]
+
+    # geometry -------------------------------------------------------------------------------
+    def create_frustum(self):
+        H_img, W_img = self.data_config["input_size"]
+        fH, fW = H_img // self.downsample, W_img // self.downsample
+        ds = torch.arange(*self.grid_config["dbound"], dtype=torch.float)
+        fr = torch.empty(ds.shape[0], fH, fW, 3)
+        fr[..., 0] = torch.linspace(0, W_img - 1, fW, dtype=torch.float).view(1, 1, fW)
+        fr[..., 1] = torch.linspace(0, H_img - 1, fH, dtype=torch.float).view(1, fH, 1)
+        fr[..., 2] = ds.view(-1, 1, 1)
+        return nn.Parameter(fr, requires_grad=False)
+
+    def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
+        """Frustum -> ego frame (BD:123-156).  3x3 inverses are taken on the host in fp32."""
+        B, N, _ = trans.shape
+        inv = lambda m: torch.inverse(m.float().cpu()).to(m.device)   # noqa: E731 (tiny, latency-free on CPU)
+        pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
+        pts = inv(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
+        pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+        if intrins.shape[3] == 4:
+            pts = pts - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3, 1)
+            intrins = intrins[:, :, :3, :3]
+        combine = rots.matmul(inv(intrins))
+        pts = combine.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+        pts = pts + trans.view(B, N, 1, 1, 1, 3)
+        if bda.shape[-1] == 4:
+            ones = torch.ones(*pts.shape[:-1], 1, dtype=pts.dtype, device=pts.device)
+            pts = bda.view(B, 1, 1, 1, 1, 4, 4).matmul(torch.cat((pts, ones), -1).unsqueeze(-1)).squeeze(-1)[..., :3]
+        else:
+            pts = bda.view(B, 1, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1)).squeeze(-1)
+        return pts
+
+    def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
+        """30-vector of camera parameters for the SE gates (BD:604-659)."""
+        B, N = rot.shape[:2]
+        if bda is None:
+            bda = torch.eye(3).to(rot).view(1, 3, 3).repeat(B, 1, 1)
+        bda = bda.view(B, 1, *bda.shape[-2:]).repeat(1, N, 1, 1)
+        kitti = intrin.shape[-1] == 4
+        parts = [intrin[:, :, 0, 0], intrin[:, :, 1, 1], intrin[:, :, 0, 2], intrin[:, :, 1, 2]]
+        if kitti:
+            parts += [intrin[:, :, 0, 3], intrin[:, :, 1, 3], intrin[:, :, 2, 3]]
+        parts += [post_rot[:, :, 0, 0], post_rot[:, :, 0, 1], post_tran[:, :, 0],
+                  post_rot[:, :, 1, 0], post_rot[:, :, 1, 1], post_tran[:, :, 1],
+                  bda[:, :, 0, 0], bda[:, :, 0, 1], bda[:, :, 1, 0], bda[:, :, 1, 1], bda[:, :, 2, 2]]
+        v = torch.stack(parts, dim=-1)
+        if kitti and bda.shape[-1] == 4:
+            v = torch.cat((v, bda[:, :, :3, -1]), dim=2)
+        sensor2ego = torch.cat([rot, tran.reshape(B, N, 3, 1)], dim=-1).reshape(B, N, -1)
+        return torch.cat([v, sensor2ego], dim=-1)
+
+    def get_depth_dist(self, x):
+        return x.softmax(dim=1)
+
+    # splat ------------------------------------------------------------------------------------
+    def voxel_pooling(self, geom_feats, x):
+        """Reference-shaped entry (VT:432-476): x [B,N,D,H,W,C] materialised -> [B,C,X,Y,Z] via the
+        bev_pool drop-in.  ``forward`` uses the fused functional.lift_splat instead."""
+        B, N, D, H, W, C = x.shape
+        vox, idx3 = F.voxel_index(geom_feats, self.bx, self.dx, self.nx, return_idx=True)
+        kept = vox >= 0
+        bcol = torch.arange(B, device=x.device, dtype=torch.int32).repeat_interleave(N * D * H * W)[:, None]
+        coords = torch.cat((idx3, bcol), 1)[kept]
+        n = [int(v) for v in self.nx.tolist()]
+        final = F.bev_pool(x.reshape(-1, C)[kept], coords, B, n[2], n[0], n[1])
+        return final.permute(0, 1, 3, 4, 2)
+
+    # losses -----------------------------------------------------------------------------------
+    def get_downsampled_gt_depth(self, gt_depths):
+        B, N, H, W = gt_depths.shape
+        ds = self.downsample
+        g = gt_depths.view(B * N, H // ds, ds, W // ds, ds).permute(0, 1, 3, 2, 4).reshape(-1, ds * ds)
+        g = torch.where(g == 0.0, torch.full_like(g, 1e5), g).min(dim=-1).values
+        db = self.grid_config["dbound"]
+        g = (g - (db[0] - db[2] / 2)) / db[2]
+        vals = g.clone()
+        g = torch.where((g < self.D + 1) & (g >= 0.0), g, torch.zeros_like(g))
+        return vals, TF.one_hot(g.long(), num_classes=self.D + 1)[:, 1:].float()
+
+    def get_depth_loss(self, depth_labels, depth_preds):
+        """BCE depth loss (VT:375-388,405-416)."""
+        if self.loss_depth_type != "bce":
+            raise NotImplementedError(self.loss_depth_type)
+        _, labels = self.get_downsampled_gt_depth(depth_labels)
+        preds = depth_preds.float().permute(0, 2, 3, 1).reshape(-1, self.D)
+        fg = labels.max(dim=1).values > 0.0
+        loss = TF.binary_cross_entropy(preds[fg], labels[fg], reduction="none").sum() / torch.clamp(fg.sum(), min=1.0)
+        return self.loss_depth_weight * loss
+
+    # forward ----------------------------------------------------------------------------------
+    def forward(self, input):
+        x, rots, trans, intrins, post_rots, post_trans, bda, mlp_input = input[:8]
+        feature_right, mlp_input_right = input[8], input[15]
+        calib = input[16]
+        # geometry first: its tiny host-side 3x3 inverses must not stall the queued device work
+        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
+        stereo = self.stereo_volume_net(x.squeeze(1), feature_right.squeeze(1), mlp_input, mlp_input_right,
+                                        calib)["single_channel"]
+        B, N, C, H, W = x.shape
+        y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
+        depth_prob = self.get_depth_dist(y[:, :self.D])
+        img_feat = y[:, self.D:self.D + self.numC_Trans]
+        depth_prob = self.volume_interaction(stereo, depth_prob)
+        bev_feat = F.lift_splat(depth_prob, img_feat, geom, self.bx, self.dx, self.nx)
+        return bev_feat, depth_prob
