@@ -82,7 +82,7 @@ CFG_K192 = dict(name="kitti_d192", input_size=(384, 1280), downsample=8, occ_siz
                 pc_range=(0.0, -25.6, -2.0, 51.2, 25.6, 4.4), dbound=(2.0, 98.0, 0.5))
 CFG_S = dict(name="small_d48", input_size=(96, 320), downsample=8, occ_size=(64, 64, 16),
              pc_range=(0.0, -12.8, -2.0, 25.6, 12.8, 4.4), dbound=(2.0, 26.0, 0.5))
-CFG_T = dict(name="tiny_d16", input_size=(48, 160), downsample=8, occ_size=(32, 32, 8),
+CFG_T = dict(name="tiny_d16", input_size=(64, 160), downsample=8, occ_size=(32, 32, 8),
              pc_range=(0.0, -6.4, -2.0, 12.8, 6.4, 4.4), dbound=(2.0, 10.0, 0.5))
 CONFIGS = {c["name"]: c for c in (CFG_K112, CFG_K192, CFG_S, CFG_T)}
 
