@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Benchmark of the StereoScene hot path on MI355X: output voxels / second, forward + backward.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = forward of a1-a16 (stereo cost volume -> MIE -> lift/splat -> 3-D encoder/neck/head ->
+4 losses) + backward, on one seeded synthetic SemanticKITTI-shaped batch per GPU, inputs resident
+in HBM.  N > 1 shards the batch (B per GPU fixed = weak scaling) and adds the gradient all-reduce
+over RCCL/xGMI (flat buckets overlapped with backward).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+VOXELS_PER_SAMPLE = 256 * 256 * 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="kitti_d192", help="kitti_d192 (BASELINE metric) | kitti_d112 | small_d48")
+    ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
+    ap.add_argument("--cpu-sample", default="auto", choices=["auto", "small", "full", "none"])
+    ap.add_argument("--forward-only", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, cfg_full):
+    """The CPU oracle (torch fp32 restatement of the reference) timed on this box's host cores.
+    Baseline only.  'auto': time one fwd+bwd step of BASELINE configs[0] (64x64x16 grid, D=48); if the
+    full-size step is predicted to fit ~60 s, run one full-size step too and report that instead."""
+    if mode == "none":
+        return None
+    from oracle import path_ref as O
+    from stereoscene_amd import model_zoo, synthetic as S
+    torch.set_num_threads(os.cpu_count())
+
+    def one(cfg):
+        m = model_zoo.build_detector(cfg, device="cpu")       # parameter container only; never run on CPU
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and v.dim() > 0 and "running" not in k
+                  and not k.endswith(("frustum", ".dx", ".bx", ".nx")) else v) for k, v in m.state_dict().items()}
+        smp = S.synthetic_sample(cfg, B=1, tag="bench0")
+        oin = [smp["x_l"], *smp["geo_l"], O.get_mlp_input(*smp["geo_l"]), smp["x_r"], *smp["geo_r"],
+               O.get_mlp_input(*smp["geo_r"]), smp["calib"]]
+        D = int(round((cfg["dbound"][1] - cfg["dbound"][0]) / cfg["dbound"][2]))
+        ocfg = dict(D=D, numC_Trans=128, warp_align_corners=True, downsample=cfg["downsample"], dbound=cfg["dbound"])
+        t0 = time.perf_counter()
+        losses, _ = O.forward_train(sd, oin, smp["gt_depths"], smp["gt_occ"], ocfg, train=True)
+        sum(losses.values()).backward()
+        dt = time.perf_counter() - t0
+        vox = cfg["occ_size"][0] * cfg["occ_size"][1] * cfg["occ_size"][2]
+        return vox / dt, dt
+
+    v, dt = one(S.CFG_S)
+    sample = f"1 fwd+bwd step of configs[0] (64x64x16 grid, D=48, B=1) in {dt:.1f} s"
+    if mode == "full" or (mode == "auto" and dt * 30 < 60):
+        v, dt = one(cfg_full)
+        sample = f"1 fwd+bwd step of {cfg_full['name']} (256x256x32 grid, B=1) in {dt:.1f} s"
+    return {"value": v, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": sample,
+            "cpu": platform.processor() or platform.machine()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL on ROCm
+
+    from stereoscene_amd import functional as F, model_zoo, synthetic as S
+    from stereoscene_amd.dp import FlatGradAllReduce
+    cfg = S.CONFIGS[args.config]
+    torch.manual_seed(rank)
+    model = model_zoo.build_detector(cfg)          # deterministic fill-by-key weights, gamma = alpha = 0.5
+    model.train()
+    reducer = FlatGradAllReduce(model, bucket_mb=64) if not args.forward_only else None
+    smp = S.synthetic_sample(cfg, B=args.batch, tag=f"bench{rank}")
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    gt_occ = smp["gt_occ"].cuda()
+
+    def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return model.forward_train(img_inputs=inputs, gt_occ=gt_occ)
+        reducer.zero_grad()
+        losses = model.forward_train(img_inputs=inputs, gt_occ=gt_occ)
+        sum(v for k, v in losses.items() if k.startswith("loss")).backward()
+        reducer.finish()
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = F.KernelTimer()
+    F.KERNEL_TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    F.KERNEL_TIMER = None
+    tmax = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    ms = dt / args.steps * 1e3
+    scale = VOXELS_PER_SAMPLE if cfg["occ_size"] == (256, 256, 32) else cfg["occ_size"][0] * cfg["occ_size"][1] * cfg["occ_size"][2]
+    value = world * args.batch * scale / (dt / args.steps)
+
+    if rank == 0:
+        ks = timer.summary()
+        g = ks.get("conv_gather", dict(launches=0, flops=0.0, ms=1e-9))
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["launches"] else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_gather_kernel (v_mfma_f32_32x32x2_f32 implicit-GEMM conv/deconv fwd+dgrad)",
+                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": g["launches"] / max(args.steps, 1),
+                "gflop_per_step": g["flops"] / 1e9 / max(args.steps, 1),
+                "ms_per_step_in_kernel": g["ms"] / max(args.steps, 1),
+                "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+                                  for k, v in ks.items() if k != "conv_gather"}}
+        out = {"metric": "voxels/sec fwd+bwd, 256x256x32 grid D=192" if args.config == "kitti_d192" else
+               f"voxels/sec fwd+bwd ({args.config})",
+               "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": f"{args.config}: stereo pair features 2x[B,640,48,160] -> 256x256x32 occupancy, "
+                                      f"D={model.img_view_transformer.D}, fwd+bwd incl. 4 losses"
+                                      + (" (forward only)" if args.forward_only else ""),
+                          "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                          "parallelism": f"dp{world}", "train_mode": True},
+               "roofline": roof,
+               "losses": {k: float(v) for k, v in losses.items()}}
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample if world == 1 else "none", cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

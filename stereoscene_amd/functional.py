@@ -16,6 +16,68 @@ import torch
 from . import capi
 
 # -------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
+# -------------------------------------------------------------------------------------------------
+
+
+class KernelTimer:
+    """Collects (kernel family, algorithmic flops, start event, end event) per C-ABI launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def span(self, family, flops):
+        return _Span(self, family, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, a, b in self.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += a.elapsed_time(b)
+        return out
+
+
+class _Span:
+    def __init__(self, timer, family, flops):
+        self.t, self.family, self.flops = timer, family, flops
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()          # torch's current stream == the stream handed to the C ABI
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.records.append((self.family, self.flops, self.a, self.b))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+KERNEL_TIMER = None
+_NOSPAN = _NoSpan()
+
+
+def _span(family, flops):
+    return KERNEL_TIMER.span(family, flops) if KERNEL_TIMER is not None else _NOSPAN
+
+
+def conv_flops(d):
+    """Algorithmic flops (2*MAC) of one conv / deconv problem (any of fwd, dgrad, wgrad)."""
+    taps = d.kd * d.kh * d.kw
+    vox = d.B * (d.Di * d.Hi * d.Wi if d.transposed else d.Do * d.Ho * d.Wo)
+    return 2.0 * vox * d.Cin * d.Cout * taps
+
+
+# -------------------------------------------------------------------------------------------------
 # layout helpers
 # -------------------------------------------------------------------------------------------------
 
@@ -276,8 +338,9 @@ class _ConvNd(torch.autograd.Function):
         wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
-        capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
-                                      capi.stream()), "ssbev_conv_fwd")
+        with _span("conv_gather", conv_flops(d)):
+            capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
+                                          capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
         ctx.cfg = (stride, padding, dilation, transposed, output_padding, kpad, bias is not None)
         return from_cl(y)
@@ -301,16 +364,19 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _packed(w5, d, 1)
             gxcl = torch.empty_like(xcl)
-            capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
-                                               capi.stream()), "ssbev_conv_bwd_data")
+            with _span("conv_gather", conv_flops(d)):
+                capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
+                                                   capi.stream()), "ssbev_conv_bwd_data")
             if kpad:
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
             gwp = torch.empty(tuple(w5.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d),
-                                                 capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_conv_bwd_weight")
+            with _span("conv_wgrad", conv_flops(d)):
+                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d),
+                                                     capi.ptr(ws), ws.numel(), capi.stream()),
+                           "ssbev_conv_bwd_weight")
             ci = slice(0, weight.shape[0]), slice(0, weight.shape[1])
             gw = gwp[ci[0], ci[1]].contiguous() if (kpad or cpad) else gwp
         if has_bias and ctx.needs_input_grad[2]:
