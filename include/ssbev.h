@@ -143,6 +143,26 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d);
 int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_conv_dims* d,
                           void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm / BatchNorm(train) over channels-last volumes with fused residual add + ReLU.
+ * Replaces the ATen group_norm / batch_norm calls behind build_norm_layer (VT:31,45,69,83,86;
+ * ATT:96,111; resnet3d.py:42-45; second_fpn_3d.py:68; occhead.py:104).
+ *   x, y, residual [B, S, C] channels-last fp32; group g = channels [g*C/G, (g+1)*C/G)
+ *   y = relu?( (x - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c] + residual? )
+ *   stats_given = 1: mean/rstd are inputs (eval-mode BatchNorm), otherwise outputs.
+ * BatchNorm3d in training mode = the same call with G = C on the tensor viewed as [1, B*S, C].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; } ssbev_norm_dims;
+size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d);
+int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                        float* y, float* mean, float* rstd, const ssbev_norm_dims* d, void* ws,
+                        size_t ws_bytes, ssbev_stream_t stream);
+/* gx (and gresidual = relu-masked gy, may be NULL), ggamma[C], gbeta[C]; y only needed when relu=1 */
+int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma,
+                        const float* mean, const float* rstd, float* gx, float* gresidual,
+                        float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws,
+                        size_t ws_bytes, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,11 @@ class ConvDims(C.Structure):
         "pd", "ph", "pw", "dd", "dh", "dw", "transposed", "relu", "accumulate")]
 
 
+class NormDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("G", C.c_int), ("S", C.c_int64), ("eps", C.c_float),
+                ("relu", C.c_int), ("stats_given", C.c_int)]
+
+
 _P = C.c_void_p
 # name -> (restype, argtypes); this table is checked against include/ssbev.h by tests/test_capi_symbols.py
 SIGNATURES = {
@@ -62,6 +67,9 @@ SIGNATURES = {
     "ssbev_conv_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),
     "ssbev_conv_bwd_weight_workspace": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_bwd_weight": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),
+    "ssbev_groupnorm_fwd": (C.c_int, [_P] * 7 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -402,3 +402,73 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     s, p, dl = _triple(stride, 2), _triple(padding, 2), _triple(dilation, 2)
     y = _ConvNd.apply(x.unsqueeze(2), weight.unsqueeze(2), bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
     return y.squeeze(2)
+
+
+# -------------------------------------------------------------------------------------------------
+# normalisation
+# -------------------------------------------------------------------------------------------------
+
+
+class _GroupNorm(torch.autograd.Function):
+    """GroupNorm on a channels-last volume with optional fused residual add and ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd):
+        lib = capi.load()
+        xcl = to_cl(_f32(x, "group_norm"))
+        Cch = xcl.shape[-1]
+        B = 1 if as_batch else xcl.shape[0]
+        S = xcl.numel() // (B * Cch)
+        rcl = to_cl(residual) if residual is not None else None
+        given = given_mean is not None
+        d = capi.NormDims(B, Cch, groups, S, float(eps), int(relu), int(given))
+        y = torch.empty_like(xcl)
+        mean = given_mean.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
+        rstd = given_rstd.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
+                                           capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
+                                           capi.stream()), "ssbev_groupnorm_fwd")
+        ctx.save_for_backward(xcl, y if relu else None, w, mean, rstd)
+        ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given)
+        ctx.mark_non_differentiable(mean, rstd)
+        return from_cl(y), mean, rstd
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gr):
+        lib = capi.load()
+        xcl, y, w, mean, rstd = ctx.saved_tensors
+        B, S, Cch, groups, eps, relu, has_res, given = ctx.meta
+        if given:
+            raise capi.SsbevError("eval-mode (given statistics) normalisation has no HIP backward; use torch for it")
+        gcl = to_cl(gy)
+        d = capi.NormDims(B, Cch, groups, S, eps, relu, 0)
+        gx = torch.empty_like(xcl)
+        gres = torch.empty_like(xcl) if has_res else None
+        gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
+        gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
+        ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
+        capi.check(lib.ssbev_groupnorm_bwd(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
+                                           capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
+                                           C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                   "ssbev_groupnorm_bwd")
+        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None
+
+
+def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False):
+    """relu?(GroupNorm(x) + residual?) on a channels-last volume (any spatial rank)."""
+    return _GroupNorm.apply(x, weight, bias, residual, int(groups), eps, relu, False, None, None)[0]
+
+
+def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False):
+    """Training-mode BatchNorm (batch statistics): returns (y, mean[C], biased_var[C])."""
+    y, mean, rstd = _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None)
+    var = 1.0 / (rstd * rstd) - eps
+    return y, mean, var
+
+
+def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, residual=None, relu=False):
+    """Inference-mode BatchNorm with the running statistics (forward only on the HIP path)."""
+    rstd = torch.rsqrt(running_var + eps)
+    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, running_mean, rstd)[0]

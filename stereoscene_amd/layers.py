@@ -117,17 +117,78 @@ class DeformConv2dPack(nn.Module):
         return out.reshape(B, self.weight.shape[0], H, W)
 
 
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm parameters; forward = relu?(GN(x) + residual?) in ONE pass of the HIP kernel
+    (``fused_relu`` is switched on by ``fuse_relu_`` when the reference places nn.ReLU right after)."""
+    fused_relu = False
+
+    def forward(self, x, residual=None, relu=None):
+        relu = self.fused_relu if relu is None else relu
+        if x.dim() < 3 or self.num_channels % 4 != 0:       # the [B, 30] camera vector: a tiny ATen op
+            y = nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+            y = y if residual is None else y + residual
+            return torch.relu(y) if relu else y
+        return F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, residual, relu)
+
+
+class BatchNorm3d(nn.BatchNorm3d):
+    """nn.BatchNorm3d parameters/buffers; training mode = batch statistics from the two-stage HIP
+    reduction (+ momentum update of the running stats), eval mode = running statistics."""
+    fused_relu = False
+
+    def forward(self, x, residual=None, relu=None):
+        relu = self.fused_relu if relu is None else relu
+        if self.training:
+            y, mean, var = F.batch_norm_train(x, self.weight, self.bias, self.eps, residual, relu)
+            if self.track_running_stats:
+                with torch.no_grad():
+                    n = x.numel() // x.shape[1]
+                    m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
+                    self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    self.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                    self.num_batches_tracked += 1
+            return y
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            # eval-mode BN is a per-channel affine map; keep it differentiable with plain device ops
+            shape = (1, -1) + (1,) * (x.dim() - 2)
+            scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+            y = x * scale.view(shape) + (self.bias - self.running_mean * scale).view(shape)
+            y = y if residual is None else y + residual
+            return torch.relu(y) if relu else y
+        return F.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, residual,
+                                 relu)
+
+
+def _last_leaf(m):
+    while isinstance(m, nn.Sequential) and len(m) > 0:
+        m = m[len(m) - 1]
+    return m
+
+
+def fuse_relu_(module):
+    """Walk every nn.Sequential below ``module``: a ReLU that directly follows one of our norm layers
+    becomes part of that layer's kernel (the nn.ReLU slot is kept as nn.Identity, so Sequential
+    indices -- i.e. state-dict keys -- do not move)."""
+    for seq in [m for m in module.modules() if isinstance(m, nn.Sequential)]:
+        for i in range(1, len(seq)):
+            prev = _last_leaf(seq[i - 1])
+            if isinstance(seq[i], nn.ReLU) and isinstance(prev, (GroupNorm, BatchNorm3d)):
+                prev.fused_relu = True
+                seq[i] = nn.Identity()
+    return module
+
+
 # ------------------------------------------------------------------ mmcv.cnn-style builders
 def build_norm_layer(cfg, num_features, postfix=""):
     cfg = dict(cfg)
     t = cfg.pop("type")
     requires_grad = cfg.pop("requires_grad", True)
     if t == "GN":
-        name, layer = "gn", nn.GroupNorm(cfg["num_groups"], num_features, eps=cfg.get("eps", 1e-5))
+        name, layer = "gn", GroupNorm(cfg["num_groups"], num_features, eps=cfg.get("eps", 1e-5))
     elif t in ("BN", "BN2d"):
         name, layer = "bn", nn.BatchNorm2d(num_features)
     elif t == "BN3d":
-        name, layer = "bn", nn.BatchNorm3d(num_features)
+        name, layer = "bn", BatchNorm3d(num_features)
     else:
         raise KeyError(f"unsupported norm type {t}")
     for p in layer.parameters():

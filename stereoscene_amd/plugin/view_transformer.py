@@ -19,7 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from .. import functional as F
-from ..layers import Conv2d, Conv3d, ConvTranspose3d, build_conv_layer, build_norm_layer
+from ..layers import (BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
+                      fuse_relu_)
 from ..registry import NECKS
 
 GN2 = dict(type="GN", num_groups=2, requires_grad=True)
@@ -130,6 +131,7 @@ class DepthNet(nn.Module):
             build_conv_layer(dict(type="DCN", in_channels=mid_channels, out_channels=mid_channels, kernel_size=3,
                                   padding=1, groups=4, im2col_step=128)),
             Conv2d(mid_channels, depth_channels, 1))
+        fuse_relu_(self)
 
     def forward(self, x, mlp_input):
         cam = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
@@ -151,6 +153,7 @@ class stereofeature_net(nn.Module):
         self.depth_mlp = Mlp(cam_channels, mid_channels, mid_channels)
         self.depth_se = SELayer(mid_channels)
         self.depth_conv = nn.Sequential(Conv2d(mid_channels, depth_channels, 1, 1, 0))
+        fuse_relu_(self)
 
     def forward(self, x, mlp_input):
         cam = mlp_input.reshape(-1, mlp_input.shape[-1])
@@ -172,17 +175,19 @@ class hourglass(nn.Module):
         self.conv2 = nn.Sequential(convbn_3d(c * 2, c * 2, 3, 1, 1), nn.ReLU(inplace=True))
         self.conv3 = nn.Sequential(convbn_3d(c * 2, c * 4, 3, 2, 1), nn.ReLU(inplace=True))
         self.conv4 = nn.Sequential(convbn_3d(c * 4, c * 4, 3, 1, 1), nn.ReLU(inplace=True))
-        self.conv5 = nn.Sequential(ConvTranspose3d(c * 4, c * 2, 3, 2, 1, 1, bias=False), nn.BatchNorm3d(c * 2))
-        self.conv6 = nn.Sequential(ConvTranspose3d(c * 2, c, 3, 2, 1, 1, bias=False), nn.BatchNorm3d(c))
+        self.conv5 = nn.Sequential(ConvTranspose3d(c * 4, c * 2, 3, 2, 1, 1, bias=False), BatchNorm3d(c * 2))
+        self.conv6 = nn.Sequential(ConvTranspose3d(c * 2, c, 3, 2, 1, 1, bias=False), BatchNorm3d(c))
         self.redir1 = convbn_3d(c, c, 1, 1, 0)
         self.redir2 = convbn_3d(c * 2, c * 2, 1, 1, 0)
+        fuse_relu_(self)
 
     def forward(self, x):
         c1 = self.conv1(x)
         c2 = self.conv2(c1)
         c4 = self.conv4(self.conv3(c2))
-        c5 = torch.relu(self.conv5(c4) + self.redir2(c2))
-        return torch.relu(self.conv6(c5) + self.redir1(x))
+        # relu(BN(deconv) + GN(1x1 conv)): the add and the ReLU ride in the GN kernel's epilogue
+        c5 = self.redir2[1](self.redir2[0](c2), residual=self.conv5(c4), relu=True)
+        return self.redir1[1](self.redir1[0](x), residual=self.conv6(c5), relu=True)
 
 
 class GwcNet_volume_encoder(nn.Module):
@@ -202,6 +207,7 @@ class GwcNet_volume_encoder(nn.Module):
         self.dres4 = hourglass(32)
         self.classif3_1 = nn.Sequential(convbn_3d(32, out_c, 3, 1, 1), nn.ReLU(inplace=True))
         self.classif3_2 = nn.Sequential(Conv3d(out_c, 1, 3, 1, 1, bias=False))
+        fuse_relu_(self)
         for m in self.modules():                          # He-normal re-initialisation (VT:189-203)
             if isinstance(m, (Conv2d, Conv3d)):
                 n = math.prod(m.kernel_size) * m.out_channels
@@ -215,7 +221,8 @@ class GwcNet_volume_encoder(nn.Module):
                                    torch.cat([mlp_input_left, mlp_input_right], 0))
         volume = F.gwc_warp(fea[:B], fea[B:], calib, self.maxdisp, self.num_groups, self.warp_align_corners)
         cost0 = self.dres0(volume)
-        cost0 = self.dres1(cost0) + cost0
+        t = self.dres1[2][0](self.dres1[0](cost0))
+        cost0 = self.dres1[2][1](t, residual=cost0)            # dres1(cost0) + cost0, add fused into the GN pass
         out3 = self.dres4(self.dres3(self.dres2(cost0)))
         cost3_1 = self.classif3_1(out3)
         pred3 = torch.softmax(self.classif3_2(cost3_1).squeeze(1), dim=1)
@@ -257,10 +264,10 @@ class CA3D(nn.Module):
 
     def __init__(self, channel):
         super().__init__()
-        self.conv1 = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), nn.GroupNorm(1, channel))
+        self.conv1 = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), GroupNorm(1, channel))
         self.conv2 = nn.Sequential(nn.Conv3d(channel, channel // 8, 1), nn.GELU(),
                                    nn.Conv3d(channel // 8, channel, 1), nn.GELU())
-        self.conv = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), nn.GroupNorm(1, channel))
+        self.conv = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), GroupNorm(1, channel))
 
     def forward(self, x):
         data = self.conv1(x)

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..layers import Conv3d, build_conv_layer, build_norm_layer, build_upsample_layer
+from ..layers import Conv3d, build_conv_layer, build_norm_layer, build_upsample_layer, fuse_relu_
 from ..registry import BACKBONES, HEADS, NECKS
 from . import losses as L
 
@@ -25,10 +25,9 @@ class BasicBlock3d(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = torch.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.bn1(self.conv1(x), relu=True)
         res = x if self.downsample is None else self.downsample(x)
-        return torch.relu(out + res)
+        return self.bn2(self.conv2(out), residual=res, relu=True)      # relu(GN(conv2) + shortcut) in one pass
 
 
 @BACKBONES.register_module()
@@ -48,6 +47,7 @@ class CustomResNet3D(nn.Module):
         self.layers = nn.ModuleList()
         for i, c in enumerate(planes[:num_stage]):
             self.layers.append(self._make_layer(c, nblocks[i], block_strides[i], norm_cfg))
+        fuse_relu_(self)
         for m in self.modules():
             if isinstance(m, Conv3d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -90,6 +90,7 @@ class SECONDFPN3D(nn.Module):
                 up = build_conv_layer(conv_cfg, in_channels=cin, out_channels=cout, kernel_size=k, stride=k)
             blocks.append(nn.Sequential(up, build_norm_layer(norm_cfg, cout)[1], nn.ReLU(inplace=True)))
         self.deblocks = nn.ModuleList(blocks)
+        fuse_relu_(self)
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
@@ -121,6 +122,7 @@ class OccHead(nn.Module):
                 build_norm_layer(norm_cfg, mid)[1], nn.ReLU(inplace=True),
                 build_conv_layer(conv_cfg, in_channels=mid, out_channels=out_channel, kernel_size=1, stride=1,
                                  padding=0)))
+        fuse_relu_(self)
         self.class_names = L.KITTI_CLASS_NAMES
         assert out_channel == len(self.class_names)
         self.class_weights = L.semkitti_class_weights()

@@ -204,3 +204,48 @@ def test_conv2d_incl_dilation(Cin, Cout, k, p, dil, bias):
     got.backward(go.to(DEV))
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------ normalisation
+@pytest.mark.parametrize("B,C,G,sp", [(1, 32, 2, (6, 8, 10)), (2, 128, 32, (4, 4, 4)), (1, 192, 32, (3, 5, 7)),
+                                       (2, 32, 1, (4, 6, 6)), (1, 640, 2, (1, 12, 40)), (1, 512, 32, (2, 2, 1))])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_group_norm_fused_fwd_bwd(B, C, G, sp, relu, res):
+    x = S.hash_normal("gn/x", (B, C) + sp) * 1.5 + 0.3
+    w = 1 + S.hash_uniform("gn/w", (C,), -0.3, 0.3)
+    b = S.hash_uniform("gn/b", (C,), -0.2, 0.2)
+    r = S.hash_normal("gn/r", (B, C) + sp) if res else None
+    xs = [t.clone().requires_grad_(True) for t in (x, w, b)] + ([r.clone().requires_grad_(True)] if res else [])
+    want = TF.group_norm(xs[0], G, xs[1], xs[2], 1e-5)
+    if res:
+        want = want + xs[3]
+    if relu:
+        want = torch.relu(want)
+    gs = [t.to(DEV).requires_grad_(True) for t in (x, w, b)] + ([r.to(DEV).requires_grad_(True)] if res else [])
+    got = F.group_norm(gs[0], G, gs[1], gs[2], 1e-5, residual=gs[3] if res else None, relu=relu)
+    assert maxdiff(got, want) < 2e-5
+    go = S.hash_normal("gn/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    for a, c in zip(gs, xs):
+        assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())
+
+
+def test_batch_norm_train_and_eval():
+    x = S.hash_normal("bn/x", (2, 64, 4, 6, 8)) * 2 + 0.5
+    w = 1 + S.hash_uniform("bn/w", (64,), -0.3, 0.3)
+    b = S.hash_uniform("bn/b", (64,), -0.2, 0.2)
+    rm, rv = torch.zeros(64), torch.ones(64)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = TF.batch_norm(xc, rm, rv, wc, bc, True, 0.1, 1e-5)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    got, mean, var = F.batch_norm_train(xg, wg, bg, 1e-5)
+    assert maxdiff(got, want) < 2e-5
+    n = x.numel() // 64
+    assert maxdiff(0.1 * mean, rm) < 1e-5 and maxdiff(0.9 + 0.1 * var * n / (n - 1), rv) < 1e-5
+    go = S.hash_normal("bn/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    assert maxdiff(xg.grad, xc.grad) < 5e-5 and maxdiff(wg.grad, wc.grad) < 2e-4 and maxdiff(bg.grad, bc.grad) < 2e-4
+    ev = F.batch_norm_eval(x.to(DEV), w.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, relu=True)
+    assert maxdiff(ev, torch.relu(TF.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5))) < 2e-5
