@@ -98,47 +98,51 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
     kds = g.sd; khs = g.sh; kws = g.sw;
   }
-  for (int a = kd0; a < g.kd; a += kds)
-    for (int bq = kh0; bq < g.kh; bq += khs)
-      for (int c = kw0; c < g.kw; c += kws) {
-        const int tap = (a * g.kh + bq) * g.kw + c;
-        const float* ap[MT];
+  // one flat loop over the (wave-uniform) tap list
+  const int nkd = (g.kd - kd0 + kds - 1) / kds, nkh = (g.kh - kh0 + khs - 1) / khs, nkw = (g.kw - kw0 + kws - 1) / kws;
+  const int ntaps = (kd0 < g.kd && kh0 < g.kh && kw0 < g.kw) ? nkd * nkh * nkw : 0;
+  for (int ti = 0; ti < ntaps; ++ti) {
+    const int c = kw0 + (ti % nkw) * kws;
+    const int bq = kh0 + ((ti / nkw) % nkh) * khs;
+    const int a = kd0 + (ti / (nkw * nkh)) * kds;
+    const int tap = (a * g.kh + bq) * g.kw + c;
+    const float* ap[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          int id, ih, iw;
-          if (g.form == 0) {
-            id = od[mt] * g.sd - g.pd + a * g.dd;
-            ih = oh[mt] * g.sh - g.ph + bq * g.dh;
-            iw = ow[mt] * g.sw - g.pw + c * g.dw;
-          } else {  // exact divisions by construction of the class / tap walk (dil == 1 when s > 1)
-            id = od[mt] + (par_d + g.pd - a * g.dd) / g.sd;
-            ih = oh[mt] + (par_h + g.ph - bq * g.dh) / g.sh;
-            iw = ow[mt] + (par_w + g.pw - c * g.dw) / g.sw;
-          }
-          const bool ok = mok[mt] && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-          ap[mt] = ok ? x + ((((size_t)ob[mt] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.Cin + 4 * lk : nullptr;
-        }
-        const float* wt = wlane + (size_t)tap * w_tap_stride;
-        for (int q = 0; q < Q; ++q) {
-          float4 av[MT], bv[NT];
-          const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            av[mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            bv[nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[mt][nt] = mfma32(av[mt].x, bv[nt].x, acc[mt][nt]);
-              acc[mt][nt] = mfma32(av[mt].y, bv[nt].y, acc[mt][nt]);
-              acc[mt][nt] = mfma32(av[mt].z, bv[nt].z, acc[mt][nt]);
-              acc[mt][nt] = mfma32(av[mt].w, bv[nt].w, acc[mt][nt]);
-            }
-        }
+    for (int mt = 0; mt < MT; ++mt) {
+      int id, ih, iw;
+      if (g.form == 0) {
+        id = od[mt] * g.sd - g.pd + a * g.dd;
+        ih = oh[mt] * g.sh - g.ph + bq * g.dh;
+        iw = ow[mt] * g.sw - g.pw + c * g.dw;
+      } else {  // exact divisions by construction of the class / tap walk (dil == 1 when s > 1)
+        id = od[mt] + (par_d + g.pd - a * g.dd) / g.sd;
+        ih = oh[mt] + (par_h + g.ph - bq * g.dh) / g.sh;
+        iw = ow[mt] + (par_w + g.pw - c * g.dw) / g.sw;
       }
+      const bool ok = mok[mt] && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+      ap[mt] = ok ? x + ((((size_t)ob[mt] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.Cin + 4 * lk : nullptr;
+    }
+    const float* wt = wlane + (size_t)tap * w_tap_stride;
+    for (int q = 0; q < Q; ++q) {
+      float4 av[MT], bv[NT];
+      const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        av[mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bv[nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = mfma32(av[mt].x, bv[nt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma32(av[mt].y, bv[nt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma32(av[mt].z, bv[nt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma32(av[mt].w, bv[nt].w, acc[mt][nt]);
+        }
+    }
+  }
 
   // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lk, col = li ---------------------------
 #pragma unroll
@@ -213,68 +217,110 @@ struct WgradGeom {
   int nchunks;
 };
 
-template <int TW>
+// One wave: (32*MQ q-channels) x (32*MP p-channels) x (TH x TW taps of one kd slice), over one chunk of
+// voxels.  Every loaded P value feeds MQ*TH*TW MFMAs and every Q value MP of them; the voxel walk is an
+// incremental (w,h,d,b) counter (no integer division in the loop).
+template <int MQ, int MP, int TH, int TW>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Qt, float* __restrict__ ws, WgradGeom g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
-  // block -> (chunk, q-tile, p-tile, tap group); the 4 waves of a block take 4 consecutive chunks
   const int chunk_id = blockIdx.x * 4 + wave;
   if (chunk_id >= g.nchunks) return;
-  const int qt = blockIdx.y % ((g.Cq + 31) / 32), pt = blockIdx.y / ((g.Cq + 31) / 32);
-  const int kw_groups = (g.kw + TW - 1) / TW;
-  const int tg = blockIdx.z;
-  const int kwg = tg % kw_groups;
-  const int khi = (tg / kw_groups) % g.kh;
-  const int kdi = tg / (kw_groups * g.kh);
-  const int qc = qt * 32 + li, pc = pt * 32 + li;
-  const bool qok = qc < g.Cq, pok = pc < g.Cp;
+  const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
+  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
+  const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
+  int tg = blockIdx.z;
+  const int kwg = tg % kw_groups; tg /= kw_groups;
+  const int khg = tg % kh_groups;
+  const int kdi = tg / kh_groups;
 
-  f32x16 acc[TW];
+  f32x16 acc[MQ][MP][TH][TW];
 #pragma unroll
-  for (int t = 0; t < TW; ++t)
+  for (int a = 0; a < MQ; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int b = 0; b < MP; ++b)
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][c][t][r] = 0.0f;
 
-  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
-  const long m_begin = (long)chunk_id * g.chunk;
-  const long m_end = min(Mtot, m_begin + g.chunk);
-  for (long m2 = m_begin; m2 < m_end; m2 += 2) {
-    const long m = m2 + lk;           // this half-wave's voxel
+  const int Mtot = g.B * g.Ds * g.Hs * g.Ws;
+  const int m_begin = chunk_id * g.chunk;
+  const int m_end = min(Mtot, m_begin + g.chunk);
+  // this half-wave's voxel walks m_begin + lk, +2, +4, ...
+  int m = m_begin + lk;
+  int w, h, d, b;
+  {
+    int r = min(m, Mtot - 1);
+    w = r % g.Ws; r /= g.Ws;
+    h = r % g.Hs; r /= g.Hs;
+    d = r % g.Ds;
+    b = r / g.Ds;
+  }
+  int qoff[MQ], poff[MP];
+  bool qok[MQ], pok[MP];
+#pragma unroll
+  for (int a = 0; a < MQ; ++a) { qoff[a] = (qt * MQ + a) * 32 + li; qok[a] = qoff[a] < g.Cq; }
+#pragma unroll
+  for (int a = 0; a < MP; ++a) { poff[a] = (pt * MP + a) * 32 + li; pok[a] = poff[a] < g.Cp; }
+
+  for (; m < m_end + lk; m += 2) {      // both halves run the same trip count; the odd tail is masked
     const bool mok = m < m_end;
-    long r = mok ? m : 0;
-    const int w = (int)(r % g.Ws); r /= g.Ws;
-    const int h = (int)(r % g.Hs); r /= g.Hs;
-    const int d = (int)(r % g.Ds);
-    const int b = (int)(r / g.Ds);
-    const float pv = (mok && pok) ? P[(size_t)m * g.Cp + pc] : 0.0f;
-    const int id = d * g.sd - g.pd + kdi * g.dd;
-    const int ih = h * g.sh - g.ph + khi * g.dh;
-    const bool rowok = mok && qok && id >= 0 && id < g.Dq && ih >= 0 && ih < g.Hq;
-    const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
+    float pv[MP];
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-      const int kwi = kwg * TW + t;
-      const int iw = w * g.sw - g.pw + kwi * g.dw;
-      const bool ok = rowok && kwi < g.kw && iw >= 0 && iw < g.Wq;
-      const float qv = ok ? Qt[(rowbase + iw) * g.Cq + qc] : 0.0f;
-      acc[t] = mfma32(qv, pv, acc[t]);
+    for (int a = 0; a < MP; ++a) pv[a] = (mok && pok[a]) ? P[(size_t)m * g.Cp + poff[a]] : 0.0f;
+    const int id = d * g.sd - g.pd + kdi * g.dd;
+    const bool dok = mok && id >= 0 && id < g.Dq;
+    const int iw0 = w * g.sw - g.pw + (kwg * TW) * g.dw;
+#pragma unroll
+    for (int c = 0; c < TH; ++c) {
+      const int khi = khg * TH + c;
+      const int ih = h * g.sh - g.ph + khi * g.dh;
+      const bool rok = dok && khi < g.kh && ih >= 0 && ih < g.Hq;
+      const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const int iw = iw0 + t * g.dw;
+        const bool ok = rok && (kwg * TW + t) < g.kw && iw >= 0 && iw < g.Wq;
+        float qv[MQ];
+#pragma unroll
+        for (int a = 0; a < MQ; ++a) qv[a] = (ok && qok[a]) ? Qt[(rowbase + iw) * g.Cq + qoff[a]] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < MQ; ++a)
+#pragma unroll
+          for (int e = 0; e < MP; ++e) acc[a][e][c][t] = mfma32(qv[a], pv[e], acc[a][e][c][t]);
+      }
+    }
+    // advance the voxel counter by 2
+    w += 2;
+    while (w >= g.Ws) {
+      w -= g.Ws;
+      if (++h >= g.Hs) { h = 0; if (++d >= g.Ds) { d = 0; ++b; } }
     }
   }
-  // partial tile -> ws[chunk][tap][q-channel][p-channel]
+  // partial tiles -> ws[chunk][tap][q-channel][p-channel]
   const int taps = g.kd * g.kh * g.kw;
 #pragma unroll
-  for (int t = 0; t < TW; ++t) {
-    const int kwi = kwg * TW + t;
-    if (kwi >= g.kw) continue;
-    const int tap = (kdi * g.kh + khi) * g.kw + kwi;
-    float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+  for (int c = 0; c < TH; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row < g.Cq && pok) dst[(size_t)row * g.Cp + pc] = acc[t][r];
+    for (int t = 0; t < TW; ++t) {
+      const int khi = khg * TH + c, kwi = kwg * TW + t;
+      if (khi >= g.kh || kwi >= g.kw) continue;
+      const int tap = (kdi * g.kh + khi) * g.kw + kwi;
+      float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+#pragma unroll
+      for (int a = 0; a < MQ; ++a)
+#pragma unroll
+        for (int e = 0; e < MP; ++e)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (qt * MQ + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < g.Cq && pok[e]) dst[(size_t)row * g.Cp + poff[e]] = acc[a][e][c][t][r];
+          }
     }
-  }
 }
 
 // gw (torch layout) = sum over chunks, in chunk order (deterministic).
@@ -320,11 +366,73 @@ int launch_gather(const float* x, const float* wp, const float* bias, float* y, 
   return ssbev_launch_status();
 }
 
+long gather_blocks(const ConvGeom& g, int MT, int NT) {
+  long M = (long)g.B * g.Do * g.Ho * g.Wo;
+  long classes = 1;
+  if (g.form == 1) {
+    classes = (long)g.sd * g.sh * g.sw;
+    M = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  return ((M + 4 * MT * 32 - 1) / (4 * MT * 32)) * ((g.Cout + NT * 32 - 1) / (NT * 32)) * classes;
+}
+
+// Largest register tile that still gives the chip >= 2 workgroups per CU; small problems (e.g. the
+// 32x32x4 stage of the voxel encoder) fall back to smaller tiles so that all 256 CUs get work.
 int dispatch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
-  if (g.Cout <= 32) return launch_gather<4, 1>(x, wp, bias, y, g, st);
-  if (g.Cout <= 64) return launch_gather<2, 2>(x, wp, bias, y, g, st);
-  return launch_gather<2, 4>(x, wp, bias, y, g, st);
+  const long want = 512;
+  if (g.Cout <= 32) {
+    if (gather_blocks(g, 4, 1) >= want) return launch_gather<4, 1>(x, wp, bias, y, g, st);
+    if (gather_blocks(g, 2, 1) >= want) return launch_gather<2, 1>(x, wp, bias, y, g, st);
+    return launch_gather<1, 1>(x, wp, bias, y, g, st);
+  }
+  if (g.Cout > 64 && gather_blocks(g, 2, 4) >= want) return launch_gather<2, 4>(x, wp, bias, y, g, st);
+  if (gather_blocks(g, 2, 2) >= want) return launch_gather<2, 2>(x, wp, bias, y, g, st);
+  if (gather_blocks(g, 1, 2) >= want) return launch_gather<1, 2>(x, wp, bias, y, g, st);
+  return launch_gather<1, 1>(x, wp, bias, y, g, st);
+}
+
+// tile configuration of the weight-gradient kernel for a problem
+struct WgradCfg { int MQ, MP, TH, TW; };
+WgradCfg wgrad_cfg(int Cp, int Cq, int kh, int kw) {
+  if (kh * kw == 1) return {2, 2, 1, 1};
+  if (Cp > 32 && Cq > 32) return {2, 2, 1, 3};
+  if (Cp <= 32 && Cq <= 32) return {1, 1, 3, 3};
+  return {1, 1, 1, 3};
+}
+
+WgradGeom make_wgrad_geom(const ssbev_conv_dims* d) {
+  WgradGeom g;
+  g.B = d->B;
+  if (!d->transposed) {
+    g.Cp = d->Cout; g.Cq = d->Cin;
+    g.Ds = d->Do; g.Hs = d->Ho; g.Ws = d->Wo; g.Dq = d->Di; g.Hq = d->Hi; g.Wq = d->Wi;
+  } else {
+    g.Cp = d->Cin; g.Cq = d->Cout;
+    g.Ds = d->Di; g.Hs = d->Hi; g.Ws = d->Wi; g.Dq = d->Do; g.Hq = d->Ho; g.Wq = d->Wo;
+  }
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
+  const WgradCfg c = wgrad_cfg(g.Cp, g.Cq, g.kh, g.kw);
+  // aim for ~3000 wave-tasks in total, chunks of at least 256 voxels
+  const long tiles = (long)((g.Cp + 32 * c.MP - 1) / (32 * c.MP)) * ((g.Cq + 32 * c.MQ - 1) / (32 * c.MQ)) * g.kd *
+                     ((g.kh + c.TH - 1) / c.TH) * ((g.kw + c.TW - 1) / c.TW);
+  long want = 3072 / (tiles > 0 ? tiles : 1);
+  if (want < 1) want = 1;
+  long chunk = (Mtot + want - 1) / want;
+  if (chunk < 256) chunk = 256;
+  chunk = (chunk + 1) & ~1L;
+  g.chunk = (int)chunk;
+  g.nchunks = (int)((Mtot + chunk - 1) / chunk);
+  return g;
+}
+
+template <int MQ, int MP, int TH, int TW>
+void launch_wgrad(const float* P, const float* Qt, float* ws, const WgradGeom& g, hipStream_t st) {
+  const int ytiles = ((g.Cq + 32 * MQ - 1) / (32 * MQ)) * ((g.Cp + 32 * MP - 1) / (32 * MP));
+  dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * ((g.kh + TH - 1) / TH) * ((g.kw + TW - 1) / TW));
+  hipLaunchKernelGGL((wgrad_kernel<MQ, MP, TH, TW>), grid, dim3(256), 0, st, P, Qt, ws, g);
 }
 
 }  // namespace
@@ -383,31 +491,6 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }
 
-static WgradGeom make_wgrad_geom(const ssbev_conv_dims* d) {
-  WgradGeom g;
-  g.B = d->B;
-  if (!d->transposed) {
-    g.Cp = d->Cout; g.Cq = d->Cin;
-    g.Ds = d->Do; g.Hs = d->Ho; g.Ws = d->Wo; g.Dq = d->Di; g.Hq = d->Hi; g.Wq = d->Wi;
-  } else {
-    g.Cp = d->Cin; g.Cq = d->Cout;
-    g.Ds = d->Di; g.Hs = d->Hi; g.Ws = d->Wi; g.Dq = d->Do; g.Hq = d->Ho; g.Wq = d->Wo;
-  }
-  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
-  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
-  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
-  // aim for ~2048 wave-tasks in total, chunks of at least 512 voxels
-  const long tiles = (long)((g.Cp + 31) / 32) * ((g.Cq + 31) / 32) * g.kd * g.kh * ((g.kw + 2) / 3);
-  long want = 4096 / (tiles > 0 ? tiles : 1);
-  if (want < 1) want = 1;
-  long chunk = (Mtot + want - 1) / want;
-  if (chunk < 512) chunk = 512;
-  chunk = (chunk + 1) & ~1L;
-  g.chunk = (int)chunk;
-  g.nchunks = (int)((Mtot + chunk - 1) / chunk);
-  return g;
-}
-
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
   const WgradGeom g = make_wgrad_geom(d);
@@ -423,14 +506,13 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
   const float* Qt = d->transposed ? gy : x;
   hipStream_t st = as_stream(stream);
   const int taps = g.kd * g.kh * g.kw;
-  const int ytiles = ((g.Cq + 31) / 32) * ((g.Cp + 31) / 32);
-  if (g.kw >= 3) {
-    dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * g.kh * ((g.kw + 2) / 3));
-    hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, P, Qt, static_cast<float*>(ws), g);
-  } else {
-    dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * g.kh * g.kw);
-    hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, P, Qt, static_cast<float*>(ws), g);
-  }
+  if ((long)g.B * g.Ds * g.Hs * g.Ws >= (1L << 31)) return SSBEV_EINVAL;
+  const WgradCfg c = wgrad_cfg(g.Cp, g.Cq, g.kh, g.kw);
+  float* wsf = static_cast<float*>(ws);
+  if (c.TH == 1 && c.TW == 1) launch_wgrad<2, 2, 1, 1>(P, Qt, wsf, g, st);
+  else if (c.MQ == 2) launch_wgrad<2, 2, 1, 3>(P, Qt, wsf, g, st);
+  else if (c.TH == 3) launch_wgrad<1, 1, 3, 3>(P, Qt, wsf, g, st);
+  else launch_wgrad<1, 1, 1, 3>(P, Qt, wsf, g, st);
   const long total = (long)taps * g.Cq * g.Cp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
                      g.nchunks, taps, g.Cq, g.Cp, total);
