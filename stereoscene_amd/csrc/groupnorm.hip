@@ -137,35 +137,20 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
   }
 }
 
-// backward finalize: per channel dgamma/dbeta (summed over samples and chunks); per (b, group)
-// ds = sum_c gamma_c * A1_c, db = sum_c gamma_c * A0_c  -> coef[b][g] = (ds, db)
+// backward finalize, part 1: one block per (b, group):
+//   ds = sum_c gamma_c * A1_c, db = sum_c gamma_c * A0_c  ->  coef[b][g] = (ds/n, db/n)
 __global__ void gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef, GnGeom g) {
-  // one block per (b, group); dgamma/dbeta accumulated by block b == 0 over all samples
   __shared__ double r0[NT], r1[NT];
   const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
   const int cpg = g.C / g.G;
   double ds = 0.0, db = 0.0;
-  for (int cc = threadIdx.x; cc < cpg; cc += NT) {
-    const int c = grp * cpg + cc;
-    double a0 = 0.0, a1 = 0.0;
-    for (int chunk = 0; chunk < g.chunks; ++chunk) {
-      const float* p = partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2;
-      a0 += p[0]; a1 += p[1];
-    }
-    ds += (double)gamma[c] * a1;
-    db += (double)gamma[c] * a0;
-    if (b == 0) {   // channel totals over all samples
-      double t0 = a0, t1 = a1;
-      for (int bb = 1; bb < g.B; ++bb)
-        for (int chunk = 0; chunk < g.chunks; ++chunk) {
-          const float* p = partial + ((size_t)(bb * g.chunks + chunk) * g.C + c) * 2;
-          t0 += p[0]; t1 += p[1];
-        }
-      dbeta[c] = (float)t0;
-      dgamma[c] = (float)t1;
-    }
+  for (int i = threadIdx.x; i < g.chunks * cpg; i += NT) {
+    const int chunk = i / cpg, c = grp * cpg + i % cpg;
+    const float* p = partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2;
+    const double gm = gamma[c];
+    db += gm * p[0];
+    ds += gm * p[1];
   }
   r0[threadIdx.x] = ds; r1[threadIdx.x] = db;
   __syncthreads();
@@ -178,6 +163,25 @@ __global__ void gn_finalize_bwd_kernel(const float* __restrict__ partial, const 
     coef[blockIdx.x * 2 + 0] = (float)(r0[0] / n);
     coef[blockIdx.x * 2 + 1] = (float)(r1[0] / n);
   }
+}
+
+// part 2: one block per channel: dbeta[c] = sum g, dgamma[c] = sum g * xhat over samples and chunks
+__global__ void gn_channel_grads_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, GnGeom g) {
+  __shared__ double r0[NT], r1[NT];
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = threadIdx.x; i < g.B * g.chunks; i += NT) {
+    const float* p = partial + ((size_t)i * g.C + c) * 2;
+    a0 += p[0]; a1 += p[1];
+  }
+  r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
+  __syncthreads();
+  for (int off = NT / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { r0[threadIdx.x] += r0[threadIdx.x + off]; r1[threadIdx.x] += r1[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { dbeta[c] = (float)r0[0]; dgamma[c] = (float)r1[0]; }
 }
 
 // gx = (gamma * g - xhat * ds/n - db/n) * rstd ;  gres = g  (g = gy masked by the fused ReLU)
@@ -280,7 +284,8 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
-  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G), dim3(NT), 0, st, partial, gamma, ggamma, gbeta, coef, g);
+  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G), dim3(NT), 0, st, partial, gamma, coef, g);
+  hipLaunchKernelGGL(gn_channel_grads_kernel, dim3(g.C), dim3(NT), 0, st, partial, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
