@@ -390,24 +390,30 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         fr[..., 2] = ds.view(-1, 1, 1)
         return nn.Parameter(fr, requires_grad=False)
 
+    @staticmethod
+    def _apply3x3(m, p):
+        """(m @ p) for m [B,N,3,3] (or [B,1,3,3]) and points p [B,N,D,H,W,3] as three broadcast
+        multiply-adds: a batched 3x3 BLAS call over 1.5 M points costs ~19 ms, this costs ~0.1 ms."""
+        m = m.unsqueeze(2).unsqueeze(2).unsqueeze(2)                      # [B,N,1,1,1,3,3]
+        x, y, z = p[..., 0:1], p[..., 1:2], p[..., 2:3]
+        return m[..., 0] * x + m[..., 1] * y + m[..., 2] * z
+
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
         """Frustum -> ego frame (BD:123-156).  3x3 inverses are taken on the host in fp32."""
         B, N, _ = trans.shape
         inv = lambda m: torch.inverse(m.float().cpu()).to(m.device)   # noqa: E731 (tiny, latency-free on CPU)
         pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
-        pts = inv(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
-        pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+        pts = self._apply3x3(inv(post_rots), pts)
+        pts = torch.cat((pts[..., :2] * pts[..., 2:3], pts[..., 2:3]), -1)
         if intrins.shape[3] == 4:
-            pts = pts - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3, 1)
+            pts = pts - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3)
             intrins = intrins[:, :, :3, :3]
-        combine = rots.matmul(inv(intrins))
-        pts = combine.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+        pts = self._apply3x3(rots.matmul(inv(intrins)), pts)
         pts = pts + trans.view(B, N, 1, 1, 1, 3)
         if bda.shape[-1] == 4:
-            ones = torch.ones(*pts.shape[:-1], 1, dtype=pts.dtype, device=pts.device)
-            pts = bda.view(B, 1, 1, 1, 1, 4, 4).matmul(torch.cat((pts, ones), -1).unsqueeze(-1)).squeeze(-1)[..., :3]
+            pts = self._apply3x3(bda[:, None, :3, :3], pts) + bda[:, :3, 3].view(B, 1, 1, 1, 1, 3)
         else:
-            pts = bda.view(B, 1, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1)).squeeze(-1)
+            pts = self._apply3x3(bda[:, None], pts)
         return pts
 
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
