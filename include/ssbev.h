@@ -126,6 +126,7 @@ typedef struct {
   int transposed;
   int relu;            /* fused epilogue: y = max(y,0) after bias                        */
   int accumulate;      /* y += result (used for residual / split accumulations)          */
+  int tile_hint;       /* 0 = library heuristic; MT*100+NT*10+QU forces a register tiling  */
 } ssbev_conv_dims;
 
 /* weight packing: src is the torch layout  conv: [Cout,Cin,kd,kh,kw]  deconv: [Cin,Cout,kd,kh,kw]

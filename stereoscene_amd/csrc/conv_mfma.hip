@@ -35,14 +35,17 @@ struct ConvGeom {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int form;                            // 0 conv gather, 1 deconv gather
   int relu, accumulate;
+  int hint;                            // 0 or MT*100+NT*10+QU
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// One wave computes an (MT*32 voxels) x (NT*32 channels) tile.
-template <int MT, int NT>
+// One wave computes an (MT*32 voxels) x (NT*32 channels) tile.  QU consecutive 8-channel k-steps are
+// unrolled as straight-line code so that all their operand loads are in flight before the first MFMA
+// of the group issues (the compiler then places counted vmcnt waits between the MFMA clusters).
+template <int MT, int NT, int QU>
 __global__ void __launch_bounds__(256)
 conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                    float* __restrict__ y, ConvGeom g) {
@@ -123,24 +126,30 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
       ap[mt] = ok ? x + ((((size_t)ob[mt] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.Cin + 4 * lk : nullptr;
     }
     const float* wt = wlane + (size_t)tap * w_tap_stride;
-    for (int q = 0; q < Q; ++q) {
-      float4 av[MT], bv[NT];
-      const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
+    for (int q0 = 0; q0 < Q; q0 += QU) {
+      float4 av[QU][MT], bv[QU][NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        av[mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
+      for (int u = 0; u < QU; ++u) {
+        const int q = q0 + u;
+        const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        bv[nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+        for (int mt = 0; mt < MT; ++mt)
+          av[u][mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NT; ++nt)
+          bv[u][nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+      }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[mt][nt] = mfma32(av[mt].x, bv[nt].x, acc[mt][nt]);
-          acc[mt][nt] = mfma32(av[mt].y, bv[nt].y, acc[mt][nt]);
-          acc[mt][nt] = mfma32(av[mt].z, bv[nt].z, acc[mt][nt]);
-          acc[mt][nt] = mfma32(av[mt].w, bv[nt].w, acc[mt][nt]);
-        }
+      for (int u = 0; u < QU; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = mfma32(av[u][mt].x, bv[u][nt].x, acc[mt][nt]);
+            acc[mt][nt] = mfma32(av[u][mt].y, bv[u][nt].y, acc[mt][nt]);
+            acc[mt][nt] = mfma32(av[u][mt].z, bv[u][nt].z, acc[mt][nt]);
+            acc[mt][nt] = mfma32(av[u][mt].w, bv[u][nt].w, acc[mt][nt]);
+          }
     }
   }
 
@@ -267,39 +276,50 @@ wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Qt, float* _
 #pragma unroll
   for (int a = 0; a < MP; ++a) { poff[a] = (pt * MP + a) * 32 + li; pok[a] = poff[a] < g.Cp; }
 
-  for (; m < m_end + lk; m += 2) {      // both halves run the same trip count; the odd tail is masked
-    const bool mok = m < m_end;
-    float pv[MP];
+  // U voxel pairs per trip: all (MP + MQ*TH*TW) * U operand loads are issued before the MFMA cluster
+  constexpr int U = (MQ * MP * TH * TW >= 9) ? 2 : 4;
+  for (; m < m_end + lk; m += 2 * U) {   // both halves run the same trip count; tails are masked
+    float pv[U][MP], qv[U][TH][TW][MQ];
 #pragma unroll
-    for (int a = 0; a < MP; ++a) pv[a] = (mok && pok[a]) ? P[(size_t)m * g.Cp + poff[a]] : 0.0f;
-    const int id = d * g.sd - g.pd + kdi * g.dd;
-    const bool dok = mok && id >= 0 && id < g.Dq;
-    const int iw0 = w * g.sw - g.pw + (kwg * TW) * g.dw;
+    for (int u = 0; u < U; ++u) {
+      const int mu = m + 2 * u;
+      const bool mok = mu < m_end;
 #pragma unroll
-    for (int c = 0; c < TH; ++c) {
-      const int khi = khg * TH + c;
-      const int ih = h * g.sh - g.ph + khi * g.dh;
-      const bool rok = dok && khi < g.kh && ih >= 0 && ih < g.Hq;
-      const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
+      for (int a = 0; a < MP; ++a) pv[u][a] = (mok && pok[a]) ? P[(size_t)mu * g.Cp + poff[a]] : 0.0f;
+      const int id = d * g.sd - g.pd + kdi * g.dd;
+      const bool dok = mok && id >= 0 && id < g.Dq;
+      const int iw0 = w * g.sw - g.pw + (kwg * TW) * g.dw;
 #pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const int iw = iw0 + t * g.dw;
-        const bool ok = rok && (kwg * TW + t) < g.kw && iw >= 0 && iw < g.Wq;
-        float qv[MQ];
+      for (int c = 0; c < TH; ++c) {
+        const int khi = khg * TH + c;
+        const int ih = h * g.sh - g.ph + khi * g.dh;
+        const bool rok = dok && khi < g.kh && ih >= 0 && ih < g.Hq;
+        const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
 #pragma unroll
-        for (int a = 0; a < MQ; ++a) qv[a] = (ok && qok[a]) ? Qt[(rowbase + iw) * g.Cq + qoff[a]] : 0.0f;
+        for (int t = 0; t < TW; ++t) {
+          const int iw = iw0 + t * g.dw;
+          const bool ok = rok && (kwg * TW + t) < g.kw && iw >= 0 && iw < g.Wq;
 #pragma unroll
-        for (int a = 0; a < MQ; ++a)
-#pragma unroll
-          for (int e = 0; e < MP; ++e) acc[a][e][c][t] = mfma32(qv[a], pv[e], acc[a][e][c][t]);
+          for (int a = 0; a < MQ; ++a) qv[u][c][t][a] = (ok && qok[a]) ? Qt[(rowbase + iw) * g.Cq + qoff[a]] : 0.0f;
+        }
+      }
+      // advance the voxel counter by 2
+      w += 2;
+      while (w >= g.Ws) {
+        w -= g.Ws;
+        if (++h >= g.Hs) { h = 0; if (++d >= g.Ds) { d = 0; ++b; } }
       }
     }
-    // advance the voxel counter by 2
-    w += 2;
-    while (w >= g.Ws) {
-      w -= g.Ws;
-      if (++h >= g.Hs) { h = 0; if (++d >= g.Ds) { d = 0; ++b; } }
-    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int a = 0; a < MQ; ++a)
+#pragma unroll
+            for (int e = 0; e < MP; ++e) acc[a][e][c][t] = mfma32(qv[u][c][t][a], pv[u][e], acc[a][e][c][t]);
   }
   // partial tiles -> ws[chunk][tap][q-channel][p-channel]
   const int taps = g.kd * g.kh * g.kw;
@@ -353,7 +373,7 @@ bool conv_dims_ok(const ssbev_conv_dims* d) {
 int pad8(int c) { return (c + 7) & ~7; }
 int pad32(int c) { return (c + 31) & ~31; }
 
-template <int MT, int NT>
+template <int MT, int NT, int QU>
 int launch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
   int classes = 1;
@@ -362,8 +382,32 @@ int launch_gather(const float* x, const float* wp, const float* bias, float* y, 
     Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
   }
   dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
-  hipLaunchKernelGGL((conv_gather_kernel<MT, NT>), grid, block, 0, st, x, wp, bias, y, g);
+  if ((g.CinPad >> 3) % QU == 0)
+    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, QU>), grid, block, 0, st, x, wp, bias, y, g);
+  else
+    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 1>), grid, block, 0, st, x, wp, bias, y, g);
   return ssbev_launch_status();
+}
+
+template <int MT, int NT>
+int launch_gather_qu(int qu, const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g,
+                     hipStream_t st) {
+  if (qu == 4) return launch_gather<MT, NT, 4>(x, wp, bias, y, g, st);
+  if (qu == 2) return launch_gather<MT, NT, 2>(x, wp, bias, y, g, st);
+  return launch_gather<MT, NT, 1>(x, wp, bias, y, g, st);
+}
+
+int launch_gather_cfg(int mt, int nt, int qu, const float* x, const float* wp, const float* bias, float* y,
+                      const ConvGeom& g, hipStream_t st) {
+  switch (mt * 10 + nt) {
+    case 41: return launch_gather_qu<4, 1>(qu, x, wp, bias, y, g, st);
+    case 21: return launch_gather_qu<2, 1>(qu, x, wp, bias, y, g, st);
+    case 11: return launch_gather_qu<1, 1>(qu, x, wp, bias, y, g, st);
+    case 24: return launch_gather_qu<2, 4>(qu, x, wp, bias, y, g, st);
+    case 22: return launch_gather_qu<2, 2>(qu, x, wp, bias, y, g, st);
+    case 12: return launch_gather_qu<1, 2>(qu, x, wp, bias, y, g, st);
+    default: return SSBEV_EINVAL;
+  }
 }
 
 long gather_blocks(const ConvGeom& g, int MT, int NT) {
@@ -380,16 +424,17 @@ long gather_blocks(const ConvGeom& g, int MT, int NT) {
 // 32x32x4 stage of the voxel encoder) fall back to smaller tiles so that all 256 CUs get work.
 int dispatch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
+  if (g.hint) return launch_gather_cfg(g.hint / 100, (g.hint / 10) % 10, g.hint % 10, x, wp, bias, y, g, st);
   const long want = 512;
   if (g.Cout <= 32) {
-    if (gather_blocks(g, 4, 1) >= want) return launch_gather<4, 1>(x, wp, bias, y, g, st);
-    if (gather_blocks(g, 2, 1) >= want) return launch_gather<2, 1>(x, wp, bias, y, g, st);
-    return launch_gather<1, 1>(x, wp, bias, y, g, st);
+    if (gather_blocks(g, 4, 1) >= want) return launch_gather_cfg(4, 1, 4, x, wp, bias, y, g, st);
+    if (gather_blocks(g, 2, 1) >= want) return launch_gather_cfg(2, 1, 4, x, wp, bias, y, g, st);
+    return launch_gather_cfg(1, 1, 4, x, wp, bias, y, g, st);
   }
-  if (g.Cout > 64 && gather_blocks(g, 2, 4) >= want) return launch_gather<2, 4>(x, wp, bias, y, g, st);
-  if (gather_blocks(g, 2, 2) >= want) return launch_gather<2, 2>(x, wp, bias, y, g, st);
-  if (gather_blocks(g, 1, 2) >= want) return launch_gather<1, 2>(x, wp, bias, y, g, st);
-  return launch_gather<1, 1>(x, wp, bias, y, g, st);
+  if (g.Cout > 64 && gather_blocks(g, 2, 4) >= want) return launch_gather_cfg(2, 4, 1, x, wp, bias, y, g, st);
+  if (gather_blocks(g, 2, 2) >= want) return launch_gather_cfg(2, 2, 1, x, wp, bias, y, g, st);
+  if (gather_blocks(g, 1, 2) >= want) return launch_gather_cfg(1, 2, 1, x, wp, bias, y, g, st);
+  return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);
 }
 
 // tile configuration of the weight-gradient kernel for a problem
@@ -473,7 +518,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo;
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
-  g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate;
+  g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate; g.hint = d->tile_hint;
   return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
 }
 
@@ -486,7 +531,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
-  g.relu = 0; g.accumulate = d->accumulate;
+  g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint;
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }

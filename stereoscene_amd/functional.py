@@ -296,6 +296,9 @@ def _triple(v, n):
     return v if len(v) == n else (v[0],) * n
 
 
+TILE_HINT = 0   # tuning hook (tools/probe_conv.py): forwarded to ssbev_conv_dims.tile_hint
+
+
 def _conv_dims(xshape_cl, wshape, stride, padding, dilation, transposed, output_padding, relu=0, accumulate=0):
     """xshape_cl = (B, Di, Hi, Wi, Cin); weights in the torch layout."""
     B, Di, Hi, Wi, Cin = xshape_cl
@@ -309,7 +312,7 @@ def _conv_dims(xshape_cl, wshape, stride, padding, dilation, transposed, output_
         outs = [(i + 2 * p - dl * (k - 1) - 1) // s + 1
                 for i, s, p, dl, k in zip((Di, Hi, Wi), stride, padding, dilation, (kd, kh, kw))]
     d = capi.ConvDims(B, Cin, Cout, Di, Hi, Wi, outs[0], outs[1], outs[2], kd, kh, kw, *stride, *padding, *dilation,
-                      int(transposed), int(relu), int(accumulate))
+                      int(transposed), int(relu), int(accumulate), int(TILE_HINT))
     return d
 
 
