@@ -420,21 +420,23 @@ long gather_blocks(const ConvGeom& g, int MT, int NT) {
   return ((M + 4 * MT * 32 - 1) / (4 * MT * 32)) * ((g.Cout + NT * 32 - 1) / (NT * 32)) * classes;
 }
 
-// Largest register tile that still gives the chip >= 2 workgroups per CU; small problems (e.g. the
-// 32x32x4 stage of the voxel encoder) fall back to smaller tiles so that all 256 CUs get work.
+// Register-tiling heuristic, fitted to a sweep of all (MT, NT, QU) variants over the hot-path layer
+// shapes on MI355X (tools/sweep_tiles.py, profiles/r1_tile_sweep.txt):
+//   * NT: 4 when Cout is a multiple of 128 and the grid still fills the chip, else 2 (Cout > 32), else 1;
+//   * MT: 2 unless that leaves fewer than ~160 workgroups;
+//   * QU (k-steps whose operand loads are issued together): deep prefetch (4) for wide tiles and for
+//     small grids (latency-bound), 1-2 when many waves per SIMD already hide the latency.
 int dispatch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   if (g.hint) return launch_gather_cfg(g.hint / 100, (g.hint / 10) % 10, g.hint % 10, x, wp, bias, y, g, st);
-  const long want = 512;
-  if (g.Cout <= 32) {
-    if (gather_blocks(g, 4, 1) >= want) return launch_gather_cfg(4, 1, 4, x, wp, bias, y, g, st);
-    if (gather_blocks(g, 2, 1) >= want) return launch_gather_cfg(2, 1, 4, x, wp, bias, y, g, st);
-    return launch_gather_cfg(1, 1, 4, x, wp, bias, y, g, st);
-  }
-  if (g.Cout > 64 && gather_blocks(g, 2, 4) >= want) return launch_gather_cfg(2, 4, 1, x, wp, bias, y, g, st);
-  if (gather_blocks(g, 2, 2) >= want) return launch_gather_cfg(2, 2, 1, x, wp, bias, y, g, st);
-  if (gather_blocks(g, 1, 2) >= want) return launch_gather_cfg(1, 2, 1, x, wp, bias, y, g, st);
-  return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);
+  const long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  if (Mtot <= 8192 && (long)g.kd * g.kh * g.kw * g.Cin <= 8192 && g.Cout > 64)   // 48x160 feature maps: many small tiles
+    return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);
+  int nt = (g.Cout % 128 == 0) ? 4 : (g.Cout > 32 ? 2 : 1);
+  if (nt == 4 && gather_blocks(g, 2, 4) < 256) nt = 2;
+  const int mt = gather_blocks(g, 2, nt) >= 160 ? 2 : 1;
+  const int qu = gather_blocks(g, mt, nt) < 512 ? 4 : (nt == 4 ? 4 : (nt == 2 ? 1 : 2));
+  return launch_gather_cfg(mt, nt, qu, x, wp, bias, y, g, st);
 }
 
 // tile configuration of the weight-gradient kernel for a problem

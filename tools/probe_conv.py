@@ -50,8 +50,16 @@ def main():
             x.grad = None; w.grad = None
             f().backward(go)
         t_fb = timeit(fb, 3)
+        xd = x.detach()
+        fw = (lambda: F.conv_transpose3d(xd, w, None, s, p, op)) if tr else (lambda: F.conv3d(xd, w, None, s, p))
+
+        def wg():
+            w.grad = None
+            fw().backward(go)
+        t_w = timeit(wg, 3) - t_f
         row = dict(layer=name, gflop=flops / 1e9, fwd_ms=t_f * 1e3, fwd_tflops=flops / t_f / 1e12,
-                   fwdbwd_ms=t_fb * 1e3, fwdbwd_tflops=3 * flops / t_fb / 1e12)
+                   fwdbwd_ms=t_fb * 1e3, fwdbwd_tflops=3 * flops / t_fb / 1e12, wgrad_ms=t_w * 1e3,
+                   wgrad_tflops=flops / t_w / 1e12)
         if use_torch:
             import torch.nn.functional as TF
             ft = (lambda: TF.conv_transpose3d(x, w, None, s, p, op)) if tr else (lambda: TF.conv3d(x, w, None, s, p))
