@@ -36,6 +36,16 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(mode, cfg_full):
     """The CPU oracle (torch fp32 restatement of the reference) timed on this box's host cores.
     Baseline only.  'auto': time one fwd+bwd step of BASELINE configs[0] (64x64x16 grid, D=48); if the
@@ -44,7 +54,10 @@ def cpu_baseline(mode, cfg_full):
         return None
     from oracle import path_ref as O
     from stereoscene_amd import model_zoo, synthetic as S
-    torch.set_num_threads(os.cpu_count())
+    # 32 threads: on the 256-thread EPYC host of the MI355X box ATen's OpenMP regions get SLOWER beyond
+    # that (measured: the 64x64x16 step takes 324 s with 256 threads); `cores` reports what was used.
+    ncores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
 
     def one(cfg):
         m = model_zoo.build_detector(cfg, device="cpu")       # parameter container only; never run on CPU
@@ -67,8 +80,8 @@ def cpu_baseline(mode, cfg_full):
     if mode == "full" or (mode == "auto" and dt * 30 < 60):
         v, dt = one(cfg_full)
         sample = f"1 fwd+bwd step of {cfg_full['name']} (256x256x32 grid, B=1) in {dt:.1f} s"
-    return {"value": v, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": sample,
-            "cpu": platform.processor() or platform.machine()}
+    return {"value": v, "unit": "voxels/s", "cores": ncores, "kind": "port", "sample": sample,
+            "cpu": _cpu_model(), "host_threads_available": os.cpu_count()}
 
 
 def main():
