@@ -343,18 +343,30 @@ wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Qt, float* _
     }
 }
 
-// gw (torch layout) = sum over chunks, in chunk order (deterministic).
+// gw (torch layout) = sum over chunks in a fixed order (deterministic).
 //   conv  : gw[co = p][ci = q][tap];  deconv: gw[ci = p][co = q][tap]   -> both are [p][q][tap]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps,
-                                    int Cq, int Cp, long total) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // i over ws-slab order [tap][q][p]
-  if (i >= total) return;
+// A workgroup owns 32 consecutive slab elements; its 8 thread rows stride over the chunks (coalesced 128-B
+// reads per chunk) and are folded through LDS in row order.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps, int Cq, int Cp,
+                    long total) {
+  __shared__ float part[8][33];
+  const int e = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + e;                 // i over ws-slab order [tap][q][p]
   float s = 0.0f;
-  for (int c = 0; c < nchunks; ++c) s += ws[(size_t)c * total + i];
-  const int p = (int)(i % Cp);
-  const int q = (int)((i / Cp) % Cq);
-  const int tap = (int)(i / ((long)Cp * Cq));
-  gw[((size_t)p * Cq + q) * taps + tap] = s;
+  if (i < total)
+    for (int c = row; c < nchunks; c += 8) s += ws[(size_t)c * total + i];
+  part[row][e] = s;
+  __syncthreads();
+  if (row == 0 && i < total) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += part[r][e];
+    const int p = (int)(i % Cp);
+    const int q = (int)((i / Cp) % Cq);
+    const int tap = (int)(i / ((long)Cp * Cq));
+    gw[((size_t)p * Cq + q) * taps + tap] = t;
+  }
 }
 
 // ---------------------------------------------------------------- host side
@@ -439,8 +451,230 @@ int dispatch_gather(const float* x, const float* wp, const float* bias, float* y
   return launch_gather_cfg(mt, nt, qu, x, wp, bias, y, g, st);
 }
 
-// tile configuration of the weight-gradient kernel for a problem
 struct WgradCfg { int MQ, MP, TH, TW; };
+
+// ---------------------------------------------------------------- weight gradient, channels-first path
+// For stride-1 "same" convolutions (the bulk of the FLOPs) the weight gradient is computed from two
+// scratch copies made on the fly:
+//   Pt  [B][D][H][Cp][W]              gy with every image row transposed to channel-major
+//   Qp  [B][D+2pd][H+2ph][Cq][Wp]     x likewise AND zero-padded by the conv padding
+// (row-blocked: the 32 channel rows a wave touches per trip lie within a few KB -- a fully channel-major
+//  [C][N] copy puts them megabytes apart and the loads become translation-bound)
+// With the reduction axis (voxels) contiguous, a lane loads FOUR k-values per operand with one float4
+// (the channels-last kernel above needs one dword load per MFMA operand), every tap is a constant
+// offset into Qp, and the zero padding removes all bounds tests from the loop.  Each 16-byte load
+// feeds 4*(MQ or MP)*taps MFMAs: the same operand economy as the forward gather kernel.
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+__global__ void __launch_bounds__(256)
+transpose_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int B, int D, int H, int W,
+                     int pd, int ph, int pw, int Dp, int Hp, int Wp) {
+  // src [B*D*H*W][C] -> dst [B][Dp][Hp][C][Wp] (interior; a padded ROW is channel-major), 64 x 32 tiles through LDS
+  __shared__ float tile[32][65];
+  const long V = (long)B * D * H * W;
+  const long v0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    const long v = v0 + r;
+    float4 t = make_float4(0, 0, 0, 0);
+    if (v < V && c0 + c4 < C) t = *reinterpret_cast<const float4*>(src + (size_t)v * C + c0 + c4);
+    tile[c4 + 0][r] = t.x; tile[c4 + 1][r] = t.y; tile[c4 + 2][r] = t.z; tile[c4 + 3][r] = t.w;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    const long v = v0 + r;
+    if (v >= V || c0 + c >= C) continue;
+    long t = v;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    dst[((((size_t)b * Dp + d + pd) * Hp + h + ph) * C + c0 + c) * Wp + w + pw] = tile[c][r];
+  }
+}
+
+struct WgradCfGeom {
+  int B, Cp, Cq, D, H, W;
+  int kd, kh, kw, dd, dh, dw;
+  int Dp, Hp, Wp;          // padded extents of Qp
+  int chunk, nchunks;      // voxels per chunk (multiple of 8)
+};
+
+template <int MQ, int MP, int TH, int TW>
+__global__ void __launch_bounds__(256)
+wgrad_cf_kernel(const float* __restrict__ Pt, const float* __restrict__ Qp, float* __restrict__ ws, WgradCfGeom g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int chunk_id = blockIdx.x * 4 + wave;
+  if (chunk_id >= g.nchunks) return;
+  const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
+  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
+  const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
+  int tg = blockIdx.z;
+  const int kwg = tg % kw_groups; tg /= kw_groups;
+  const int khg = tg % kh_groups;
+  const int kdi = tg / kh_groups;
+
+  f32x16 acc[MQ][MP][TH][TW];
+#pragma unroll
+  for (int a = 0; a < MQ; ++a)
+#pragma unroll
+    for (int b = 0; b < MP; ++b)
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][c][t][r] = 0.0f;
+
+  const long N = (long)g.B * g.D * g.H * g.W;
+  const long m_begin = (long)chunk_id * g.chunk;
+  const long m_end = min(N, m_begin + g.chunk);
+  // channel of this lane in every tile (clamped: out-of-range channels are discarded at the store)
+  int pch[MP], qch[MQ];
+#pragma unroll
+  for (int a = 0; a < MP; ++a) pch[a] = min((pt * MP + a) * 32 + li, g.Cp - 1);
+#pragma unroll
+  for (int a = 0; a < MQ; ++a) qch[a] = min((qt * MQ + a) * 32 + li, g.Cq - 1);
+  // One trip covers 32 voxels: the lane pair (li,0),(li,1) of a channel row consumes one whole 128-B line
+  // (J = 4 float4 per lane), so no load relies on the line surviving in L1 until a later trip.
+  // Each float4 group is 4 voxels of one row (W % 4 == 0); its (w,h,d,b) is tracked incrementally.
+  constexpr int J = 4;
+  long m = m_begin + 4 * J * lk;
+  int w, h, d, b;
+  {
+    long r = min(m, N - 4);
+    w = (int)(r % g.W); r /= g.W;
+    h = (int)(r % g.H); r /= g.H;
+    d = (int)(r % g.D);
+    b = (int)(r / g.D);
+  }
+  auto advance = [&](int step) {
+    w += step;
+    while (w >= g.W) {
+      w -= g.W;
+      if (++h >= g.H) { h = 0; if (++d >= g.D) { d = 0; ++b; } }
+    }
+  };
+  for (; m < m_end + 4 * J * lk; m += 8 * J) {      // same trip count in both halves; tails are masked
+    float4 pv[J][MP];
+    f4u qv[J][TH][TW][MQ];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const long mj = m + 4 * j;
+      const bool ok = mj < m_end;
+      const size_t prow = ok ? (((size_t)b * g.D + d) * g.H + h) * g.Cp : 0;     // row (b,d,h) of Pt
+#pragma unroll
+      for (int a = 0; a < MP; ++a)
+        pv[j][a] = ok ? *reinterpret_cast<const float4*>(Pt + (prow + pch[a]) * g.W + w) : make_float4(0, 0, 0, 0);
+      // padded coordinates of tap (kdi, khg*TH, kwg*TW): the conv padding is already inside Qp
+      const size_t qrow = ok ? ((size_t)b * g.Dp + d + kdi * g.dd) * g.Hp + h + khg * TH * g.dh : 0;
+      const int qw = ok ? w + kwg * TW * g.dw : 0;
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          const bool tok = ok && (khg * TH + c) < g.kh && (kwg * TW + t) < g.kw;
+          const size_t row = tok ? qrow + (size_t)c * g.dh : qrow;
+          const int ww = tok ? qw + t * g.dw : qw;
+#pragma unroll
+          for (int a = 0; a < MQ; ++a)
+            qv[j][c][t][a] = *reinterpret_cast<const f4u*>(Qp + (row * g.Cq + qch[a]) * g.Wp + ww);
+        }
+      advance(4);
+    }
+    advance(4 * J);      // skip the other half-wave's 16 voxels
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int a = 0; a < MQ; ++a)
+#pragma unroll
+            for (int e = 0; e < MP; ++e) {
+              acc[a][e][c][t] = mfma32(qv[j][c][t][a].x, pv[j][e].x, acc[a][e][c][t]);
+              acc[a][e][c][t] = mfma32(qv[j][c][t][a].y, pv[j][e].y, acc[a][e][c][t]);
+              acc[a][e][c][t] = mfma32(qv[j][c][t][a].z, pv[j][e].z, acc[a][e][c][t]);
+              acc[a][e][c][t] = mfma32(qv[j][c][t][a].w, pv[j][e].w, acc[a][e][c][t]);
+            }
+  }
+  const int taps = g.kd * g.kh * g.kw;
+#pragma unroll
+  for (int c = 0; c < TH; ++c)
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const int khi = khg * TH + c, kwi = kwg * TW + t;
+      if (khi >= g.kh || kwi >= g.kw) continue;
+      const int tap = (kdi * g.kh + khi) * g.kw + kwi;
+      float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+#pragma unroll
+      for (int a = 0; a < MQ; ++a)
+#pragma unroll
+        for (int e = 0; e < MP; ++e) {
+          const int pc = (pt * MP + e) * 32 + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (qt * MQ + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = acc[a][e][c][t][r];
+          }
+        }
+    }
+}
+
+bool wgrad_cf_applicable(const ssbev_conv_dims* d) {
+  if (d->transposed || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
+  if (d->Wo % 4 != 0 || ((long)d->B * d->Do * d->Ho * d->Wo) % 8 != 0) return false;
+  if (2 * d->pd != d->dd * (d->kd - 1) || 2 * d->ph != d->dh * (d->kh - 1) || 2 * d->pw != d->dw * (d->kw - 1)) return false;
+  return true;
+}
+
+WgradCfGeom make_wgrad_cf_geom(const ssbev_conv_dims* d, WgradCfg* cfg_out) {
+  WgradCfGeom g;
+  g.B = d->B; g.Cp = d->Cout; g.Cq = d->Cin; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  g.Dp = d->Di + 2 * d->pd; g.Hp = d->Hi + 2 * d->ph;
+  g.Wp = ((d->Wi + 2 * d->pw + 3) & ~3) + 4;          // +4: slack for the last row's unaligned float4
+  WgradCfg c;
+  if (d->kh * d->kw == 1) c = {2, 2, 1, 1};
+  else if (g.Cp > 32 && g.Cq > 32) c = {2, 2, 1, 3};
+  else if (g.Cp <= 32 && g.Cq <= 32) c = {1, 1, 3, 3};
+  else c = {1, 1, 1, 3};
+  *cfg_out = c;
+  const long N = (long)g.B * g.D * g.H * g.W;
+  const long tiles = (long)((g.Cp + 32 * c.MP - 1) / (32 * c.MP)) * ((g.Cq + 32 * c.MQ - 1) / (32 * c.MQ)) * g.kd *
+                     ((g.kh + c.TH - 1) / c.TH) * ((g.kw + c.TW - 1) / c.TW);
+  // Workgroups (= 4 chunks x one tile) are sized so that their count is just BELOW a multiple of the
+  // number of workgroups the chip holds at once (PMC: with 3.09 "rounds" the SIMDs idled 27 % of the time).
+  const int acc_regs = 16 * c.MQ * c.MP * c.TH * c.TW;
+  const long resident = 256L * (acc_regs > 128 ? 1 : (acc_regs > 64 ? 2 : 3));
+  long best_cb = 1;
+  for (long rounds = 8; rounds >= 1; --rounds) {
+    const long cb = (resident * rounds) / (tiles > 0 ? tiles : 1);       // chunk-blocks per tile
+    if (cb >= 1 && (N + 4 * cb - 1) / (4 * cb) >= 512) { best_cb = cb; break; }
+  }
+  long chunk = (N + 4 * best_cb - 1) / (4 * best_cb);
+  if (chunk < 512) chunk = 512;
+  chunk = (chunk + 31) & ~31L;
+  g.chunk = (int)chunk;
+  g.nchunks = (int)((N + chunk - 1) / chunk);
+  return g;
+}
+
+size_t align256b(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int MQ, int MP, int TH, int TW>
+void launch_wgrad_cf(const float* Pt, const float* Qp, float* ws, const WgradCfGeom& g, hipStream_t st) {
+  const int ytiles = ((g.Cq + 32 * MQ - 1) / (32 * MQ)) * ((g.Cp + 32 * MP - 1) / (32 * MP));
+  dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * ((g.kh + TH - 1) / TH) * ((g.kw + TW - 1) / TW));
+  hipLaunchKernelGGL((wgrad_cf_kernel<MQ, MP, TH, TW>), grid, dim3(256), 0, st, Pt, Qp, ws, g);
+}
+
+// tile configuration of the weight-gradient kernel for a problem
 WgradCfg wgrad_cfg(int Cp, int Cq, int kh, int kw) {
   if (kh * kw == 1) return {2, 2, 1, 1};
   if (Cp > 32 && Cq > 32) return {2, 2, 1, 3};
@@ -540,6 +774,14 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
 
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
+  if (wgrad_cf_applicable(d)) {
+    WgradCfg c;
+    const WgradCfGeom g = make_wgrad_cf_geom(d, &c);
+    const size_t N = (size_t)g.B * g.D * g.H * g.W;
+    return align256b((size_t)g.nchunks * d->kd * d->kh * d->kw * g.Cp * g.Cq * sizeof(float)) +
+           align256b((size_t)g.Cp * N * sizeof(float)) +
+           align256b(((size_t)g.Cq * g.B * g.Dp * g.Hp * g.Wp + 16) * sizeof(float));
+  }
   const WgradGeom g = make_wgrad_geom(d);
   return (size_t)g.nchunks * d->kd * d->kh * d->kw * g.Cp * g.Cq * sizeof(float);
 }
@@ -548,6 +790,31 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  if (wgrad_cf_applicable(d)) {
+    hipStream_t st = as_stream(stream);
+    WgradCfg c;
+    const WgradCfGeom g = make_wgrad_cf_geom(d, &c);
+    const size_t N = (size_t)g.B * g.D * g.H * g.W;
+    const int taps = g.kd * g.kh * g.kw;
+    char* base = static_cast<char*>(ws);
+    float* partial = reinterpret_cast<float*>(base);
+    float* Pt = reinterpret_cast<float*>(base + align256b((size_t)g.nchunks * taps * g.Cp * g.Cq * sizeof(float)));
+    float* Qp = reinterpret_cast<float*>(reinterpret_cast<char*>(Pt) + align256b((size_t)g.Cp * N * sizeof(float)));
+    const size_t qbytes = ((size_t)g.Cq * g.B * g.Dp * g.Hp * g.Wp + 16) * sizeof(float);
+    if (hipMemsetAsync(Qp, 0, qbytes, st) != hipSuccess) return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(N, 64), cdiv(g.Cp, 32)), dim3(256), 0, st, gy, Pt, g.Cp, g.B,
+                       g.D, g.H, g.W, 0, 0, 0, g.D, g.H, g.W);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(N, 64), cdiv(g.Cq, 32)), dim3(256), 0, st, x, Qp, g.Cq, g.B,
+                       g.D, g.H, g.W, d->pd, d->ph, d->pw, g.Dp, g.Hp, g.Wp);
+    if (c.TH == 1 && c.TW == 1) launch_wgrad_cf<2, 2, 1, 1>(Pt, Qp, partial, g, st);
+    else if (c.MQ == 2) launch_wgrad_cf<2, 2, 1, 3>(Pt, Qp, partial, g, st);
+    else if (c.TH == 3) launch_wgrad_cf<1, 1, 3, 3>(Pt, Qp, partial, g, st);
+    else launch_wgrad_cf<1, 1, 1, 3>(Pt, Qp, partial, g, st);
+    const long total = (long)taps * g.Cq * g.Cp;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, g.nchunks, taps, g.Cq,
+                       g.Cp, total);
+    return ssbev_launch_status();
+  }
   const WgradGeom g = make_wgrad_geom(d);
   const float* P = d->transposed ? x : gy;
   const float* Qt = d->transposed ? gy : x;
@@ -561,7 +828,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
   else if (c.TH == 3) launch_wgrad<1, 1, 3, 3>(P, Qt, wsf, g, st);
   else launch_wgrad<1, 1, 1, 3>(P, Qt, wsf, g, st);
   const long total = (long)taps * g.Cq * g.Cp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
                      g.nchunks, taps, g.Cq, g.Cp, total);
   return ssbev_launch_status();
 }
