@@ -652,7 +652,9 @@ WgradCfGeom make_wgrad_cf_geom(const ssbev_conv_dims* d, WgradCfg* cfg_out) {
   // number of workgroups the chip holds at once (PMC: with 3.09 "rounds" the SIMDs idled 27 % of the time).
   const int acc_regs = 16 * c.MQ * c.MP * c.TH * c.TW;
   const long resident = 256L * (acc_regs > 128 ? 1 : (acc_regs > 64 ? 2 : 3));
-  long best_cb = 1;
+  long best_cb = N / (4 * 512L) / (tiles > 0 ? 1 : 1);     // fallback: as many 512-voxel chunks as exist
+  if (best_cb < 1) best_cb = 1;
+  if (best_cb > resident) best_cb = resident;               // (one tile, huge volume: a single round is enough)
   for (long rounds = 8; rounds >= 1; --rounds) {
     const long cb = (resident * rounds) / (tiles > 0 ? tiles : 1);       // chunk-blocks per tile
     if (cb >= 1 && (N + 4 * cb - 1) / (4 * cb) >= 512) { best_cb = cb; break; }
