@@ -164,6 +164,16 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
                         float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws,
                         size_t ws_bytes, ssbev_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Trilinear x2 upsample (align_corners=False) of channels-last volumes, forward and gather-form
+ * backward.  Replaces F.interpolate(..., mode='trilinear') at occhead.py:293-294 and
+ * bevdepth_occupancy.py:293 (logits [B,20,128,128,16] -> [B,20,256,256,32]).
+ *   x [B, D, H, W, C] -> y [B, 2D, 2H, 2W, C];  C % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, D, H, W, C; } ssbev_upsample_dims;
+int ssbev_trilinear2x_fwd(const float* x, float* y, const ssbev_upsample_dims* d, ssbev_stream_t stream);
+int ssbev_trilinear2x_bwd(const float* gy, float* gx, const ssbev_upsample_dims* d, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ class NormDims(C.Structure):
                 ("relu", C.c_int), ("stats_given", C.c_int)]
 
 
+class UpsampleDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int)]
+
+
 _P = C.c_void_p
 # name -> (restype, argtypes); this table is checked against include/ssbev.h by tests/test_capi_symbols.py
 SIGNATURES = {
@@ -70,6 +74,8 @@ SIGNATURES = {
     "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd": (C.c_int, [_P] * 7 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
+    "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
 }
 
 _lib = None

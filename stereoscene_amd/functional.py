@@ -475,3 +475,44 @@ def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, residu
     """Inference-mode BatchNorm with the running statistics (forward only on the HIP path)."""
     rstd = torch.rsqrt(running_var + eps)
     return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, running_mean, rstd)[0]
+
+
+# -------------------------------------------------------------------------------------------------
+# trilinear x2 upsample of the logits
+# -------------------------------------------------------------------------------------------------
+
+
+class _Trilinear2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = capi.load()
+        xcl = to_cl(_f32(x, "trilinear2x"))
+        B, D, H, W, Cch = xcl.shape
+        d = capi.UpsampleDims(B, D, H, W, Cch)
+        y = torch.empty(B, 2 * D, 2 * H, 2 * W, Cch, dtype=torch.float32, device=x.device)
+        capi.check(lib.ssbev_trilinear2x_fwd(capi.ptr(xcl), capi.ptr(y), C.byref(d), capi.stream()),
+                   "ssbev_trilinear2x_fwd")
+        ctx.dims = (B, D, H, W, Cch)
+        return from_cl(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = capi.load()
+        B, D, H, W, Cch = ctx.dims
+        gcl = to_cl(gy)
+        d = capi.UpsampleDims(B, D, H, W, Cch)
+        gx = torch.empty(B, D, H, W, Cch, dtype=torch.float32, device=gy.device)
+        capi.check(lib.ssbev_trilinear2x_bwd(capi.ptr(gcl), capi.ptr(gx), C.byref(d), capi.stream()),
+                   "ssbev_trilinear2x_bwd")
+        return from_cl(gx)
+
+
+def upsample_trilinear(x, size):
+    """F.interpolate(x, size, mode='trilinear', align_corners=False); the exact-x2 case the path uses
+    (logits -> label grid) runs on the HIP kernel, any other ratio on ATen's device kernel."""
+    size = tuple(int(v) for v in size)
+    if tuple(x.shape[-3:]) == size:
+        return x
+    if all(o == 2 * i for o, i in zip(size, x.shape[-3:])) and x.shape[1] % 4 == 0:
+        return _Trilinear2x.apply(x)
+    return torch.nn.functional.interpolate(x.contiguous(), size=size, mode="trilinear", align_corners=False)

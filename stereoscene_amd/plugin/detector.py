@@ -75,8 +75,8 @@ class BEVDepthOccupancy(nn.Module):
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img, img_metas=img_metas)
         out = self.pts_bbox_head(voxel_feats=voxel_feats, points=points_occ, img_metas=img_metas)
         out["evaluation_semantic"] = 0
-        out["output_voxels"] = TF.interpolate(out["output_voxels"][0].contiguous(), size=gt_occ.shape[1:],
-                                              mode="trilinear", align_corners=False)
+        from ..functional import upsample_trilinear
+        out["output_voxels"] = upsample_trilinear(out["output_voxels"][0], gt_occ.shape[1:])
         out["target_voxels"] = gt_occ
         return out
 

@@ -82,7 +82,8 @@ def ssc_counts(pred, gt, n_classes=20, recompute_mask=False):
 def occ_losses(logits, gt_occ, class_weights, tag="0", w_ce=1.0, w_sem=1.0, w_geo=1.0, compute_metric=False):
     """occhead.py:291-361: trilinear upsample to the label grid, CE + sem_scal + geo_scal (+ metric)."""
     if logits.shape[-3:] != gt_occ.shape[-3:]:
-        logits = TF.interpolate(logits.contiguous(), size=gt_occ.shape[-3:], mode="trilinear", align_corners=False)
+        from ..functional import upsample_trilinear
+        logits = upsample_trilinear(logits, gt_occ.shape[-3:])
     t = gt_occ.long()
     out = {}
     if w_ce > 0:

@@ -254,3 +254,19 @@ def test_batch_norm_train_and_eval():
     assert maxdiff(xg.grad, xc.grad) < 5e-5 and maxdiff(wg.grad, wc.grad) < 2e-4 and maxdiff(bg.grad, bc.grad) < 2e-4
     ev = F.batch_norm_eval(x.to(DEV), w.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, relu=True)
     assert maxdiff(ev, torch.relu(TF.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5))) < 2e-5
+
+
+# ------------------------------------------------------------------------------------ trilinear x2
+@pytest.mark.parametrize("B,C,sp", [(1, 20, (8, 8, 4)), (2, 4, (3, 5, 2)), (1, 20, (16, 12, 8))])
+def test_trilinear2x_fwd_bwd(B, C, sp):
+    x = S.hash_normal("tri/x", (B, C) + sp)
+    xc = x.clone().requires_grad_(True)
+    size = tuple(2 * v for v in sp)
+    want = TF.interpolate(xc, size=size, mode="trilinear", align_corners=False)
+    xg = x.to(DEV).requires_grad_(True)
+    got = F.upsample_trilinear(xg, size)
+    assert got.shape == want.shape and maxdiff(got, want) < 1e-5
+    go = S.hash_normal("tri/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    assert maxdiff(xg.grad, xc.grad) < 1e-5
