@@ -50,6 +50,10 @@ class UpsampleDims(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int)]
 
 
+class AttnDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Dh", C.c_int)]
+
+
 _P = C.c_void_p
 # name -> (restype, argtypes); this table is checked against include/ssbev.h by tests/test_capi_symbols.py
 SIGNATURES = {
@@ -76,6 +80,10 @@ SIGNATURES = {
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
+    "ssbev_bri_attention_supported": (C.c_int, [C.POINTER(AttnDims)]),
+    "ssbev_bri_attention_workspace": (C.c_size_t, [C.POINTER(AttnDims)]),
+    "ssbev_bri_attention_fwd": (C.c_int, [_P] * 6 + [C.POINTER(AttnDims), _P]),
+    "ssbev_bri_attention_bwd": (C.c_int, [_P] * 11 + [C.POINTER(AttnDims), _P, C.c_size_t, _P]),
 }
 
 _lib = None

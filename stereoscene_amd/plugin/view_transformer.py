@@ -254,7 +254,10 @@ class attention(nn.Module):
         Q = self._affine(self.query_conv, q).view(B, D, hw)                   # [B,D,HW] (tokens contiguous)
         K = self._affine(self.key_conv, kv).view(B, D, hw)
         V = self._affine(self.value_conv, kv).view(B, D, hw)
-        out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
+        if F.bri_attention_supported(B, hw, D):
+            out = F.bri_attention(Q, K, V, conf).view(B, C, D, H, W)      # flash-style HIP kernels, no HW x HW matrix
+        else:                                                             # head sizes without a specialisation
+            out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
         return self.gamma * out + kv
 
 

@@ -270,3 +270,34 @@ def test_trilinear2x_fwd_bwd(B, C, sp):
     want.backward(go)
     got.backward(go.to(DEV))
     assert maxdiff(xg.grad, xc.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ BRI attention
+@pytest.mark.parametrize("B,Dh,T", [(2, 16, 96), (1, 48, 480), (1, 112, 256), (1, 192, 320)])
+def test_bri_attention_fwd_bwd_vs_dense(B, Dh, T):
+    q = torch.softmax(S.hash_normal("bri/q", (B, Dh, T), 2.0), 1) * 3.0 + 0.1
+    k = torch.softmax(S.hash_normal("bri/k", (B, Dh, T), 2.0), 1) * 5.0 - 0.2
+    v = S.hash_normal("bri/v", (B, Dh, T))
+    conf = S.hash_uniform("bri/c", (B, T), 0.1, 1.0)
+    cs = [t.clone().requires_grad_(True) for t in (q, k, v, conf)]
+    att = torch.softmax(torch.bmm(cs[0].transpose(1, 2) * 40.0, cs[1]), -1) * cs[3].unsqueeze(1)   # sharp softmax
+    want = torch.bmm(cs[2], att.transpose(1, 2))
+    gs = [t.to(DEV).requires_grad_(True) for t in (q, k, v, conf)]
+    assert F.bri_attention_supported(B, T, Dh)
+    got = F.bri_attention(gs[0] * 40.0, gs[1], gs[2], gs[3])
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal("bri/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    for a, c in zip(gs, cs):
+        assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
+
+
+def test_bri_attention_golden_module():
+    """The attention module (scalar affine q/k/v + gamma) against the reference fixture."""
+    from stereoscene_amd.plugin.view_transformer import attention
+    g = load_golden("attention")
+    att = attention(1).to(DEV)
+    att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})
+    out = att(torch.from_numpy(g["q"]).to(DEV), torch.from_numpy(g["kv"]).to(DEV))
+    assert maxdiff(out, torch.from_numpy(g["out"])) < 2e-6
