@@ -92,9 +92,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
     torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world,       # RCCL on ROCm
+                                device_id=torch.device("cuda", local))
 
     from stereoscene_amd import functional as F, model_zoo, synthetic as S
     from stereoscene_amd.dp import FlatGradAllReduce
@@ -119,7 +121,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +137,7 @@ def main():
     dt = time.perf_counter() - t0
     F.KERNEL_TIMER = None
     tmax = torch.tensor([dt], device="cuda")
-    if world > 1:
+    if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     ms = dt / args.steps * 1e3
@@ -168,7 +170,7 @@ def main():
                "losses": {k: float(v) for k, v in losses.items()}}
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample if world == 1 else "none", cfg)
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -15,7 +15,8 @@ import torch.distributed as dist
 class FlatGradAllReduce:
     def __init__(self, module, bucket_mb=64, process_group=None, average=True):
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.active else 1
         self.average = average
         params = [p for p in module.parameters() if p.requires_grad]
         # gradients become ready roughly in reverse registration order (head -> ... -> stereo net)
@@ -44,7 +45,7 @@ class FlatGradAllReduce:
     def _on_grad(self, p):
         b = self._bucket_of[p]
         self._arrived[b] += 1
-        if self._arrived[b] == self.buckets[b][2] and self.world > 1:
+        if self._arrived[b] == self.buckets[b][2] and self.active:
             s, e, _ = self.buckets[b]
             self._handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
 
@@ -54,15 +55,14 @@ class FlatGradAllReduce:
 
     def finish(self):
         """Wait for the in-flight buckets (call after backward()); returns bytes exchanged per rank."""
-        if self.world > 1:
-            fired = set()
+        if self.active:
             for h in self._handles:
                 h.wait()
             # parameters that received no gradient this step never fire their hook: reduce their buckets now
             for b, (s, e, c) in enumerate(self.buckets):
                 if self._arrived[b] != c:
                     dist.all_reduce(self.flat[s:e], group=self.group)
-            if self.average:
+            if self.average and self.world > 1:
                 self.flat.div_(self.world)
         self._handles = []
         self._arrived = [0] * len(self.buckets)
