@@ -201,34 +201,35 @@ bri_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV, dconf
-// block = 2 waves, 32 keys; K and V' of the block live in LDS; every wave stages the Q and dO tiles of its
-// query block.  Tiles are S[i][j] (a lane owns one key):
+// block = 4 waves = 4 consecutive 32-key blocks; the Q and dO tiles of the current 32-query tile are staged
+// ONCE per block in LDS and serve all four waves, both as the row operand of S / dP (rows = queries) and as
+// the row operand of the two accumulations (rows = head dim).  K and V' of a wave's own keys come from
+// L1/L2 as coalesced B-operand loads.  The query range is split over blockIdx.z; every split writes its
+// partial dK / dV' / dconf slab, summed in split order by bri_dkv_finish_kernel (deterministic).
 //   dV'^T[d][j] += sum_i dO[d][i] * P[i][j]        dK^T[d][j] += sum_i Q[d][i] * dS[i][j]
 template <int DH>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 bri_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                    const float* __restrict__ conf, const float* __restrict__ go, const float* __restrict__ lse,
-                   const float* __restrict__ dd, float* __restrict__ gk, float* __restrict__ gv,
-                   float* __restrict__ gconf, int T) {
+                   const float* __restrict__ dd, float* __restrict__ part, int T, int nsplit) {
   constexpr int NDT = (DH + 31) / 32, DHP = NDT * 32, DH2 = DH / 2;
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
-  const int b = blockIdx.y, j0 = blockIdx.x * 32;
+  const int b = blockIdx.y, split = blockIdx.z;
+  const int j0 = (blockIdx.x * 4 + wave) * 32;
+  const bool jok = j0 < T;
   const float* qb = q + (size_t)b * DH * T;
   const float* gb = go + (size_t)b * DH * T;
+  const float* kb = k + (size_t)b * DH * T;
+  const float* vb = v + (size_t)b * DH * T;
   const float* lb = lse + (size_t)b * T;
   const float* db = dd + (size_t)b * T;
-  float* ks = lds;                       // [DH][32] K  of the block
-  float* vs = lds + DH * 32;             // [DH][32] V' of the block (conf folded in)
-  float* qt = lds + 2 * DH * 32 + (size_t)wave * (2 * DHP * TS + 64);
-  float* gt = qt + DHP * TS;
-  float* lt = gt + DHP * TS;             // [64]: lse and Dd of the wave's 32 queries
-  for (int e = threadIdx.x; e < DH * 32; e += 128) {
-    const int d = e >> 5, j = e & 31;
-    ks[e] = k[((size_t)b * DH + d) * T + j0 + j];
-    vs[e] = v[((size_t)b * DH + d) * T + j0 + j] * conf[(size_t)b * T + j0 + j];
-  }
+  float* qt = lds;                    // [DHP][TS]  Q  tile of the current queries
+  float* gt = lds + DHP * TS;         // [DHP][TS]  dO tile
+  float* lt = lds + 2 * DHP * TS;     // [64]       lse | Dd of the 32 queries
+  const float cj = jok ? conf[(size_t)b * T + j0 + li] : 0.0f;
+  const int jc = jok ? j0 + li : 0;
   f32x16 ak[NDT], av[NDT];
 #pragma unroll
   for (int t = 0; t < NDT; ++t)
@@ -236,12 +237,18 @@ bri_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
     for (int r = 0; r < 16; ++r) { ak[t][r] = 0.0f; av[t][r] = 0.0f; }
 
   const int ntiles = T / 32;
-  for (int it = wave; it < ntiles; it += 2) {
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int it_end = min(ntiles, (split + 1) * per);
+  for (int it = split * per; it < it_end; ++it) {
     const int i0 = it * 32;
     __syncthreads();
-    stage_tile<DH, DHP>(qb, T, i0, nullptr, qt, lane);
-    stage_tile<DH, DHP>(gb, T, i0, nullptr, gt, lane);
-    if (lk == 0) lt[li] = lb[i0 + li]; else lt[32 + li] = db[i0 + li];
+    // cooperative staging: 4 waves x (rows d = wave*2 + lk, +8, ...)
+    for (int d = wave * 2 + lk; d < DHP; d += 8) {
+      qt[d * TS + li] = d < DH ? qb[(size_t)d * T + i0 + li] : 0.0f;
+      gt[d * TS + li] = d < DH ? gb[(size_t)d * T + i0 + li] : 0.0f;
+    }
+    if (threadIdx.x < 32) lt[threadIdx.x] = lb[i0 + threadIdx.x];
+    else if (threadIdx.x < 64) lt[threadIdx.x] = db[i0 + threadIdx.x - 32];
     __syncthreads();
     f32x16 s, dp;
 #pragma unroll
@@ -249,8 +256,8 @@ bri_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
 #pragma unroll 8
     for (int st = 0; st < DH2; ++st) {
       const int d = 2 * st + lk;
-      s = mfma32(qt[d * TS + li], ks[d * 32 + li], s);           // rows = queries, cols = keys
-      dp = mfma32(gt[d * TS + li], vs[d * 32 + li], dp);
+      s = mfma32(qt[d * TS + li], kb[(size_t)d * T + jc], s);           // rows = queries, cols = keys
+      dp = mfma32(gt[d * TS + li], vb[(size_t)d * T + jc] * cj, dp);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -267,35 +274,42 @@ bri_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
         ak[t] = mfma32(qt[(t * 32 + li) * TS + crow(st, lk)], dp[st], ak[t]);
       }
   }
-  if (((ntiles - wave + 1) / 2) < ((ntiles + 1) / 2)) { __syncthreads(); __syncthreads(); }
-  __syncthreads();
-  // merge the two waves: park dK^T in the wave's Q-tile region, dV'^T in its dO-tile region
+  if (!jok) return;
+  // partial slabs: part[split][b][{dK, dV'}][DH][T]
+  float* pk = part + (((size_t)split * gridDim.y + b) * 2 + 0) * DH * T;
+  float* pv = part + (((size_t)split * gridDim.y + b) * 2 + 1) * DH * T;
 #pragma unroll
   for (int t = 0; t < NDT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      qt[(t * 32 + crow(r, lk)) * TS + li] = ak[t][r];
-      gt[(t * 32 + crow(r, lk)) * TS + li] = av[t][r];
+      const int d = t * 32 + crow(r, lk);
+      if (d < DH) {
+        pk[(size_t)d * T + j0 + li] = ak[t][r];
+        pv[(size_t)d * T + j0 + li] = av[t][r];
+      }
     }
-  __syncthreads();
-  const float* w0 = lds + 2 * DH * 32;
-  const float* w1 = w0 + (2 * DHP * TS + 64);
-  // thread (j = tid & 31, dgroup = tid >> 5): walks d = dgroup, dgroup+4, ...; dconf reduced per key
-  const int j = threadIdx.x & 31, dg = threadIdx.x >> 5;
-  const float cj = conf[(size_t)b * T + j0 + j];
+}
+
+// gk = sum_s dK_s ; gv = conf * sum_s dV'_s ; gconf[j] = sum_d v[d][j] * sum_s dV'_s[d][j]
+__global__ void bri_dkv_finish_kernel(const float* __restrict__ part, const float* __restrict__ v,
+                                      const float* __restrict__ conf, float* __restrict__ gk, float* __restrict__ gv,
+                                      float* __restrict__ gconf, int Dh, int T, int nsplit, int B) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= T) return;
+  const float cj = conf[(size_t)b * T + j];
   float gc = 0.0f;
-  for (int d = dg; d < DH; d += 4) {
-    const float dk = w0[d * TS + j] + w1[d * TS + j];
-    const float dvp = w0[DHP * TS + d * TS + j] + w1[DHP * TS + d * TS + j];
-    gk[((size_t)b * DH + d) * T + j0 + j] = dk;
-    gv[((size_t)b * DH + d) * T + j0 + j] = dvp * cj;
-    gc += dvp * v[((size_t)b * DH + d) * T + j0 + j];
+  for (int d = 0; d < Dh; ++d) {
+    float dk = 0.0f, dv = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      dk += part[((((size_t)s * B + b) * 2 + 0) * Dh + d) * T + j];
+      dv += part[((((size_t)s * B + b) * 2 + 1) * Dh + d) * T + j];
+    }
+    gk[((size_t)b * Dh + d) * T + j] = dk;
+    gv[((size_t)b * Dh + d) * T + j] = dv * cj;
+    gc += dv * v[((size_t)b * Dh + d) * T + j];
   }
-  __syncthreads();
-  float* red = lds;    // K/V' staging is no longer needed
-  red[dg * 32 + j] = gc;
-  __syncthreads();
-  if (threadIdx.x < 32) gconf[(size_t)b * T + j0 + j] = red[j] + red[32 + j] + red[64 + j] + red[96 + j];
+  gconf[(size_t)b * T + j] = gc;
 }
 
 // Dd[i] = sum_d dO[d][i] * O[d][i]
@@ -311,7 +325,8 @@ __global__ void bri_rowdot_kernel(const float* __restrict__ go, const float* __r
 
 template <int DH> size_t fwd_lds() { constexpr int DHP = ((DH + 31) / 32) * 32; return ((size_t)DH * 32 + 4 * (DHP * TS + 64)) * 4; }
 template <int DH> size_t dq_lds() { constexpr int DHP = ((DH + 31) / 32) * 32; return ((size_t)2 * DH * 32 + 4 * DHP * TS) * 4; }
-template <int DH> size_t dkv_lds() { constexpr int DHP = ((DH + 31) / 32) * 32; return ((size_t)2 * DH * 32 + 2 * (2 * DHP * TS + 64)) * 4; }
+template <int DH> size_t dkv_lds() { constexpr int DHP = ((DH + 31) / 32) * 32; return ((size_t)2 * DHP * TS + 64) * 4; }
+inline int dkv_splits(int T, int B) { int kb = (T / 32 + 3) / 4 * B; int s = (512 + kb - 1) / kb; return s < 1 ? 1 : (s > 16 ? 16 : s); }
 
 template <typename K>
 bool set_lds(K kern, size_t bytes) {
@@ -339,8 +354,12 @@ int run_bwd(const float* q, const float* k, const float* v, const float* conf, c
   auto k2 = bri_bwd_dkv_kernel<DH>;
   if (!set_lds(k1, dq_lds<DH>()) || !set_lds(k2, dkv_lds<DH>())) return SSBEV_ELAUNCH;
   hipLaunchKernelGGL(k1, dim3(d->T / 32, d->B), dim3(256), dq_lds<DH>(), st, q, k, v, conf, gout, lse, dd, gq, d->T);
-  hipLaunchKernelGGL(k2, dim3(d->T / 32, d->B), dim3(128), dkv_lds<DH>(), st, q, k, v, conf, gout, lse, dd, gk, gv,
-                     gconf, d->T);
+  const int ns = dkv_splits(d->T, d->B);
+  float* part = dd + (size_t)d->B * d->T;
+  hipLaunchKernelGGL(k2, dim3((d->T / 32 + 3) / 4, d->B, ns), dim3(256), dkv_lds<DH>(), st, q, k, v, conf, gout, lse, dd,
+                     part, d->T, ns);
+  hipLaunchKernelGGL(bri_dkv_finish_kernel, dim3(cdiv(d->T, 256), d->B), dim3(256), 0, st, part, v, conf, gk, gv, gconf,
+                     DH, d->T, ns, d->B);
   return ssbev_launch_status();
 }
 
@@ -356,7 +375,9 @@ extern "C" {
 int ssbev_bri_attention_supported(const ssbev_attn_dims* d) { return attn_ok(d) ? 1 : 0; }
 
 size_t ssbev_bri_attention_workspace(const ssbev_attn_dims* d) {
-  return attn_ok(d) ? (size_t)d->B * d->T * sizeof(float) : 0;
+  if (!attn_ok(d)) return 0;
+  // Dd[B][T] + dK/dV' partial slabs of the query splits
+  return ((size_t)d->B * d->T + (size_t)dkv_splits(d->T, d->B) * d->B * 2 * d->Dh * d->T) * sizeof(float);
 }
 
 int ssbev_bri_attention_fwd(const float* q, const float* k, const float* v, const float* conf, float* out, float* lse,

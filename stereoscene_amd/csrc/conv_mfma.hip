@@ -586,21 +586,18 @@ wgrad_cf_kernel(const float* __restrict__ Pt, const float* __restrict__ Qp, floa
       advance(4);
     }
     advance(4 * J);      // skip the other half-wave's 16 voxels
+    // component-major order: consecutive MFMAs go to DIFFERENT accumulators (no back-to-back dependent issue)
+#define SSBEV_WG_STEP(COMP)                                                                              \
+    _Pragma("unroll") for (int c = 0; c < TH; ++c)                                                         \
+    _Pragma("unroll") for (int t = 0; t < TW; ++t)                                                         \
+    _Pragma("unroll") for (int a = 0; a < MQ; ++a)                                                         \
+    _Pragma("unroll") for (int e = 0; e < MP; ++e)                                                         \
+      acc[a][e][c][t] = mfma32(qv[j][c][t][a].COMP, pv[j][e].COMP, acc[a][e][c][t]);
 #pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int c = 0; c < TH; ++c)
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int a = 0; a < MQ; ++a)
-#pragma unroll
-            for (int e = 0; e < MP; ++e) {
-              acc[a][e][c][t] = mfma32(qv[j][c][t][a].x, pv[j][e].x, acc[a][e][c][t]);
-              acc[a][e][c][t] = mfma32(qv[j][c][t][a].y, pv[j][e].y, acc[a][e][c][t]);
-              acc[a][e][c][t] = mfma32(qv[j][c][t][a].z, pv[j][e].z, acc[a][e][c][t]);
-              acc[a][e][c][t] = mfma32(qv[j][c][t][a].w, pv[j][e].w, acc[a][e][c][t]);
-            }
+    for (int j = 0; j < J; ++j) {
+      SSBEV_WG_STEP(x) SSBEV_WG_STEP(y) SSBEV_WG_STEP(z) SSBEV_WG_STEP(w)
+    }
+#undef SSBEV_WG_STEP
   }
   const int taps = g.kd * g.kh * g.kw;
 #pragma unroll
