@@ -65,9 +65,22 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
   }
   const long Mtot = (long)g.B * Dc * Hc * Wc;
-  const long m_wave = ((long)blockIdx.x * 4 + wave) * (MT * 32);
+  // XCD-aware remap (workgroup L runs on XCD L % 8, each XCD has its own L2): give every XCD one contiguous
+  // range of tiles, N-tile index fastest, so that neighbouring voxel tiles -- which share their kd/kh halo
+  // rows and their whole A operand across N tiles -- hit the SAME L2 instead of eight different ones.
+  int bx, by;
+  {
+    const unsigned n = gridDim.x * gridDim.y;
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    bx = (int)(Lp / gridDim.y);
+    by = (int)(Lp % gridDim.y);
+  }
+  const long m_wave = ((long)bx * 4 + wave) * (MT * 32);
   if (m_wave >= Mtot) return;
-  const int n0 = blockIdx.y * (NT * 32);
+  const int n0 = by * (NT * 32);
 
   // ---- decode this lane's voxel for every M sub-tile ----------------------------------------
   int ob[MT], od[MT], oh[MT], ow[MT];
@@ -507,12 +520,25 @@ __global__ void __launch_bounds__(256)
 wgrad_cf_kernel(const float* __restrict__ Pt, const float* __restrict__ Qp, float* __restrict__ ws, WgradCfGeom g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
-  const int chunk_id = blockIdx.x * 4 + wave;
+  // XCD-aware remap: the gridDim.y*gridDim.z workgroups that walk the SAME voxel chunks (different channel
+  // tiles / tap groups) get consecutive slots of ONE XCD, so they stream the chunk through one shared L2.
+  unsigned bx, byy, bz;
+  {
+    const unsigned per = gridDim.y * gridDim.z, n = gridDim.x * per;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    bx = Lp / per;
+    byy = (Lp % per) % gridDim.y;
+    bz = (Lp % per) / gridDim.y;
+  }
+  const int chunk_id = bx * 4 + wave;
   if (chunk_id >= g.nchunks) return;
   const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
-  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
+  const int qt = byy % nqt, pt = byy / nqt;
   const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
-  int tg = blockIdx.z;
+  int tg = bz;
   const int kwg = tg % kw_groups; tg /= kw_groups;
   const int khg = tg % kh_groups;
   const int kdi = tg / kh_groups;
