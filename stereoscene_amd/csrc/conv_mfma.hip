@@ -114,30 +114,43 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
     kds = g.sd; khs = g.sh; kws = g.sw;
   }
-  // one flat loop over the (wave-uniform) tap list
+  // One flat loop over the (wave-uniform) tap list.  Per-tap lane work is reduced to a mask test and one
+  // pointer add: along each axis the source coordinate is  base + i*step  (i = tap ordinal), so validity
+  // is a per-axis bit mask computed once, and the tap's address offset is wave-uniform (scalar registers).
   const int nkd = (g.kd - kd0 + kds - 1) / kds, nkh = (g.kh - kh0 + khs - 1) / khs, nkw = (g.kw - kw0 + kws - 1) / kws;
   const int ntaps = (kd0 < g.kd && kh0 < g.kh && kw0 < g.kw) ? nkd * nkh * nkw : 0;
+  int step_d, step_h, step_w;
+  if (g.form == 0) { step_d = g.dd; step_h = g.dh; step_w = g.dw; }
+  else { step_d = -(kds * g.dd) / g.sd; step_h = -(khs * g.dh) / g.sh; step_w = -(kws * g.dw) / g.sw; }
+  const float* pbase[MT];
+  unsigned vmask[MT];          // bit (ia*8+ib)*8+ic ... packed as three per-axis masks: d | h<<8 | w<<16
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int bd, bh, bw;
+    if (g.form == 0) {
+      bd = od[mt] * g.sd - g.pd; bh = oh[mt] * g.sh - g.ph; bw = ow[mt] * g.sw - g.pw;
+    } else {
+      bd = od[mt] + (par_d + g.pd - kd0 * g.dd) / g.sd;
+      bh = oh[mt] + (par_h + g.ph - kh0 * g.dh) / g.sh;
+      bw = ow[mt] + (par_w + g.pw - kw0 * g.dw) / g.sw;
+    }
+    unsigned m = 0;
+    for (int i = 0; i < nkd && i < 8; ++i) { const int v = bd + i * step_d; m |= (v >= 0 && v < g.Di) ? (1u << i) : 0u; }
+    for (int i = 0; i < nkh && i < 8; ++i) { const int v = bh + i * step_h; m |= (v >= 0 && v < g.Hi) ? (1u << (8 + i)) : 0u; }
+    for (int i = 0; i < nkw && i < 8; ++i) { const int v = bw + i * step_w; m |= (v >= 0 && v < g.Wi) ? (1u << (16 + i)) : 0u; }
+    vmask[mt] = mok[mt] ? m : 0u;
+    // may point outside the tensor for border voxels; only dereferenced under the mask
+    pbase[mt] = x + ((((long)ob[mt] * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin + 4 * lk;
+  }
   for (int ti = 0; ti < ntaps; ++ti) {
-    const int c = kw0 + (ti % nkw) * kws;
-    const int bq = kh0 + ((ti / nkw) % nkh) * khs;
-    const int a = kd0 + (ti / (nkw * nkh)) * kds;
+    const int ic = ti % nkw, ib = (ti / nkw) % nkh, ia = ti / (nkw * nkh);
+    const int c = kw0 + ic * kws, bq = kh0 + ib * khs, a = kd0 + ia * kds;
     const int tap = (a * g.kh + bq) * g.kw + c;
+    const long toff = (((long)ia * step_d * g.Hi + (long)ib * step_h) * g.Wi + (long)ic * step_w) * g.Cin;   // uniform
+    const unsigned need = (1u << ia) | (1u << (8 + ib)) | (1u << (16 + ic));
     const float* ap[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      int id, ih, iw;
-      if (g.form == 0) {
-        id = od[mt] * g.sd - g.pd + a * g.dd;
-        ih = oh[mt] * g.sh - g.ph + bq * g.dh;
-        iw = ow[mt] * g.sw - g.pw + c * g.dw;
-      } else {  // exact divisions by construction of the class / tap walk (dil == 1 when s > 1)
-        id = od[mt] + (par_d + g.pd - a * g.dd) / g.sd;
-        ih = oh[mt] + (par_h + g.ph - bq * g.dh) / g.sh;
-        iw = ow[mt] + (par_w + g.pw - c * g.dw) / g.sw;
-      }
-      const bool ok = mok[mt] && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-      ap[mt] = ok ? x + ((((size_t)ob[mt] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.Cin + 4 * lk : nullptr;
-    }
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = ((vmask[mt] & need) == need) ? pbase[mt] + toff : nullptr;
     const float* wt = wlane + (size_t)tap * w_tap_stride;
     for (int q0 = 0; q0 < Q; q0 += QU) {
       float4 av[QU][MT], bv[QU][NT];
@@ -389,6 +402,7 @@ bool conv_dims_ok(const ssbev_conv_dims* d) {
   if (d->Di <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
   if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || d->sd <= 0 || d->sh <= 0 || d->sw <= 0) return false;
   if (d->dd <= 0 || d->dh <= 0 || d->dw <= 0 || d->pd < 0 || d->ph < 0 || d->pw < 0) return false;
+  if (d->kd > 8 || d->kh > 8 || d->kw > 8) return false;
   const bool strided = d->sd > 1 || d->sh > 1 || d->sw > 1;
   const bool dilated = d->dd > 1 || d->dh > 1 || d->dw > 1;
   if (strided && dilated) return false;

@@ -223,8 +223,9 @@ bool gn_ok(const ssbev_norm_dims* d) {
 GnGeom make_geom(const ssbev_norm_dims* d) {
   GnGeom g;
   g.B = d->B; g.C = d->C; g.G = d->G; g.S = d->S; g.eps = d->eps; g.relu = d->relu;
-  // ~2048 blocks over the chip, each at least 64 voxels
-  long chunks = 2048 / d->B;
+  // ~768 blocks over the chip (3 per CU), each at least 64 voxels: enough to saturate HBM, few enough that
+  // the single-workgroup-per-group finalize pass stays in the 10-us range
+  long chunks = 768 / d->B;
   if (chunks < 1) chunks = 1;
   long len = (d->S + chunks - 1) / chunks;
   if (len < 64) len = 64;
