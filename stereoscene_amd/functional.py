@@ -26,23 +26,24 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def span(self, family, flops):
-        return _Span(self, family, flops)
+    def span(self, family, flops, nbytes=0.0):
+        return _Span(self, family, flops, nbytes)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, a, b in self.records:
-            d = out.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+        for fam, flops, nbytes, a, b in self.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += a.elapsed_time(b)
         return out
 
 
 class _Span:
-    def __init__(self, timer, family, flops):
-        self.t, self.family, self.flops = timer, family, flops
+    def __init__(self, timer, family, flops, nbytes):
+        self.t, self.family, self.flops, self.nbytes = timer, family, flops, nbytes
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -51,7 +52,7 @@ class _Span:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.records.append((self.family, self.flops, self.a, self.b))
+        self.t.records.append((self.family, self.flops, self.nbytes, self.a, self.b))
 
 
 class _NoSpan:
@@ -66,8 +67,14 @@ KERNEL_TIMER = None
 _NOSPAN = _NoSpan()
 
 
-def _span(family, flops):
-    return KERNEL_TIMER.span(family, flops) if KERNEL_TIMER is not None else _NOSPAN
+def _span(family, flops, nbytes=0.0):
+    return KERNEL_TIMER.span(family, flops, nbytes) if KERNEL_TIMER is not None else _NOSPAN
+
+
+def conv_bytes(d):
+    """Algorithmic bytes of one conv problem: every input, weight and output element touched once."""
+    taps = d.kd * d.kh * d.kw
+    return 4.0 * (d.B * d.Di * d.Hi * d.Wi * d.Cin + d.B * d.Do * d.Ho * d.Wo * d.Cout + taps * d.Cin * d.Cout)
 
 
 def conv_flops(d):
@@ -341,7 +348,7 @@ class _ConvNd(torch.autograd.Function):
         wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
-        with _span("conv_gather", conv_flops(d)):
+        with _span("conv_gather", conv_flops(d), conv_bytes(d)):
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
                                           capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
@@ -367,7 +374,7 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _packed(w5, d, 1)
             gxcl = torch.empty_like(xcl)
-            with _span("conv_gather", conv_flops(d)):
+            with _span("conv_gather", conv_flops(d), conv_bytes(d)):
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
                                                    capi.stream()), "ssbev_conv_bwd_data")
             if kpad:
@@ -376,7 +383,7 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gwp = torch.empty(tuple(w5.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            with _span("conv_wgrad", conv_flops(d)):
+            with _span("conv_wgrad", conv_flops(d), conv_bytes(d)):
                 capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d),
                                                      capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_conv_bwd_weight")
