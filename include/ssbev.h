@@ -191,6 +191,19 @@ int ssbev_bri_attention_bwd(const float* q, const float* k, const float* v, cons
                             float* gk, float* gv, float* gconf, const ssbev_attn_dims* d, void* ws,
                             size_t ws_bytes, ssbev_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimiser step over one flat fp32 parameter buffer: global gradient L2 norm + fused AdamW with
+ * clip-by-global-norm (the reference recipe, stereoscene.py:203-209: AdamW lr 1e-4 wd 0.01,
+ * grad_clip max_norm 5).  torch.optim.AdamW semantics (decoupled decay, bias correction).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float lr, beta1, beta2, eps, weight_decay, max_grad_norm; int step; } ssbev_adamw_cfg;
+size_t ssbev_grad_norm_workspace(void);
+int ssbev_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t ws_bytes,
+                    ssbev_stream_t stream);
+/* grad_norm: device pointer to the norm (may be NULL or max_grad_norm <= 0 to disable clipping) */
+int ssbev_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                     const ssbev_adamw_cfg* c, const float* grad_norm, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,11 @@ class AttnDims(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Dh", C.c_int)]
 
 
+class AdamWCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int)]
+
+
 _P = C.c_void_p
 # name -> (restype, argtypes); this table is checked against include/ssbev.h by tests/test_capi_symbols.py
 SIGNATURES = {
@@ -80,6 +85,9 @@ SIGNATURES = {
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
+    "ssbev_grad_norm_workspace": (C.c_size_t, []),
+    "ssbev_grad_norm": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),
+    "ssbev_adamw_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(AdamWCfg), _P, _P]),
     "ssbev_bri_attention_supported": (C.c_int, [C.POINTER(AttnDims)]),
     "ssbev_bri_attention_workspace": (C.c_size_t, [C.POINTER(AttnDims)]),
     "ssbev_bri_attention_fwd": (C.c_int, [_P] * 6 + [C.POINTER(AttnDims), _P]),
