@@ -36,6 +36,7 @@ struct ConvGeom {
   int form;                            // 0 conv gather, 1 deconv gather
   int relu, accumulate;
   int hint;                            // 0 or MT*100+NT*10+QU
+  int chunk_taps;                      // LDSB variant: taps staged in LDS per pass
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -45,10 +46,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // One wave computes an (MT*32 voxels) x (NT*32 channels) tile.  QU consecutive 8-channel k-steps are
 // unrolled as straight-line code so that all their operand loads are in flight before the first MFMA
 // of the group issues (the compiler then places counted vmcnt waits between the MFMA clusters).
-template <int MT, int NT, int QU>
-__global__ void __launch_bounds__(256)
+// LDSB: the packed weights of this N tile (all taps) are copied ONCE per workgroup into LDS and the B operand
+// is read with ds_read_b128.  For the 32-channel cost-volume layers the 110 KB of weights do not fit the
+// 32 KB L1, so without this every wave streams them from L2 for each of its 64 voxels (as much L2 traffic
+// as the activations themselves); a 16-wave workgroup amortises one copy over 1024 voxels.
+template <int MT, int NT, int QU, int WPB = 4, bool LDSB = false>
+__global__ void __launch_bounds__(WPB * 64)
 conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                    float* __restrict__ y, ConvGeom g) {
+  extern __shared__ __align__(16) float wlds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
@@ -78,9 +84,10 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     bx = (int)(Lp / gridDim.y);
     by = (int)(Lp % gridDim.y);
   }
-  const long m_wave = ((long)bx * 4 + wave) * (MT * 32);
-  if (m_wave >= Mtot) return;
+  const long m_wave = ((long)bx * WPB + wave) * (MT * 32);
   const int n0 = by * (NT * 32);
+  const bool active = m_wave < Mtot;
+  if (!LDSB && !active) return;        // (LDSB: idle waves still take part in the staging barriers)
 
   // ---- decode this lane's voxel for every M sub-tile ----------------------------------------
   int ob[MT], od[MT], oh[MT], ow[MT];
@@ -142,10 +149,26 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     // may point outside the tensor for border voxels; only dereferenced under the mask
     pbase[mt] = x + ((((long)ob[mt] * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin + 4 * lk;
   }
-  for (int ti = 0; ti < ntaps; ++ti) {
+  const int taps_total = g.kd * g.kh * g.kw;
+  const int chunk_taps = LDSB ? g.chunk_taps : taps_total;
+  int ti = 0;
+  for (int t0 = 0; t0 < taps_total; t0 += chunk_taps) {
+  if (LDSB) {   // stage taps [t0, t0+chunk): rows [tap][q][kh] x (NT*32 couts) x float4 of the packed weights
+    const int rows = min(chunk_taps, taps_total - t0) * Q * 2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * NT * 32; i += WPB * 64) {
+      const int r = i / (NT * 32), cc = i - r * (NT * 32);
+      reinterpret_cast<float4*>(wlds)[i] =
+          reinterpret_cast<const float4*>(wp)[((size_t)t0 * Q * 2 + r) * g.CoutPad + n0 + cc];
+    }
+    __syncthreads();
+  }
+  for (; ti < ntaps; ++ti) {
     const int ic = ti % nkw, ib = (ti / nkw) % nkh, ia = ti / (nkw * nkh);
     const int c = kw0 + ic * kws, bq = kh0 + ib * khs, a = kd0 + ia * kds;
     const int tap = (a * g.kh + bq) * g.kw + c;
+    if (tap >= t0 + chunk_taps) break;         // belongs to the next staged chunk
+    if (LDSB && !active) continue;
     const long toff = (((long)ia * step_d * g.Hi + (long)ib * step_h) * g.Wi + (long)ic * step_w) * g.Cin;   // uniform
     const unsigned need = (1u << ia) | (1u << (8 + ib)) | (1u << (16 + ic));
     const float* ap[MT];
@@ -163,7 +186,8 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
           av[u][mt] = (ap[mt] && cok) ? *reinterpret_cast<const float4*>(ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          bv[u][nt] = *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+          bv[u][nt] = LDSB ? reinterpret_cast<const float4*>(wlds)[(((tap - t0) * Q + q) * 2 + lk) * (NT * 32) + nt * 32 + li]
+                           : *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
       }
 #pragma unroll
       for (int u = 0; u < QU; ++u)
@@ -178,6 +202,8 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
           }
     }
   }
+  }   // staged tap chunks
+  if (LDSB && !active) return;
 
   // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lk, col = li ---------------------------
 #pragma unroll
@@ -428,6 +454,35 @@ int launch_gather(const float* x, const float* wp, const float* bias, float* y, 
   return ssbev_launch_status();
 }
 
+// 16-wave workgroups with LDS-resident weights (small-channel layers)
+template <int MT, int QU>
+int launch_gather_ldsb(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+  constexpr int WPB = 16;
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  int classes = 1;
+  if (g.form == 1) {
+    classes = g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  const size_t per_tap = (size_t)(g.CinPad >> 3) * 2 * 32 * 16;
+  const int taps_total = g.kd * g.kh * g.kw;
+  int chunk = (int)((144 * 1024) / per_tap);
+  if (chunk < 1) return SSBEV_EINVAL;
+  if (chunk > taps_total) chunk = taps_total;
+  const int passes = (taps_total + chunk - 1) / chunk;
+  chunk = (taps_total + passes - 1) / passes;            // equalise the passes
+  ConvGeom gg = g;
+  gg.chunk_taps = chunk;
+  const size_t lds = per_tap * chunk;
+  auto kern = conv_gather_kernel<MT, 1, QU, WPB, true>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  dim3 grid(cdiv(Mtot, WPB * MT * 32), cdiv(g.Cout, 32), classes), block(WPB * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, x, wp, bias, y, gg);
+  return ssbev_launch_status();
+}
+
 template <int MT, int NT>
 int launch_gather_qu(int qu, const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g,
                      hipStream_t st) {
@@ -445,6 +500,8 @@ int launch_gather_cfg(int mt, int nt, int qu, const float* x, const float* wp, c
     case 24: return launch_gather_qu<2, 4>(qu, x, wp, bias, y, g, st);
     case 22: return launch_gather_qu<2, 2>(qu, x, wp, bias, y, g, st);
     case 12: return launch_gather_qu<1, 2>(qu, x, wp, bias, y, g, st);
+    case 91: return launch_gather_ldsb<2, 2>(x, wp, bias, y, g, st);      // tuning hook: LDS-resident weights
+    case 92: return launch_gather_ldsb<1, 2>(x, wp, bias, y, g, st);
     default: return SSBEV_EINVAL;
   }
 }
@@ -471,6 +528,12 @@ int dispatch_gather(const float* x, const float* wp, const float* bias, float* y
   const long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
   if (Mtot <= 8192 && (long)g.kd * g.kh * g.kw * g.Cin <= 8192 && g.Cout > 64)   // 48x160 feature maps: many small tiles
     return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);
+  {
+    const size_t wbytes = (size_t)g.kd * g.kh * g.kw * (g.CinPad >> 3) * 2 * 32 * 16;
+    if (g.Cout <= 32 && wbytes <= 144 * 1024 && wbytes >= 32 * 1024 && (g.CinPad >> 3) % 2 == 0 &&
+        gather_blocks(g, 2, 1) >= 2048)
+      return launch_gather_ldsb<2, 2>(x, wp, bias, y, g, st);
+  }
   int nt = (g.Cout % 128 == 0) ? 4 : (g.Cout > 32 ? 2 : 1);
   if (nt == 4 && gather_blocks(g, 2, 4) < 256) nt = 2;
   const int mt = gather_blocks(g, 2, nt) >= 160 ? 2 : 1;
@@ -794,6 +857,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate; g.hint = d->tile_hint;
+  g.chunk_taps = 0;
   return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
 }
 
@@ -806,7 +870,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
-  g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint;
+  g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint; g.chunk_taps = 0;
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }

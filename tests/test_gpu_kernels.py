@@ -301,3 +301,25 @@ def test_bri_attention_golden_module():
     att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})
     out = att(torch.from_numpy(g["q"]).to(DEV), torch.from_numpy(g["kv"]).to(DEV))
     assert maxdiff(out, torch.from_numpy(g["out"])) < 2e-6
+
+
+@pytest.mark.parametrize("hint", [910, 920])
+@pytest.mark.parametrize("tr", [False, True])
+def test_conv_lds_resident_weights_variant(hint, tr):
+    """The 16-wave / LDS-weights gather variant (forced through the tile hint), conv and deconv forms."""
+    B, Cin, Cout, D, H, W = 1, 32, 32, 9, 10, 36
+    x = S.hash_normal("lw/x", (B, Cin, D, H, W))
+    w = S.hash_uniform("lw/w", (Cin, Cout, 3, 3, 3) if tr else (Cout, Cin, 3, 3, 3), -1, 1) * 0.06
+    xc = x.clone().requires_grad_(True)
+    want = TF.conv_transpose3d(xc, w, None, 2, 1, 1) if tr else TF.conv3d(xc, w, None, 1, 1)
+    xg = x.to(DEV).requires_grad_(True)
+    F.TILE_HINT = hint
+    try:
+        got = F.conv_transpose3d(xg, w.to(DEV), None, 2, 1, 1) if tr else F.conv3d(xg, w.to(DEV), None, 1, 1)
+        assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+        go = S.hash_normal("lw/go", tuple(want.shape))
+        want.backward(go)
+        got.backward(go.to(DEV))
+        assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    finally:
+        F.TILE_HINT = 0
