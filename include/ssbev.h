@@ -204,6 +204,24 @@ int ssbev_grad_norm(const float* g, int64_t n, float* norm_out, void* ws, size_t
 int ssbev_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                      const ssbev_adamw_cfg* c, const float* grad_norm, ssbev_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused occupancy-head epilogue: x2 trilinear upsample + softmax + every reduction the SemanticKITTI
+ * losses (CE_ssc / sem_scal / geo_scal, utils/semkitti.py:67-149) and the train-time metric
+ * (occhead.py:345-359) need, in one pass over the coarse logits; nothing of the fine grid is stored.
+ *   logits [B, D, H, W, 20] channels-last;  label [B, 2D, 2H, 2W] uint8 (255 = ignore);  class_weight[20]
+ *   sums[ssbev_occ_loss_num_sums()] (double): ce_num, ce_den, M, sum_p[20], nom[20], cnt[20], conf[20][20]
+ *   backward: coef[41] = dL/d{ce_num, sum_p[20], nom[20]}  ->  grad_logits [B, D, H, W, 20]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, D, H, W, C; } ssbev_occloss_dims;
+int ssbev_occ_loss_num_sums(void);
+size_t ssbev_occ_loss_workspace(const ssbev_occloss_dims* d);
+int ssbev_occ_loss_fwd(const float* logits, const uint8_t* label, const float* class_weight, double* sums,
+                       const ssbev_occloss_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+size_t ssbev_occ_loss_bwd_workspace(const ssbev_occloss_dims* d);
+int ssbev_occ_loss_bwd(const float* logits, const uint8_t* label, const float* class_weight,
+                       const float* coef, float* grad_logits, const ssbev_occloss_dims* d, void* ws,
+                       size_t ws_bytes, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

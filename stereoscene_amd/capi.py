@@ -85,6 +85,11 @@ SIGNATURES = {
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
+    "ssbev_occ_loss_num_sums": (C.c_int, []),
+    "ssbev_occ_loss_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
+    "ssbev_occ_loss_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
+    "ssbev_occ_loss_bwd_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
+    "ssbev_occ_loss_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
     "ssbev_grad_norm_workspace": (C.c_size_t, []),
     "ssbev_grad_norm": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),
     "ssbev_adamw_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(AdamWCfg), _P, _P]),

@@ -570,3 +570,50 @@ class _BriAttention(torch.autograd.Function):
 
 def bri_attention(q, k, v, conf):
     return _BriAttention.apply(q, k, v, conf)
+
+
+# -------------------------------------------------------------------------------------------------
+# fused occupancy-head epilogue
+# -------------------------------------------------------------------------------------------------
+
+
+class _OccLossSums(torch.autograd.Function):
+    """logits [B,20,D,H,W] (coarse), label uint8 [B,2D,2H,2W] -> (diff [41] f64: ce_num, sum_p[20], nom[20];
+    aux [3+20+400] f64: ce_den, M, (unused), cnt[20], conf[20][20]).  Only ``diff`` carries gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, label_u8, class_weight):
+        lib = capi.load()
+        xcl = to_cl(_f32(logits, "occ_loss"))
+        B, D, H, W, Cch = xcl.shape
+        d = capi.UpsampleDims(B, D, H, W, Cch)
+        ns = lib.ssbev_occ_loss_num_sums()
+        sums = torch.empty(ns, dtype=torch.float64, device=logits.device)
+        cw = class_weight.to(device=logits.device, dtype=torch.float32).contiguous()
+        lab = label_u8.contiguous()
+        ws = _ws(lib.ssbev_occ_loss_workspace(C.byref(d)), logits.device)
+        capi.check(lib.ssbev_occ_loss_fwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(sums), C.byref(d),
+                                          capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_fwd")
+        ctx.save_for_backward(xcl, lab, cw)
+        nc = Cch
+        diff = torch.cat((sums[0:1], sums[3:3 + 2 * nc]))
+        aux = torch.cat((sums[1:3], sums[3 + 2 * nc:]))
+        ctx.mark_non_differentiable(aux)
+        return diff, aux
+
+    @staticmethod
+    def backward(ctx, gdiff, _gaux):
+        lib = capi.load()
+        xcl, lab, cw = ctx.saved_tensors
+        B, D, H, W, Cch = xcl.shape
+        d = capi.UpsampleDims(B, D, H, W, Cch)
+        coef = gdiff.to(torch.float32).contiguous()
+        gx = torch.empty_like(xcl)
+        ws = _ws(lib.ssbev_occ_loss_bwd_workspace(C.byref(d)), xcl.device)
+        capi.check(lib.ssbev_occ_loss_bwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(coef), capi.ptr(gx),
+                                          C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_bwd")
+        return from_cl(gx), None, None
+
+
+def occ_loss_sums(logits, label_u8, class_weight):
+    return _OccLossSums.apply(logits, label_u8, class_weight)

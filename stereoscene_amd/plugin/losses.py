@@ -79,8 +79,53 @@ def ssc_counts(pred, gt, n_classes=20, recompute_mask=False):
     return tp, fp, fn, tpc, fpc, fnc
 
 
+def _nll1(v):
+    return -torch.clamp(torch.log(v), min=-100.0)
+
+
+def occ_losses_fused(logits, gt_occ, class_weights, tag="0", w_ce=1.0, w_sem=1.0, w_geo=1.0, compute_metric=False):
+    """Same losses / metric as ``occ_losses`` from the sums of the fused HIP epilogue (one pass over the coarse
+    logits; the up-sampled logits, probabilities and one-hot volumes are never materialised)."""
+    from ..functional import occ_loss_sums
+    nc = logits.shape[1]
+    label = gt_occ.to(torch.uint8)                      # classes 0..19, 255 = ignore
+    diff, aux = occ_loss_sums(logits, label, class_weights)
+    ce_num, sum_p, nom = diff[0], diff[1:1 + nc], diff[1 + nc:1 + 2 * nc]
+    ce_den, M, cnt, conf = aux[0], aux[1], aux[2:2 + nc], aux[2 + nc:].view(nc, nc)
+    out = {}
+    if w_ce > 0:
+        out[f"loss_voxel_ce_{tag}"] = (ce_num / ce_den).float() * w_ce
+    if w_sem > 0:
+        present = cnt > 0
+        neg = M - cnt
+        spec_num = neg - (sum_p - nom)
+        one = torch.ones_like(sum_p)
+        loss_c = torch.where(sum_p > 0, _nll1(nom / torch.where(sum_p > 0, sum_p, one)), torch.zeros_like(sum_p))
+        loss_c = loss_c + _nll1(nom / cnt.clamp_min(1.0))
+        loss_c = loss_c + torch.where(neg > 0, _nll1(spec_num / neg.clamp_min(1.0)), torch.zeros_like(sum_p))
+        out[f"loss_voxel_sem_scal_{tag}"] = ((loss_c * present).sum() / present.sum()).float() * w_sem
+    if w_geo > 0:
+        occ_t = M - cnt[0]
+        inter = occ_t - (sum_p[0] - nom[0])
+        geo = _nll1(inter / (M - sum_p[0])) + _nll1(inter / occ_t) + _nll1(nom[0] / cnt[0])
+        out[f"loss_voxel_geo_scal_{tag}"] = geo.float() * w_geo
+    if compute_metric:
+        with torch.no_grad():
+            tp = conf[1:, 1:].sum()
+            fp = conf[0, 1:].sum()
+            fn = conf[1:, 0].sum()
+            tpc = conf.diagonal()
+            fpc = conf.sum(0) - tpc
+            fnc = conf.sum(1) - tpc
+            out[f"sc_iou_{tag}"] = (tp / (tp + fp + fn)).float()
+            out[f"ssc_miou_{tag}"] = (tpc / (tpc + fpc + fnc + 1e-5))[1:].mean().float()
+    return out
+
+
 def occ_losses(logits, gt_occ, class_weights, tag="0", w_ce=1.0, w_sem=1.0, w_geo=1.0, compute_metric=False):
     """occhead.py:291-361: trilinear upsample to the label grid, CE + sem_scal + geo_scal (+ metric)."""
+    if (logits.is_cuda and logits.shape[1] == 20 and all(o == 2 * i for o, i in zip(gt_occ.shape[-3:], logits.shape[-3:]))):
+        return occ_losses_fused(logits, gt_occ, class_weights, tag, w_ce, w_sem, w_geo, compute_metric)
     if logits.shape[-3:] != gt_occ.shape[-3:]:
         from ..functional import upsample_trilinear
         logits = upsample_trilinear(logits, gt_occ.shape[-3:])

@@ -323,3 +323,25 @@ def test_conv_lds_resident_weights_variant(hint, tr):
         assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     finally:
         F.TILE_HINT = 0
+
+
+# ------------------------------------------------------------------------------------ fused head epilogue
+def test_fused_occ_loss_matches_unfused_and_oracle():
+    from stereoscene_amd.plugin import losses as L
+    lg = S.hash_normal("ol/logits", (2, 20, 8, 6, 4), 2.0)
+    gt = S.synthetic_sample(dict(S.CFG_T, occ_size=(16, 12, 8)), B=2, tag="ol")["gt_occ"]
+    cw = L.semkitti_class_weights()
+    # oracle (CPU, autograd)
+    lc = lg.clone().requires_grad_(True)
+    want = O.occ_losses(lc, gt)
+    sum(want.values()).backward()
+    lgg = lg.to(DEV).requires_grad_(True)
+    got = L.occ_losses_fused(lgg, gt.to(DEV), cw.to(DEV), "0", 1.0, 1.0, 1.0, compute_metric=True)
+    for k, v in want.items():
+        assert abs(float(got[k]) - float(v)) < 2e-5 * max(1.0, abs(float(v))), k
+    sum(v for k, v in got.items() if k.startswith("loss")).backward()
+    assert maxdiff(lgg.grad, lc.grad) < 2e-6
+    up = O.upsample_logits(lg, gt.shape[-3:]).argmax(1)
+    tp, fp, fn, tpc, fpc, fnc = O.ssc_counts(up.numpy(), gt.numpy())
+    sc, miou, _ = O.ssc_scores(tp, fp, fn, tpc, fpc, fnc)
+    assert abs(float(got["sc_iou_0"]) - sc) < 1e-6 and abs(float(got["ssc_miou_0"]) - miou) < 1e-6
