@@ -25,6 +25,10 @@
 // two-stage reduction).
 #include "common.h"
 
+#include <array>
+#include <map>
+#include <mutex>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -725,6 +729,362 @@ wgrad_cf_kernel(const float* __restrict__ Pt, const float* __restrict__ Qp, floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of stride-1 3x3 / 3x3x3 "same" convolutions with BOTH operands staged through LDS.
+//
+// gw[tap][ci][co] = sum_v x[v + tap][ci] * gy[v][co]  -- the reduction axis is the voxel axis, so the MFMA
+// operands are x^T and gy^T.  Read from channels-last global memory that is one dword per lane per MFMA
+// with every tap re-reading its shifted row through L1/L2 (PMC on the channel-major variant above: L1 hit
+// rate 40 %, 5x the L2 requests of the forward kernel, one wave per SIMD, matrix pipe 62 % busy).  Here a
+// workgroup walks output rows (b, d, h) of one w-segment: every step it brings RG new x rows per kd plane
+// (plus halo columns) and RG gy rows into LDS with global_load_lds_dwordx4 (global -> LDS without passing
+// through registers; border rows / halo columns / channel padding read a 16-byte zero constant instead, so
+// there is no predication anywhere in the MFMA loop), and its waves take all their operands from LDS:
+//     P (gy):  lds_gy[row][w][co]                   lane (li, lk) -> [w = 2ks + lk][co = 32e + li]
+//     Q (x):   lds_x[plane][ring slot][w+1+j][ci]   the 3x3 (i, j) taps = 3 ring slots x 3 column shifts
+// i.e. per k-step 4 conflict-free LDS instructions (one ds_read_b32 + three ds_read2_b32; the third column of
+// step ks is the first of step ks+1) feed 9 MFMAs, and one global 16-byte load feeds 9 * 16 MFMAs.  x rows
+// live in a ring of 2*RG+2 slots per plane (a row is loaded once and used by three output rows); the loads
+// of step s+1 are issued before the MFMAs of step s, so one barrier per step suffices.
+// Wave roles: wave = (z * MPB + e) * MQB + a  ->  32 ci (a) x 32 co (e) x kd plane z, 9 accumulators each.
+struct WgradLdsGeom {
+  int B, D, H, W, Cp, Cq, kd, pd;
+  int RG, Wseg, nseg, nrg;        // output rows per step, w-segment length, segments per row, row groups per plane
+  int NG;                         // B * D * nrg row groups in total
+  int gpc, nranges;               // row groups per chunk, chunks per segment
+  int nslot;                      // 2 * RG + 2
+};
+
+constexpr int kWgLdsMaxX = 8, kWgLdsMaxG = 4;    // global->LDS wave instructions (x rows, gy rows) per wave and step
+__device__ const float kWgZeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int MQB, int MPB, int KDB>
+__global__ void __launch_bounds__(64 * MQB * MPB * KDB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, float* __restrict__ ws, WgradLdsGeom g) {
+  constexpr int NW = MQB * MPB * KDB, CQ = 32 * MQB, CP = 32 * MPB, MAXX = kWgLdsMaxX, MAXG = kWgLdsMaxG;
+  extern __shared__ __align__(16) float wl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  unsigned bx, byy, bz;
+  {   // XCD-aware remap: the workgroups that walk the SAME chunk (other channel tiles / kd) share one L2
+    const unsigned per = gridDim.y * gridDim.z, n = gridDim.x * per;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    bx = Lp / per;
+    byy = (Lp % per) % gridDim.y;
+    bz = (Lp % per) / gridDim.y;
+  }
+  const int chunk_id = bx;
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * g.Wseg;
+  const int nqt = (g.Cq + CQ - 1) / CQ;
+  const int qt = byy % nqt, pt = byy / nqt;
+  const int kd0 = bz * KDB;
+  const int a = wave % MQB, e = (wave / MQB) % MPB, z = wave / (MQB * MPB);
+
+  const int xrow_f = (g.Wseg + 2) * CQ;          // floats per staged x row
+  const int xplane_f = g.nslot * xrow_f;
+  const int grow_f = g.Wseg * CP;
+  float* xl = wl;                                // [KDB][nslot][Wseg+2][CQ]
+  float* gl = wl + KDB * xplane_f;               // [2][RG][Wseg][CP]
+
+  // Staging work lists: one entry = one wave instruction = 64 consecutive 16-byte items of ONE row.
+  // x entries q = wave + n * NW < nxi (plane-major rows, nxc chunks per row); gy entries likewise over RG * ngc.
+  // Per lane: the float offset of its item relative to the step's base pointer (row, plane and column folded
+  // in; -1 = read zeros, -2 = lane past the row end).  Wave-uniform: row / plane / LDS offset of the entry.
+  const int xper_row = (g.Wseg + 2) * (CQ / 4), gper_row = g.Wseg * (CP / 4);
+  const int nxc = (xper_row + 63) >> 6, ngc = (gper_row + 63) >> 6;
+  const int nxi = KDB * g.RG * nxc, ngi = g.RG * ngc;
+  const int xplane_g = g.H * g.W * g.Cq;                       // floats per (b, d) plane of x
+  int xoff[MAXX], xmeta[MAXX], goff[MAXG], gmeta[MAXG];        // meta: rr | pl << 8 | lds float offset << 10
+#pragma unroll
+  for (int n = 0; n < MAXX; ++n) {
+    const int q = wave + n * NW;
+    int off = -2, meta = -1;
+    if (q < nxi) {
+      const int pr = q / nxc, ch = q % nxc, pl = pr / g.RG, rr = pr % g.RG;
+      const int j = ch * 64 + lane;
+      if (j < xper_row) {
+        const int u = j / (CQ / 4), c = qt * CQ + (j % (CQ / 4)) * 4, wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.Cq) ? pl * xplane_g + (rr * g.W + wsrc) * g.Cq + c : -1;
+      }
+      meta = rr | (pl << 8) | ((pl * xplane_f + ch * 256) << 10);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+#pragma unroll
+  for (int n = 0; n < MAXG; ++n) {
+    const int q = wave + n * NW;
+    int off = -2, meta = -1;
+    if (q < ngi) {
+      const int rr = q / ngc, ch = q % ngc;
+      const int j = ch * 64 + lane;
+      if (j < gper_row) {
+        const int u = j / (CP / 4), c = pt * CP + (j % (CP / 4)) * 4;
+        off = c < g.Cp ? (rr * g.W + w0 + u) * g.Cp + c : -1;
+      }
+      meta = rr | ((rr * grow_f + ch * 256) << 10);
+    }
+    goff[n] = off;
+    gmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+
+  // global -> LDS.  stage_x: padded x rows [hp0, hp0+RG) of planes (b, d + kd0 + pl - pd) into their ring slots;
+  // stage_gy: gy row group Gn into buffer buf.  Everything but the final address add is wave-uniform.
+  auto stage_x = [&](int b, int d, int hp0) {
+    const int slot0 = hp0 % g.nslot;
+    const int d0 = d + kd0 - g.pd;
+    const float* base = X + ((long)(b * g.D + d0) * g.H + (hp0 - 1)) * (long)(g.W * g.Cq);
+#pragma unroll
+    for (int n = 0; n < MAXX; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int rr = meta & 255, pl = (meta >> 8) & 3;
+      const int h = hp0 - 1 + rr, dp = d0 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      int slot = slot0 + rr;
+      slot = slot >= g.nslot ? slot - g.nslot : slot;
+      float* dst = xl + (meta >> 10) + slot * xrow_f;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+  auto stage_gy = [&](int Gn, int buf) {
+    const float* base = GY + (long)Gn * g.RG * (long)(g.W * g.Cp);
+    float* dbase = gl + buf * g.RG * grow_f;
+#pragma unroll
+    for (int n = 0; n < MAXG; ++n) {
+      const int meta = gmeta[n];
+      if (meta < 0) break;
+      const int off = goff[n];
+      const float* src = off >= 0 ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dbase + (meta >> 10), 16, 0, 0);
+    }
+  };
+
+  int cur = 0;
+  bool fresh = true;                    // the x ring does not hold this plane yet
+  const int nks = g.Wseg >> 1;
+  int hg = g_begin % g.nrg, d, b;
+  {
+    const int bd = g_begin / g.nrg;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = hg * g.RG;           // first output row of the step == first padded x row it needs
+    if (fresh) {
+      // padded rows [h0, h0 + RG + 2) in batches of RG rows; the very first step also brings its gy rows
+      for (int r0 = 0; r0 < g.RG + 2; r0 += g.RG) stage_x(b, d, h0 + r0);
+      if (G == g_begin) stage_gy(G, cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool has_next = G + 1 < g_end;
+    const bool same_plane = has_next && hg + 1 < g.nrg;
+    if (has_next) stage_gy(G + 1, cur ^ 1);
+    if (same_plane) stage_x(b, d, h0 + g.RG + 2);
+
+    {
+      const float* gyb = gl + cur * g.RG * grow_f + e * 32 + li + lk * CP;
+      const float* xb = xl + z * xplane_f + a * 32 + li + lk * CQ;
+      int s0 = h0 % g.nslot;
+      for (int rr = 0; rr < g.RG; ++rr) {
+        int s1 = s0 + 1; if (s1 >= g.nslot) s1 -= g.nslot;
+        int s2 = s1 + 1; if (s2 >= g.nslot) s2 -= g.nslot;
+        const float* x0 = xb + s0 * xrow_f;
+        const float* x1 = xb + s1 * xrow_f;
+        const float* x2 = xb + s2 * xrow_f;
+        const float* gp = gyb + rr * grow_f;
+        // two k-steps per trip; the operands of the next k-step are in flight while the 9 MFMAs of this one
+        // issue.  All LDS addresses are (walking pointer + immediate).  The last trip prefetches one k-step
+        // past the row (never consumed; the launch reserves slack behind the gy buffers for it).
+        const float* p0 = x0;
+        const float* p1 = x1;
+        const float* p2 = x2;
+        const float* pg = gp;
+        float c0 = p0[0], c1 = p1[0], c2 = p2[0];
+        float pA = pg[0];
+        float a01 = p0[CQ], a02 = p0[2 * CQ], a11 = p1[CQ], a12 = p1[2 * CQ], a21 = p2[CQ], a22 = p2[2 * CQ];
+        for (int ks = 0; ks < nks; ks += 2) {
+          acc[0][0] = mfma32(c0, pA, acc[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          const float pB = pg[2 * CP];
+          const float b01 = p0[3 * CQ], b02 = p0[4 * CQ];
+          const float b11 = p1[3 * CQ], b12 = p1[4 * CQ];
+          const float b21 = p2[3 * CQ], b22 = p2[4 * CQ];
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][0] = mfma32(c1, pA, acc[1][0]);
+          acc[2][0] = mfma32(c2, pA, acc[2][0]);
+          acc[0][1] = mfma32(a01, pA, acc[0][1]);
+          acc[1][1] = mfma32(a11, pA, acc[1][1]);
+          acc[2][1] = mfma32(a21, pA, acc[2][1]);
+          acc[0][2] = mfma32(a02, pA, acc[0][2]);
+          acc[1][2] = mfma32(a12, pA, acc[1][2]);
+          acc[2][2] = mfma32(a22, pA, acc[2][2]);
+          __builtin_amdgcn_sched_barrier(0);
+          c0 = a02; c1 = a12; c2 = a22;
+          acc[0][0] = mfma32(c0, pB, acc[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          pA = pg[4 * CP];
+          a01 = p0[5 * CQ]; a02 = p0[6 * CQ];
+          a11 = p1[5 * CQ]; a12 = p1[6 * CQ];
+          a21 = p2[5 * CQ]; a22 = p2[6 * CQ];
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][0] = mfma32(c1, pB, acc[1][0]);
+          acc[2][0] = mfma32(c2, pB, acc[2][0]);
+          acc[0][1] = mfma32(b01, pB, acc[0][1]);
+          acc[1][1] = mfma32(b11, pB, acc[1][1]);
+          acc[2][1] = mfma32(b21, pB, acc[2][1]);
+          acc[0][2] = mfma32(b02, pB, acc[0][2]);
+          acc[1][2] = mfma32(b12, pB, acc[1][2]);
+          acc[2][2] = mfma32(b22, pB, acc[2][2]);
+          __builtin_amdgcn_sched_barrier(0);
+          c0 = b02; c1 = b12; c2 = b22;
+          p0 += 4 * CQ; p1 += 4 * CQ; p2 += 4 * CQ; pg += 4 * CP;
+        }
+        s0 = s1;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fresh = !same_plane;
+    cur ^= 1;
+    if (++hg == g.nrg) {
+      hg = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+
+  const int taps = g.kd * 9;
+  const int kdi = kd0 + z;
+  if (kdi < g.kd) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int tap = (kdi * 3 + i) * 3 + j;
+        float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+        const int pc = pt * CP + e * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = qt * CQ + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = acc[i][j][r];
+        }
+      }
+  }
+}
+
+constexpr int kWgLdsRowVox = 32;                 // target voxels (= 2 x MFMA k-steps) per step
+constexpr size_t kWgLdsMaxBytes = 64 * 1024;     // LDS per workgroup (two workgroups per CU; M0-addressable)
+
+struct WgradLdsPlan {
+  WgradLdsGeom g;
+  int cfg;              // 0: <2,2,1> (64 ci x 64 co, one kd per workgroup), 1: <1,1,3> (32 x 32, all kd)
+  int nchunks;
+  size_t lds_bytes;
+  bool ok;
+};
+
+WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d);
+
+// the chunking search is a few 10k iterations: done once per problem shape
+WgradLdsPlan plan_wgrad_lds(const ssbev_conv_dims* d) {
+  static std::mutex mu;
+  static std::map<std::array<int, 21>, WgradLdsPlan> cache;
+  const std::array<int, 21> key = {d->B, d->Cin, d->Cout, d->Di, d->Hi, d->Wi, d->Do, d->Ho, d->Wo, d->kd, d->kh,
+                                   d->kw, d->sd, d->sh, d->sw, d->pd, d->ph, d->pw, d->dd * 64 + d->dh * 8 + d->dw,
+                                   d->transposed, 0};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const WgradLdsPlan p = plan_wgrad_lds_uncached(d);
+  cache.emplace(key, p);
+  return p;
+}
+
+WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
+  WgradLdsPlan p;
+  p.ok = false;
+  if (d->transposed || d->sd != 1 || d->sh != 1 || d->sw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return p;
+  if (d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || (d->kd != 1 && d->kd != 3) || d->pd != d->kd / 2) return p;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return p;
+  if (d->Wo % 4 != 0 || d->Cin % 4 != 0 || d->Cout % 4 != 0) return p;
+  WgradLdsGeom& g = p.g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo; g.Cp = d->Cout; g.Cq = d->Cin; g.kd = d->kd; g.pd = d->pd;
+  p.cfg = (g.Cp <= 32 && g.Cq <= 32 && g.kd == 3) ? 1 : 0;
+  const int CQ = p.cfg ? 32 : 64, CP = CQ, KDB = p.cfg ? 3 : 1, NW = p.cfg ? 3 : 4;
+  const long tiles = (long)cdiv(g.Cq, CQ) * cdiv(g.Cp, CP) * (g.kd / KDB);
+  double best = 1e30;
+  for (int Wseg = 4; Wseg <= g.W && Wseg <= 80; Wseg += 4) {
+    if (g.W % Wseg) continue;
+    // rows per step: aim at >= 16 MFMA k-steps per barrier, within the staging registers and LDS
+    int RG = 1;
+    while (RG * 2 <= g.H && g.H % (RG * 2) == 0 && RG * 2 <= 16 && RG * Wseg < kWgLdsRowVox) RG *= 2;
+    auto fits = [&](int rg) {
+      return (long)KDB * rg * cdiv((Wseg + 2) * (CQ / 4), 64) <= (long)kWgLdsMaxX * NW &&
+             (long)rg * cdiv(Wseg * (CP / 4), 64) <= (long)kWgLdsMaxG * NW;
+    };
+    auto lds_of = [&](int rg) {
+      return ((size_t)KDB * (2 * rg + 2) * (Wseg + 2) * CQ + 2ul * rg * Wseg * CP) * sizeof(float);
+    };
+    while (RG > 1 && (!fits(RG) || lds_of(RG) > kWgLdsMaxBytes)) RG /= 2;
+    const size_t lds = lds_of(RG);
+    if (!fits(RG) || lds > kWgLdsMaxBytes || g.H % RG) continue;
+    const int nseg = g.W / Wseg, nrg = g.H / RG;
+    const long NG = (long)g.B * g.D * nrg;
+    const long resident = 512;                       // two workgroups per CU
+    const double step_cost = (double)RG * Wseg / 2 + 3.0;          // MFMA k-steps + barrier / staging overhead
+    for (long nr = 1; nr <= NG && nr <= 2048; ++nr) {
+      const long gpc = (NG + nr - 1) / nr;
+      const long nranges = (NG + gpc - 1) / gpc;
+      if (nranges != nr) continue;
+      const long blocks = tiles * nseg * nranges;
+      const size_t wsb = (size_t)nseg * nranges * g.kd * 9 * g.Cp * g.Cq * sizeof(float);
+      if (wsb > (768ul << 20)) break;
+      const long rounds = (blocks + resident - 1) / resident;
+      const double planes = 1.0 + (double)gpc / nrg;
+      const double t = rounds * (gpc * step_cost + planes * 2.5 * step_cost + 30.0) * (1.0 + 2.0 / Wseg);
+      if (t < best) {
+        best = t;
+        g.RG = RG; g.Wseg = Wseg; g.nseg = nseg; g.nrg = nrg; g.NG = (int)NG; g.gpc = (int)gpc;
+        g.nranges = (int)nranges; g.nslot = 2 * RG + 2;
+        p.nchunks = (int)(nseg * nranges);
+        p.lds_bytes = lds;
+        p.ok = true;
+      }
+    }
+  }
+  return p;
+}
+
+template <int MQB, int MPB, int KDB>
+int launch_wgrad_lds(const float* x, const float* gy, float* ws, const WgradLdsPlan& p, hipStream_t st) {
+  const WgradLdsGeom& g = p.g;
+  auto kern = wgrad_lds_kernel<MQB, MPB, KDB>;
+  if (p.lds_bytes > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)p.lds_bytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB);
+  hipLaunchKernelGGL(kern, grid, block, p.lds_bytes + 1024, st, x, gy, ws, g);      // +1 KB: prefetch slack
+  return SSBEV_OK;
+}
+
 bool wgrad_cf_applicable(const ssbev_conv_dims* d) {
   if (d->transposed || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
@@ -856,7 +1216,8 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo;
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
-  g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate; g.hint = d->tile_hint;
+  g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate;
+  g.hint = d->tile_hint >= 10 ? d->tile_hint : 0;       // hints below 10 select weight-gradient variants
   g.chunk_taps = 0;
   return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
 }
@@ -870,13 +1231,18 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
-  g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint; g.chunk_taps = 0;
+  g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint >= 10 ? d->tile_hint : 0; g.chunk_taps = 0;
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }
 
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
+  {
+    const WgradLdsPlan lp = plan_wgrad_lds(d);
+    if (lp.ok && d->tile_hint != 7)
+      return align256b((size_t)lp.nchunks * d->kd * 9 * d->Cout * d->Cin * sizeof(float));
+  }
   if (wgrad_cf_applicable(d)) {
     WgradCfg c;
     const WgradCfGeom g = make_wgrad_cf_geom(d, &c);
@@ -893,6 +1259,21 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  {
+    const WgradLdsPlan lp = plan_wgrad_lds(d);
+    if (lp.ok && d->tile_hint != 7) {          // tile_hint 7: force the channel-major path (tests / A-B timing)
+      hipStream_t st = as_stream(stream);
+      float* partial = static_cast<float*>(ws);
+      const int rc = lp.cfg ? launch_wgrad_lds<1, 1, 3>(x, gy, partial, lp, st)
+                            : launch_wgrad_lds<2, 2, 1>(x, gy, partial, lp, st);
+      if (rc != SSBEV_OK) return rc;
+      const int taps = d->kd * 9;
+      const long total = (long)taps * d->Cin * d->Cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, lp.nchunks, taps,
+                         d->Cin, d->Cout, total);
+      return ssbev_launch_status();
+    }
+  }
   if (wgrad_cf_applicable(d)) {
     hipStream_t st = as_stream(stream);
     WgradCfg c;

@@ -26,13 +26,24 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def span(self, family, flops, nbytes=0.0):
-        return _Span(self, family, flops, nbytes)
+    def span(self, family, flops, nbytes=0.0, tag=None):
+        return _Span(self, family, flops, nbytes, tag)
+
+    def by_tag(self):
+        """{(family, tag): dict(launches, flops, ms)} -- the per-layer table of tools/layer_table.py."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, nbytes, a, b, tag in self.records:
+            d = out.setdefault((fam, tag), dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += a.elapsed_time(b)
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, nbytes, a, b in self.records:
+        for fam, flops, nbytes, a, b, _tag in self.records:
             d = out.setdefault(fam, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
@@ -42,8 +53,8 @@ class KernelTimer:
 
 
 class _Span:
-    def __init__(self, timer, family, flops, nbytes):
-        self.t, self.family, self.flops, self.nbytes = timer, family, flops, nbytes
+    def __init__(self, timer, family, flops, nbytes, tag=None):
+        self.t, self.family, self.flops, self.nbytes, self.tag = timer, family, flops, nbytes, tag
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -52,7 +63,7 @@ class _Span:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.records.append((self.family, self.flops, self.nbytes, self.a, self.b))
+        self.t.records.append((self.family, self.flops, self.nbytes, self.a, self.b, self.tag))
 
 
 class _NoSpan:
@@ -67,8 +78,13 @@ KERNEL_TIMER = None
 _NOSPAN = _NoSpan()
 
 
-def _span(family, flops, nbytes=0.0):
-    return KERNEL_TIMER.span(family, flops, nbytes) if KERNEL_TIMER is not None else _NOSPAN
+def _span(family, flops, nbytes=0.0, tag=None):
+    return KERNEL_TIMER.span(family, flops, nbytes, tag) if KERNEL_TIMER is not None else _NOSPAN
+
+
+def _conv_tag(d, role):
+    return (f"{role:5s} {'T' if d.transposed else 'C'} {d.Cin:3d}->{d.Cout:3d} in {d.Di}x{d.Hi}x{d.Wi} "
+            f"k{d.kd}{d.kh}{d.kw} s{d.sd}{d.sh}{d.sw} d{d.dd}{d.dh}{d.dw}")
 
 
 def conv_bytes(d):
@@ -348,7 +364,7 @@ class _ConvNd(torch.autograd.Function):
         wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
-        with _span("conv_gather", conv_flops(d), conv_bytes(d)):
+        with _span("conv_gather", conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd")):
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
                                           capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
@@ -374,7 +390,7 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _packed(w5, d, 1)
             gxcl = torch.empty_like(xcl)
-            with _span("conv_gather", conv_flops(d), conv_bytes(d)):
+            with _span("conv_gather", conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad")):
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
                                                    capi.stream()), "ssbev_conv_bwd_data")
             if kpad:
@@ -383,7 +399,7 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gwp = torch.empty(tuple(w5.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            with _span("conv_wgrad", conv_flops(d), conv_bytes(d)):
+            with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
                 capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d),
                                                      capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_conv_bwd_weight")

@@ -193,6 +193,51 @@ def test_conv3d_family_fwd_bwd(case):
         assert maxdiff(bg.grad, bc.grad) < 5e-5 * max(1.0, bc.grad.abs().max().item())
 
 
+WGRAD_LDS_CASES = [
+    # (B, Cin, Cout, D, H, W): stride-1 3x3x3 "same" convs -> the LDS-staged weight-gradient kernel; the shapes walk the
+    # planner's branches (32x32 all-kd workgroups, 64x64 tiles, rows per step 1/2/4/8, w-segments, channel clamps)
+    (1, 32, 32, 5, 8, 16), (2, 32, 32, 4, 6, 40), (1, 4, 32, 6, 4, 8), (1, 32, 1, 4, 8, 4), (1, 128, 128, 6, 8, 16),
+    (1, 96, 80, 3, 4, 8), (1, 64, 64, 3, 24, 80), (1, 256, 256, 4, 16, 8), (1, 512, 64, 4, 8, 4), (2, 32, 32, 3, 5, 160),
+    (1, 64, 192, 9, 10, 12),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_LDS_CASES)
+def test_wgrad_lds_matches_aten_and_channel_major_path(case):
+    B, Cin, Cout, D, H, W = case
+    x = S.hash_normal(f"wl/x{case}", (B, Cin, D, H, W))
+    w = S.hash_uniform(f"wl/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    go = S.hash_normal(f"wl/go{case}", (B, Cout, D, H, W))
+    wc = w.clone().requires_grad_(True)
+    TF.conv3d(x, wc, None, 1, 1).backward(go)
+    grads = []
+    for hint in (0, 7):                       # 7 = force the channel-major (transposed-copy) kernel
+        F.TILE_HINT = hint
+        try:
+            wg = w.to(DEV).requires_grad_(True)
+            F.conv3d(x.to(DEV), wg, None, 1, 1).backward(go.to(DEV))
+        finally:
+            F.TILE_HINT = 0
+        grads.append(wg.grad.cpu())
+        assert (grads[-1] - wc.grad).abs().max().item() < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    assert (grads[0] - grads[1]).abs().max().item() < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+def test_wgrad_lds_2d_and_determinism():
+    x = S.hash_normal("wl2/x", (2, 640, 12, 160))
+    w = S.hash_uniform("wl2/w", (72, 640, 3, 3), -1, 1) * (3.0 / (640 * 9)) ** 0.5
+    go = S.hash_normal("wl2/go", (2, 72, 12, 160))
+    wc = w.clone().requires_grad_(True)
+    TF.conv2d(x, wc, None, 1, 1).backward(go)
+    outs = []
+    for _ in range(2):
+        wg = w.to(DEV).requires_grad_(True)
+        F.conv2d(x.to(DEV), wg, None, 1, 1).backward(go.to(DEV))
+        outs.append(wg.grad)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].cpu() - wc.grad).abs().max().item() < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("Cin,Cout,k,p,dil,bias", [(640, 128, 3, 1, 1, True), (128, 64, 1, 0, 1, True),
                                                   (64, 64, 3, 6, 6, False), (64, 64, 3, 18, 18, False)])
 def test_conv2d_incl_dilation(Cin, Cout, k, p, dil, bias):
