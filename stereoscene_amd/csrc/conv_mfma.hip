@@ -25,6 +25,7 @@
 // two-stage reduction).
 #include "common.h"
 
+#include <algorithm>
 #include <array>
 #include <map>
 #include <mutex>
@@ -730,6 +731,103 @@ wgrad_cf_kernel(const float* __restrict__ Pt, const float* __restrict__ Qp, floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of a stride-1 1x1(x1) convolution: a plain [Cq x N] x [N x Cp] GEMM whose reduction axis is
+// the voxel axis.  HBM-bound (both activations are read once, 2 flop per loaded byte at C = 32), so no staging:
+// lane (li, lk) reads channel li of voxel v + lk straight from the channels-last rows (each half wave = one
+// 128-byte line), U k-steps of loads in flight per wave, many light waves per SIMD.
+template <int MQ, int MP>
+__global__ void __launch_bounds__(1024)
+wgrad_1x1_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ ws, long N, int Cq,
+                 int Cp, int chunk, int nchunks) {
+  constexpr int U = 8;
+  __shared__ float red[8][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int chunk_id = blockIdx.x * 16 + wave;          // chunks past the end are empty ranges
+  const int nqt = (Cq + 32 * MQ - 1) / (32 * MQ);
+  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
+  int pch[MP], qch[MQ];
+#pragma unroll
+  for (int e = 0; e < MP; ++e) pch[e] = min((pt * MP + e) * 32 + li, Cp - 1);
+#pragma unroll
+  for (int a = 0; a < MQ; ++a) qch[a] = min((qt * MQ + a) * 32 + li, Cq - 1);
+  f32x16 acc[MQ][MP];
+#pragma unroll
+  for (int a = 0; a < MQ; ++a)
+#pragma unroll
+    for (int e = 0; e < MP; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][e][r] = 0.0f;
+  const long v_begin = min(N, (long)chunk_id * chunk), v_end = min(N, v_begin + chunk);
+  for (long v0 = v_begin; v0 < v_end; v0 += 2 * U) {
+    float pv[U][MP], qv[U][MQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = v0 + 2 * u + lk;
+      const bool ok = v < v_end;
+      const long vs = ok ? v : v_begin;
+#pragma unroll
+      for (int e = 0; e < MP; ++e) { const float t = P[vs * Cp + pch[e]]; pv[u][e] = ok ? t : 0.0f; }
+#pragma unroll
+      for (int a = 0; a < MQ; ++a) qv[u][a] = Q[vs * Cq + qch[a]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < MQ; ++a)
+#pragma unroll
+        for (int e = 0; e < MP; ++e) acc[a][e] = mfma32(qv[u][a], pv[u][e], acc[a][e]);
+  }
+  // the 16 waves of the workgroup are folded through LDS in a fixed order (two passes of 8), one 32x32 tile at
+  // a time; thread t owns element t of the tile
+  float* dst = ws + (size_t)blockIdx.x * Cq * Cp;
+#pragma unroll
+  for (int a = 0; a < MQ; ++a)
+#pragma unroll
+    for (int e = 0; e < MP; ++e) {
+      float t = 0.0f;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 3) == pass) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[wave & 7][r * 64 + lane] = acc[a][e][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w][threadIdx.x];
+        __syncthreads();
+      }
+      const int r = threadIdx.x >> 6;
+      const int row = (qt * MQ + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int pc = (pt * MP + e) * 32 + li;
+      if (row < Cq && pc < Cp) dst[(size_t)row * Cp + pc] = t;
+    }
+}
+
+struct Wgrad1x1Plan { bool ok; int MQ, MP, chunk, nchunks; long N; int Cp, Cq; };
+
+Wgrad1x1Plan plan_wgrad_1x1(const ssbev_conv_dims* d) {
+  Wgrad1x1Plan p;
+  p.ok = d->kd == 1 && d->kh == 1 && d->kw == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->pd == 0 && d->ph == 0 &&
+         d->pw == 0 && d->Di == d->Do && d->Hi == d->Ho && d->Wi == d->Wo;
+  if (!p.ok) return p;
+  p.Cp = d->transposed ? d->Cin : d->Cout;
+  p.Cq = d->transposed ? d->Cout : d->Cin;
+  p.N = (long)d->B * d->Do * d->Ho * d->Wo;
+  p.MQ = p.Cq > 32 ? 2 : 1;
+  p.MP = p.Cp > 32 ? 2 : 1;
+  const long tiles = (long)cdiv(p.Cq, 32 * p.MQ) * cdiv(p.Cp, 32 * p.MP);
+  // ~32 waves per CU in total (16 loads in flight each), at least 256 voxels per wave, partials bounded to 64 MB
+  long waves = std::max(16L, 8192 / tiles);
+  waves = std::min(waves, std::max(1L, p.N / 256));
+  waves = std::min(waves, std::max(1L, (64L << 20) / ((long)p.Cq * p.Cp * 4)));
+  long chunk = (p.N + waves - 1) / waves;
+  chunk = (chunk + 15) & ~15L;
+  p.chunk = (int)chunk;
+  p.nchunks = (int)cdiv((p.N + chunk - 1) / chunk, 16);       // partial tiles = workgroups (16 waves folded in LDS)
+  return p;
+}
+
 // Weight gradient of stride-1 3x3 / 3x3x3 "same" convolutions with BOTH operands staged through LDS.
 //
 // gw[tap][ci][co] = sum_v x[v + tap][ci] * gy[v][co]  -- the reduction axis is the voxel axis, so the MFMA
@@ -1239,6 +1337,10 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
   {
+    const Wgrad1x1Plan p1 = plan_wgrad_1x1(d);
+    if (p1.ok && d->tile_hint != 7) return align256b((size_t)p1.nchunks * p1.Cq * p1.Cp * sizeof(float));
+  }
+  {
     const WgradLdsPlan lp = plan_wgrad_lds(d);
     if (lp.ok && d->tile_hint != 7)
       return align256b((size_t)lp.nchunks * d->kd * 9 * d->Cout * d->Cin * sizeof(float));
@@ -1259,6 +1361,28 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  {
+    const Wgrad1x1Plan p1 = plan_wgrad_1x1(d);
+    if (p1.ok && d->tile_hint != 7) {
+      hipStream_t st = as_stream(stream);
+      const float* P = d->transposed ? x : gy;
+      const float* Q = d->transposed ? gy : x;
+      float* partial = static_cast<float*>(ws);
+      dim3 grid(p1.nchunks, cdiv(p1.Cq, 32 * p1.MQ) * cdiv(p1.Cp, 32 * p1.MP)), block(1024);
+      if (p1.MQ == 2 && p1.MP == 2)
+        hipLaunchKernelGGL((wgrad_1x1_kernel<2, 2>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
+      else if (p1.MQ == 2)
+        hipLaunchKernelGGL((wgrad_1x1_kernel<2, 1>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
+      else if (p1.MP == 2)
+        hipLaunchKernelGGL((wgrad_1x1_kernel<1, 2>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
+      else
+        hipLaunchKernelGGL((wgrad_1x1_kernel<1, 1>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
+      const long total = (long)p1.Cq * p1.Cp;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, p1.nchunks, 1, p1.Cq,
+                         p1.Cp, total);
+      return ssbev_launch_status();
+    }
+  }
   {
     const WgradLdsPlan lp = plan_wgrad_lds(d);
     if (lp.ok && d->tile_hint != 7) {          // tile_hint 7: force the channel-major path (tests / A-B timing)

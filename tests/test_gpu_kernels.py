@@ -157,6 +157,10 @@ CONV_CASES = [
     (1, 32, 1, 4, 5, 6, 3, 1, 1, 1, False, 0, True),
     (1, 192, 20, 4, 4, 4, 1, 1, 0, 1, False, 0, False),
     (1, 384, 192, 3, 4, 4, 3, 1, 1, 1, False, 0, False),
+    # 1x1x1 weight gradients (dedicated streaming kernel): odd voxel counts, 64-wide tiles, many chunks
+    (2, 32, 32, 9, 11, 13, 1, 1, 0, 1, False, 0, False),
+    (1, 64, 96, 8, 8, 8, 1, 1, 0, 1, False, 0, True),
+    (1, 32, 32, 32, 48, 160, 1, 1, 0, 1, False, 0, False),
     # large-M problems: exercise the big register tiles <4,1>, <2,2>, <2,4> of the gather kernel
     (1, 32, 32, 32, 64, 136, 3, 1, 1, 1, False, 0, False),
     (1, 32, 64, 64, 64, 72, 3, 2, 1, 1, False, 0, False),
