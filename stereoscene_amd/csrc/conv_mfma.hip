@@ -828,38 +828,43 @@ Wgrad1x1Plan plan_wgrad_1x1(const ssbev_conv_dims* d) {
   return p;
 }
 
-// Weight gradient of stride-1 3x3 / 3x3x3 "same" convolutions with BOTH operands staged through LDS.
+// Weight gradient of 3x3 / 3x3x3 convolutions (stride 1 "same", stride-2 k3 p1, and the k3 s2 p1 op1 transposed
+// convolution) with BOTH operands staged through LDS.
 //
-// gw[tap][ci][co] = sum_v x[v + tap][ci] * gy[v][co]  -- the reduction axis is the voxel axis, so the MFMA
-// operands are x^T and gy^T.  Read from channels-last global memory that is one dword per lane per MFMA
-// with every tap re-reading its shifted row through L1/L2 (PMC on the channel-major variant above: L1 hit
-// rate 40 %, 5x the L2 requests of the forward kernel, one wave per SIMD, matrix pipe 62 % busy).  Here a
-// workgroup walks output rows (b, d, h) of one w-segment: every step it brings RG new x rows per kd plane
-// (plus halo columns) and RG gy rows into LDS with global_load_lds_dwordx4 (global -> LDS without passing
-// through registers; border rows / halo columns / channel padding read a 16-byte zero constant instead, so
-// there is no predication anywhere in the MFMA loop), and its waves take all their operands from LDS:
-//     P (gy):  lds_gy[row][w][co]                   lane (li, lk) -> [w = 2ks + lk][co = 32e + li]
-//     Q (x):   lds_x[plane][ring slot][w+1+j][ci]   the 3x3 (i, j) taps = 3 ring slots x 3 column shifts
-// i.e. per k-step 4 conflict-free LDS instructions (one ds_read_b32 + three ds_read2_b32; the third column of
-// step ks is the first of step ks+1) feed 9 MFMAs, and one global 16-byte load feeds 9 * 16 MFMAs.  x rows
-// live in a ring of 2*RG+2 slots per plane (a row is loaded once and used by three output rows); the loads
-// of step s+1 are issued before the MFMAs of step s, so one barrier per step suffices.
-// Wave roles: wave = (z * MPB + e) * MQB + a  ->  32 ci (a) x 32 co (e) x kd plane z, 9 accumulators each.
+// gw[tap][cq][cp] = sum_v Q[S*v + tap - 1][cq] * P[v][cp]: P is the tensor on the coarse grid (gy of a
+// convolution, x of a transposed one), Q the tensor the taps slide over, S the stride.  The reduction axis is
+// the voxel axis, so the MFMA operands are Q^T and P^T.  Read from channels-last global memory that is one
+// dword per lane per MFMA with every tap re-reading its shifted row through L1/L2 (PMC on the channel-major
+// variant below: L1 hit rate 40 %, 5x the L2 requests of the forward kernel, one wave per SIMD, matrix pipe
+// 62 % busy).  Here a workgroup walks P rows (b, d, h) of one w-segment: every step it brings S*RG new Q rows
+// per kd plane (plus halo columns) and RG P rows into LDS with global_load_lds_dwordx4 (global -> LDS without
+// passing through registers; border rows / halo columns / channel padding read a 16-byte zero constant
+// instead, so there is no predication anywhere in the MFMA loop), and its waves take all operands from LDS:
+//     P:  lds_p[row][w][cp]                           lane (li, lk) -> [w = 2ks + lk][cp = 32e + li]
+//     Q:  lds_q[plane][ring slot][S*w + j][cq]        the 3x3 (i, j) taps = 3 ring slots x 3 column shifts
+// At stride 1 a k-step costs 4 conflict-free LDS instructions (one ds_read_b32 + three ds_read2_b32; the third
+// column of step ks is the first of step ks+1) for 9 MFMAs, and one global 16-byte load feeds 9 * 16 MFMAs.
+// Q rows live in a ring of slots per plane (a row is loaded once and used by up to three P rows); the loads of
+// step s+1 are issued before the MFMAs of step s, so one barrier per step suffices.
+// Wave roles: wave = ((ksp * KDB + z) * MPB + e) * MQB + a -> 32 cq (a) x 32 cp (e) x kd plane z, 9 accumulators;
+// KSPLIT > 1 splits the k-steps of a row between waves (their partial tiles go to separate workspace slabs).
 struct WgradLdsGeom {
-  int B, D, H, W, Cp, Cq, kd, pd;
-  int RG, Wseg, nseg, nrg;        // output rows per step, w-segment length, segments per row, row groups per plane
-  int NG;                         // B * D * nrg row groups in total
+  int B, Dp, Hp, Wp;              // grid of P
+  int Dq, Hq, Wq;                 // grid of Q
+  int Cp, Cq, kd, pd, SD;         // SD = stride along d (1 for 2-D problems)
+  int RG, Wseg, nseg, nrg;        // P rows per step, w-segment length (P voxels), segments per row, row groups per plane
+  int NG;                         // B * Dp * nrg row groups in total
   int gpc, nranges;               // row groups per chunk, chunks per segment
-  int nslot;                      // 2 * RG + 2
+  int nslot;                      // ring slots per plane
 };
 
-constexpr int kWgLdsMaxX = 8, kWgLdsMaxG = 4;    // global->LDS wave instructions (x rows, gy rows) per wave and step
+constexpr int kWgLdsMaxX = 8, kWgLdsMaxG = 4;    // global->LDS wave instructions (Q rows, P rows) per wave and step
 __device__ const float kWgZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int MQB, int MPB, int KDB>
-__global__ void __launch_bounds__(64 * MQB * MPB * KDB) __attribute__((amdgpu_waves_per_eu(2, 2)))
-wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, float* __restrict__ ws, WgradLdsGeom g) {
-  constexpr int NW = MQB * MPB * KDB, CQ = 32 * MQB, CP = 32 * MPB, MAXX = kWgLdsMaxX, MAXG = kWgLdsMaxG;
+template <int MQB, int MPB, int KDB, int KSPLIT, int S>
+__global__ void __launch_bounds__(64 * MQB * MPB * KDB * KSPLIT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, float* __restrict__ ws, WgradLdsGeom g) {
+  constexpr int NW = MQB * MPB * KDB * KSPLIT, CQ = 32 * MQB, CP = 32 * MPB, MAXX = kWgLdsMaxX, MAXG = kWgLdsMaxG;
   extern __shared__ __align__(16) float wl[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -881,33 +886,35 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
   const int nqt = (g.Cq + CQ - 1) / CQ;
   const int qt = byy % nqt, pt = byy / nqt;
   const int kd0 = bz * KDB;
-  const int a = wave % MQB, e = (wave / MQB) % MPB, z = wave / (MQB * MPB);
+  const int a = wave % MQB, e = (wave / MQB) % MPB, z = (wave / (MQB * MPB)) % KDB, ksp = wave / (MQB * MPB * KDB);
 
-  const int xrow_f = (g.Wseg + 2) * CQ;          // floats per staged x row
+  const int ncol = S * g.Wseg + 2;               // staged Q columns: Q w = S*w0 - 1 + u
+  const int xrow_f = ncol * CQ;                  // floats per staged Q row
   const int xplane_f = g.nslot * xrow_f;
   const int grow_f = g.Wseg * CP;
-  float* xl = wl;                                // [KDB][nslot][Wseg+2][CQ]
+  const int rows_new = S * g.RG;                 // Q rows brought per step and plane
+  float* xl = wl;                                // [KDB][nslot][ncol][CQ]
   float* gl = wl + KDB * xplane_f;               // [2][RG][Wseg][CP]
 
   // Staging work lists: one entry = one wave instruction = 64 consecutive 16-byte items of ONE row.
-  // x entries q = wave + n * NW < nxi (plane-major rows, nxc chunks per row); gy entries likewise over RG * ngc.
+  // Q entries q = wave + n * NW < nxi (plane-major rows, nxc chunks per row); P entries likewise over RG * ngc.
   // Per lane: the float offset of its item relative to the step's base pointer (row, plane and column folded
   // in; -1 = read zeros, -2 = lane past the row end).  Wave-uniform: row / plane / LDS offset of the entry.
-  const int xper_row = (g.Wseg + 2) * (CQ / 4), gper_row = g.Wseg * (CP / 4);
+  const int xper_row = ncol * (CQ / 4), gper_row = g.Wseg * (CP / 4);
   const int nxc = (xper_row + 63) >> 6, ngc = (gper_row + 63) >> 6;
-  const int nxi = KDB * g.RG * nxc, ngi = g.RG * ngc;
-  const int xplane_g = g.H * g.W * g.Cq;                       // floats per (b, d) plane of x
+  const int nxi = KDB * rows_new * nxc, ngi = g.RG * ngc;
+  const int xplane_g = g.Hq * g.Wq * g.Cq;                     // floats per (b, d) plane of Q
   int xoff[MAXX], xmeta[MAXX], goff[MAXG], gmeta[MAXG];        // meta: rr | pl << 8 | lds float offset << 10
 #pragma unroll
   for (int n = 0; n < MAXX; ++n) {
     const int q = wave + n * NW;
     int off = -2, meta = -1;
     if (q < nxi) {
-      const int pr = q / nxc, ch = q % nxc, pl = pr / g.RG, rr = pr % g.RG;
+      const int pr = q / nxc, ch = q % nxc, pl = pr / rows_new, rr = pr % rows_new;
       const int j = ch * 64 + lane;
       if (j < xper_row) {
-        const int u = j / (CQ / 4), c = qt * CQ + (j % (CQ / 4)) * 4, wsrc = w0 + u - 1;
-        off = (wsrc >= 0 && wsrc < g.W && c < g.Cq) ? pl * xplane_g + (rr * g.W + wsrc) * g.Cq + c : -1;
+        const int u = j / (CQ / 4), c = qt * CQ + (j % (CQ / 4)) * 4, wsrc = S * w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.Wq && c < g.Cq) ? pl * xplane_g + (rr * g.Wq + wsrc) * g.Cq + c : -1;
       }
       meta = rr | (pl << 8) | ((pl * xplane_f + ch * 256) << 10);
     }
@@ -923,7 +930,7 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
       const int j = ch * 64 + lane;
       if (j < gper_row) {
         const int u = j / (CP / 4), c = pt * CP + (j % (CP / 4)) * 4;
-        off = c < g.Cp ? (rr * g.W + w0 + u) * g.Cp + c : -1;
+        off = c < g.Cp ? (rr * g.Wp + w0 + u) * g.Cp + c : -1;
       }
       meta = rr | ((rr * grow_f + ch * 256) << 10);
     }
@@ -941,19 +948,19 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
 
   const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
 
-  // global -> LDS.  stage_x: padded x rows [hp0, hp0+RG) of planes (b, d + kd0 + pl - pd) into their ring slots;
-  // stage_gy: gy row group Gn into buffer buf.  Everything but the final address add is wave-uniform.
-  auto stage_x = [&](int b, int d, int hp0) {
+  // global -> LDS.  stage_q: padded Q rows [hp0, hp0 + S*RG) of planes (b, SD*d - pd + kd0 + pl) into their ring
+  // slots; stage_p: P row group Gn into buffer buf.  Everything but the final address add is wave-uniform.
+  auto stage_q = [&](int b, int d, int hp0) {
     const int slot0 = hp0 % g.nslot;
-    const int d0 = d + kd0 - g.pd;
-    const float* base = X + ((long)(b * g.D + d0) * g.H + (hp0 - 1)) * (long)(g.W * g.Cq);
+    const int d0 = g.SD * d + kd0 - g.pd;
+    const float* base = Qg + ((long)(b * g.Dq + d0) * g.Hq + (hp0 - 1)) * (long)(g.Wq * g.Cq);
 #pragma unroll
     for (int n = 0; n < MAXX; ++n) {
       const int meta = xmeta[n];
       if (meta < 0) break;
       const int rr = meta & 255, pl = (meta >> 8) & 3;
       const int h = hp0 - 1 + rr, dp = d0 + pl;
-      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      const bool rowok = h >= 0 && h < g.Hq && dp >= 0 && dp < g.Dq;
       int slot = slot0 + rr;
       slot = slot >= g.nslot ? slot - g.nslot : slot;
       float* dst = xl + (meta >> 10) + slot * xrow_f;
@@ -962,8 +969,8 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
       if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
     }
   };
-  auto stage_gy = [&](int Gn, int buf) {
-    const float* base = GY + (long)Gn * g.RG * (long)(g.W * g.Cp);
+  auto stage_p = [&](int Gn, int buf) {
+    const float* base = Pg + (long)Gn * g.RG * (long)(g.Wp * g.Cp);
     float* dbase = gl + buf * g.RG * grow_f;
 #pragma unroll
     for (int n = 0; n < MAXG; ++n) {
@@ -976,86 +983,126 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
   };
 
   int cur = 0;
-  bool fresh = true;                    // the x ring does not hold this plane yet
-  const int nks = g.Wseg >> 1;
+  bool fresh = true;                    // the Q ring does not hold this plane yet
+  const int nks = (g.Wseg >> 1) / KSPLIT, ks0 = ksp * nks;     // this wave's k-steps of a row
   int hg = g_begin % g.nrg, d, b;
   {
     const int bd = g_begin / g.nrg;
-    b = bd / g.D; d = bd % g.D;
+    b = bd / g.Dp; d = bd % g.Dp;
   }
   for (int G = g_begin; G < g_end; ++G) {
-    const int h0 = hg * g.RG;           // first output row of the step == first padded x row it needs
+    const int h0 = hg * g.RG;           // first P row of the step; its first padded Q row is S * h0
     if (fresh) {
-      // padded rows [h0, h0 + RG + 2) in batches of RG rows; the very first step also brings its gy rows
-      for (int r0 = 0; r0 < g.RG + 2; r0 += g.RG) stage_x(b, d, h0 + r0);
-      if (G == g_begin) stage_gy(G, cur);
+      // padded Q rows [S*h0, S*h0 + S*(RG-1) + 3) in batches of S*RG; the very first step also brings its P rows
+      for (int r0 = 0; r0 < S * (g.RG - 1) + 3; r0 += rows_new) stage_q(b, d, S * h0 + r0);
+      if (G == g_begin) stage_p(G, cur);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     const bool has_next = G + 1 < g_end;
     const bool same_plane = has_next && hg + 1 < g.nrg;
-    if (has_next) stage_gy(G + 1, cur ^ 1);
-    if (same_plane) stage_x(b, d, h0 + g.RG + 2);
+    if (has_next) stage_p(G + 1, cur ^ 1);
+    if (same_plane) stage_q(b, d, S * (h0 + g.RG) + 3 - S);
 
     {
-      const float* gyb = gl + cur * g.RG * grow_f + e * 32 + li + lk * CP;
-      const float* xb = xl + z * xplane_f + a * 32 + li + lk * CQ;
-      int s0 = h0 % g.nslot;
+      const float* gyb = gl + cur * g.RG * grow_f + e * 32 + li + (lk + 2 * ks0) * CP;
+      const float* xb = xl + z * xplane_f + a * 32 + li + (lk + 2 * ks0) * S * CQ;
+      int s0 = (S * h0) % g.nslot;
       for (int rr = 0; rr < g.RG; ++rr) {
         int s1 = s0 + 1; if (s1 >= g.nslot) s1 -= g.nslot;
         int s2 = s1 + 1; if (s2 >= g.nslot) s2 -= g.nslot;
-        const float* x0 = xb + s0 * xrow_f;
-        const float* x1 = xb + s1 * xrow_f;
-        const float* x2 = xb + s2 * xrow_f;
-        const float* gp = gyb + rr * grow_f;
-        // two k-steps per trip; the operands of the next k-step are in flight while the 9 MFMAs of this one
-        // issue.  All LDS addresses are (walking pointer + immediate).  The last trip prefetches one k-step
-        // past the row (never consumed; the launch reserves slack behind the gy buffers for it).
-        const float* p0 = x0;
-        const float* p1 = x1;
-        const float* p2 = x2;
-        const float* pg = gp;
-        float c0 = p0[0], c1 = p1[0], c2 = p2[0];
-        float pA = pg[0];
-        float a01 = p0[CQ], a02 = p0[2 * CQ], a11 = p1[CQ], a12 = p1[2 * CQ], a21 = p2[CQ], a22 = p2[2 * CQ];
-        for (int ks = 0; ks < nks; ks += 2) {
-          acc[0][0] = mfma32(c0, pA, acc[0][0]);
-          __builtin_amdgcn_sched_barrier(0);
-          const float pB = pg[2 * CP];
-          const float b01 = p0[3 * CQ], b02 = p0[4 * CQ];
-          const float b11 = p1[3 * CQ], b12 = p1[4 * CQ];
-          const float b21 = p2[3 * CQ], b22 = p2[4 * CQ];
-          __builtin_amdgcn_sched_barrier(0);
-          acc[1][0] = mfma32(c1, pA, acc[1][0]);
-          acc[2][0] = mfma32(c2, pA, acc[2][0]);
-          acc[0][1] = mfma32(a01, pA, acc[0][1]);
-          acc[1][1] = mfma32(a11, pA, acc[1][1]);
-          acc[2][1] = mfma32(a21, pA, acc[2][1]);
-          acc[0][2] = mfma32(a02, pA, acc[0][2]);
-          acc[1][2] = mfma32(a12, pA, acc[1][2]);
-          acc[2][2] = mfma32(a22, pA, acc[2][2]);
-          __builtin_amdgcn_sched_barrier(0);
-          c0 = a02; c1 = a12; c2 = a22;
-          acc[0][0] = mfma32(c0, pB, acc[0][0]);
-          __builtin_amdgcn_sched_barrier(0);
-          pA = pg[4 * CP];
-          a01 = p0[5 * CQ]; a02 = p0[6 * CQ];
-          a11 = p1[5 * CQ]; a12 = p1[6 * CQ];
-          a21 = p2[5 * CQ]; a22 = p2[6 * CQ];
-          __builtin_amdgcn_sched_barrier(0);
-          acc[1][0] = mfma32(c1, pB, acc[1][0]);
-          acc[2][0] = mfma32(c2, pB, acc[2][0]);
-          acc[0][1] = mfma32(b01, pB, acc[0][1]);
-          acc[1][1] = mfma32(b11, pB, acc[1][1]);
-          acc[2][1] = mfma32(b21, pB, acc[2][1]);
-          acc[0][2] = mfma32(b02, pB, acc[0][2]);
-          acc[1][2] = mfma32(b12, pB, acc[1][2]);
-          acc[2][2] = mfma32(b22, pB, acc[2][2]);
-          __builtin_amdgcn_sched_barrier(0);
-          c0 = b02; c1 = b12; c2 = b22;
-          p0 += 4 * CQ; p1 += 4 * CQ; p2 += 4 * CQ; pg += 4 * CP;
+        // All LDS addresses are (walking pointer + immediate); two k-steps per trip, the operands of the next
+        // k-step in flight while the MFMAs of this one issue.  The last trip prefetches one k-step past the
+        // row (never consumed; the launch reserves slack behind the P buffers for it).
+        const float* p0 = xb + s0 * xrow_f;
+        const float* p1 = xb + s1 * xrow_f;
+        const float* p2 = xb + s2 * xrow_f;
+        const float* pg = gyb + rr * grow_f;
+        if constexpr (S == 1) {
+          float c0 = p0[0], c1 = p1[0], c2 = p2[0];
+          float pA = pg[0];
+          float a01 = p0[CQ], a02 = p0[2 * CQ], a11 = p1[CQ], a12 = p1[2 * CQ], a21 = p2[CQ], a22 = p2[2 * CQ];
+          for (int ks = 0; ks < nks; ks += 2) {
+            acc[0][0] = mfma32(c0, pA, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float pB = pg[2 * CP];
+            const float b01 = p0[3 * CQ], b02 = p0[4 * CQ];
+            const float b11 = p1[3 * CQ], b12 = p1[4 * CQ];
+            const float b21 = p2[3 * CQ], b22 = p2[4 * CQ];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma32(c1, pA, acc[1][0]);
+            acc[2][0] = mfma32(c2, pA, acc[2][0]);
+            acc[0][1] = mfma32(a01, pA, acc[0][1]);
+            acc[1][1] = mfma32(a11, pA, acc[1][1]);
+            acc[2][1] = mfma32(a21, pA, acc[2][1]);
+            acc[0][2] = mfma32(a02, pA, acc[0][2]);
+            acc[1][2] = mfma32(a12, pA, acc[1][2]);
+            acc[2][2] = mfma32(a22, pA, acc[2][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = a02; c1 = a12; c2 = a22;
+            acc[0][0] = mfma32(c0, pB, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            pA = pg[4 * CP];
+            a01 = p0[5 * CQ]; a02 = p0[6 * CQ];
+            a11 = p1[5 * CQ]; a12 = p1[6 * CQ];
+            a21 = p2[5 * CQ]; a22 = p2[6 * CQ];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma32(c1, pB, acc[1][0]);
+            acc[2][0] = mfma32(c2, pB, acc[2][0]);
+            acc[0][1] = mfma32(b01, pB, acc[0][1]);
+            acc[1][1] = mfma32(b11, pB, acc[1][1]);
+            acc[2][1] = mfma32(b21, pB, acc[2][1]);
+            acc[0][2] = mfma32(b02, pB, acc[0][2]);
+            acc[1][2] = mfma32(b12, pB, acc[1][2]);
+            acc[2][2] = mfma32(b22, pB, acc[2][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = b02; c1 = b12; c2 = b22;
+            p0 += 4 * CQ; p1 += 4 * CQ; p2 += 4 * CQ; pg += 4 * CP;
+          }
+        } else {
+          // stride 2: lane column = 2 * (2ks + lk) + j, consecutive k-steps share no column
+          float pA = pg[0];
+          float a00 = p0[0], a01 = p0[CQ], a02 = p0[2 * CQ];
+          float a10 = p1[0], a11 = p1[CQ], a12 = p1[2 * CQ];
+          float a20 = p2[0], a21 = p2[CQ], a22 = p2[2 * CQ];
+          for (int ks = 0; ks < nks; ks += 2) {
+            acc[0][0] = mfma32(a00, pA, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float pB = pg[2 * CP];
+            const float b00 = p0[4 * CQ], b01 = p0[5 * CQ], b02 = p0[6 * CQ];
+            const float b10 = p1[4 * CQ], b11 = p1[5 * CQ], b12 = p1[6 * CQ];
+            const float b20 = p2[4 * CQ], b21 = p2[5 * CQ], b22 = p2[6 * CQ];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma32(a10, pA, acc[1][0]);
+            acc[2][0] = mfma32(a20, pA, acc[2][0]);
+            acc[0][1] = mfma32(a01, pA, acc[0][1]);
+            acc[1][1] = mfma32(a11, pA, acc[1][1]);
+            acc[2][1] = mfma32(a21, pA, acc[2][1]);
+            acc[0][2] = mfma32(a02, pA, acc[0][2]);
+            acc[1][2] = mfma32(a12, pA, acc[1][2]);
+            acc[2][2] = mfma32(a22, pA, acc[2][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = mfma32(b00, pB, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            pA = pg[4 * CP];
+            a00 = p0[8 * CQ]; a01 = p0[9 * CQ]; a02 = p0[10 * CQ];
+            a10 = p1[8 * CQ]; a11 = p1[9 * CQ]; a12 = p1[10 * CQ];
+            a20 = p2[8 * CQ]; a21 = p2[9 * CQ]; a22 = p2[10 * CQ];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma32(b10, pB, acc[1][0]);
+            acc[2][0] = mfma32(b20, pB, acc[2][0]);
+            acc[0][1] = mfma32(b01, pB, acc[0][1]);
+            acc[1][1] = mfma32(b11, pB, acc[1][1]);
+            acc[2][1] = mfma32(b21, pB, acc[2][1]);
+            acc[0][2] = mfma32(b02, pB, acc[0][2]);
+            acc[1][2] = mfma32(b12, pB, acc[1][2]);
+            acc[2][2] = mfma32(b22, pB, acc[2][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            p0 += 8 * CQ; p1 += 8 * CQ; p2 += 8 * CQ; pg += 4 * CP;
+          }
         }
-        s0 = s1;
+        s0 += S;
+        if (s0 >= g.nslot) s0 -= g.nslot;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1064,7 +1111,7 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
     cur ^= 1;
     if (++hg == g.nrg) {
       hg = 0;
-      if (++d == g.D) { d = 0; ++b; }
+      if (++d == g.Dp) { d = 0; ++b; }
     }
   }
 
@@ -1076,7 +1123,7 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int tap = (kdi * 3 + i) * 3 + j;
-        float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+        float* dst = ws + ((((size_t)chunk_id * KSPLIT + ksp) * taps + tap) * g.Cq) * g.Cp;
         const int pc = pt * CP + e * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1087,13 +1134,14 @@ wgrad_lds_kernel(const float* __restrict__ X, const float* __restrict__ GY, floa
   }
 }
 
-constexpr int kWgLdsRowVox = 32;                 // target voxels (= 2 x MFMA k-steps) per step
+constexpr int kWgLdsRowVox = 32;                 // target P voxels (= 2 x MFMA k-steps) per step
 constexpr size_t kWgLdsMaxBytes = 64 * 1024;     // LDS per workgroup (two workgroups per CU; M0-addressable)
 
 struct WgradLdsPlan {
   WgradLdsGeom g;
-  int cfg;              // 0: <2,2,1> (64 ci x 64 co, one kd per workgroup), 1: <1,1,3> (32 x 32, all kd)
-  int nchunks;
+  int cfg;              // 0: <2,2,1,1,1>  1: <1,1,1,4,1>  2: <1,2,1,2,2>  3: <2,2,1,1,2>
+  int ksplit;
+  int nchunks;          // workgroup chunks (workspace slabs = nchunks * ksplit)
   size_t lds_bytes;
   bool ok;
 };
@@ -1118,49 +1166,68 @@ WgradLdsPlan plan_wgrad_lds(const ssbev_conv_dims* d) {
 WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   WgradLdsPlan p;
   p.ok = false;
-  if (d->transposed || d->sd != 1 || d->sh != 1 || d->sw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return p;
-  if (d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || (d->kd != 1 && d->kd != 3) || d->pd != d->kd / 2) return p;
-  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return p;
-  if (d->Wo % 4 != 0 || d->Cin % 4 != 0 || d->Cout % 4 != 0) return p;
+  if (d->dd != 1 || d->dh != 1 || d->dw != 1 || d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1) return p;
+  if ((d->kd != 1 && d->kd != 3) || d->pd != d->kd / 2 || d->Cin % 4 != 0 || d->Cout % 4 != 0) return p;
+  if (d->sh != d->sw || (d->kd == 3 && d->sd != d->sh) || (d->kd == 1 && d->sd != 1)) return p;
+  const int S = d->sh;
   WgradLdsGeom& g = p.g;
-  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo; g.Cp = d->Cout; g.Cq = d->Cin; g.kd = d->kd; g.pd = d->pd;
-  p.cfg = (g.Cp <= 32 && g.Cq <= 32 && g.kd == 3) ? 1 : 0;
-  const int CQ = p.cfg ? 32 : 64, CP = CQ, KDB = p.cfg ? 3 : 1, NW = p.cfg ? 3 : 4;
+  g.B = d->B; g.kd = d->kd; g.pd = d->pd; g.SD = d->kd == 3 ? S : 1;
+  if (S == 1) {
+    if (d->transposed || d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return p;
+  } else if (S == 2) {
+    // conv k3 s2 p1 on even extents (out = in / 2), or its transpose k3 s2 p1 op1 (out = 2 * in)
+    const int big[3] = {d->transposed ? d->Do : d->Di, d->transposed ? d->Ho : d->Hi, d->transposed ? d->Wo : d->Wi};
+    const int small[3] = {d->transposed ? d->Di : d->Do, d->transposed ? d->Hi : d->Ho, d->transposed ? d->Wi : d->Wo};
+    if (big[1] != 2 * small[1] || big[2] != 2 * small[2] || big[0] != g.SD * small[0]) return p;
+  } else {
+    return p;
+  }
+  if (!d->transposed) {          // P = gy on the output grid, Q = x
+    g.Dp = d->Do; g.Hp = d->Ho; g.Wp = d->Wo; g.Dq = d->Di; g.Hq = d->Hi; g.Wq = d->Wi; g.Cp = d->Cout; g.Cq = d->Cin;
+  } else {                       // P = x on the input grid, Q = gy
+    g.Dp = d->Di; g.Hp = d->Hi; g.Wp = d->Wi; g.Dq = d->Do; g.Hq = d->Ho; g.Wq = d->Wo; g.Cp = d->Cin; g.Cq = d->Cout;
+  }
+  if (g.Wp % 4 != 0) return p;
+  if (S == 1) p.cfg = (g.Cp <= 32 && g.Cq <= 32) ? 1 : 0;
+  else p.cfg = g.Cq <= 32 ? 2 : 3;
+  const int CQ = (p.cfg == 1 || p.cfg == 2) ? 32 : 64, CP = p.cfg == 1 ? 32 : 64, KDB = 1, NW = 4;
+  p.ksplit = p.cfg == 1 ? 4 : (p.cfg == 2 ? 2 : 1);
   const long tiles = (long)cdiv(g.Cq, CQ) * cdiv(g.Cp, CP) * (g.kd / KDB);
   double best = 1e30;
-  for (int Wseg = 4; Wseg <= g.W && Wseg <= 80; Wseg += 4) {
-    if (g.W % Wseg) continue;
-    // rows per step: aim at >= 16 MFMA k-steps per barrier, within the staging registers and LDS
+  for (int Wseg = 4 * p.ksplit; Wseg <= g.Wp && Wseg <= 80; Wseg += 4 * p.ksplit) {
+    if (g.Wp % Wseg) continue;
+    const int ncol = S * Wseg + 2;
+    // rows per step: aim at >= 16 MFMA k-steps per wave and barrier, within the staging lists and LDS
     int RG = 1;
-    while (RG * 2 <= g.H && g.H % (RG * 2) == 0 && RG * 2 <= 16 && RG * Wseg < kWgLdsRowVox) RG *= 2;
+    while (RG * 2 <= g.Hp && g.Hp % (RG * 2) == 0 && RG * 2 <= 16 && RG * Wseg < kWgLdsRowVox * p.ksplit) RG *= 2;
     auto fits = [&](int rg) {
-      return (long)KDB * rg * cdiv((Wseg + 2) * (CQ / 4), 64) <= (long)kWgLdsMaxX * NW &&
+      return (long)KDB * S * rg * cdiv(ncol * (CQ / 4), 64) <= (long)kWgLdsMaxX * NW &&
              (long)rg * cdiv(Wseg * (CP / 4), 64) <= (long)kWgLdsMaxG * NW;
     };
     auto lds_of = [&](int rg) {
-      return ((size_t)KDB * (2 * rg + 2) * (Wseg + 2) * CQ + 2ul * rg * Wseg * CP) * sizeof(float);
+      return ((size_t)KDB * (2 * S * rg + 3 - S) * ncol * CQ + 2ul * rg * Wseg * CP) * sizeof(float);
     };
     while (RG > 1 && (!fits(RG) || lds_of(RG) > kWgLdsMaxBytes)) RG /= 2;
     const size_t lds = lds_of(RG);
-    if (!fits(RG) || lds > kWgLdsMaxBytes || g.H % RG) continue;
-    const int nseg = g.W / Wseg, nrg = g.H / RG;
-    const long NG = (long)g.B * g.D * nrg;
+    if (!fits(RG) || lds > kWgLdsMaxBytes || g.Hp % RG) continue;
+    const int nseg = g.Wp / Wseg, nrg = g.Hp / RG;
+    const long NG = (long)g.B * g.Dp * nrg;
     const long resident = 512;                       // two workgroups per CU
-    const double step_cost = (double)RG * Wseg / 2 + 3.0;          // MFMA k-steps + barrier / staging overhead
+    const double step_cost = (double)RG * Wseg / 2 / p.ksplit + 3.0;     // MFMA k-steps + barrier / staging overhead
     for (long nr = 1; nr <= NG && nr <= 2048; ++nr) {
       const long gpc = (NG + nr - 1) / nr;
       const long nranges = (NG + gpc - 1) / gpc;
       if (nranges != nr) continue;
       const long blocks = tiles * nseg * nranges;
-      const size_t wsb = (size_t)nseg * nranges * g.kd * 9 * g.Cp * g.Cq * sizeof(float);
+      const size_t wsb = (size_t)nseg * nranges * p.ksplit * g.kd * 9 * g.Cp * g.Cq * sizeof(float);
       if (wsb > (768ul << 20)) break;
       const long rounds = (blocks + resident - 1) / resident;
       const double planes = 1.0 + (double)gpc / nrg;
-      const double t = rounds * (gpc * step_cost + planes * 2.5 * step_cost + 30.0) * (1.0 + 2.0 / Wseg);
+      const double t = rounds * (gpc * step_cost + planes * 2.5 * step_cost + 30.0) * (1.0 + 2.0 / (S * Wseg));
       if (t < best) {
         best = t;
         g.RG = RG; g.Wseg = Wseg; g.nseg = nseg; g.nrg = nrg; g.NG = (int)NG; g.gpc = (int)gpc;
-        g.nranges = (int)nranges; g.nslot = 2 * RG + 2;
+        g.nranges = (int)nranges; g.nslot = 2 * S * RG + 3 - S;
         p.nchunks = (int)(nseg * nranges);
         p.lds_bytes = lds;
         p.ok = true;
@@ -1170,17 +1237,25 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   return p;
 }
 
-template <int MQB, int MPB, int KDB>
-int launch_wgrad_lds(const float* x, const float* gy, float* ws, const WgradLdsPlan& p, hipStream_t st) {
+template <int MQB, int MPB, int KDB, int KSPLIT, int S>
+int launch_wgrad_lds(const float* P, const float* Q, float* ws, const WgradLdsPlan& p, hipStream_t st) {
   const WgradLdsGeom& g = p.g;
-  auto kern = wgrad_lds_kernel<MQB, MPB, KDB>;
-  if (p.lds_bytes > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)p.lds_bytes) != hipSuccess)
-    return SSBEV_ELAUNCH;
-  dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB);
-  hipLaunchKernelGGL(kern, grid, block, p.lds_bytes + 1024, st, x, gy, ws, g);      // +1 KB: prefetch slack
+  auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S>;
+  dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB * KSPLIT);
+  hipLaunchKernelGGL(kern, grid, block, p.lds_bytes + 1024, st, P, Q, ws, g);      // +1 KB: prefetch slack
   return SSBEV_OK;
+}
+
+int run_wgrad_lds(const float* x, const float* gy, float* ws, const ssbev_conv_dims* d, const WgradLdsPlan& p,
+                  hipStream_t st) {
+  const float* P = d->transposed ? x : gy;
+  const float* Q = d->transposed ? gy : x;
+  switch (p.cfg) {
+    case 0: return launch_wgrad_lds<2, 2, 1, 1, 1>(P, Q, ws, p, st);
+    case 1: return launch_wgrad_lds<1, 1, 1, 4, 1>(P, Q, ws, p, st);
+    case 2: return launch_wgrad_lds<1, 2, 1, 2, 2>(P, Q, ws, p, st);
+    default: return launch_wgrad_lds<2, 2, 1, 1, 2>(P, Q, ws, p, st);
+  }
 }
 
 bool wgrad_cf_applicable(const ssbev_conv_dims* d) {
@@ -1343,7 +1418,7 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   {
     const WgradLdsPlan lp = plan_wgrad_lds(d);
     if (lp.ok && d->tile_hint != 7)
-      return align256b((size_t)lp.nchunks * d->kd * 9 * d->Cout * d->Cin * sizeof(float));
+      return align256b((size_t)lp.nchunks * lp.ksplit * d->kd * 9 * d->Cout * d->Cin * sizeof(float));
   }
   if (wgrad_cf_applicable(d)) {
     WgradCfg c;
@@ -1388,13 +1463,12 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
     if (lp.ok && d->tile_hint != 7) {          // tile_hint 7: force the channel-major path (tests / A-B timing)
       hipStream_t st = as_stream(stream);
       float* partial = static_cast<float*>(ws);
-      const int rc = lp.cfg ? launch_wgrad_lds<1, 1, 3>(x, gy, partial, lp, st)
-                            : launch_wgrad_lds<2, 2, 1>(x, gy, partial, lp, st);
+      const int rc = run_wgrad_lds(x, gy, partial, d, lp, st);
       if (rc != SSBEV_OK) return rc;
       const int taps = d->kd * 9;
-      const long total = (long)taps * d->Cin * d->Cout;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, lp.nchunks, taps,
-                         d->Cin, d->Cout, total);
+      const long total = (long)taps * lp.g.Cq * lp.g.Cp;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw,
+                         lp.nchunks * lp.ksplit, taps, lp.g.Cq, lp.g.Cp, total);
       return ssbev_launch_status();
     }
   }

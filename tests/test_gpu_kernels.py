@@ -198,28 +198,37 @@ def test_conv3d_family_fwd_bwd(case):
 
 
 WGRAD_LDS_CASES = [
-    # (B, Cin, Cout, D, H, W): stride-1 3x3x3 "same" convs -> the LDS-staged weight-gradient kernel; the shapes walk the
-    # planner's branches (32x32 all-kd workgroups, 64x64 tiles, rows per step 1/2/4/8, w-segments, channel clamps)
-    (1, 32, 32, 5, 8, 16), (2, 32, 32, 4, 6, 40), (1, 4, 32, 6, 4, 8), (1, 32, 1, 4, 8, 4), (1, 128, 128, 6, 8, 16),
-    (1, 96, 80, 3, 4, 8), (1, 64, 64, 3, 24, 80), (1, 256, 256, 4, 16, 8), (1, 512, 64, 4, 8, 4), (2, 32, 32, 3, 5, 160),
-    (1, 64, 192, 9, 10, 12),
+    # (B, Cin, Cout, D, H, W, stride, transposed): 3x3x3 convs whose weight gradient runs on the LDS-staged kernel; the
+    # shapes walk the planner's branches (32x32 k-split workgroups, 64x64 tiles, rows per step 1/2/4/8, w-segments,
+    # channel clamps, stride-2 conv and its transpose)
+    (1, 32, 32, 5, 8, 16, 1, False), (2, 32, 32, 4, 6, 48, 1, False), (1, 4, 32, 6, 4, 16, 1, False),
+    (1, 32, 1, 4, 8, 16, 1, False), (1, 128, 128, 6, 8, 16, 1, False), (1, 96, 80, 3, 4, 8, 1, False),
+    (1, 64, 64, 3, 24, 80, 1, False), (1, 256, 256, 4, 16, 8, 1, False), (1, 512, 64, 4, 8, 4, 1, False),
+    (2, 32, 32, 3, 5, 160, 1, False), (1, 64, 192, 9, 10, 12, 1, False),
+    (1, 32, 64, 8, 12, 32, 2, False), (2, 64, 128, 6, 8, 16, 2, False), (1, 128, 256, 4, 8, 32, 2, False),
+    (1, 32, 64, 6, 10, 160, 2, False),
+    (1, 64, 32, 4, 6, 16, 2, True), (1, 128, 64, 3, 4, 8, 2, True), (2, 64, 32, 3, 5, 80, 2, True),
 ]
 
 
 @pytest.mark.parametrize("case", WGRAD_LDS_CASES)
-def test_wgrad_lds_matches_aten_and_channel_major_path(case):
-    B, Cin, Cout, D, H, W = case
+def test_wgrad_lds_matches_aten_and_fallback_path(case):
+    B, Cin, Cout, D, H, W, st, tr = case
     x = S.hash_normal(f"wl/x{case}", (B, Cin, D, H, W))
-    w = S.hash_uniform(f"wl/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
-    go = S.hash_normal(f"wl/go{case}", (B, Cout, D, H, W))
+    wshape = (Cin, Cout, 3, 3, 3) if tr else (Cout, Cin, 3, 3, 3)
+    w = S.hash_uniform(f"wl/w{case}", wshape, -1, 1) * (3.0 / (Cin * 27)) ** 0.5
     wc = w.clone().requires_grad_(True)
-    TF.conv3d(x, wc, None, 1, 1).backward(go)
+    want = TF.conv_transpose3d(x, wc, None, st, 1, st - 1) if tr else TF.conv3d(x, wc, None, st, 1)
+    go = S.hash_normal(f"wl/go{case}", tuple(want.shape))
+    want.backward(go)
     grads = []
-    for hint in (0, 7):                       # 7 = force the channel-major (transposed-copy) kernel
+    for hint in (0, 7):                       # 7 = force the older kernels (channel-major copies / direct global)
         F.TILE_HINT = hint
         try:
             wg = w.to(DEV).requires_grad_(True)
-            F.conv3d(x.to(DEV), wg, None, 1, 1).backward(go.to(DEV))
+            xg = x.to(DEV)
+            got = F.conv_transpose3d(xg, wg, None, st, 1, st - 1) if tr else F.conv3d(xg, wg, None, st, 1)
+            got.backward(go.to(DEV))
         finally:
             F.TILE_HINT = 0
         grads.append(wg.grad.cpu())
