@@ -222,6 +222,15 @@ int ssbev_occ_loss_bwd(const float* logits, const uint8_t* label, const float* c
                        const float* coef, float* grad_logits, const ssbev_occloss_dims* d, void* ws,
                        size_t ws_bytes, ssbev_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Softmax along a strided axis: x = [outer][C][inner] (inner contiguous), y = softmax over C.
+ * Replaces F.softmax(dim=1) on the depth-major matching distribution (ViewTransformerLSSVoxel.py:255-259)
+ * and F.softmax(q, dim=2) of the BRI confidence (attention.py:66-68); bwd: gx = y * (gy - sum_c y * gy).
+ * ------------------------------------------------------------------------------------------ */
+int ssbev_softmax_axis_fwd(const float* x, float* y, int64_t outer, int C, int64_t inner, ssbev_stream_t stream);
+int ssbev_softmax_axis_bwd(const float* y, const float* gy, float* gx, int64_t outer, int C, int64_t inner,
+                           ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

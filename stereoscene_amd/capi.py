@@ -85,6 +85,8 @@ SIGNATURES = {
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
+    "ssbev_softmax_axis_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
+    "ssbev_softmax_axis_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_occ_loss_num_sums": (C.c_int, []),
     "ssbev_occ_loss_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),

@@ -505,6 +505,9 @@ int launch_gather_cfg(int mt, int nt, int qu, const float* x, const float* wp, c
     case 24: return launch_gather_qu<2, 4>(qu, x, wp, bias, y, g, st);
     case 22: return launch_gather_qu<2, 2>(qu, x, wp, bias, y, g, st);
     case 12: return launch_gather_qu<1, 2>(qu, x, wp, bias, y, g, st);
+    case 15: return launch_gather_qu<1, 5>(qu, x, wp, bias, y, g, st);
+    case 14: return launch_gather_qu<1, 4>(qu, x, wp, bias, y, g, st);
+    case 31: return launch_gather_qu<3, 1>(qu, x, wp, bias, y, g, st);
     case 91: return launch_gather_ldsb<2, 2>(x, wp, bias, y, g, st);      // tuning hook: LDS-resident weights
     case 92: return launch_gather_ldsb<1, 2>(x, wp, bias, y, g, st);
     default: return SSBEV_EINVAL;
@@ -531,7 +534,11 @@ int dispatch_gather(const float* x, const float* wp, const float* bias, float* y
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   if (g.hint) return launch_gather_cfg(g.hint / 100, (g.hint / 10) % 10, g.hint % 10, x, wp, bias, y, g, st);
   const long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
-  if (Mtot <= 8192 && (long)g.kd * g.kh * g.kw * g.Cin <= 8192 && g.Cout > 64)   // 48x160 feature maps: many small tiles
+  // 48x160 feature maps (7680 pixels = 240 row tiles): <1,5> makes 240 x (Cout/160) waves -- 960 of the chip's 1024
+  // SIMDs busy in ONE round for Cout = 640, each A operand feeding five column tiles (sweep: 98 vs 81 TF/s)
+  if (Mtot <= 8192 && g.Cout % 160 == 0 && g.Cout >= 640 && g.form == 0)
+    return launch_gather_cfg(1, 5, 4, x, wp, bias, y, g, st);
+  if (Mtot <= 8192 && (long)g.kd * g.kh * g.kw * g.Cin <= 8192 && g.Cout > 64)   // other small maps: many small tiles
     return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);
   {
     const size_t wbytes = (size_t)g.kd * g.kh * g.kw * (g.CinPad >> 3) * 2 * 32 * 16;
@@ -813,6 +820,7 @@ Wgrad1x1Plan plan_wgrad_1x1(const ssbev_conv_dims* d) {
   if (!p.ok) return p;
   p.Cp = d->transposed ? d->Cin : d->Cout;
   p.Cq = d->transposed ? d->Cout : d->Cin;
+  if ((long)p.Cp * p.Cq > 128L * 128L) { p.ok = false; return p; }      // wide layers are MFMA-bound: tiled kernels
   p.N = (long)d->B * d->Do * d->Ho * d->Wo;
   p.MQ = p.Cq > 32 ? 2 : 1;
   p.MP = p.Cp > 32 ? 2 : 1;

@@ -34,9 +34,10 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for fam, flops, nbytes, a, b, tag in self.records:
-            d = out.setdefault((fam, tag), dict(launches=0, flops=0.0, ms=0.0))
+            d = out.setdefault((fam, tag), dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += a.elapsed_time(b)
         return out
 
@@ -453,9 +454,11 @@ class _GroupNorm(torch.autograd.Function):
         rstd = given_rstd.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
         w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
-                                           capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
-                                           capi.stream()), "ssbev_groupnorm_fwd")
+        nb = 4.0 * xcl.numel() * (3 + (residual is not None) - 2 * given)      # stats read + apply read/write
+        with _span("groupnorm", 0.0, nb, f"fwd   N C={Cch} G={groups} S={S} res={int(residual is not None)}"):
+            capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
+                                               capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
+                                               capi.stream()), "ssbev_groupnorm_fwd")
         ctx.save_for_backward(xcl, y if relu else None, w, mean, rstd)
         ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given)
         ctx.mark_non_differentiable(mean, rstd)
@@ -475,10 +478,12 @@ class _GroupNorm(torch.autograd.Function):
         gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
-        capi.check(lib.ssbev_groupnorm_bwd(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
-                                           capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
-                                           C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                   "ssbev_groupnorm_bwd")
+        nb = 4.0 * xcl.numel() * (5 + relu + has_res)      # stats: x, gy (, y); apply: x, gy (, y) -> gx (, gres)
+        with _span("groupnorm", 0.0, nb, f"bwd   N C={Cch} G={groups} S={S} res={int(has_res)}"):
+            capi.check(lib.ssbev_groupnorm_bwd(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
+                                               capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
+                                               C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm_bwd")
         return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None
 
 
@@ -498,6 +503,49 @@ def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, residu
     """Inference-mode BatchNorm with the running statistics (forward only on the HIP path)."""
     rstd = torch.rsqrt(running_var + eps)
     return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, running_mean, rstd)[0]
+
+
+# -------------------------------------------------------------------------------------------------
+# softmax along a strided axis
+# -------------------------------------------------------------------------------------------------
+
+
+class _SoftmaxAxis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim):
+        lib = capi.load()
+        x = _f32(x, "softmax").contiguous()
+        outer = 1
+        for n in x.shape[:dim]:
+            outer *= n
+        Cn = x.shape[dim]
+        inner = x.numel() // (outer * Cn)
+        y = torch.empty_like(x)
+        capi.check(lib.ssbev_softmax_axis_fwd(capi.ptr(x), capi.ptr(y), outer, Cn, inner, capi.stream()),
+                   "ssbev_softmax_axis_fwd")
+        ctx.save_for_backward(y)
+        ctx.meta = (outer, Cn, inner)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = capi.load()
+        (y,) = ctx.saved_tensors
+        outer, Cn, inner = ctx.meta
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        capi.check(lib.ssbev_softmax_axis_bwd(capi.ptr(y), capi.ptr(gy), capi.ptr(gx), outer, Cn, inner, capi.stream()),
+                   "ssbev_softmax_axis_bwd")
+        return gx, None
+
+
+def softmax(x, dim):
+    """softmax over ``dim``.  A non-innermost axis of a standard-contiguous tensor runs on the strided-axis HIP kernel;
+    an axis that is innermost in memory (channels-last 2-D maps) is already a single fast row kernel in ATen."""
+    dim = dim % x.dim()
+    if x.is_cuda and x.is_contiguous() and dim != x.dim() - 1:
+        return _SoftmaxAxis.apply(x, dim)
+    return torch.softmax(x, dim)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -225,7 +225,7 @@ class GwcNet_volume_encoder(nn.Module):
         cost0 = self.dres1[2][1](t, residual=cost0)            # dres1(cost0) + cost0, add fused into the GN pass
         out3 = self.dres4(self.dres3(self.dres2(cost0)))
         cost3_1 = self.classif3_1(out3)
-        pred3 = torch.softmax(self.classif3_2(cost3_1).squeeze(1), dim=1)
+        pred3 = F.softmax(self.classif3_2(cost3_1).squeeze(1), dim=1)
         return {"multi_channel": cost3_1, "single_channel": pred3}
 
 
@@ -250,7 +250,7 @@ class attention(nn.Module):
     def forward(self, q, kv):
         B, C, D, H, W = kv.shape
         hw = H * W
-        conf = torch.softmax(q, dim=2).amax(dim=2).view(B, hw)                # [B,HW]
+        conf = F.softmax(q, dim=2).amax(dim=2).view(B, hw)                # [B,HW]
         Q = self._affine(self.query_conv, q).view(B, D, hw)                   # [B,D,HW] (tokens contiguous)
         K = self._affine(self.key_conv, kv).view(B, D, hw)
         V = self._affine(self.value_conv, kv).view(B, D, hw)
@@ -337,7 +337,7 @@ class volume_interaction(nn.Module):
         x = torch.relu(self.redir1(torch.cat((a, b), dim=1)))
         x = self.CA3D(self.dres1(x))
         x = torch.relu(self.redir2(x)).squeeze(1)
-        return torch.softmax(x, dim=1)
+        return F.softmax(x, dim=1)
 
 
 # ------------------------------------------------------------------------------- the transformer
@@ -439,7 +439,7 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         return torch.cat([v, sensor2ego], dim=-1)
 
     def get_depth_dist(self, x):
-        return x.softmax(dim=1)
+        return F.softmax(x, dim=1)
 
     # splat ------------------------------------------------------------------------------------
     def voxel_pooling(self, geom_feats, x):

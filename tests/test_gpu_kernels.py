@@ -403,3 +403,17 @@ def test_fused_occ_loss_matches_unfused_and_oracle():
     tp, fp, fn, tpc, fpc, fnc = O.ssc_counts(up.numpy(), gt.numpy())
     sc, miou, _ = O.ssc_scores(tp, fp, fn, tpc, fpc, fnc)
     assert abs(float(got["sc_iou_0"]) - sc) < 1e-6 and abs(float(got["ssc_miou_0"]) - miou) < 1e-6
+
+
+@pytest.mark.parametrize("shape,dim", [((2, 48, 6, 20), 1), ((1, 1, 192, 12, 40), 2), ((3, 7, 5), 0), ((2, 5, 33), 2)])
+def test_softmax_strided_axis(shape, dim):
+    x = S.hash_normal(f"sm/x{shape}", shape, 3.0)
+    go = S.hash_normal(f"sm/g{shape}", shape)
+    xc = x.clone().requires_grad_(True)
+    want = torch.softmax(xc, dim)
+    want.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    got = F.softmax(xg, dim)
+    got.backward(go.to(DEV))
+    assert maxdiff(got, want) < 1e-6
+    assert maxdiff(xg.grad, xc.grad) < 1e-6

@@ -27,8 +27,8 @@ tab = t.by_tag()
 F.KERNEL_TIMER = None
 rows = sorted(tab.items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(v["ms"] for v in tab.values()) / steps
-print(f"total conv time {tot:.1f} ms/step")
+print(f"total timed-span time {tot:.1f} ms/step")
 for (fam, tag), v in rows:
     ms = v["ms"] / steps
     print(f"{ms:7.2f} ms  {v['launches'] / steps:4.0f}x  {v['flops'] / v['ms'] / 1e9:6.1f} TF/s  "
-          f"{v['flops'] / steps / 1e9:8.1f} GF  {fam:12s} {tag}")
+          f"{v['flops'] / steps / 1e9:8.1f} GF  {v['bytes'] / v['ms'] / 1e9:6.2f} TB/s  {fam:12s} {tag}")

@@ -11,13 +11,14 @@ def timeit(fn, n=4):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 for name, B, ci, co, k, p, dil in L2D:
+    if len(sys.argv) > 1 and sys.argv[1] not in name: continue
     x = torch.randn(B, ci, 48, 160, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = torch.randn(co, ci, k, k, device="cuda") * 0.02
     f = lambda: F.conv2d(x, w, None, 1, p, dil)
     y = f(); go = torch.randn_like(y)
     flops = 2.0 * B * 48 * 160 * co * ci * k * k
     row = {}
-    for mt, nt in ((4, 1), (2, 1), (1, 1), (2, 4), (2, 2), (1, 2)):
+    for mt, nt in ((1, 1), (2, 4), (2, 2), (1, 2), (1, 4), (1, 5), (3, 1)):
         for qu in (1, 2, 4):
             F.TILE_HINT = mt * 100 + nt * 10 + qu
             tf = timeit(f)
