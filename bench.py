@@ -127,8 +127,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = F.KernelTimer()
-    F.KERNEL_TIMER = timer
+    # HIP events around every launch of the dominant kernel family (two event records per launch cost ~10 us of
+    # queue time: timing every family as tools/layer_table.py does adds 2.5 ms to a step)
+    timer = F.KernelTimer(families={"conv_gather", "conv_wgrad"} if os.environ.get('SSBEV_TIME_WGRAD') else {"conv_gather"})
+    F.KERNEL_TIMER = None if os.environ.get('SSBEV_NO_TIMER') else timer
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

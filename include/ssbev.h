@@ -231,6 +231,18 @@ int ssbev_softmax_axis_fwd(const float* x, float* y, int64_t outer, int C, int64
 int ssbev_softmax_axis_bwd(const float* y, const float* gy, float* gx, int64_t outer, int C, int64_t inner,
                            ssbev_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Deformable convolution v1, sampling stages (mmcv DeformConv2dPack as built by DepthNet, bevdepth.py:490-498;
+ * mmcv/ops/csrc deform_conv: deformable_im2col / deformable_col2im / deformable_col2im_coord).  stride 1,
+ * deform_groups 1.  x [B,H,W,C], offset [B,H,W,2*k*k] (channel 2t = dy, 2t+1 = dx of tap t),
+ * cols / gcols [G][B*H*W][k*k*(C/G)]: slab g is a channels-last [B, k*k*C/G, H, W] tensor, so the grouped
+ * contraction is ssbev_conv_fwd with a 1x1 kernel per group.  col2im overwrites gx (atomic corner adds) and goffset.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, C, H, W, G, k, pad, dil; } ssbev_dcn_dims;
+int ssbev_dcn_im2col(const float* x, const float* offset, float* cols, const ssbev_dcn_dims* d, ssbev_stream_t stream);
+int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, float* gx, float* goffset,
+                     const ssbev_dcn_dims* d, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

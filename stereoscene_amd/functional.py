@@ -23,10 +23,13 @@ from . import capi
 class KernelTimer:
     """Collects (kernel family, algorithmic flops, start event, end event) per C-ABI launch."""
 
-    def __init__(self):
+    def __init__(self, families=None):
         self.records = []
+        self.families = families      # None = every instrumented family; a set restricts the event traffic
 
     def span(self, family, flops, nbytes=0.0, tag=None):
+        if self.families is not None and family not in self.families:
+            return _NOSPAN
         return _Span(self, family, flops, nbytes, tag)
 
     def by_tag(self):
@@ -429,6 +432,51 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     s, p, dl = _triple(stride, 2), _triple(padding, 2), _triple(dilation, 2)
     y = _ConvNd.apply(x.unsqueeze(2), weight.unsqueeze(2), bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
     return y.squeeze(2)
+
+
+# -------------------------------------------------------------------------------------------------
+# deformable convolution v1 (DepthNet's DCN)
+# -------------------------------------------------------------------------------------------------
+
+
+class _DcnIm2col(torch.autograd.Function):
+    """x [B,C,H,W], offset [B,2*k*k,H,W] -> cols [G, B*H*W, k*k*C/G] (bilinear taps, group-major)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, groups, k, pad, dil):
+        lib = capi.load()
+        xcl, ocl = to_cl(_f32(x, "dcn")), to_cl(_f32(offset, "dcn"))
+        B, H, W, Cch = xcl.shape
+        d = capi.DcnDims(B, Cch, H, W, groups, k, pad, dil)
+        cols = torch.empty(groups, B * H * W, k * k * (Cch // groups), dtype=torch.float32, device=x.device)
+        capi.check(lib.ssbev_dcn_im2col(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(cols), C.byref(d), capi.stream()),
+                   "ssbev_dcn_im2col")
+        ctx.save_for_backward(xcl, ocl)
+        ctx.d = d
+        return cols
+
+    @staticmethod
+    def backward(ctx, gcols):
+        lib = capi.load()
+        xcl, ocl = ctx.saved_tensors
+        gx, goff = torch.empty_like(xcl), torch.empty_like(ocl)
+        capi.check(lib.ssbev_dcn_col2im(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(gcols.contiguous()), capi.ptr(gx),
+                                        capi.ptr(goff), C.byref(ctx.d), capi.stream()), "ssbev_dcn_col2im")
+        return from_cl(gx), from_cl(goff), None, None, None, None
+
+
+def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
+    """mmcv deform_conv2d (v1, stride 1, deform_groups 1, no bias): HIP sampling + one dense MFMA 1x1 conv per group."""
+    Cout, Cg, k, _ = weight.shape
+    B, _, H, W = x.shape
+    cols = _DcnIm2col.apply(x, offset, int(groups), int(k), int(padding), int(dilation))
+    Cog = Cout // groups
+    outs = []
+    for g in range(groups):
+        colg = cols[g].view(B, H, W, k * k * Cg).permute(0, 3, 1, 2)            # channels-last [B, K*Cg, H, W]
+        wg = weight[g * Cog:(g + 1) * Cog].permute(0, 2, 3, 1).reshape(Cog, k * k * Cg, 1, 1)
+        outs.append(conv2d(colg, wg, None, 1, 0, 1))
+    return torch.cat(outs, dim=1) if groups > 1 else outs[0]
 
 
 # -------------------------------------------------------------------------------------------------

@@ -73,8 +73,8 @@ class Conv2d(_ConvBase):
 
 class DeformConv2dPack(nn.Module):
     """mmcv ``DCN`` (DeformConv2dPack, DCNv1) as used at BD:490-498: ``weight`` [Cout, Cin/g, k, k],
-    ``conv_offset`` (3x3 conv, bias, zero-initialised).  The bilinear tap gather runs as torch
-    device ops; the grouped contraction is a batched GEMM."""
+    ``conv_offset`` (3x3 conv, bias, zero-initialised).  Bilinear tap sampling (and its adjoint) are HIP kernels;
+    the grouped contraction runs as one dense MFMA 1x1 convolution per group over the sampled columns."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
                  deform_groups=1, im2col_step=128, bias=False):
@@ -89,7 +89,10 @@ class DeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.bias)
 
     def forward(self, x):
-        off = self.conv_offset(x)
+        return F.deform_conv2d(x, self.conv_offset(x), self.weight, self.groups, self.padding, self.dilation)
+
+    def _forward_reference(self, x, off):
+        """The same operator in plain tensor ops (used by the parity test of the HIP sampling kernels)."""
         B, C, H, W = x.shape
         k, K = self.k, self.k * self.k
         dev = x.device

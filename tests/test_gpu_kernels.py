@@ -417,3 +417,26 @@ def test_softmax_strided_axis(shape, dim):
     got.backward(go.to(DEV))
     assert maxdiff(got, want) < 1e-6
     assert maxdiff(xg.grad, xc.grad) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 48, 4, 12, 20, 1, 1), (1, 64, 64, 1, 9, 14, 1, 1), (1, 32, 32, 4, 10, 12, 2, 2)])
+def test_deform_conv_hip_sampling_matches_tensor_op_formulation(cfg):
+    from stereoscene_amd.layers import DeformConv2dPack
+    B, Cin, Cout, G, H, W, pad, dil = cfg
+    torch.manual_seed(0)
+    layer = DeformConv2dPack(Cin, Cout, 3, 1, pad, dil, groups=G).to(DEV)
+    with torch.no_grad():      # offsets of a few pixels, so that border / outside / fractional cases all occur
+        layer.conv_offset.weight.copy_(S.hash_normal("dcn/ow", tuple(layer.conv_offset.weight.shape), 0.15).to(DEV))
+        layer.conv_offset.bias.copy_(S.hash_normal("dcn/ob", tuple(layer.conv_offset.bias.shape), 1.5).to(DEV))
+    x = S.hash_normal(f"dcn/x{cfg}", (B, Cin, H, W)).to(DEV)
+    go = S.hash_normal(f"dcn/go{cfg}", (B, Cout, H, W)).to(DEV)
+    res = []
+    for ref in (False, True):
+        xi = x.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        off = layer.conv_offset(xi)
+        y = layer._forward_reference(xi, off) if ref else F.deform_conv2d(xi, off, layer.weight, G, pad, dil)
+        y.backward(go)
+        res.append((y.detach(), xi.grad.clone(), layer.weight.grad.clone(), layer.conv_offset.weight.grad.clone()))
+    for a, b in zip(*res):
+        assert maxdiff(a, b) < 5e-5 * max(1.0, b.abs().max().item())
