@@ -426,6 +426,47 @@ wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nc
   }
 }
 
+// Same reduction for layers with many channels (where the OUTPUT is the big object: 28 MB for 512x512x27): the kernel
+// above writes gw[p][q][tap] one float at a time (a 108-byte stride between the lanes of a wave: every 4-byte store
+// dirties its own sector).  Here a workgroup owns 32 p x 8 q x all taps: the chunk sums are taken with coalesced 128-byte
+// reads, transposed through LDS, and written as 32 runs of 8*taps contiguous floats.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_tiled_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps, int Cq, int Cp,
+                          long total) {
+  extern __shared__ float tile[];                 // [32 p][8 q * taps] with an odd pitch
+  const int P = 8 * taps + 1;
+  const int e = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const int p0 = blockIdx.x * 32, q0 = blockIdx.y * 8;
+  const bool ok = p0 + e < Cp && q0 + row < Cq;
+  for (int tap = 0; tap < taps; ++tap) {
+    float s = 0.0f;
+    if (ok) {
+      const float* src = ws + ((size_t)tap * Cq + q0 + row) * Cp + p0 + e;
+#pragma unroll 4
+      for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * total];
+    }
+    tile[e * P + row * taps + tap] = s;
+  }
+  __syncthreads();
+  const int run = 8 * taps;
+  for (int j = threadIdx.x; j < 32 * run; j += 256) {
+    const int pe = j / run, r = j - pe * run;
+    const int q = q0 + r / taps, tap = r % taps, pp = p0 + pe;
+    if (pp < Cp && q < Cq) gw[((size_t)pp * Cq + q) * taps + tap] = tile[pe * P + r];
+  }
+}
+
+void launch_wgrad_reduce(const float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
+  const long total = (long)taps * Cq * Cp;
+  if (taps <= 32 && (long)cdiv(Cp, 32) * cdiv(Cq, 8) >= 128) {
+    hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(cdiv(Cp, 32), cdiv(Cq, 8)), dim3(256),
+                       (size_t)32 * (8 * taps + 1) * sizeof(float), st, partial, gw, nchunks, taps, Cq, Cp, total);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, nchunks, taps, Cq, Cp,
+                       total);
+  }
+}
+
 // ---------------------------------------------------------------- host side
 bool conv_dims_ok(const ssbev_conv_dims* d) {
   if (!d) return false;
@@ -1460,9 +1501,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
         hipLaunchKernelGGL((wgrad_1x1_kernel<1, 2>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
       else
         hipLaunchKernelGGL((wgrad_1x1_kernel<1, 1>), grid, block, 0, st, P, Q, partial, p1.N, p1.Cq, p1.Cp, p1.chunk, p1.nchunks);
-      const long total = (long)p1.Cq * p1.Cp;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, p1.nchunks, 1, p1.Cq,
-                         p1.Cp, total);
+      launch_wgrad_reduce(partial, gw, p1.nchunks, 1, p1.Cq, p1.Cp, st);
       return ssbev_launch_status();
     }
   }
@@ -1473,10 +1512,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
       float* partial = static_cast<float*>(ws);
       const int rc = run_wgrad_lds(x, gy, partial, d, lp, st);
       if (rc != SSBEV_OK) return rc;
-      const int taps = d->kd * 9;
-      const long total = (long)taps * lp.g.Cq * lp.g.Cp;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw,
-                         lp.nchunks * lp.ksplit, taps, lp.g.Cq, lp.g.Cp, total);
+      launch_wgrad_reduce(partial, gw, lp.nchunks * lp.ksplit, d->kd * 9, lp.g.Cq, lp.g.Cp, st);
       return ssbev_launch_status();
     }
   }
@@ -1500,9 +1536,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
     else if (c.MQ == 2) launch_wgrad_cf<2, 2, 1, 3>(Pt, Qp, partial, g, st);
     else if (c.TH == 3) launch_wgrad_cf<1, 1, 3, 3>(Pt, Qp, partial, g, st);
     else launch_wgrad_cf<1, 1, 1, 3>(Pt, Qp, partial, g, st);
-    const long total = (long)taps * g.Cq * g.Cp;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, g.nchunks, taps, g.Cq,
-                       g.Cp, total);
+    launch_wgrad_reduce(partial, gw, g.nchunks, taps, g.Cq, g.Cp, st);
     return ssbev_launch_status();
   }
   const WgradGeom g = make_wgrad_geom(d);
@@ -1517,9 +1551,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
   else if (c.MQ == 2) launch_wgrad<2, 2, 1, 3>(P, Qt, wsf, g, st);
   else if (c.TH == 3) launch_wgrad<1, 1, 3, 3>(P, Qt, wsf, g, st);
   else launch_wgrad<1, 1, 1, 3>(P, Qt, wsf, g, st);
-  const long total = (long)taps * g.Cq * g.Cp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
-                     g.nchunks, taps, g.Cq, g.Cp, total);
+  launch_wgrad_reduce(static_cast<const float*>(ws), gw, g.nchunks, taps, g.Cq, g.Cp, st);
   return ssbev_launch_status();
 }
 

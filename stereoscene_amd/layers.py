@@ -134,9 +134,10 @@ class GroupNorm(nn.GroupNorm):
         return F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, residual, relu)
 
 
-class BatchNorm3d(nn.BatchNorm3d):
-    """nn.BatchNorm3d parameters/buffers; training mode = batch statistics from the two-stage HIP
-    reduction (+ momentum update of the running stats), eval mode = running statistics."""
+class _HipBatchNorm:
+    """Mixin: nn.BatchNormNd parameters/buffers; training mode = batch statistics from the two-stage HIP
+    reduction (+ momentum update of the running stats), eval mode = running statistics.  Optional fused
+    residual add and ReLU: relu?(BN(x) + residual?) in one streaming pass."""
     fused_relu = False
 
     def forward(self, x, residual=None, relu=None):
@@ -162,6 +163,14 @@ class BatchNorm3d(nn.BatchNorm3d):
                                  relu)
 
 
+class BatchNorm3d(_HipBatchNorm, nn.BatchNorm3d):
+    pass
+
+
+class BatchNorm2d(_HipBatchNorm, nn.BatchNorm2d):
+    pass
+
+
 def _last_leaf(m):
     while isinstance(m, nn.Sequential) and len(m) > 0:
         m = m[len(m) - 1]
@@ -175,7 +184,7 @@ def fuse_relu_(module):
     for seq in [m for m in module.modules() if isinstance(m, nn.Sequential)]:
         for i in range(1, len(seq)):
             prev = _last_leaf(seq[i - 1])
-            if isinstance(seq[i], nn.ReLU) and isinstance(prev, (GroupNorm, BatchNorm3d)):
+            if isinstance(seq[i], nn.ReLU) and isinstance(prev, (GroupNorm, BatchNorm3d, BatchNorm2d)):
                 prev.fused_relu = True
                 seq[i] = nn.Identity()
     return module
@@ -189,7 +198,7 @@ def build_norm_layer(cfg, num_features, postfix=""):
     if t == "GN":
         name, layer = "gn", GroupNorm(cfg["num_groups"], num_features, eps=cfg.get("eps", 1e-5))
     elif t in ("BN", "BN2d"):
-        name, layer = "bn", nn.BatchNorm2d(num_features)
+        name, layer = "bn", BatchNorm2d(num_features)
     elif t == "BN3d":
         name, layer = "bn", BatchNorm3d(num_features)
     else:

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from .. import functional as F
-from ..layers import (BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
+from ..layers import (BatchNorm2d, BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
                       fuse_relu_)
 from ..registry import NECKS
 
@@ -60,24 +60,24 @@ class BasicBlock2d(nn.Module):
     def __init__(self, inplanes, planes):
         super().__init__()
         self.conv1 = Conv2d(inplanes, planes, 3, 1, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
 
     def forward(self, x):
-        y = torch.relu(self.bn1(self.conv1(x)))
-        return torch.relu(self.bn2(self.conv2(y)) + x)
+        y = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(y), residual=x, relu=True)
 
 
 class _ASPPModule(nn.Module):
     def __init__(self, inplanes, planes, kernel_size, padding, dilation):
         super().__init__()
         self.atrous_conv = Conv2d(inplanes, planes, kernel_size, 1, padding, dilation, bias=False)
-        self.bn = nn.BatchNorm2d(planes)
+        self.bn = BatchNorm2d(planes)
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x):
-        return torch.relu(self.bn(self.atrous_conv(x)))
+        return self.bn(self.atrous_conv(x), relu=True)
 
 
 class ASPP(nn.Module):
@@ -95,7 +95,7 @@ class ASPP(nn.Module):
             build_norm_layer(GN2, mid_channels)[1],
             nn.ReLU())
         self.conv1 = Conv2d(int(mid_channels * 5), mid_channels, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(mid_channels)
+        self.bn1 = BatchNorm2d(mid_channels)
         self.dropout = nn.Dropout(0.5)
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, Conv2d)):
@@ -107,7 +107,7 @@ class ASPP(nn.Module):
         g = torch.relu(self.global_avg_pool[2](g))[..., None, None]
         g = g.expand(-1, -1, x.shape[2], x.shape[3])                 # bilinear(align_corners) of a 1x1 map
         y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), dim=1)
-        return self.dropout(torch.relu(self.bn1(self.conv1(y))))
+        return self.dropout(self.bn1(self.conv1(y), relu=True))
 
 
 class DepthNet(nn.Module):
