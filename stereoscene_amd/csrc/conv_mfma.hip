@@ -1183,8 +1183,8 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
   }
 }
 
-constexpr int kWgLdsRowVox = 32;                 // target P voxels (= 2 x MFMA k-steps) per step
-constexpr size_t kWgLdsMaxBytes = 64 * 1024;     // LDS per workgroup (two workgroups per CU; M0-addressable)
+constexpr int kWgLdsRowVox = 64;                 // target P voxels (= 2 x MFMA k-steps) per step
+constexpr size_t kWgLdsMaxBytes = 79 * 1024;     // LDS per workgroup (two workgroups per CU; M0-addressable)
 
 struct WgradLdsPlan {
   WgradLdsGeom g;
@@ -1291,7 +1291,11 @@ int launch_wgrad_lds(const float* P, const float* Q, float* ws, const WgradLdsPl
   const WgradLdsGeom& g = p.g;
   auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S>;
   dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB * KSPLIT);
-  hipLaunchKernelGGL(kern, grid, block, p.lds_bytes + 1024, st, P, Q, ws, g);      // +1 KB: prefetch slack
+  const size_t lds = p.lds_bytes + 1024;                                            // +1 KB: prefetch slack
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, grid, block, lds, st, P, Q, ws, g);
   return SSBEV_OK;
 }
 

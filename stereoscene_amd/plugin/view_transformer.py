@@ -13,6 +13,7 @@ VT = projects/mmdet3d_plugin/occupancy/image2bev/ViewTransformerLSSVoxel.py
 BD = .../image2bev/ViewTransformerLSSBEVDepth.py, ATT = .../image2bev/attention.py
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -254,9 +255,13 @@ class attention(nn.Module):
         Q = self._affine(self.query_conv, q).view(B, D, hw)                   # [B,D,HW] (tokens contiguous)
         K = self._affine(self.key_conv, kv).view(B, D, hw)
         V = self._affine(self.value_conv, kv).view(B, D, hw)
-        if F.bri_attention_supported(B, hw, D):
-            out = F.bri_attention(Q, K, V, conf).view(B, C, D, H, W)      # flash-style HIP kernels, no HW x HW matrix
-        else:                                                             # head sizes without a specialisation
+        # Two realisations of the same operator.  Default: six plain NN GEMMs (rocBLAS fp32 MFMA, 75-123 TF/s on these
+        # 7680 x 7680 x 192 shapes) around the materialised T x T attention matrix (236 MB per direction -- nothing on a
+        # 288 GB part).  SSBEV_BRI=flash selects the hand-written flash-style kernels (no T x T matrix, 0.7 GB less saved
+        # state per sample) which currently run at ~45 TF/s: 8 ms/step slower at D=192 (profiles/r1k_bri_paths.txt).
+        if os.environ.get("SSBEV_BRI", "gemm") == "flash" and F.bri_attention_supported(B, hw, D):
+            out = F.bri_attention(Q, K, V, conf).view(B, C, D, H, W)
+        else:
             out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
         return self.gamma * out + kv
 

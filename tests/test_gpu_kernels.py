@@ -351,9 +351,11 @@ def test_bri_attention_fwd_bwd_vs_dense(B, Dh, T):
         assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
 
 
-def test_bri_attention_golden_module():
-    """The attention module (scalar affine q/k/v + gamma) against the reference fixture."""
+@pytest.mark.parametrize("path", ["gemm", "flash"])
+def test_bri_attention_golden_module(path, monkeypatch):
+    """The attention module (scalar affine q/k/v + gamma) against the reference fixture, both realisations."""
     from stereoscene_amd.plugin.view_transformer import attention
+    monkeypatch.setenv("SSBEV_BRI", path)
     g = load_golden("attention")
     att = attention(1).to(DEV)
     att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})
