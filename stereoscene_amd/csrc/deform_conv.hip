@@ -77,9 +77,10 @@ __device__ __forceinline__ void atomic_add4(float* p, float w, const float4& gva
   unsafeAtomicAdd(p + 3, w * gval.w);
 }
 
+// Offset gradient: one workgroup per output pixel, deterministic reduction over the channels.
 __global__ void __launch_bounds__(256)
-dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ gcols,
-                  float* __restrict__ gx, float* __restrict__ goff, DcnGeom g) {
+dcn_coord_grad_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ gcols,
+                      float* __restrict__ goff, DcnGeom g) {
   __shared__ float red[4][32];
   const long pix = blockIdx.x;
   const int ow = (int)(pix % g.W), oh = (int)((pix / g.W) % g.H);
@@ -87,11 +88,9 @@ dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ off, co
   const int K = g.k * g.k, q = g.C >> 2, Cg = g.C / g.G;
   const long BHW = (long)g.B * g.H * g.W;
   const float* xb = x + b * (long)g.H * g.W * g.C;
-  float* gxb = gx + b * (long)g.H * g.W * g.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int tap = 0; tap < K; ++tap) {
     const Sample s = make_sample(off, pix, oh, ow, tap, g);
-    const float w00 = (1.f - s.lh) * (1.f - s.lw), w01 = (1.f - s.lh) * s.lw, w10 = s.lh * (1.f - s.lw), w11 = s.lh * s.lw;
     float dh = 0.f, dw = 0.f;
     for (int cq = threadIdx.x; cq < q; cq += 256) {
       const int c = cq * 4, grp = c / Cg, cg = c - grp * Cg;
@@ -103,12 +102,8 @@ dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ off, co
       // d val / d h = -(1-lw) v00 - lw v01 + (1-lw) v10 + lw v11 ;  d val / d w = -(1-lh) v00 + (1-lh) v01 - lh v10 + lh v11
       dh += (1.f - s.lw) * (d10 - d00) + s.lw * (d11 - d01);
       dw += (1.f - s.lh) * (d01 - d00) + s.lh * (d11 - d10);
-      if (s.ok00) atomic_add4(gxb + o00, w00, gc);
-      if (s.ok01) atomic_add4(gxb + o00 + g.C, w01, gc);
-      if (s.ok10) atomic_add4(gxb + o00 + (long)g.W * g.C, w10, gc);
-      if (s.ok11) atomic_add4(gxb + o00 + (long)g.W * g.C + g.C, w11, gc);
     }
-    // deterministic workgroup reduction of (dh, dw): lanes by xor-shuffle, waves through LDS in fixed order
+    // lanes by xor-shuffle, waves through LDS in fixed order
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
       dh += __shfl_xor(dh, m, 64);
@@ -123,9 +118,73 @@ dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ off, co
   }
 }
 
+// Input gradient.  Every sample adds to four corner pixels (unordered fp32 atomics, as in mmcv).  Sent straight to
+// L2 that is 4 x 9 atomics per output pixel and channel (177 M per DepthNet step: 2.2 ms).  A workgroup therefore owns a
+// TH x TW tile of output pixels and a 32-channel slice, accumulates into an LDS window that covers the tile plus a
+// reach of R pixels (ds_add_f32; samples that land outside the window -- offsets larger than R -- go to global
+// memory directly), and flushes the window with one global atomic per touched element: ~9x fewer L2 atomics.
+constexpr int kDcnTH = 4, kDcnTW = 16, kDcnR = 3, kDcnCC = 32;
+constexpr int kDcnWH = kDcnTH + 2 * kDcnR + 1, kDcnWW = kDcnTW + 2 * kDcnR + 1, kDcnPitch = kDcnCC + 1;
+
+__global__ void __launch_bounds__(256)
+dcn_input_grad_kernel(const float* __restrict__ off, const float* __restrict__ gcols, float* __restrict__ gx, DcnGeom g) {
+  __shared__ float win[kDcnWH * kDcnWW * kDcnPitch];
+  const int tiles_w = (g.W + kDcnTW - 1) / kDcnTW;
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x % tiles_w;
+  const int c0 = blockIdx.y * kDcnCC;
+  const long b = blockIdx.z;
+  const int h_lo = th * kDcnTH - kDcnR, w_lo = tw * kDcnTW - kDcnR;
+  const int K = g.k * g.k, Cg = g.C / g.G;
+  const long BHW = (long)g.B * g.H * g.W;
+  for (int i = threadIdx.x; i < kDcnWH * kDcnWW * kDcnPitch; i += 256) win[i] = 0.0f;
+  __syncthreads();
+  float* gxb = gx + b * (long)g.H * g.W * g.C;
+  const int px = threadIdx.x >> 2, qsub = threadIdx.x & 3;            // 64 pixels x 4 threads, 8 channels each
+  const int oh = th * kDcnTH + px / kDcnTW, ow = tw * kDcnTW + px % kDcnTW;
+  if (oh < g.H && ow < g.W) {
+    const long pix = (b * g.H + oh) * g.W + ow;
+    const int c = c0 + qsub * 8;
+    if (c < g.C) {
+      const int grp = c / Cg, cg = c - grp * Cg;
+      for (int tap = 0; tap < K; ++tap) {
+        const Sample s = make_sample(off, pix, oh, ow, tap, g);
+        if (!s.inside) continue;
+        const float* gp = gcols + (((long)grp * BHW + pix) * K + tap) * Cg + cg;
+        const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        const float wgt[4] = {(1.f - s.lh) * (1.f - s.lw), (1.f - s.lh) * s.lw, s.lh * (1.f - s.lw), s.lh * s.lw};
+        const bool okc[4] = {s.ok00, s.ok01, s.ok10, s.ok11};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          if (!okc[k4]) continue;
+          const int hc = s.h0 + (k4 >> 1), wc = s.w0 + (k4 & 1);
+          const int wh = hc - h_lo, wwc = wc - w_lo;
+          if (wh >= 0 && wh < kDcnWH && wwc >= 0 && wwc < kDcnWW) {
+            float* dst = win + (wh * kDcnWW + wwc) * kDcnPitch + qsub * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(dst + e, wgt[k4] * gv[e]);
+          } else {
+            float* dst = gxb + ((long)hc * g.W + wc) * g.C + c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, wgt[k4] * gv[e]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDcnWH * kDcnWW * kDcnCC; i += 256) {
+    const int e = i % kDcnCC, wp = i / kDcnCC;
+    const int hc = h_lo + wp / kDcnWW, wc = w_lo + wp % kDcnWW;
+    const float v = win[wp * kDcnPitch + e];
+    if (v != 0.0f && hc >= 0 && hc < g.H && wc >= 0 && wc < g.W && c0 + e < g.C)
+      unsafeAtomicAdd(gxb + ((long)hc * g.W + wc) * g.C + c0 + e, v);
+  }
+}
+
 bool dcn_ok(const ssbev_dcn_dims* d) {
   return d && d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->G > 0 && d->C % d->G == 0 && (d->C / d->G) % 4 == 0 &&
-         d->k >= 1 && d->k * d->k <= 16 && d->dil >= 1 && d->pad >= 0;
+         (d->C / d->G) % 8 == 0 && d->k >= 1 && d->k * d->k <= 16 && d->dil >= 1 && d->pad >= 0;
 }
 
 DcnGeom to_geom(const ssbev_dcn_dims* d) { return DcnGeom{d->B, d->C, d->H, d->W, d->G, d->k, d->pad, d->dil}; }
@@ -146,8 +205,11 @@ int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, fl
   if (!dcn_ok(d) || !x || !offset || !gcols || !gx || !goffset) return SSBEV_EINVAL;
   hipStream_t st = as_stream(stream);
   if (hipMemsetAsync(gx, 0, (size_t)d->B * d->H * d->W * d->C * sizeof(float), st) != hipSuccess) return SSBEV_ELAUNCH;
-  hipLaunchKernelGGL(dcn_col2im_kernel, dim3((unsigned)((long)d->B * d->H * d->W)), dim3(256), 0, st, x, offset, gcols,
-                     gx, goffset, to_geom(d));
+  hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3((unsigned)((long)d->B * d->H * d->W)), dim3(256), 0, st, x, offset,
+                     gcols, goffset, to_geom(d));
+  const int tiles = ((d->H + kDcnTH - 1) / kDcnTH) * ((d->W + kDcnTW - 1) / kDcnTW);
+  hipLaunchKernelGGL(dcn_input_grad_kernel, dim3(tiles, (d->C + kDcnCC - 1) / kDcnCC, d->B), dim3(256), 0, st, offset,
+                     gcols, gx, to_geom(d));
   return ssbev_launch_status();
 }
 
