@@ -1311,6 +1311,249 @@ int run_wgrad_lds(const float* x, const float* gy, float* ws, const ssbev_conv_d
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 "same" convolution (forward and data gradient) for <= 32 input and <= 32 output channels: the
+// cost-volume layers (32 -> 32 at 192 x 48 x 160, and the 32 -> 1 / 2 -> 32 heads).  With so few channels the generic
+// gather kernel above is bound by its A-operand delivery, not by the matrix pipe: every one of the 27 taps fetches
+// the 128-byte voxel lines of its tile as 64 separate 16-byte L1 accesses (17 ms/step at 80 TF/s, LDS-resident
+// weights included).  Here
+//   * the input rows live in LDS: a workgroup walks output rows (b, d, h) of one 32-voxel w-segment and keeps a ring
+//     of 4 row slots x 3 depth planes (34 voxels x 32 channels each), filled with global_load_lds_dwordx4 -- every
+//     voxel line is read from L2 once per workgroup, as whole coalesced kilobytes, and used by all 27 taps;
+//   * the weights live in REGISTERS: the 27 taps are dealt to the 4 waves (7/7/7/6), each wave holds its taps'
+//     32 x 32 matrices as MFMA A operands (112 VGPRs) for the whole kernel: no weight traffic at all;
+//   * MFMA roles: rows = output channel, columns = voxel, k = input channel.  The B operand of a tap is one
+//     ds_read_b128 per 8 channels (4 k-steps); a 16-byte XOR swizzle of the channel quads (applied on the GLOBAL side
+//     of the LDS load, whose LDS side must stay lane-contiguous) makes the 32 voxel lanes of a read conflict-free;
+//   * the four partial 32 x 32 tiles of a row are summed through LDS in wave order (deterministic) and every wave
+//     stores a quarter of the channels (+ bias, ReLU).
+struct ConvTapGeom {
+  int B, D, H, W, K, N;           // K input channels (multiple of 4, <= 32), N output channels (<= 32)
+  int nseg, NG, gpc;              // 32-voxel segments per row, B*D*H rows, rows per chunk
+  int relu, has_bias;
+};
+
+constexpr int kTapWseg = 32, kTapCols = kTapWseg + 2, kTapRowF = kTapCols * 32, kTapSlots = 4;
+constexpr int kTapPlaneF = kTapSlots * kTapRowF, kTapRingF = 3 * kTapPlaneF;
+constexpr size_t kTapLdsBytes = (size_t)(kTapRingF + 4 * 16 * 64) * sizeof(float);
+constexpr int kTapPackedElems = 4 * 7 * 16 * 64;
+
+// w_packed[((wave * 7 + tt) * 16 + q * 4 + c) * 64 + lane] = Weff[n = lane & 31][k = 8q + 4 (lane >> 5) + c][tap = wave + 4 tt]
+//   mode 0 (forward):        Weff[n][k][tap] = w[n][k][tap]            (torch layout [Cout][Cin][27])
+//   mode 1 (data gradient):  Weff[n][k][tap] = w[k][n][26 - tap]       (roles swapped, taps mirrored)
+__global__ void __launch_bounds__(256)
+pack_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kTapPackedElems) return;
+  const int lane = i & 63, r = (i >> 6) & 15, wt = i >> 10;
+  const int tt = wt % 7, wave = wt / 7;
+  const int tap = wave + 4 * tt, n = lane & 31, k = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (tap < 27 && n < N && k < K)
+    v = mode == 0 ? w[((size_t)n * Cin + k) * 27 + tap] : w[((size_t)k * Cin + n) * 27 + (26 - tap)];
+  wp[i] = v;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                float* __restrict__ Y, ConvTapGeom g) {
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [3 planes][4 slots][34 voxels][32 channels], 16-byte swizzled
+  float* red = tl + kTapRingF;               // [4 waves][16 rows][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+
+  // weights of this wave's taps: A operands, resident for the whole kernel
+  float wr[7][16];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[tt][r] = wp[((wave * 7 + tt) * 16 + r) * 64 + lane];
+  const int ntap = wave < 3 ? 7 : 6;
+
+  unsigned chunk_id;
+  {   // XCD-aware remap: the five w-segments of a row range share one L2
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * kTapWseg;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+
+  // staging entries: one entry = 64 consecutive 16-byte items of one (plane, row); item = (voxel u, physical quad p4),
+  // LDS offset u*32 + p4*4 (lane-contiguous), source quad p4 ^ (u & 7)
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 entries per row
+  int xoff[4], xmeta[4];                                        // per wave: ceil(15 / 4) entries
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int q = wave + n * 4;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ (u & 7)) << 2), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kTapPlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  // padded row hp (= input row hp - 1) of planes d-1, d, d+1 -> ring slot hp & 3
+  auto stage_row = [&](int b, int d, int hp) {
+    const float* base = X + ((long)(b * g.D + d - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = ring + (meta >> 4) + (hp & 3) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+
+  // per-tap constants: plane offset, row shift, column shift (wave-uniform)
+  int tp_plane[7], tp_kh[7], tp_kw[7];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    const int t = min(wave + 4 * tt, 26);
+    tp_plane[tt] = (t / 9) * kTapPlaneF; tp_kh[tt] = (t / 3) % 3; tp_kw[tt] = t % 3;
+  }
+  const int nb = 8 * wave + 4 * lk;          // first of the 4 output channels this lane stores
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
+  }
+
+  bool fresh = true;
+  int h = g_begin % g.H, d, b;
+  {
+    const int bd = g_begin / g.H;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    if (fresh) {
+      stage_row(b, d, h); stage_row(b, d, h + 1); stage_row(b, d, h + 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h + 1 < g.H;
+    if (same_plane) stage_row(b, d, h + 3);
+
+    f32x16 acc4[4];                      // one chain per channel octet: consecutive MFMAs are independent
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc4[q][r] = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt) {
+      if (tt < ntap) {
+        const int u = li + tp_kw[tt];
+        const float* rowp = ring + tp_plane[tt] + ((h + tp_kh[tt]) & 3) * kTapRowF + u * 32;
+        const int sw = u & 7;
+        float4 xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 0], xv[q].x, acc4[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 1], xv[q].y, acc4[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 2], xv[q].z, acc4[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 3], xv[q].w, acc4[q]);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+    // fold the four tap groups: every wave publishes its partial tile, then sums rows 4*wave .. 4*wave+3
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        o[i] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+               red[(3 * 16 + r) * 64 + lane] + bv[i];
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      const int wv = w0 + li;
+      if (wv < g.W) {
+        float* dst = Y + (((long)(b * g.D + d) * g.H + h) * g.W + wv) * g.N + nb;
+        if ((g.N & 3) == 0) {
+          if (nb < g.N) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < g.N) dst[i] = o[i];
+        }
+      }
+    }
+    __syncthreads();                       // the partial buffer is reused by the next row
+    fresh = !same_plane;
+    if (++h == g.H) {
+      h = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+}
+
+// tile_hint 8 forces the generic gather kernels (A/B timing), 9 forces this kernel on small problems (tests)
+bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->accumulate || d->tile_hint == 8) return false;
+  if (d->Cin > 32 || d->Cout > 32) return false;
+  const int K = mode == 0 ? d->Cin : d->Cout;
+  if (K % 4 != 0) return false;
+  if (K < 16 && d->tile_hint != 9) return false;     // few input channels: the generic kernel has little to fetch
+  // worth it only when the volume fills the chip with row walks: >= 1024 (segment, row-range) workgroups of >= 16 rows
+  // (tile_hint 9 forces it on any size: tests)
+  return d->tile_hint == 9 || (long)d->B * d->Do * d->Ho * ((d->Wo + kTapWseg - 1) / kTapWseg) >= 1024L * 16;
+}
+
+int launch_conv_tap(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                    hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + kTapWseg - 1) / kTapWseg;
+  g.NG = g.B * g.D * g.H;
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  // two workgroups per CU; whole rounds of 512 workgroups, >= 16 rows each
+  long nranges = 512 / g.nseg;
+  for (long rounds = 8; rounds >= 1; --rounds) {
+    const long nr = (512 * rounds) / g.nseg;
+    if ((g.NG + nr - 1) / nr >= 24) { nranges = nr; break; }
+  }
+  if (nranges < 1) nranges = 1;
+  g.gpc = (int)((g.NG + nranges - 1) / nranges);
+  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  auto kern = conv_tap_kernel;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kTapLdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nranges * g.nseg)), dim3(256), kTapLdsBytes, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
 bool wgrad_cf_applicable(const ssbev_conv_dims* d) {
   if (d->transposed || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
@@ -1413,12 +1656,18 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   // big enough for either role assignment (forward or data-gradient operand)
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
-  return taps * (a > b ? a : b);
+  const size_t generic = taps * (a > b ? a : b);
+  return generic > (size_t)kTapPackedElems ? generic : (size_t)kTapPackedElems;
 }
 
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (conv_tap_applicable(d, mode)) {        // register-resident tap-split layout (see conv_tap_kernel)
+    hipLaunchKernelGGL(pack_tap_kernel, dim3(cdiv(kTapPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed,
+                       d->Cout, d->Cin, mode);
+    return ssbev_launch_status();
+  }
   const int taps = d->kd * d->kh * d->kw;
   // forward: K = Cin, N = Cout; data gradient: K = Cout, N = Cin
   const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
@@ -1437,13 +1686,14 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
                    const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
+  if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
   g.B = d->B; g.Cin = d->Cin; g.Cout = d->Cout; g.CinPad = pad8(d->Cin); g.CoutPad = pad32(d->Cout);
   g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo;
   g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate;
-  g.hint = d->tile_hint >= 10 ? d->tile_hint : 0;       // hints below 10 select weight-gradient variants
+  g.hint = d->tile_hint >= 10 ? d->tile_hint : 0;       // hints below 10 select other kernel families
   g.chunk_taps = 0;
   return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
 }
@@ -1451,6 +1701,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin
   g.B = d->B; g.Cin = d->Cout; g.Cout = d->Cin; g.CinPad = pad8(d->Cout); g.CoutPad = pad32(d->Cin);
   g.Di = d->Do; g.Hi = d->Ho; g.Wi = d->Wo; g.Do = d->Di; g.Ho = d->Hi; g.Wo = d->Wi;

@@ -442,3 +442,28 @@ def test_deform_conv_hip_sampling_matches_tensor_op_formulation(cfg):
         res.append((y.detach(), xi.grad.clone(), layer.weight.grad.clone(), layer.conv_offset.weight.grad.clone()))
     for a, b in zip(*res):
         assert maxdiff(a, b) < 5e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 5, 6, 40, True), (2, 4, 32, 4, 5, 33, False), (1, 32, 1, 3, 7, 64, True),
+                                  (1, 32, 20, 6, 9, 96, False), (1, 2, 32, 4, 4, 32, True), (1, 32, 32, 9, 3, 160, False)])
+def test_conv_tap_split_lds_kernel(case):
+    """The register-weights / LDS-rows kernel of the <= 32-channel 3x3x3 layers (forced with tile hint 9) against ATen,
+    forward and data gradient; the weight gradient of the same call runs on its usual kernels."""
+    B, Cin, Cout, D, H, W, has_bias = case
+    x = S.hash_normal(f"tap/x{case}", (B, Cin, D, H, W))
+    w = S.hash_uniform(f"tap/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    b = S.hash_uniform(f"tap/b{case}", (Cout,), -0.5, 0.5) if has_bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv3d(xc, wc, b, 1, 1)
+    go = S.hash_normal(f"tap/go{case}", tuple(want.shape))
+    want.backward(go)
+    F.TILE_HINT = 9
+    try:
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        got = F.conv3d(xg, wg, b.to(DEV) if has_bias else None, 1, 1)
+        got.backward(go.to(DEV))
+    finally:
+        F.TILE_HINT = 0
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
