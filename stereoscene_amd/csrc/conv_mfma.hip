@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // is read with ds_read_b128.  For the 32-channel cost-volume layers the 110 KB of weights do not fit the
 // 32 KB L1, so without this every wave streams them from L2 for each of its 64 voxels (as much L2 traffic
 // as the activations themselves); a 16-wave workgroup amortises one copy over 1024 voxels.
-template <int MT, int NT, int QU, int WPB = 4, bool LDSB = false>
+template <int MT, int NT, int QU, int WPB = 4, bool LDSB = false, bool PIPE = false>
 __global__ void __launch_bounds__(WPB * 64)
 conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                    float* __restrict__ y, ConvGeom g) {
@@ -154,6 +154,90 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
     // may point outside the tensor for border voxels; only dereferenced under the mask
     pbase[mt] = x + ((((long)ob[mt] * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin + 4 * lk;
   }
+  if constexpr (!LDSB && PIPE) {
+    // Software-pipelined walk over the flat (tap, channel-group) sequence: the operands of group n+1 are requested
+    // right after the first MFMA of group n and consumed one group later.  Used for the <1,5> tiling of the 48x160
+    // maps (one wave per SIMD, nothing else hides the L1/L2 latency: 98 -> 110 TF/s); the tilings that run several
+    // waves per SIMD lose more from the doubled operand registers than they gain (measured), so they keep the
+    // plain loop below.
+    const int ngq = Q / QU, G = ntaps * ngq;
+    int l_ti = 0, l_q0 = 0;
+    const float* l_ap[MT];
+    const float* l_wt = wlane;
+    auto tap_state = [&](int t) {
+      const int ic = t % nkw, ib = (t / nkw) % nkh, ia = t / (nkw * nkh);
+      const int c = kw0 + ic * kws, bq = kh0 + ib * khs, a = kd0 + ia * kds;
+      const int tap = (a * g.kh + bq) * g.kw + c;
+      const long toff = (((long)ia * step_d * g.Hi + (long)ib * step_h) * g.Wi + (long)ic * step_w) * g.Cin;   // uniform
+      const unsigned need = (1u << ia) | (1u << (8 + ib)) | (1u << (16 + ic));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) l_ap[mt] = ((vmask[mt] & need) == need) ? pbase[mt] + toff : nullptr;
+      l_wt = wlane + (size_t)tap * w_tap_stride;
+    };
+    auto load = [&](float4 (&av)[QU][MT], float4 (&bv)[QU][NT]) {
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+        const int q = l_q0 + u;
+        const bool cok = (8 * q + 4 * lk) < g.Cin;   // Cin is padded to 8 only in the packed weights
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          av[u][mt] = (l_ap[mt] && cok) ? *reinterpret_cast<const float4*>(l_ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bv[u][nt] = *reinterpret_cast<const float4*>(l_wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+      }
+      l_q0 += QU;
+      if (l_q0 >= Q) {
+        l_q0 = 0;
+        if (++l_ti < ntaps) tap_state(l_ti);
+      }
+    };
+    auto mm_head = [&](const float4 (&av)[QU][MT], const float4 (&bv)[QU][NT]) {
+      acc[0][0] = mfma32(av[0][0].x, bv[0][0].x, acc[0][0]);
+    };
+    auto mm_tail = [&](const float4 (&av)[QU][MT], const float4 (&bv)[QU][NT]) {
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (u + mt + nt != 0) acc[mt][nt] = mfma32(av[u][mt].x, bv[u][nt].x, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[u][mt].y, bv[u][nt].y, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[u][mt].z, bv[u][nt].z, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[u][mt].w, bv[u][nt].w, acc[mt][nt]);
+      }
+    };
+    float4 avA[QU][MT], bvA[QU][NT], avB[QU][MT], bvB[QU][NT];
+    if (G > 0) {
+      tap_state(0);
+      load(avA, bvA);
+    }
+    for (int gi = 0; gi < G; gi += 2) {
+      mm_head(avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 1 < G) load(avB, bvB);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_tail(avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 1 >= G) break;
+      mm_head(avB, bvB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 2 < G) load(avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_tail(avB, bvB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   const int taps_total = g.kd * g.kh * g.kw;
   const int chunk_taps = LDSB ? g.chunk_taps : taps_total;
   int ti = 0;
@@ -194,20 +278,20 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
           bv[u][nt] = LDSB ? reinterpret_cast<const float4*>(wlds)[(((tap - t0) * Q + q) * 2 + lk) * (NT * 32) + nt * 32 + li]
                            : *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
       }
+      // component-major: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
+#define SSBEV_GATHER_STEP(COMP)                                                              \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
+        acc[mt][nt] = mfma32(av[u][mt].COMP, bv[u][nt].COMP, acc[mt][nt]);
 #pragma unroll
-      for (int u = 0; u < QU; ++u)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = mfma32(av[u][mt].x, bv[u][nt].x, acc[mt][nt]);
-            acc[mt][nt] = mfma32(av[u][mt].y, bv[u][nt].y, acc[mt][nt]);
-            acc[mt][nt] = mfma32(av[u][mt].z, bv[u][nt].z, acc[mt][nt]);
-            acc[mt][nt] = mfma32(av[u][mt].w, bv[u][nt].w, acc[mt][nt]);
-          }
+      for (int u = 0; u < QU; ++u) {
+        SSBEV_GATHER_STEP(x) SSBEV_GATHER_STEP(y) SSBEV_GATHER_STEP(z) SSBEV_GATHER_STEP(w)
+      }
+#undef SSBEV_GATHER_STEP
     }
   }
   }   // staged tap chunks
+  }   // LDSB path
   if (LDSB && !active) return;
 
   // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lk, col = li ---------------------------
@@ -493,10 +577,11 @@ int launch_gather(const float* x, const float* wp, const float* bias, float* y, 
     Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
   }
   dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
+  constexpr bool PIPE = NT == 5;
   if ((g.CinPad >> 3) % QU == 0)
-    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, QU>), grid, block, 0, st, x, wp, bias, y, g);
+    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, QU, 4, false, PIPE>), grid, block, 0, st, x, wp, bias, y, g);
   else
-    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 1>), grid, block, 0, st, x, wp, bias, y, g);
+    hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 1, 4, false, PIPE>), grid, block, 0, st, x, wp, bias, y, g);
   return ssbev_launch_status();
 }
 
@@ -577,7 +662,7 @@ int dispatch_gather(const float* x, const float* wp, const float* bias, float* y
   const long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
   // 48x160 feature maps (7680 pixels = 240 row tiles): <1,5> makes 240 x (Cout/160) waves -- 960 of the chip's 1024
   // SIMDs busy in ONE round for Cout = 640, each A operand feeding five column tiles (sweep: 98 vs 81 TF/s)
-  if (Mtot <= 8192 && g.Cout % 160 == 0 && g.Cout >= 640 && g.form == 0)
+  if (Mtot <= 8192 && g.Cout % 160 == 0 && g.Cout >= 640 && g.sd * g.sh * g.sw == 1)
     return launch_gather_cfg(1, 5, 4, x, wp, bias, y, g, st);
   if (Mtot <= 8192 && (long)g.kd * g.kh * g.kw * g.Cin <= 8192 && g.Cout > 64)   // other small maps: many small tiles
     return launch_gather_cfg(1, 1, 1, x, wp, bias, y, g, st);

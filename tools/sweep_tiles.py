@@ -31,6 +31,7 @@ for name, ci, co, (D, H, W), k, s, p, tr, op in LAYERS:
                 continue
             row[F.TILE_HINT] = (flops / tf / 1e12, flops / max(tb, 1e-9) / 1e12)
     F.TILE_HINT = 0
+    auto = flops / timeit(f) / 1e12
     bf = max(row.items(), key=lambda kv: kv[1][0]); bb = max(row.items(), key=lambda kv: kv[1][1])
-    print(f"{name:34s} fwd best {bf[0]} {bf[1][0]:6.1f} TF | dgrad best {bb[0]} {bb[1][1]:6.1f} TF | " +
+    print(f"{name:34s} auto {auto:5.1f} | fwd best {bf[0]} {bf[1][0]:6.1f} TF | dgrad best {bb[0]} {bb[1][1]:6.1f} TF | " +
           " ".join(f"{h}:{a:.0f}/{b:.0f}" for h, (a, b) in sorted(row.items())), flush=True)
