@@ -151,14 +151,14 @@ def main():
         g = ks.get("conv_gather", dict(launches=0, flops=0.0, ms=1e-9))
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["launches"] else 0.0
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r1l_pmc_traffic.json")
         if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
             # command (committed summary; PMC collection cannot run inside the timed process)
-            t = json.load(open(tfile))["kernels"].get("conv_gather")
+            t = json.load(open(tfile))["kernels"].get("conv_fwd_dgrad")
             if t:
-                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1_pmc_traffic.json"
-        roof = {"bound": "mfma", "kernel": "conv_gather_kernel (v_mfma_f32_32x32x2_f32 implicit-GEMM conv/deconv fwd+dgrad)",
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1l_pmc_traffic.json"
+        roof = {"bound": "mfma", "kernel": "conv forward + data-gradient family: conv_gather_kernel<MT,NT,QU> and conv_tap_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes/launch",
                 "traffic_source": traffic_src,
