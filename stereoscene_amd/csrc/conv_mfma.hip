@@ -634,6 +634,10 @@ int launch_gather_cfg(int mt, int nt, int qu, const float* x, const float* wp, c
     case 15: return launch_gather_qu<1, 5>(qu, x, wp, bias, y, g, st);
     case 14: return launch_gather_qu<1, 4>(qu, x, wp, bias, y, g, st);
     case 31: return launch_gather_qu<3, 1>(qu, x, wp, bias, y, g, st);
+    case 23: return launch_gather_qu<2, 3>(qu, x, wp, bias, y, g, st);
+    case 26: return launch_gather_qu<2, 6>(qu, x, wp, bias, y, g, st);
+    case 16: return launch_gather_qu<1, 6>(qu, x, wp, bias, y, g, st);
+    case 13: return launch_gather_qu<1, 3>(qu, x, wp, bias, y, g, st);
     case 91: return launch_gather_ldsb<2, 2>(x, wp, bias, y, g, st);      // tuning hook: LDS-resident weights
     case 92: return launch_gather_ldsb<1, 2>(x, wp, bias, y, g, st);
     default: return SSBEV_EINVAL;
@@ -672,6 +676,9 @@ int dispatch_gather(const float* x, const float* wp, const float* bias, float* y
         gather_blocks(g, 2, 1) >= 2048)
       return launch_gather_ldsb<2, 2>(x, wp, bias, y, g, st);
   }
+  // 192-wide outputs (the occupancy head's 384 -> 192 conv and its data gradient): six column tiles per wave, the A
+  // operand is fetched once per 192 output channels (sweep: 133 vs 118 TF/s for <2,2>)
+  if (g.Cout % 192 == 0 && gather_blocks(g, 2, 6) >= 256) return launch_gather_cfg(2, 6, 4, x, wp, bias, y, g, st);
   int nt = (g.Cout % 128 == 0) ? 4 : (g.Cout > 32 ? 2 : 1);
   if (nt == 4 && gather_blocks(g, 2, 4) < 256) nt = 2;
   const int mt = gather_blocks(g, 2, nt) >= 160 ? 2 : 1;

@@ -467,3 +467,25 @@ def test_conv_tap_split_lds_kernel(case):
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("hint", [154, 144, 314, 264, 234, 164, 134, 152, 261])
+def test_conv_wide_and_odd_register_tilings(hint):
+    """The <1,5> (software-pipelined), <2,6>, <2,3>, <1,6>, <1,3>, <1,4>, <3,1> tilings forced through the tile hint on a
+    problem whose channel counts are not multiples of the tile widths (partial column tiles, partial row tiles)."""
+    B, Cin, Cout, D, H, W = 1, 40, 200, 5, 7, 12
+    x = S.hash_normal("wt/x", (B, Cin, D, H, W))
+    w = S.hash_uniform("wt/w", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    xc = x.clone().requires_grad_(True)
+    want = TF.conv3d(xc, w, None, 1, 1)
+    go = S.hash_normal("wt/go", tuple(want.shape))
+    want.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    F.TILE_HINT = hint
+    try:
+        got = F.conv3d(xg, w.to(DEV), None, 1, 1)
+        got.backward(go.to(DEV))
+    finally:
+        F.TILE_HINT = 0
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())

@@ -12,13 +12,14 @@ def timeit(fn, n=4):
 
 res = {}
 for name, ci, co, (D, H, W), k, s, p, tr, op in LAYERS:
+    if len(sys.argv) > 1 and sys.argv[1] not in name: continue
     x = torch.randn(1, ci, D, H, W, device="cuda").contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     w = (torch.randn((ci, co, k, k, k) if tr else (co, ci, k, k, k), device="cuda") * 0.05)
     f = (lambda: F.conv_transpose3d(x, w, None, s, p, op)) if tr else (lambda: F.conv3d(x, w, None, s, p))
     y = f(); go = torch.randn_like(y)
     flops = 2.0 * (y.numel() // co) * co * ci * k ** 3 if not tr else 2.0 * (x.numel() // ci) * ci * co * k ** 3
     row = {}
-    for mt, nt in ((4, 1), (2, 1), (1, 1), (2, 4), (2, 2), (1, 2)):
+    for mt, nt in (((2, 4), (2, 2), (2, 3), (2, 6), (1, 6), (1, 3), (1, 2)) if len(sys.argv) > 1 else ((4, 1), (2, 1), (1, 1), (2, 4), (2, 2), (1, 2))):
         for qu in (1, 2, 4):
             F.TILE_HINT = mt * 100 + nt * 10 + qu
             try:
