@@ -1543,33 +1543,55 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
     const bool same_plane = G + 1 < g_end && h + 1 < g.H;
     if (same_plane) stage_row(b, d, h + 3);
 
-    f32x16 acc4[4];                      // one chain per channel octet: consecutive MFMAs are independent
+    // Two accumulator chains (even / odd channel octets); the four ds_read_b128 of tap t+1 are issued right after
+    // the first MFMA of tap t and consumed one tap (16 MFMAs) later.
+    f32x16 acc2[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc4[q][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.0f;
+    float4 xa[4], xb4[4];
+    auto fetch = [&](int tt, float4 (&xv)[4]) {
+      const int u = li + tp_kw[tt];
+      const float* rowp = ring + tp_plane[tt] + ((h + tp_kh[tt]) & 3) * kTapRowF + u * 32;
+      const int sw = u & 7;
 #pragma unroll
-    for (int tt = 0; tt < 7; ++tt) {
+      for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
+    };
+    auto mm_head = [&](int tt, const float4 (&xv)[4]) { acc2[0] = mfma32(wr[tt][0], xv[0].x, acc2[0]); };
+    auto mm_tail = [&](int tt, const float4 (&xv)[4]) {
+#pragma unroll
+      for (int q = 1; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 0], xv[q].x, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 1], xv[q].y, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 2], xv[q].z, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 3], xv[q].w, acc2[q & 1]);
+    };
+    fetch(0, xa);
+#pragma unroll
+    for (int tt = 0; tt < 7; tt += 2) {
       if (tt < ntap) {
-        const int u = li + tp_kw[tt];
-        const float* rowp = ring + tp_plane[tt] + ((h + tp_kh[tt]) & 3) * kTapRowF + u * 32;
-        const int sw = u & 7;
-        float4 xv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 0], xv[q].x, acc4[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 1], xv[q].y, acc4[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 2], xv[q].z, acc4[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc4[q] = mfma32(wr[tt][4 * q + 3], xv[q].w, acc4[q]);
+        mm_head(tt, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 1 < 7 && tt + 1 < ntap) fetch(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_tail(tt, xa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tt + 1 < 7 && tt + 1 < ntap) {
+        mm_head(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 2 < 7 && tt + 2 < ntap) fetch(tt + 2, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_tail(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[0][r] + acc2[1][r];
     // fold the four tap groups: every wave publishes its partial tile, then sums rows 4*wave .. 4*wave+3
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
