@@ -85,28 +85,44 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
   }
 }
 
-// forward finalize: one thread block per (b, group): mean / rstd in double
-__global__ void gn_finalize_fwd_kernel(const float* __restrict__ partial, float* __restrict__ mean,
-                                       float* __restrict__ rstd, GnGeom g) {
-  __shared__ double s0[NT], s1[NT];
-  const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
-  const int cpg = g.C / g.G;
-  double a = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < g.chunks * cpg; i += NT) {
-    const int chunk = i / cpg, c = grp * cpg + i % cpg;
-    const float* p = partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2;
-    a += p[0]; q += p[1];
-  }
+constexpr int FT = 1024;     // threads of the (tiny, latency-bound) finalize kernels
+
+// block-wide sum of two doubles (fixed tree: deterministic)
+__device__ __forceinline__ void block_sum2(double& a, double& q, double* s0, double* s1) {
   s0[threadIdx.x] = a; s1[threadIdx.x] = q;
   __syncthreads();
-  for (int off = NT / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
+  for (int off = FT / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
     __syncthreads();
   }
+  a = s0[0]; q = s1[0];
+}
+
+// forward finalize: one thread block per (b, group): mean / rstd in double.  Only B*G workgroups exist (2 for GN(2) at
+// B = 1), so the kernel is pure latency: 1024 threads, 8-byte loads, four independent partial sums per thread.
+__global__ void __launch_bounds__(FT)
+gn_finalize_fwd_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd, GnGeom g) {
+  __shared__ double s0[FT], s1[FT];
+  const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
+  const int cpg = g.C / g.G, n_el = g.chunks * cpg;
+  double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * FT;
+      if (i < n_el) {
+        const int chunk = i / cpg, c = grp * cpg + i % cpg;
+        const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+        a[k] += p.x; q[k] += p.y;
+      }
+    }
+  }
+  double sa = (a[0] + a[1]) + (a[2] + a[3]), sq = (q[0] + q[1]) + (q[2] + q[3]);
+  block_sum2(sa, sq, s0, s1);
   if (threadIdx.x == 0) {
     const double n = (double)g.S * cpg;
-    const double m = s0[0] / n;
-    double var = s1[0] / n - m * m;
+    const double m = sa / n;
+    double var = sq / n - m * m;
     if (var < 0.0) var = 0.0;
     mean[blockIdx.x] = (float)m;
     rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)g.eps));
@@ -138,50 +154,55 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
 }
 
 // backward finalize, part 1: one block per (b, group):
-//   ds = sum_c gamma_c * A1_c, db = sum_c gamma_c * A0_c  ->  coef[b][g] = (ds/n, db/n)
-__global__ void gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                       float* __restrict__ coef, GnGeom g) {
-  __shared__ double r0[NT], r1[NT];
-  const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
-  const int cpg = g.C / g.G;
-  double ds = 0.0, db = 0.0;
-  for (int i = threadIdx.x; i < g.chunks * cpg; i += NT) {
-    const int chunk = i / cpg, c = grp * cpg + i % cpg;
-    const float* p = partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2;
-    const double gm = gamma[c];
-    db += gm * p[0];
-    ds += gm * p[1];
+// backward finalize, ONE launch for both small reductions over the chunk partials:
+//   workgroups [0, B*G):      per (b, group)  ds/n = sum_c gamma_c * sum(g * xhat), db/n = sum_c gamma_c * sum(g)
+//   workgroups [B*G, B*G+C):  per channel     dbeta[c] = sum g, dgamma[c] = sum g * xhat over samples and chunks
+__global__ void __launch_bounds__(FT)
+gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, float* __restrict__ coef,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, GnGeom g) {
+  __shared__ double r0[FT], r1[FT];
+  const int nbg = g.B * g.G;
+  if ((int)blockIdx.x < nbg) {
+    const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
+    const int cpg = g.C / g.G, n_el = g.chunks * cpg;
+    double ds[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * FT;
+        if (i < n_el) {
+          const int chunk = i / cpg, c = grp * cpg + i % cpg;
+          const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+          const double gm = gamma[c];
+          db[k] += gm * p.x;
+          ds[k] += gm * p.y;
+        }
+      }
+    }
+    double s = (ds[0] + ds[1]) + (ds[2] + ds[3]), t = (db[0] + db[1]) + (db[2] + db[3]);
+    block_sum2(s, t, r0, r1);
+    if (threadIdx.x == 0) {
+      const double n = (double)g.S * cpg;
+      coef[blockIdx.x * 2 + 0] = (float)(s / n);
+      coef[blockIdx.x * 2 + 1] = (float)(t / n);
+    }
+  } else {
+    const int c = blockIdx.x - nbg, n_el = g.B * g.chunks;
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * FT;
+        if (i < n_el) {
+          const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)i * g.C + c) * 2);
+          a0[k] += p.x; a1[k] += p.y;
+        }
+      }
+    }
+    double s = (a0[0] + a0[1]) + (a0[2] + a0[3]), t = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    block_sum2(s, t, r0, r1);
+    if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)t; }
   }
-  r0[threadIdx.x] = ds; r1[threadIdx.x] = db;
-  __syncthreads();
-  for (int off = NT / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { r0[threadIdx.x] += r0[threadIdx.x + off]; r1[threadIdx.x] += r1[threadIdx.x + off]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const double n = (double)g.S * cpg;
-    coef[blockIdx.x * 2 + 0] = (float)(r0[0] / n);
-    coef[blockIdx.x * 2 + 1] = (float)(r1[0] / n);
-  }
-}
-
-// part 2: one block per channel: dbeta[c] = sum g, dgamma[c] = sum g * xhat over samples and chunks
-__global__ void gn_channel_grads_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta, GnGeom g) {
-  __shared__ double r0[NT], r1[NT];
-  const int c = blockIdx.x;
-  double a0 = 0.0, a1 = 0.0;
-  for (int i = threadIdx.x; i < g.B * g.chunks; i += NT) {
-    const float* p = partial + ((size_t)i * g.C + c) * 2;
-    a0 += p[0]; a1 += p[1];
-  }
-  r0[threadIdx.x] = a0; r1[threadIdx.x] = a1;
-  __syncthreads();
-  for (int off = NT / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { r0[threadIdx.x] += r0[threadIdx.x + off]; r1[threadIdx.x] += r1[threadIdx.x + off]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { dbeta[c] = (float)r0[0]; dgamma[c] = (float)r1[0]; }
 }
 
 // gx = (gamma * g - xhat * ds/n - db/n) * rstd ;  gres = g  (g = gy masked by the fused ReLU)
@@ -263,7 +284,7 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   if (!d->stats_given) {
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
                        nullptr, partial, g);
-    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(NT), 0, st, partial, mean, rstd, g);
+    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
@@ -285,8 +306,7 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
-  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G), dim3(NT), 0, st, partial, gamma, coef, g);
-  hipLaunchKernelGGL(gn_channel_grads_kernel, dim3(g.C), dim3(NT), 0, st, partial, ggamma, gbeta, g);
+  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
