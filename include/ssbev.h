@@ -222,6 +222,12 @@ int ssbev_occ_loss_bwd(const float* logits, const uint8_t* label, const float* c
                        const float* coef, float* grad_logits, const ssbev_occloss_dims* d, void* ws,
                        size_t ws_bytes, ssbev_stream_t stream);
 
+/* Running statistics of a training-mode BatchNorm from the (mean, rstd) ssbev_groupnorm_fwd returned with G == C over the
+ * batch: running_mean <- (1-m) running_mean + m mean; running_var <- (1-m) running_var + m var n/(n-1)
+ * (torch.nn.BatchNorm3d as built at ViewTransformerLSSVoxel.py:83-88; n = elements per channel). */
+int ssbev_bn_update_running(const float* mean, const float* rstd, float* running_mean, float* running_var, int C,
+                            float momentum, float eps, int64_t n, ssbev_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Softmax along a strided axis: x = [outer][C][inner] (inner contiguous), y = softmax over C.
  * Replaces F.softmax(dim=1) on the depth-major matching distribution (ViewTransformerLSSVoxel.py:255-259)

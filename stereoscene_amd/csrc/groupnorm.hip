@@ -261,6 +261,17 @@ size_t lds_bytes(const GnGeom& g) {
   return (size_t)rows * g.C * 2 * sizeof(float);
 }
 
+// running statistics of a training-mode BatchNorm (nn.BatchNorm semantics: unbiased variance in the running buffer)
+__global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         float* __restrict__ rm, float* __restrict__ rv, int C, float m, float eps,
+                                         float unbias) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float var = 1.0f / (rstd[c] * rstd[c]) - eps;
+  rm[c] = (1.0f - m) * rm[c] + m * mean[c];
+  rv[c] = (1.0f - m) * rv[c] + m * (var * unbias);
+}
+
 }  // namespace
 
 extern "C" {
@@ -290,6 +301,14 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
   hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y, g,
                      total4);
+  return ssbev_launch_status();
+}
+
+int ssbev_bn_update_running(const float* mean, const float* rstd, float* running_mean, float* running_var, int C,
+                            float momentum, float eps, int64_t n, ssbev_stream_t stream) {
+  if (!mean || !rstd || !running_mean || !running_var || C <= 0 || n <= 0) return SSBEV_EINVAL;
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv((size_t)C, 256)), dim3(256), 0, as_stream(stream), mean, rstd,
+                     running_mean, running_var, C, momentum, eps, (float)((double)n / (double)(n > 1 ? n - 1 : 1)));
   return ssbev_launch_status();
 }
 

@@ -490,6 +490,7 @@ class _GroupNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd):
         lib = capi.load()
+        ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) statistics outputs
         xcl = to_cl(_f32(x, "group_norm"))
         Cch = xcl.shape[-1]
         B = 1 if as_batch else xcl.shape[0]
@@ -541,10 +542,16 @@ def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False):
 
 
 def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False):
-    """Training-mode BatchNorm (batch statistics): returns (y, mean[C], biased_var[C])."""
-    y, mean, rstd = _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None)
-    var = 1.0 / (rstd * rstd) - eps
-    return y, mean, var
+    """Training-mode BatchNorm (batch statistics): returns (y, mean[C], rstd[C])."""
+    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None)
+
+
+def bn_update_running_(running_mean, running_var, mean, rstd, momentum, eps, n):
+    """In-place momentum update of BatchNorm running statistics from the batch (mean, rstd): one launch."""
+    lib = capi.load()
+    capi.check(lib.ssbev_bn_update_running(capi.ptr(mean), capi.ptr(rstd), capi.ptr(running_mean), capi.ptr(running_var),
+                                           running_mean.numel(), float(momentum), float(eps), int(n), capi.stream()),
+               "ssbev_bn_update_running")
 
 
 def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, residual=None, relu=False):

@@ -143,13 +143,12 @@ class _HipBatchNorm:
     def forward(self, x, residual=None, relu=None):
         relu = self.fused_relu if relu is None else relu
         if self.training:
-            y, mean, var = F.batch_norm_train(x, self.weight, self.bias, self.eps, residual, relu)
+            y, mean, rstd = F.batch_norm_train(x, self.weight, self.bias, self.eps, residual, relu)
             if self.track_running_stats:
                 with torch.no_grad():
-                    n = x.numel() // x.shape[1]
                     m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
-                    self.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                    self.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                    F.bn_update_running_(self.running_mean, self.running_var, mean, rstd, m, self.eps,
+                                         x.numel() // x.shape[1])
                     self.num_batches_tracked += 1
             return y
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
