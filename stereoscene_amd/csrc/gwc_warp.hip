@@ -14,6 +14,8 @@
 // reduction happens inside one lane (no cross-lane traffic needed for cpg=2..8).
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int MAX_CPG = 8;
@@ -130,7 +132,7 @@ constexpr int MAX_SRC = 4;
 constexpr int WTILE = 32;
 
 template <int CPG, bool FOR_LEFT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 gwc_warp_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ other,
                     const float* __restrict__ calib, float* __restrict__ gout, int B, int C, int G, int D,
                     int H, int W, float down, int align_corners) {
@@ -175,6 +177,7 @@ gwc_warp_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ ot
     float acc[CPG];
 #pragma unroll
     for (int c = 0; c < CPG; ++c) acc[c] = 0.0f;
+#pragma unroll 4
     for (int k = 0; k < D; ++k) {
       const XTap t = taps[k];
       const float* gk = grow + (size_t)k * plane;
@@ -256,7 +259,8 @@ int launch_bwd(const float* gvol, const float* l, const float* r, const float* c
             hipSuccess)
       return SSBEV_ELAUNCH;
   }
-  dim3 grid(d->B * d->H, cdiv(d->W, WTILE)), block(256);
+  // one thread per (pixel, source group) of the tile: the 192-plane walk is the only serial loop left
+  dim3 grid(d->B * d->H, cdiv(d->W, WTILE)), block(std::min(1024, std::max(256, WTILE * d->G)));
   hipLaunchKernelGGL(kl, grid, block, lds, st, gvol, r, calib, gl, d->B, d->C, d->G, d->D, d->H, d->W, d->down,
                      d->align_corners);
   hipLaunchKernelGGL(kr, grid, block, lds, st, gvol, l, calib, gr, d->B, d->C, d->G, d->D, d->H, d->W, d->down,
