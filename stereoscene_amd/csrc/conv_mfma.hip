@@ -184,7 +184,9 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
           av[u][mt] = (l_ap[mt] && cok) ? *reinterpret_cast<const float4*>(l_ap[mt] + 8 * q) : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          bv[u][nt] = *reinterpret_cast<const float4*>(l_wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+          bv[u][nt] = (n0 + nt * 32 < g.CoutPad)      // column tiles past the padded weights (forced tilings): zeros
+                          ? *reinterpret_cast<const float4*>(l_wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4)
+                          : make_float4(0, 0, 0, 0);
       }
       l_q0 += QU;
       if (l_q0 >= Q) {
@@ -276,7 +278,9 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           bv[u][nt] = LDSB ? reinterpret_cast<const float4*>(wlds)[(((tap - t0) * Q + q) * 2 + lk) * (NT * 32) + nt * 32 + li]
-                           : *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4);
+                      : (n0 + nt * 32 < g.CoutPad)
+                            ? *reinterpret_cast<const float4*>(wt + ((size_t)q * 2 * g.CoutPad + nt * 32) * 4)
+                            : make_float4(0, 0, 0, 0);
       }
       // component-major: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #define SSBEV_GATHER_STEP(COMP)                                                              \
