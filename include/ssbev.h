@@ -249,6 +249,20 @@ int ssbev_dcn_im2col(const float* x, const float* offset, float* cols, const ssb
 int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, float* gx, float* goffset,
                      const ssbev_dcn_dims* d, ssbev_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Winograd F(2x2x2, 3x3x3) transforms for stride-1 3x3x3 "same" convolutions (even D, H, W; channels-last).
+ * T = B * D/2 * H/2 * W/2 tiles, 64 frequencies.  The element-wise stage between them is 64 plain GEMMs
+ * [T x Cin] x [Cin x Cout] (forward / data gradient) or [Cin x T] x [T x Cout] (weight gradient).
+ *   input_transform:   x  [B,D,H,W,C] -> V [64][T][C]   (B^T d B; also used on gy for the data gradient)
+ *   output_transform:  M  [64][T][C]  -> y [B,D,H,W,C]  (A^T M A)
+ *   output_adjoint:    gy [B,D,H,W,C] -> Z [64][T][C]   (A gy A^T, weight gradient)
+ * Replaces nn.Conv3d at resnet3d.py:18-32, second_fpn_3d.py:53-69 (3x3x3 convs), occhead.py:100-107.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, D, H, W, C; } ssbev_wino_dims;
+int ssbev_wino_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,10 @@ class DcnDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "G", "k", "pad", "dil")]
 
 
+class WinoDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "D", "H", "W", "C")]
+
+
 class UpsampleDims(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int)]
 
@@ -92,6 +96,9 @@ SIGNATURES = {
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_dcn_col2im": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_bn_update_running": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int64, _P]),
+    "ssbev_wino_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_softmax_axis_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_softmax_axis_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_occ_loss_num_sums": (C.c_int, []),

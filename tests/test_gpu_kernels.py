@@ -491,3 +491,22 @@ def test_conv_wide_and_odd_register_tilings(hint):
         F.TILE_HINT = 0
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 96, 96, 4, 6, 8), (2, 128, 96, 6, 4, 4), (1, 384, 192, 2, 4, 6), (1, 100, 128, 8, 2, 10)])
+def test_winograd_conv3d_matches_aten(case):
+    """F(2x2x2, 3x3x3) path (HIP transforms + 64 GEMMs) of the wide stride-1 layers: forward, data and weight gradient."""
+    B, Cin, Cout, D, H, W = case
+    x = S.hash_normal(f"wino/x{case}", (B, Cin, D, H, W))
+    w = S.hash_uniform(f"wino/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv3d(xc, wc, None, 1, 1)
+    go = S.hash_normal(f"wino/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert F.WINOGRAD and F.wino_conv3d_applicable(xg, wg, (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    got = F.conv3d(xg, wg, None, 1, 1)
+    got.backward(go.to(DEV))
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
