@@ -129,7 +129,10 @@ def main():
         step()
     # HIP events around every launch of the dominant kernel family (two event records per launch cost ~10 us of
     # queue time: timing every family as tools/layer_table.py does adds 2.5 ms to a step)
-    timer = F.KernelTimer(families={"conv_gather", "conv_wgrad"} if os.environ.get('SSBEV_TIME_WGRAD') else {"conv_gather"})
+    fams = {"conv_gather", "conv_winograd"}
+    if os.environ.get("SSBEV_TIME_WGRAD"):
+        fams |= {"conv_wgrad", "conv_winograd_wgrad"}
+    timer = F.KernelTimer(families=fams)
     F.KERNEL_TIMER = None if os.environ.get('SSBEV_NO_TIMER') else timer
     fence()
     t0 = time.perf_counter()
@@ -148,28 +151,45 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        g = ks.get("conv_gather", dict(launches=0, flops=0.0, ms=1e-9))
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["launches"] else 0.0
+        zero = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
+        g, wino = ks.get("conv_gather", zero), ks.get("conv_winograd", zero)
+        fam_flops, fam_ms, fam_n = g["flops"] + wino["flops"], g["ms"] + wino["ms"], g["launches"] + wino["launches"]
+        executed = g["flops"] + wino["bytes"]       # Winograd spans carry their executed GEMM FLOPs (F(2,3)^3: /3.375, F(2,3)^2: /2.25)
+        achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_n else 0.0
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r1l_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r1n_pmc_traffic.json")
         if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
             # command (committed summary; PMC collection cannot run inside the timed process)
             t = json.load(open(tfile))["kernels"].get("conv_fwd_dgrad")
             if t:
-                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1l_pmc_traffic.json"
-        roof = {"bound": "mfma", "kernel": "conv forward + data-gradient family: conv_gather_kernel<MT,NT,QU> and conv_tap_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1n_pmc_traffic.json"
+        tf = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0      # noqa: E731
+        roof = {"bound": "mfma",
+                "kernel": "convolution forward + data gradient, every launch of the step: direct MFMA kernels (conv_gather_kernel"
+                          "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 "
+                          "layers, Winograd F(2,3)^3 / F(2,3)^2 pipelines (wino*_input_kernel -> 64 / 16 batched fp32 GEMMs -> wino*_output_kernel)",
+                "flop_convention": "achieved counts direct-convolution FLOPs (2*voxels*Cin*Cout*taps: what the operator computes, "
+                                   "SURVEY 8(d)); the Winograd launches execute 3.375x (3-D) / 2.25x (2-D) fewer multiply-adds, see frac_executed",
                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes/launch",
-                "traffic_source": traffic_src,
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "frac_executed": executed / (fam_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if fam_n else 0.0,
+                "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": g.get("bytes", 0.0) / max(g["launches"], 1),
-                "algorithmic_gflop_per_launch": g["flops"] / 1e9 / max(g["launches"], 1),
-                "avg_launch_ms": g["ms"] / max(g["launches"], 1),
-                "launches_per_step": g["launches"] / max(args.steps, 1),
-                "gflop_per_step": g["flops"] / 1e9 / max(args.steps, 1),
-                "ms_per_step_in_kernel": g["ms"] / max(args.steps, 1),
-                "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
-                                  for k, v in ks.items() if k != "conv_gather"}}
+                "algorithmic_gflop_per_launch": fam_flops / 1e9 / max(fam_n, 1),
+                "avg_launch_ms": fam_ms / max(fam_n, 1),
+                "launches_per_step": fam_n / max(args.steps, 1),
+                "gflop_per_step": fam_flops / 1e9 / max(args.steps, 1),
+                "ms_per_step_in_kernel": fam_ms / max(args.steps, 1),
+                "direct": {"launches_per_step": g["launches"] / args.steps, "ms_per_step": g["ms"] / args.steps,
+                           "gflop_per_step": g["flops"] / 1e9 / args.steps, "tflops": tf(g)},
+                "winograd": {"launches_per_step": wino["launches"] / args.steps, "ms_per_step": wino["ms"] / args.steps,
+                             "direct_conv_gflop_per_step": wino["flops"] / 1e9 / args.steps,
+                             "executed_gemm_gflop_per_step": wino["bytes"] / 1e9 / args.steps,
+                             "effective_tflops": tf(wino),
+                             "executed_tflops": wino["bytes"] / (wino["ms"] * 1e-3) / 1e12 if wino["ms"] > 0 else 0.0},
+                "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": tf(v)}
+                                  for k, v in ks.items() if k not in ("conv_gather", "conv_winograd")}}
         out = {"metric": "voxels/sec fwd+bwd, 256x256x32 grid D=192" if args.config == "kitti_d192" else
                f"voxels/sec fwd+bwd ({args.config})",
                "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -262,6 +262,11 @@ typedef struct { int B, D, H, W, C; } ssbev_wino_dims;
 int ssbev_wino_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* 2-D variant F(2x2, 3x3) for the 3x3 conv2d layers of DepthNet (ViewTransformerLSSBEVDepth.py:461-504): 16 frequencies,
+ * T = B * D * H/2 * W/2 (D is a batch axis), buffers [16][T][C]. */
+int ssbev_wino2d_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 
 #ifdef __cplusplus
 }

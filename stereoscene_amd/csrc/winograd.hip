@@ -142,6 +142,94 @@ wino_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z, 
   for (int xi = 0; xi < 64; ++xi) Z[((long)xi * T + tile) * g.C + c] = v[xi];
 }
 
+// ---- 2-D variant, F(2x2, 3x3): 16 frequencies, tiles over (h, w); the D axis of the dims struct is a batch axis ----
+__global__ void __launch_bounds__(256)
+wino2d_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom g, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  long t = i / g.C;
+  const long tile = t;
+  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
+  const int th = (int)(t % (g.H / 2));
+  const long bd = t / (g.H / 2);                     // b * D + d
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int h = 2 * th - 1 + e;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int w = 2 * tw - 1 + f;
+      const bool ok = h >= 0 && h < g.H && w >= 0 && w < g.W;
+      v[e * 4 + f] = ok ? x[((bd * g.H + h) * g.W + w) * g.C + c] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bt4(v + e * 4, 1);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) bt4(v + f, 4);
+  const long T = total / g.C;
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) V[((long)xi * T + tile) * g.C + c] = v[xi];
+}
+
+__global__ void __launch_bounds__(256)
+wino2d_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  long t = i / g.C;
+  const long tile = t;
+  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
+  const int th = (int)(t % (g.H / 2));
+  const long bd = t / (g.H / 2);
+  const long T = total / g.C;
+  float m[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) m[xi] = M[((long)xi * T + tile) * g.C + c];
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r[e * 2 + 0] = m[e * 4] + m[e * 4 + 1] + m[e * 4 + 2];
+    r[e * 2 + 1] = m[e * 4 + 1] - m[e * 4 + 2] - m[e * 4 + 3];
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const float y0 = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f], y1 = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f];
+    const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
+    y[base] = y0;
+    y[base + (long)g.W * g.C] = y1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wino2d_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z, WinoGeom g, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  long t = i / g.C;
+  const long tile = t;
+  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
+  const int th = (int)(t % (g.H / 2));
+  const long bd = t / (g.H / 2);
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) v[e * 4 + f] = gy[((bd * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) a4(v + e * 4, 1);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) a4(v + f, 4);
+  const long T = total / g.C;
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) Z[((long)xi * T + tile) * g.C + c] = v[xi];
+}
+
+bool wino2d_ok(const ssbev_wino_dims* d) {
+  return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0;
+}
+
 bool wino_ok(const ssbev_wino_dims* d) {
   return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->D % 2 == 0 && d->H % 2 == 0 && d->W % 2 == 0;
 }
@@ -158,6 +246,19 @@ extern "C" {
     hipLaunchKernelGGL(KERNEL, dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total); \
     return ssbev_launch_status();                                                                                  \
   }
+
+#define SSBEV_WINO2D_ENTRY(NAME, KERNEL)                                                                           \
+  int NAME(const float* src, float* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                       \
+    if (!wino2d_ok(d) || !src || !dst) return SSBEV_EINVAL;                                                        \
+    const long total = (long)d->B * d->D * (d->H / 2) * (d->W / 2) * d->C;                                         \
+    const WinoGeom g{d->B, d->D, d->H, d->W, d->C};                                                                \
+    hipLaunchKernelGGL(KERNEL, dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total); \
+    return ssbev_launch_status();                                                                                  \
+  }
+
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform, wino2d_input_kernel)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform, wino2d_output_kernel)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint, wino2d_output_adjoint_kernel)
 
 SSBEV_WINO_ENTRY(ssbev_wino_input_transform, wino_input_kernel)
 SSBEV_WINO_ENTRY(ssbev_wino_output_transform, wino_output_kernel)

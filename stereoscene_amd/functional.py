@@ -425,7 +425,7 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     stride-1 3x3x3 layers."""
     st, pd, dl = _triple(stride, 3), _triple(padding, 3), _triple(dilation, 3)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x, weight, st, pd, dl):
-        y = _WinoConv3d.apply(x, weight)
+        y = _WinoConv.apply(x, weight)
         return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
     return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0))
 
@@ -437,9 +437,14 @@ def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
-    """F.conv2d replacement: a depth-1 volume through the same kernel (groups=1)."""
+    """F.conv2d replacement: a depth-1 volume through the same kernels (groups=1); wide 3x3 stride-1 layers via
+    Winograd F(2x2,3x3)."""
     s, p, dl = _triple(stride, 2), _triple(padding, 2), _triple(dilation, 2)
-    y = _ConvNd.apply(x.unsqueeze(2), weight.unsqueeze(2), bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
+    x5, w5 = x.unsqueeze(2), weight.unsqueeze(2)
+    if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x5, w5, (1,) + s, (0,) + p, (1,) + dl):
+        y = _WinoConv.apply(x5, w5).squeeze(2)
+        return y if bias is None else y + bias.view(1, -1, 1, 1)
+    y = _ConvNd.apply(x5, w5, bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
     return y.squeeze(2)
 
 
@@ -464,48 +469,63 @@ def _wino_call(name, src, dims, out_shape):
     return dst
 
 
-class _WinoConv3d(torch.autograd.Function):
-    """3x3x3 / stride 1 / pad 1 convolution as Winograd F(2,3)^3: HIP transforms + 64 plain GEMMs (3.375x fewer MACs).
-    x logical [B,Cin,D,H,W] (even D,H,W), weight [Cout,Cin,3,3,3]."""
+class _WinoConv(torch.autograd.Function):
+    """3x3(x3) / stride 1 / pad 1 convolution as Winograd F(2,3)^n: HIP transforms + 4^n plain GEMMs (2.25x / 3.375x fewer
+    MACs).  x logical [B,Cin,D,H,W] channels-last, weight [Cout,Cin,kd,3,3] with kd = 3 (3-D, even D,H,W) or kd = 1
+    (2-D over (H,W), even H,W; D is a batch axis)."""
 
     @staticmethod
     def forward(ctx, x, weight):
-        xcl = to_cl(_f32(x, "wino_conv3d"))
+        xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
-        Cout = weight.shape[0]
-        T = B * (D // 2) * (H // 2) * (W // 2)
+        Cout, three_d = weight.shape[0], weight.shape[2] == 3
+        nf = 64 if three_d else 16
+        T = B * (D // 2 if three_d else D) * (H // 2) * (W // 2)
+        pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         G = _wino_g(x.device)
         w = weight.detach()
-        U = torch.einsum("ai,bj,ck,oqijk->abcqo", G, G, G, w).reshape(64, Cin, Cout)
-        with _span("conv_gather", conv_flops_3x3(B, D, H, W, Cin, Cout), 0.0, f"wino fwd {Cin}->{Cout} {D}x{H}x{W}"):
-            V = _wino_call("ssbev_wino_input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (64, T, Cin))
+        if three_d:
+            U = torch.einsum("ai,bj,ck,oqijk->abcqo", G, G, G, w).reshape(nf, Cin, Cout)
+        else:
+            U = torch.einsum("bj,ck,oqjk->bcqo", G, G, w[:, :, 0]).reshape(nf, Cin, Cout)
+        fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
+        with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino fwd {Cin}->{Cout} {D}x{H}x{W}"):
+            V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
             M = torch.bmm(V, U)
-            y = _wino_call("ssbev_wino_output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
+            y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(V, weight)
-        ctx.geom = (B, D, H, W, Cin, Cout, T)
+        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl)
         return from_cl(y)
 
     @staticmethod
     def backward(ctx, gy):
         V, weight = ctx.saved_tensors
-        B, D, H, W, Cin, Cout, T = ctx.geom
+        B, D, H, W, Cin, Cout, T, three_d, fl = ctx.geom
+        nf = 64 if three_d else 16
+        pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         gcl = to_cl(gy)
         G = _wino_g(gy.device)
         w = weight.detach()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            Ut = torch.einsum("ai,bj,ck,oqijk->abcoq", G, G, G, w.flip(2, 3, 4)).reshape(64, Cout, Cin)
-            with _span("conv_gather", conv_flops_3x3(B, D, H, W, Cin, Cout), 0.0, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
-                Vg = _wino_call("ssbev_wino_input_transform", gcl, capi.WinoDims(B, D, H, W, Cout), (64, T, Cout))
+            if three_d:
+                Ut = torch.einsum("ai,bj,ck,oqijk->abcoq", G, G, G, w.flip(2, 3, 4)).reshape(nf, Cout, Cin)
+            else:
+                Ut = torch.einsum("bj,ck,oqjk->bcoq", G, G, w[:, :, 0].flip(2, 3)).reshape(nf, Cout, Cin)
+            with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+                Vg = _wino_call(pre + "input_transform", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
                 Mx = torch.bmm(Vg, Ut)
                 del Vg
-                gxcl = _wino_call("ssbev_wino_output_transform", Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
+                gxcl = _wino_call(pre + "output_transform", Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
-            with _span("conv_wgrad", conv_flops_3x3(B, D, H, W, Cin, Cout), 0.0, f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
-                Z = _wino_call("ssbev_wino_output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (64, T, Cout))
-                gU = torch.bmm(V.transpose(1, 2), Z).view(4, 4, 4, Cin, Cout)
-            gw = torch.einsum("ai,bj,ck,abcqo->oqijk", G, G, G, gU)
+            with _span("conv_winograd_wgrad", fl, fl / (3.375 if three_d else 2.25), f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
+                Z = _wino_call(pre + "output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
+                gU = torch.bmm(V.transpose(1, 2), Z)
+            if three_d:
+                gw = torch.einsum("ai,bj,ck,abcqo->oqijk", G, G, G, gU.view(4, 4, 4, Cin, Cout))
+            else:
+                gw = torch.einsum("bj,ck,bcqo->oqjk", G, G, gU.view(4, 4, Cin, Cout)).unsqueeze(2)
         return gx, gw
 
 
@@ -514,10 +534,17 @@ def conv_flops_3x3(B, D, H, W, Cin, Cout):
 
 
 def wino_conv3d_applicable(x, weight, stride, padding, dilation):
-    """Wide stride-1 3x3x3 'same' layers on even grids; narrow ones are memory-bound in the 8x larger transformed domain."""
-    return (x.is_cuda and tuple(weight.shape[2:]) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1)
-            and tuple(dilation) == (1, 1, 1) and weight.shape[0] >= 96 and weight.shape[1] >= 96
-            and weight.shape[1] % 4 == 0 and all(int(n) % 2 == 0 for n in x.shape[2:]))
+    """Wide stride-1 3x3x3 (or 1x3x3) 'same' layers on even grids; narrow ones are memory-bound in the 8x (4x) larger
+    transformed domain."""
+    k = tuple(weight.shape[2:])
+    if not (x.is_cuda and tuple(stride) == (1, 1, 1) and tuple(dilation) == (1, 1, 1) and weight.shape[0] >= 96
+            and weight.shape[1] >= 96 and weight.shape[1] % 4 == 0):
+        return False
+    if k == (3, 3, 3):
+        return tuple(padding) == (1, 1, 1) and all(int(n) % 2 == 0 for n in x.shape[2:])
+    if k == (1, 3, 3):
+        return tuple(padding) == (0, 1, 1) and all(int(n) % 2 == 0 for n in x.shape[3:])
+    return False
 
 
 # -------------------------------------------------------------------------------------------------

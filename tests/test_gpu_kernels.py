@@ -510,3 +510,23 @@ def test_winograd_conv3d_matches_aten(case):
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(2, 96, 128, 6, 10, True), (1, 640, 96, 12, 40, False), (1, 128, 100, 4, 8, True)])
+def test_winograd_conv2d_matches_aten(case):
+    """2-D F(2x2, 3x3) path of the wide 3x3 conv2d layers (DepthNet): forward, data and weight gradient, bias."""
+    B, Cin, Cout, H, W, has_bias = case
+    x = S.hash_normal(f"wino2/x{case}", (B, Cin, H, W))
+    w = S.hash_uniform(f"wino2/w{case}", (Cout, Cin, 3, 3), -1, 1) * (3.0 / (Cin * 9)) ** 0.5
+    b = S.hash_uniform(f"wino2/b{case}", (Cout,), -0.5, 0.5) if has_bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv2d(xc, wc, b, 1, 1)
+    go = S.hash_normal(f"wino2/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert F.wino_conv3d_applicable(xg.unsqueeze(2), wg.unsqueeze(2), (1, 1, 1), (0, 1, 1), (1, 1, 1))
+    got = F.conv2d(xg, wg, b.to(DEV) if has_bias else None, 1, 1)
+    got.backward(go.to(DEV))
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
