@@ -267,6 +267,11 @@ int ssbev_wino_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* 
 int ssbev_wino2d_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* Weight side: U = G w G^T (mode 0: U [NF][Cin][Cout] from torch-layout w [Cout][Cin][taps]; mode 1: the data-gradient
+ * operand [NF][Cout][Cin] from the mirrored taps), and gw = G^T gU G for the weight gradient.  ndim = 3 (27 taps, NF = 64)
+ * or 2 (9 taps, NF = 16). */
+int ssbev_wino_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream);
+int ssbev_wino_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,8 @@ SIGNATURES = {
     "ssbev_wino_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_weight_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ssbev_wino_weight_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

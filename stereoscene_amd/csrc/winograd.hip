@@ -230,6 +230,87 @@ bool wino2d_ok(const ssbev_wino_dims* d) {
   return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0;
 }
 
+// ---- weight transforms (tiny: one thread per (cin, cout) pair) ---------------------------------------------------
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  U = G g G^T per axis.  w is the torch layout [Cout][Cin][taps].
+__device__ __forceinline__ void g4(const float* g, int s, float* o, int so) {      // 3 -> 4
+  const float g0 = g[0], g1 = g[s], g2 = g[2 * s];
+  o[0] = g0; o[so] = 0.5f * (g0 + g1 + g2); o[2 * so] = 0.5f * (g0 - g1 + g2); o[3 * so] = g2;
+}
+__device__ __forceinline__ void gt3(const float* u, int s, float* o, int so) {     // G^T u : 4 -> 3
+  const float u0 = u[0], u1 = u[s], u2 = u[2 * s], u3 = u[3 * s];
+  o[0] = u0 + 0.5f * (u1 + u2); o[so] = 0.5f * (u1 - u2); o[2 * so] = 0.5f * (u1 + u2) + u3;
+}
+
+// mode 0: U[xi][ci][co] = G w[co][ci] G^T          (forward)            U is [NF][Cin][Cout]
+// mode 1: U[xi][co][ci] = G flip(w[co][ci]) G^T    (data gradient)      U is [NF][Cout][Cin]
+template <int ND>
+__global__ void __launch_bounds__(256)
+wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int mode) {
+  constexpr int TAPS = ND == 3 ? 27 : 9, NF = ND == 3 ? 64 : 16;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * Cin) return;
+  const int co = mode == 0 ? i % Cout : i / Cin, ci = mode == 0 ? i / Cout : i % Cin;   // fastest index = U's last axis
+  float g[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) g[t] = w[((size_t)co * Cin + ci) * TAPS + (mode == 0 ? t : TAPS - 1 - t)];
+  float u[NF];
+  if (ND == 3) {
+    float a[36], b[48];                       // [3][3][4], [3][4][4]
+#pragma unroll
+    for (int p = 0; p < 9; ++p) g4(g + p * 3, 1, a + p * 4, 1);                              // w axis
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) g4(a + d * 12 + f, 4, b + d * 16 + f, 4);                   // h axis
+#pragma unroll
+    for (int p = 0; p < 16; ++p) g4(b + p, 16, u + p, 16);                                  // d axis
+  } else {
+    float a[12];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) g4(g + p * 3, 1, a + p * 4, 1);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) g4(a + f, 4, u + f, 4);
+  }
+  const size_t plane = (size_t)Cout * Cin;
+  const size_t pos = mode == 0 ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) U[xi * plane + pos] = u[xi];
+}
+
+// gw[co][ci][taps] = G^T gU[.][ci][co] G  (weight gradient; gU is [NF][Cin][Cout])
+template <int ND>
+__global__ void __launch_bounds__(256)
+wino_weight_grad_kernel(const float* __restrict__ gU, float* __restrict__ gw, int Cout, int Cin) {
+  constexpr int TAPS = ND == 3 ? 27 : 9, NF = ND == 3 ? 64 : 16;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * Cin) return;
+  const int co = i % Cout, ci = i / Cout;
+  const size_t plane = (size_t)Cout * Cin;
+  float u[NF];
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) u[xi] = gU[xi * plane + (size_t)ci * Cout + co];
+  float g[TAPS];
+  if (ND == 3) {
+    float a[48], b[36];                       // [4][4][3] after w, [4][3][3] after h
+#pragma unroll
+    for (int p = 0; p < 16; ++p) gt3(u + p * 4, 1, a + p * 3, 1);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) gt3(a + d * 12 + f, 3, b + d * 9 + f, 3);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) gt3(b + p, 9, g + p, 9);
+  } else {
+    float a[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) gt3(u + p * 4, 1, a + p * 3, 1);
+#pragma unroll
+    for (int f = 0; f < 3; ++f) gt3(a + f, 3, g + f, 3);
+  }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) gw[((size_t)co * Cin + ci) * TAPS + t] = g[t];
+}
+
 bool wino_ok(const ssbev_wino_dims* d) {
   return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->D % 2 == 0 && d->H % 2 == 0 && d->W % 2 == 0;
 }
@@ -255,6 +336,22 @@ extern "C" {
     hipLaunchKernelGGL(KERNEL, dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total); \
     return ssbev_launch_status();                                                                                  \
   }
+
+int ssbev_wino_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream) {
+  if (!w || !U || Cout <= 0 || Cin <= 0 || (ndim != 2 && ndim != 3) || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  const dim3 grid(cdiv((size_t)Cout * Cin, 256)), block(256);
+  if (ndim == 3) hipLaunchKernelGGL(wino_weight_kernel<3>, grid, block, 0, as_stream(stream), w, U, Cout, Cin, mode);
+  else hipLaunchKernelGGL(wino_weight_kernel<2>, grid, block, 0, as_stream(stream), w, U, Cout, Cin, mode);
+  return ssbev_launch_status();
+}
+
+int ssbev_wino_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream) {
+  if (!gU || !gw || Cout <= 0 || Cin <= 0 || (ndim != 2 && ndim != 3)) return SSBEV_EINVAL;
+  const dim3 grid(cdiv((size_t)Cout * Cin, 256)), block(256);
+  if (ndim == 3) hipLaunchKernelGGL(wino_weight_grad_kernel<3>, grid, block, 0, as_stream(stream), gU, gw, Cout, Cin);
+  else hipLaunchKernelGGL(wino_weight_grad_kernel<2>, grid, block, 0, as_stream(stream), gU, gw, Cout, Cin);
+  return ssbev_launch_status();
+}
 
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform, wino2d_input_kernel)
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform, wino2d_output_kernel)

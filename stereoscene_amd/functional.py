@@ -482,12 +482,11 @@ class _WinoConv(torch.autograd.Function):
         nf = 64 if three_d else 16
         T = B * (D // 2 if three_d else D) * (H // 2) * (W // 2)
         pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
-        G = _wino_g(x.device)
-        w = weight.detach()
-        if three_d:
-            U = torch.einsum("ai,bj,ck,oqijk->abcqo", G, G, G, w).reshape(nf, Cin, Cout)
-        else:
-            U = torch.einsum("bj,ck,oqjk->bcqo", G, G, w[:, :, 0]).reshape(nf, Cin, Cout)
+        lib = capi.load()
+        w = weight.detach().contiguous()
+        U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
+        capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0,
+                                                   capi.stream()), "ssbev_wino_weight_transform")
         fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
         with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino fwd {Cin}->{Cout} {D}x{H}x{W}"):
             V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
@@ -504,14 +503,13 @@ class _WinoConv(torch.autograd.Function):
         nf = 64 if three_d else 16
         pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         gcl = to_cl(gy)
-        G = _wino_g(gy.device)
-        w = weight.detach()
+        lib = capi.load()
+        w = weight.detach().contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if three_d:
-                Ut = torch.einsum("ai,bj,ck,oqijk->abcoq", G, G, G, w.flip(2, 3, 4)).reshape(nf, Cout, Cin)
-            else:
-                Ut = torch.einsum("bj,ck,oqjk->bcoq", G, G, w[:, :, 0].flip(2, 3)).reshape(nf, Cout, Cin)
+            Ut = torch.empty(nf, Cout, Cin, dtype=torch.float32, device=gy.device)
+            capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(Ut), Cout, Cin, 3 if three_d else 2, 1,
+                                                       capi.stream()), "ssbev_wino_weight_transform")
             with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 Vg = _wino_call(pre + "input_transform", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
                 Mx = torch.bmm(Vg, Ut)
@@ -522,10 +520,9 @@ class _WinoConv(torch.autograd.Function):
             with _span("conv_winograd_wgrad", fl, fl / (3.375 if three_d else 2.25), f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 Z = _wino_call(pre + "output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
                 gU = torch.bmm(V.transpose(1, 2), Z)
-            if three_d:
-                gw = torch.einsum("ai,bj,ck,abcqo->oqijk", G, G, G, gU.view(4, 4, 4, Cin, Cout))
-            else:
-                gw = torch.einsum("bj,ck,bcqo->oqjk", G, G, gU.view(4, 4, Cin, Cout)).unsqueeze(2)
+            gw = torch.empty_like(w)
+            capi.check(lib.ssbev_wino_weight_grad(capi.ptr(gU), capi.ptr(gw), Cout, Cin, 3 if three_d else 2,
+                                                  capi.stream()), "ssbev_wino_weight_grad")
         return gx, gw
 
 
