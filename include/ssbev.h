@@ -272,6 +272,12 @@ int ssbev_wino2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims
  * or 2 (9 taps, NF = 16). */
 int ssbev_wino_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream);
 int ssbev_wino_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream);
+/* Depth-fused frequency GEMM of the 3-D path: P = ssbev_wino2d_input_transform(x) [16][B*D*Thw][K] -> Mo [16][B*D*Thw][N]
+ * (-> ssbev_wino2d_output_transform); the depth axis of F(2,3) is applied in registers (d->C = K input channels of this
+ * product; mode 0 forward: K = Cin, N = Cout; mode 1 data gradient: K = Cout, N = Cin). */
+size_t ssbev_wino_dgemm_packed_elems(int Cout, int Cin);
+int ssbev_wino_dgemm_pack(const float* w, float* Wp, int Cout, int Cin, int mode, ssbev_stream_t stream);
+int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream);
 
 #ifdef __cplusplus
 }

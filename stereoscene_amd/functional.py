@@ -469,6 +469,30 @@ def _wino_call(name, src, dims, out_shape):
     return dst
 
 
+# Opt-in: (h,w)-only transforms + the depth axis of F(2,3) inside a hand-written MFMA GEMM kernel (half the HBM traffic of
+# the batched-GEMM pipeline, but this first version of the kernel runs at 60-75 TF/s and does not beat it yet:
+# 128->128 1.34 vs 1.41 ms, 384->192 4.6 vs 3.6 ms; tools/wino_gemm_probe.py)
+WINO_DEPTH_FUSED = os.environ.get("SSBEV_WINO_DEPTH_FUSED", "0") != "0"
+
+
+def _wino_depth_fused(xcl, w, B, D, H, W, K, N, mode):
+    """3-D Winograd conv of a channels-last volume with K input / N output channels: (h,w) transform -> depth-fused
+    frequency GEMM (HIP MFMA kernel, the depth axis of F(2,3) done in registers) -> (h,w) output transform.
+    mode 0: forward (w [N,K,3,3,3]); mode 1: data gradient (w [K,N,3,3,3], mirrored taps)."""
+    lib = capi.load()
+    Cout, Cin = (N, K) if mode == 0 else (K, N)
+    R = B * D * (H // 2) * (W // 2)
+    P = _wino_call("ssbev_wino2d_input_transform", xcl, capi.WinoDims(B, D, H, W, K), (16, R, K))
+    Wp = torch.empty(lib.ssbev_wino_dgemm_packed_elems(Cout, Cin), dtype=torch.float32, device=xcl.device)
+    capi.check(lib.ssbev_wino_dgemm_pack(capi.ptr(w), capi.ptr(Wp), Cout, Cin, mode, capi.stream()), "ssbev_wino_dgemm_pack")
+    Mo = torch.empty(16, R, N, dtype=torch.float32, device=xcl.device)
+    dims = capi.WinoDims(B, D, H, W, K)
+    capi.check(lib.ssbev_wino_dgemm(capi.ptr(P), capi.ptr(Wp), capi.ptr(Mo), C.byref(dims), N, capi.stream()),
+               "ssbev_wino_dgemm")
+    del P
+    return _wino_call("ssbev_wino2d_output_transform", Mo, capi.WinoDims(B, D, H, W, N), (B, D, H, W, N))
+
+
 class _WinoConv(torch.autograd.Function):
     """3x3(x3) / stride 1 / pad 1 convolution as Winograd F(2,3)^n: HIP transforms + 4^n plain GEMMs (2.25x / 3.375x fewer
     MACs).  x logical [B,Cin,D,H,W] channels-last, weight [Cout,Cin,kd,3,3] with kd = 3 (3-D, even D,H,W) or kd = 1
@@ -484,29 +508,38 @@ class _WinoConv(torch.autograd.Function):
         pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         lib = capi.load()
         w = weight.detach().contiguous()
-        U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
-        capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0,
-                                                   capi.stream()), "ssbev_wino_weight_transform")
         fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
+        fused = three_d and WINO_DEPTH_FUSED
+        if not fused:
+            U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
+            capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0,
+                                                       capi.stream()), "ssbev_wino_weight_transform")
         with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino fwd {Cin}->{Cout} {D}x{H}x{W}"):
-            V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-            M = torch.bmm(V, U)
-            y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
-        ctx.save_for_backward(V, weight)
-        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl)
+            if fused:      # (h,w)-transformed tensors only (4x), the depth axis of F(2,3) inside the GEMM kernel
+                y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
+                V = None
+            else:
+                V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
+                M = torch.bmm(V, U)
+                y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
+        ctx.save_for_backward(xcl if fused else V, weight)
+        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused)
         return from_cl(y)
 
     @staticmethod
     def backward(ctx, gy):
-        V, weight = ctx.saved_tensors
-        B, D, H, W, Cin, Cout, T, three_d, fl = ctx.geom
+        V, weight = ctx.saved_tensors            # (depth-fused path: V is the channels-last input, transformed below)
+        B, D, H, W, Cin, Cout, T, three_d, fl, fused = ctx.geom
         nf = 64 if three_d else 16
         pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         gcl = to_cl(gy)
         lib = capi.load()
         w = weight.detach().contiguous()
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and fused:
+            with _span("conv_winograd", fl, fl / 3.375, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+                gx = from_cl(_wino_depth_fused(gcl, w, B, D, H, W, Cout, Cin, 1))
+        elif ctx.needs_input_grad[0]:
             Ut = torch.empty(nf, Cout, Cin, dtype=torch.float32, device=gy.device)
             capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(Ut), Cout, Cin, 3 if three_d else 2, 1,
                                                        capi.stream()), "ssbev_wino_weight_transform")
@@ -518,6 +551,8 @@ class _WinoConv(torch.autograd.Function):
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
             with _span("conv_winograd_wgrad", fl, fl / (3.375 if three_d else 2.25), f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
+                if fused:
+                    V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 Z = _wino_call(pre + "output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
                 gU = torch.bmm(V.transpose(1, 2), Z)
             gw = torch.empty_like(w)
