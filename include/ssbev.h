@@ -278,6 +278,9 @@ int ssbev_wino_weight_grad(const float* gU, float* gw, int Cout, int Cin, int nd
 size_t ssbev_wino_dgemm_packed_elems(int Cout, int Cin);
 int ssbev_wino_dgemm_pack(const float* w, float* Wp, int Cout, int Cin, int mode, ssbev_stream_t stream);
 int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream);
+/* Batched frequency GEMM of the plain 3-D pipeline: Cm[xi][T][N] = A[xi][T][K] x U[xi][K][N] for the 64 frequencies, A
+ * streamed through LDS once, U in the ssbev_wino_dgemm_pack layout. */
+int ssbev_wino_bgemm(const float* A, const float* Wp, float* Cm, int64_t T, int K, int N, ssbev_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,11 +10,13 @@
 // T = B * D/2 * H/2 * W/2 (even extents).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
 
 struct WinoGeom { int B, D, H, W, C; };
+__device__ const float kWinoZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
 // 1-D F(2,3) transforms, in place on 4 values with stride `s`
 __device__ __forceinline__ void bt4(float* v, int s) {        // B^T d
@@ -417,6 +419,129 @@ wino_dgemm_kernel(const float* __restrict__ P, const float* __restrict__ Wp, flo
   }
 }
 
+// ---- batched frequency GEMM  C[xi][T][N] = A[xi][T][K] x B[xi][K][N]  (the element-wise stage of the plain pipeline) ----
+// HBM-streaming design: the big operand A (transformed activations, read exactly once) is staged through LDS with
+// global_load_lds_dwordx4 -- whole kilobytes per instruction, 16-byte XOR swizzle on the global side so that the MFMA
+// A-operand reads (one ds_read_b128 = 4 k-values of a row per lane) are conflict-free -- in a ring of 3 stages of BK = 64
+// columns; the small operand B (transformed weights, Wp[xi][q][kh][n][4], L2-resident) is read as coalesced float4 like
+// the convolution kernels' weights.  A workgroup owns 64 rows and up to 4*NT*32 columns: its 4 waves share the A tile
+// (wave w -> columns [w*NT*32, ...)), so A leaves LDS four times per HBM read.  Light waves (32*NT accumulators): three
+// workgroups per CU.
+struct WinoBgemmGeom { long T; int K, N, NPad; };
+
+constexpr int kBgBM = 64, kBgBK = 64, kBgStages = 3;
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+wino_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ Wp, float* __restrict__ Cm, WinoBgemmGeom g) {
+  extern __shared__ __align__(16) float al[];            // [stages][64 rows][64 k], float4 slots swizzled by (row & 7)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int xi = blockIdx.z;
+  const int n0 = (blockIdx.y * 4 + wave) * (NT * 32);
+  const bool col_active = n0 < g.N;
+  const float* Ax = A + (long)xi * g.T * g.K;
+  float* Cx = Cm + (long)xi * g.T * g.N;
+  const int Q = (g.K + 7) >> 3, nstage = (g.K + kBgBK - 1) / kBgBK;
+  const size_t fstride = (size_t)Q * 2 * g.NPad * 4;
+  const float* wl = Wp + (size_t)xi * fstride + ((size_t)lk * g.NPad + n0 + li) * 4;
+  // persistent walk: this workgroup owns row blocks rb0, rb0+1, ..., the LDS ring runs across row-block boundaries so
+  // that the loads of the next block are in flight while this one is multiplied
+  const long nrb = (g.T + kBgBM - 1) / kBgBM;
+  const long rb_per = (nrb + gridDim.x - 1) / gridDim.x;
+  const long rb_begin = (long)blockIdx.x * rb_per, rb_end = min(nrb, rb_begin + rb_per);
+  const long total = (rb_end - rb_begin) * nstage;       // flat (row block, k stage) sequence
+  if (total <= 0) return;
+
+  // staging: a stage = 64 rows x 16 float4 slots = 1024 items = 16 wave instructions, 4 per wave (the LDS destination of a
+  // global_load_lds is wave-uniform base + lane * 16: the 64 items of one instruction are consecutive)
+  auto issue = [&](long s) {
+    const long rb = rb_begin + s / nstage;
+    const int k0 = (int)(s % nstage) * kBgBK, buf = (int)(s % kBgStages);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int jbase = (wave + 4 * e) * 64;
+      const int j = jbase + lane, row = j >> 4, slot = j & 15;
+      const int src_slot = (slot & 8) | ((slot & 7) ^ (row & 7));
+      const long r = rb * kBgBM + row;
+      const int k = k0 + src_slot * 4;
+      const float* src = (r < g.T && k < g.K) ? Ax + r * g.K + k : kWinoZeros;
+      __builtin_amdgcn_global_load_lds(src, al + buf * (kBgBM * kBgBK) + jbase * 4, 16, 0, 0);
+    }
+  };
+  wf32x16 acc[2][NT];
+  // weights of a stage: 8 coalesced float4 per column tile; double-buffered in registers and requested BEFORE the A tile
+  // of the stage after next, so that (in-order return) waiting for them never waits for the newest A tile
+  float4 bvA[kBgBK / 8][NT], bvB[kBgBK / 8][NT];
+  auto load_b = [&](long s, float4 (&bv)[kBgBK / 8][NT]) {
+    const int st = (int)(s % nstage);
+#pragma unroll
+    for (int qq = 0; qq < kBgBK / 8; ++qq) {
+      const int q = st * (kBgBK / 8) + qq;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bv[qq][nt] = (col_active && q < Q && n0 + nt * 32 < g.NPad)
+                         ? *reinterpret_cast<const float4*>(wl + ((size_t)q * 2 * g.NPad + nt * 32) * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  issue(0);
+  load_b(0, bvA);
+  if (total > 1) issue(1);
+  for (long s = 0; s < total; ++s) {
+    const int st = (int)(s % nstage), buf = (int)(s % kBgStages);
+    float4 (&bv)[kBgBK / 8][NT] = (s & 1) ? bvB : bvA;
+    if (st == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    // outstanding, oldest first: A(s), B(s), A(s+1) -> stage s is complete once at most A(s+1)'s four loads remain
+    if (s + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < total) { if (s & 1) load_b(s + 1, bvA); else load_b(s + 1, bvB); }
+    if (s + 2 < total) issue(s + 2);
+    if (col_active) {
+      const float* ab = al + buf * (kBgBM * kBgBK);
+#pragma unroll
+      for (int qq = 0; qq < kBgBK / 8; ++qq) {
+        float4 av[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = mt * 32 + li;
+          const int slot = 2 * qq + lk;                              // logical float4 slot (k = 8 qq + 4 lk ..+3)
+          av[mt] = *reinterpret_cast<const float4*>(ab + row * kBgBK + (((slot & 8) | ((slot & 7) ^ (row & 7))) << 2));
+        }
+#define SSBEV_BG_COMP(COMP)                                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                    \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                   \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].COMP, bv[qq][nt].COMP, acc[mt][nt], 0, 0, 0);
+        SSBEV_BG_COMP(x) SSBEV_BG_COMP(y) SSBEV_BG_COMP(z) SSBEV_BG_COMP(w)
+#undef SSBEV_BG_COMP
+      }
+      if (st == nstage - 1) {                                        // row block finished: store its tile
+        const long r0 = (rb_begin + s / nstage) * kBgBM;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = n0 + nt * 32 + li;
+            if (co >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const long row = r0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+              if (row < g.T) Cx[row * g.N + co] = acc[mt][nt][r];
+            }
+          }
+      }
+    }
+  }
+}
+
 // packed weights of the depth-fused GEMM: Wp[xi = xi_d*16 + xi_hw][q][kh][n][t] = U[xi][k = 8q+4kh+t][n]
 //   mode 0: U = G w[n][k] G^T (forward, K = Cin, N = Cout)   mode 1: U = G flip(w[k][n]) G^T (data gradient, K = Cout, N = Cin)
 __global__ void __launch_bounds__(256)
@@ -528,6 +653,24 @@ int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_win
     default: return SSBEV_EINVAL;
   }
 #undef SSBEV_WG_LAUNCH
+  return ssbev_launch_status();
+}
+
+// A [64][T][K], Wp = ssbev_wino_dgemm_pack(...) ([64][K/8][2][NPad][4]), Cm [64][T][N]
+int ssbev_wino_bgemm(const float* A, const float* Wp, float* Cm, int64_t T, int K, int N, ssbev_stream_t stream) {
+  if (!A || !Wp || !Cm || T <= 0 || K <= 0 || N <= 0 || K % 4 != 0) return SSBEV_EINVAL;
+  const WinoBgemmGeom g{(long)T, K, N, (N + 31) & ~31};
+  const int nt = N > 128 ? 2 : 1;
+  // persistent workgroups: ~3 per CU over the 64 frequencies and column groups, each walking >= 4 row blocks
+  const long nrb = ((long)T + kBgBM - 1) / kBgBM;
+  const int ycols = cdiv(N, 4 * nt * 32);
+  long gx = std::max(1L, (768L + 64 * ycols - 1) / (64 * ycols));
+  gx = std::min(gx, std::max(1L, nrb / 4));
+  dim3 grid((unsigned)gx, ycols, 64), block(256);
+  const size_t lds = (size_t)kBgStages * kBgBM * kBgBK * sizeof(float);
+  hipStream_t st = as_stream(stream);
+  if (nt == 2) hipLaunchKernelGGL(wino_bgemm_kernel<2>, grid, block, lds, st, A, Wp, Cm, g);
+  else hipLaunchKernelGGL(wino_bgemm_kernel<1>, grid, block, lds, st, A, Wp, Cm, g);
   return ssbev_launch_status();
 }
 

@@ -475,6 +475,23 @@ def _wino_call(name, src, dims, out_shape):
 WINO_DEPTH_FUSED = os.environ.get("SSBEV_WINO_DEPTH_FUSED", "0") != "0"
 
 
+# Opt-in: hand-written LDS-streaming MFMA kernel for the 64 frequency GEMMs (default: one rocBLAS batched GEMM, which is
+# still 20-40 % faster on these shapes: tools/wino_gemm_probe.py)
+WINO_OWN_GEMM = os.environ.get("SSBEV_WINO_OWN_GEMM", "0") != "0"
+
+
+def _wino_bgemm(V, w, Cout, Cin, mode):
+    """M[xi] = V[xi] @ U[xi] for the 64 frequencies on the LDS-streaming MFMA kernel (mode 0 forward, 1 data gradient)."""
+    lib = capi.load()
+    T, K = V.shape[1], V.shape[2]
+    N = Cout if mode == 0 else Cin
+    Wp = torch.empty(lib.ssbev_wino_dgemm_packed_elems(Cout, Cin), dtype=torch.float32, device=V.device)
+    capi.check(lib.ssbev_wino_dgemm_pack(capi.ptr(w), capi.ptr(Wp), Cout, Cin, mode, capi.stream()), "ssbev_wino_dgemm_pack")
+    M = torch.empty(64, T, N, dtype=torch.float32, device=V.device)
+    capi.check(lib.ssbev_wino_bgemm(capi.ptr(V), capi.ptr(Wp), capi.ptr(M), T, K, N, capi.stream()), "ssbev_wino_bgemm")
+    return M
+
+
 def _wino_depth_fused(xcl, w, B, D, H, W, K, N, mode):
     """3-D Winograd conv of a channels-last volume with K input / N output channels: (h,w) transform -> depth-fused
     frequency GEMM (HIP MFMA kernel, the depth axis of F(2,3) done in registers) -> (h,w) output transform.
@@ -520,7 +537,7 @@ class _WinoConv(torch.autograd.Function):
                 V = None
             else:
                 V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-                M = torch.bmm(V, U)
+                M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM) else torch.bmm(V, U)
                 y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(xcl if fused else V, weight)
         ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused)
@@ -545,7 +562,7 @@ class _WinoConv(torch.autograd.Function):
                                                        capi.stream()), "ssbev_wino_weight_transform")
             with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 Vg = _wino_call(pre + "input_transform", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
-                Mx = torch.bmm(Vg, Ut)
+                Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM) else torch.bmm(Vg, Ut)
                 del Vg
                 gxcl = _wino_call(pre + "output_transform", Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)

@@ -493,9 +493,9 @@ def test_conv_wide_and_odd_register_tilings(hint):
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("depth_fused", [False, True])
+@pytest.mark.parametrize("variant", ["rocblas", "own_gemm", "depth_fused"])
 @pytest.mark.parametrize("case", [(1, 96, 96, 4, 6, 8), (2, 128, 96, 6, 4, 4), (1, 384, 192, 2, 4, 6), (1, 100, 128, 8, 2, 10)])
-def test_winograd_conv3d_matches_aten(case, depth_fused, monkeypatch):
+def test_winograd_conv3d_matches_aten(case, variant, monkeypatch):
     """F(2x2x2, 3x3x3) path (HIP transforms + 64 GEMMs) of the wide stride-1 layers: forward, data and weight gradient."""
     B, Cin, Cout, D, H, W = case
     x = S.hash_normal(f"wino/x{case}", (B, Cin, D, H, W))
@@ -506,7 +506,9 @@ def test_winograd_conv3d_matches_aten(case, depth_fused, monkeypatch):
     want.backward(go)
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     assert F.WINOGRAD and F.wino_conv3d_applicable(xg, wg, (1, 1, 1), (1, 1, 1), (1, 1, 1))
-    monkeypatch.setattr(F, "WINO_DEPTH_FUSED", depth_fused)     # batched-GEMM pipeline / depth-fused MFMA GEMM kernel
+    # frequency stage: rocBLAS batched GEMM (default) / own LDS-streaming MFMA GEMM / depth-fused MFMA GEMM kernel
+    monkeypatch.setattr(F, "WINO_DEPTH_FUSED", variant == "depth_fused")
+    monkeypatch.setattr(F, "WINO_OWN_GEMM", variant == "own_gemm")
     got = F.conv3d(xg, wg, None, 1, 1)
     got.backward(go.to(DEV))
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
