@@ -586,8 +586,8 @@ def wino_conv3d_applicable(x, weight, stride, padding, dilation):
     """Wide stride-1 3x3x3 (or 1x3x3) 'same' layers on even grids; narrow ones are memory-bound in the 8x (4x) larger
     transformed domain."""
     k = tuple(weight.shape[2:])
-    if not (x.is_cuda and tuple(stride) == (1, 1, 1) and tuple(dilation) == (1, 1, 1) and weight.shape[0] >= 96
-            and weight.shape[1] >= 96 and weight.shape[1] % 4 == 0):
+    if not (x.is_cuda and tuple(stride) == (1, 1, 1) and tuple(dilation) == (1, 1, 1) and weight.shape[0] >= 64
+            and weight.shape[1] >= 64 and weight.shape[1] % 4 == 0):
         return False
     if k == (3, 3, 3):
         return tuple(padding) == (1, 1, 1) and all(int(n) % 2 == 0 for n in x.shape[2:])
