@@ -2,6 +2,8 @@
 logits -> SSC counts -> dataset-level scores with the reference's key names and rounding
 (semantic_kitti_lss_dataset.py:231-287; apis/test.py:141-224 gathers per-rank results through pickle files,
 here the integer counts are summed over ranks with one all-reduce)."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -40,3 +42,44 @@ def scores_from_counts(acc):
     out = {f"semkitti_{k}": round(float(v) * 100, 2) for k, v in res.items()}
     out["semkitti_combined_IoU"] = out["semkitti_SC_IoU"] + out["semkitti_SSC_mIoU"]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# test-set submission writer and checkpoint loading
+# ---------------------------------------------------------------------------------------------------------------------
+# SemanticKITTI `learning_map_inv` (semantickitti.yaml:144-164 of the reference, the file get_inv_map() opens at
+# utils/semkitti_io.py:99-112): training id -> raw lidarseg label id
+LEARNING_MAP_INV = np.array([0, 10, 11, 15, 18, 20, 30, 31, 32, 40, 44, 48, 49, 50, 51, 70, 71, 72, 80, 81], dtype=np.int32)
+
+
+def save_output_semantic_kitti(output_voxels, save_path, sequence_id, frame_id):
+    """``save_output_semantic_kitti`` of apis/test.py:49-64: argmax over the class axis of ``output_voxels`` [C,X,Y,Z],
+    remap to raw label ids, write ``<save_path>/sequences/<seq>/predictions/<frame>.label`` as uint16.  Returns the path."""
+    pred = torch.argmax(output_voxels, dim=0).cpu().numpy().reshape(-1)
+    raw = LEARNING_MAP_INV[pred].astype(np.uint16)
+    folder = os.path.join(save_path, "sequences", str(sequence_id), "predictions")
+    os.makedirs(folder, exist_ok=True)
+    path = os.path.join(folder, f"{frame_id}.label")
+    with open(path, "wb") as f:
+        raw.tofile(f)
+    return path
+
+
+def load_checkpoint(model, path_or_state, strict=False):
+    """Load a reference checkpoint (``pretrain_stereoscene.pth``: a dict with 'state_dict', or a bare state dict) into the
+    hot-path modules.  Parameter names are the reference's (tests/test_layout.py checks the key set against the
+    reference-generated manifest), so this is a filtered ``load_state_dict``: keys of the image backbone / neck (outside the
+    path) are reported, not loaded.  Returns (missing, unexpected_outside_path)."""
+    state = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, os.PathLike)) else path_or_state
+    state = state.get("state_dict", state)
+    own = model.state_dict()
+    inside = {k: v for k, v in state.items() if k in own}
+    outside = sorted(k for k in state if k not in own)
+    for k, v in inside.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise ValueError(f"checkpoint tensor {k}: shape {tuple(v.shape)} != model {tuple(own[k].shape)}")
+    missing = sorted(k for k in own if k not in inside)
+    if strict and missing:
+        raise KeyError(f"{len(missing)} hot-path tensors missing from the checkpoint, e.g. {missing[:3]}")
+    model.load_state_dict(inside, strict=False)
+    return missing, outside
