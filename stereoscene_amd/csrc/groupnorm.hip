@@ -42,8 +42,12 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
   const int c4 = tid % q, r = tid / q;
   if (r < rows) {
     const int c = c4 * 4;
-    float mu = 0.0f, rs = 1.0f;
     const int cpg = g.C / g.G;
+    float mu4[4] = {0.f, 0.f, 0.f, 0.f}, rs4[4] = {1.f, 1.f, 1.f, 1.f};      // this thread's channels never change
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mu4[k] = mean[b * g.G + (c + k) / cpg]; rs4[k] = rstd[b * g.G + (c + k) / cpg]; }
+    }
     // a float4 never straddles groups when cpg % 4 == 0; otherwise handled per component below
     const size_t base = (size_t)b * g.S * g.C;
     for (long s = s0 + r; s < s1; s += rows) {
@@ -63,10 +67,8 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int grp = (c + k) / cpg;
-          mu = mean[b * g.G + grp]; rs = rstd[b * g.G + grp];
           a0[k] += gs[k];
-          a1[k] += gs[k] * (xs[k] - mu) * rs;
+          a1[k] += gs[k] * (xs[k] - mu4[k]) * rs4[k];
         }
       }
     }
@@ -135,25 +137,41 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
                     const float* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
                     float* __restrict__ y, GnGeom g, long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total4; i += (long)gridDim.x * NT) {
-    const int c = (int)(i % q) * 4;
+  const long stride = (long)gridDim.x * NT;
+  const bool fixed = stride % q == 0;            // see gn_apply_bwd_kernel
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * 4, bcur = -1;
+  float gam[4], bet[4], mu[4], rs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
+  for (; i < total4; i += stride) {
     const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) {
+      c = (int)(i % q) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
+    }
+    if (!fixed || b != bcur) {
+      bcur = b;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int grp = b * g.G + (c + k) / cpg;
+        mu[k] = mean[grp]; rs[k] = rstd[grp];
+      }
+    }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
     float rr[4] = {0, 0, 0, 0};
     if (res) { const float4 t = reinterpret_cast<const float4*>(res)[i]; rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int grp = (c + k) / cpg;
-      const float mu = mean[b * g.G + grp], rs = rstd[b * g.G + grp];
-      float o = (v[k] - mu) * rs * gamma[c + k] + beta[c + k] + rr[k];
+      float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
       v[k] = g.relu ? fmaxf(o, 0.0f) : o;
     }
     reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
-// backward finalize, part 1: one block per (b, group):
 // backward finalize, ONE launch for both small reductions over the chunk partials:
 //   workgroups [0, B*G):      per (b, group)  ds/n = sum_c gamma_c * sum(g * xhat), db/n = sum_c gamma_c * sum(g)
 //   workgroups [B*G, B*G+C):  per channel     dbeta[c] = sum g, dgamma[c] = sum g * xhat over samples and chunks
@@ -212,9 +230,30 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
                     const float* __restrict__ coef, float* __restrict__ gx, float* __restrict__ gres, GnGeom g,
                     long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total4; i += (long)gridDim.x * NT) {
-    const int c = (int)(i % q) * 4;
+  const long stride = (long)gridDim.x * NT;
+  // the launch makes `stride` a multiple of q whenever it can: a thread then always owns the same four channels and
+  // the per-channel / per-group constants leave the streaming loop
+  const bool fixed = stride % q == 0;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * 4, bcur = -1;
+  float gam[4], mu[4], rs[4], c0[4], c1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; mu[k] = 0.f; rs[k] = 0.f; c0[k] = 0.f; c1[k] = 0.f; }
+  for (; i < total4; i += stride) {
     const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) {
+      c = (int)(i % q) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gam[k] = gamma[c + k];
+    }
+    if (!fixed || b != bcur) {
+      bcur = b;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int grp = b * g.G + (c + k) / cpg;
+        mu[k] = mean[grp]; rs[k] = rstd[grp]; c0[k] = coef[grp * 2]; c1[k] = coef[grp * 2 + 1];
+      }
+    }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 gv = reinterpret_cast<const float4*>(gy)[i];
     float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -226,14 +265,22 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int grp = (c + k) / cpg;
-      const float mu = mean[b * g.G + grp], rs = rstd[b * g.G + grp];
-      const float xh = (xs[k] - mu) * rs;
-      o[k] = (gamma[c + k] * gs[k] - xh * coef[(b * g.G + grp) * 2] - coef[(b * g.G + grp) * 2 + 1]) * rs;
+      const float xh = (xs[k] - mu[k]) * rs[k];
+      o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k];
     }
     reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (gres) reinterpret_cast<float4*>(gres)[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
   }
+}
+
+// grid of the streaming apply kernels: <= 16384 workgroups, and (workgroups * NT) a multiple of the float4 count per
+// voxel q so that every thread keeps its channels for the whole grid-stride loop
+unsigned apply_blocks(long total4, int q) {
+  long blocks = min((long)cdiv(total4, NT), 16384L);
+  long m = q;                                   // smallest block multiple: q / gcd(q, NT)
+  for (long a = NT, bb = q; bb;) { const long t = a % bb; a = bb; bb = t; m = q / a; }
+  if (blocks >= m) blocks -= blocks % m;
+  return (unsigned)(blocks > 0 ? blocks : 1);
 }
 
 bool gn_ok(const ssbev_norm_dims* d) {
@@ -298,7 +345,7 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
     hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
-  const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
+  const unsigned blocks = apply_blocks(total4, g.C / 4);
   hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y, g,
                      total4);
   return ssbev_launch_status();
@@ -327,7 +374,7 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
   hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
-  const unsigned blocks = (unsigned)min((long)cdiv(total4, NT), 16384L);
+  const unsigned blocks = apply_blocks(total4, g.C / 4);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
                      gresidual, g, total4);
   return ssbev_launch_status();
