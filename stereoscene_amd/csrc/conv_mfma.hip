@@ -1,28 +1,29 @@
 // Dense N-d convolution family as im2col-free implicit GEMM on the gfx950 matrix cores.
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate, 157 TF/s chip peak).
-// Layout: channels-last activations [B, D, H, W, C]; GEMM rows M = output voxels, columns N =
-// output channels, reduction K = taps x input channels.
+// Layout: channels-last activations [B, D, H, W, C].  Kernels in this file:
 //
-//   A operand (32 voxels x 2 k):  lane (i = lane&31, kh = lane>>5) reads ONE float4 =
-//       x[voxel_i + tap][8q + 4kh .. +3] straight from global/L2 (a voxel's channel vector is
-//       contiguous, so the pair of lanes (i,0),(i,1) consumes a full 32-B sector and a wave a
-//       set of whole 128-B lines); the 4 components feed 4 consecutive MFMAs.  No LDS, no
-//       im2col buffer: the "patch matrix" only ever exists as addresses.
-//   B operand (2 k x 32 couts):   weights are pre-packed so that lane (j, kh) reads one float4
-//       Wp[tap][q][kh][j][0..3] = W[cout j][cin 8q+4kh+0..3][tap]  (512 B contiguous per half wave,
-//       shared by every wave on the chip -> L1/L2 resident).
-//   C/D: lane holds column j (one output channel) and 16 rows; a store instruction writes
-//       32 consecutive floats (128 B) per voxel.
-//
-// Two gather forms cover every forward and data-gradient problem of the path:
-//   form 0 (conv):    in = o*stride - pad + k*dil
-//   form 1 (deconv):  in = (o + pad - k*dil)/stride   -- outputs are enumerated per PARITY CLASS
-//                     (o mod stride) so that the valid taps are uniform over a tile: no wasted
-//                     MFMAs on transposed convolutions (stride-2 k3: 27 taps spread over 8 classes;
-//                     k=s deconvs of the FPN: one 1x1x1 GEMM per class).
-// The weight gradient is a third kernel (reduction over voxels, split-K with a deterministic
-// two-stage reduction).
+//   conv_gather_kernel<MT,NT,QU>   forward / data gradient of every conv, deconv, strided, dilated, 1x1 layer that has no
+//                                  more specialised kernel.  GEMM rows M = output voxels, columns N = output channels,
+//                                  K = taps x input channels.  A operand: lane (i = lane&31, kh = lane>>5) reads ONE
+//                                  float4 = x[voxel_i + tap][8q + 4kh .. +3] straight from global/L2 (a voxel's channel
+//                                  vector is contiguous); the 4 components feed 4 consecutive MFMAs.  No LDS, no im2col
+//                                  buffer: the "patch matrix" only ever exists as addresses.  B operand: weights
+//                                  pre-packed so that lane (j, kh) reads one float4 Wp[tap][q][kh][j][0..3] (512 B
+//                                  contiguous per half wave, L1/L2 resident).  Two gather forms: form 0 (conv)
+//                                  in = o*stride - pad + k*dil; form 1 (deconv) in = (o + pad - k*dil)/stride with the
+//                                  outputs enumerated per PARITY CLASS (o mod stride) so that the valid taps are uniform
+//                                  over a tile: no wasted MFMAs on transposed convolutions.  Register tilings chosen per
+//                                  problem from measured sweeps (dispatch_gather); <1,5> is software pipelined.
+//   conv_tap_kernel                forward / data gradient of the <= 32-channel stride-1 3x3x3 layers: input rows in an
+//                                  LDS ring (global_load_lds), weights in registers, taps split over the waves.
+//   wgrad_lds_kernel<...>          weight gradient of the 3x3(x3) layers (stride 1, stride 2, transposed): both operands
+//                                  staged through LDS, 9 accumulators per wave.
+//   wgrad_1x1_kernel, wgrad_cf_kernel, wgrad_kernel   weight gradients outside that family (1x1 streaming; dilated via
+//                                  channel-major copies; k = s deconvs), wgrad_reduce(_tiled)_kernel folds the split-K
+//                                  partial tiles in a fixed order (deterministic, no float atomics).
+// The wide (>= 64 channel) stride-1 3x3(x3) layers normally do not come here at all: functional.conv3d / conv2d route them
+// through the Winograd path (winograd.hip).
 #include "common.h"
 
 #include <algorithm>
