@@ -1633,6 +1633,169 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3x3 stride-1 "heads" with 32 input channels and <= 4 output channels (classif3_2 / redir2:
+// 32 -> 1).  On the MFMA kernel such a layer costs as much as a full 32 -> 32 one (31 of 32 tile columns are padding).
+// Here it is a VALU reduction over the LDS ring of conv_tap_kernel:
+//     gw[tap][ci][n] = sum_v x[v + tap][ci] * gy[v][n]
+// thread (tap = tid / 8, channel quad = tid % 8) keeps 4 x NP accumulators; per voxel it reads its x quad from the ring
+// (one ds_read_b128) and gy[v][0..NP) as an LDS broadcast.  Partial tiles per workgroup, folded by wgrad_reduce_kernel.
+constexpr int kThinNP = 4;
+
+__global__ void __launch_bounds__(256)
+wgrad_thin_kernel(const float* __restrict__ X, const float* __restrict__ GY, float* __restrict__ ws, ConvTapGeom g) {
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [3 planes][4 slots][34 voxels][32 channels], 16-byte swizzled
+  float* gyl = tl + kTapRingF;               // [2 buffers][32 voxels][NP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * kTapWseg;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+
+  // x staging exactly as in conv_tap_kernel (K = 32 channels of x)
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;
+  int xoff[4], xmeta[4];
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int q = wave + n * 4;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ (u & 7)) << 2), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kTapPlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  auto stage_row = [&](int b, int d, int hp) {
+    const float* base = X + ((long)(b * g.D + d - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = ring + (meta >> 4) + (hp & 3) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+  // gy row of the step: 32 voxels x N floats (N <= 4), zero-padded to NP, through registers (tiny)
+  auto load_gy = [&](int b, int d, int h, int buf) {
+    if (tid < kTapWseg * kThinNP) {
+      const int v = tid / kThinNP, n = tid % kThinNP, wv = w0 + v;
+      float val = 0.0f;
+      if (wv < g.W && n < g.N) val = GY[(((long)(b * g.D + d) * g.H + h) * g.W + wv) * g.N + n];
+      gyl[buf * kTapWseg * kThinNP + tid] = val;
+    }
+  };
+
+  const int tap = tid >> 3, quad = tid & 7;          // 32 tap slots (27 valid) x 8 channel quads
+  const int tpl = min(tap, 26);
+  const int kd = tpl / 9, kh = (tpl / 3) % 3, kw = tpl % 3;
+  float acc[kThinNP][4];
+#pragma unroll
+  for (int n = 0; n < kThinNP; ++n)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[n][c] = 0.0f;
+
+  bool fresh = true;
+  int h = g_begin % g.H, d, b;
+  {
+    const int bd = g_begin / g.H;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int buf = G & 1;
+    if (fresh) {
+      stage_row(b, d, h); stage_row(b, d, h + 1); stage_row(b, d, h + 2);
+      load_gy(b, d, h, buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool has_next = G + 1 < g_end;
+    const bool same_plane = has_next && h + 1 < g.H;
+    if (same_plane) stage_row(b, d, h + 3);
+    if (has_next) {                                   // next row's gy into the other buffer
+      int hn = h + 1, dn = d, bn = b;
+      if (hn == g.H) { hn = 0; if (++dn == g.D) { dn = 0; ++bn; } }
+      load_gy(bn, dn, hn, buf ^ 1);
+    }
+    if (tap < 27) {
+      const float* rowp = ring + kd * kTapPlaneF + ((h + kh) & 3) * kTapRowF;
+      const float* gp = gyl + buf * kTapWseg * kThinNP;
+#pragma unroll 4
+      for (int v = 0; v < kTapWseg; ++v) {
+        const int u = v + kw;
+        const float4 xq = *reinterpret_cast<const float4*>(rowp + u * 32 + ((quad ^ (u & 7)) << 2));
+        const float4 gv = *reinterpret_cast<const float4*>(gp + v * kThinNP);
+        const float gn[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int n = 0; n < kThinNP; ++n) {
+          acc[n][0] += gn[n] * xq.x; acc[n][1] += gn[n] * xq.y; acc[n][2] += gn[n] * xq.z; acc[n][3] += gn[n] * xq.w;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fresh = !same_plane;
+    if (++h == g.H) {
+      h = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+  // partial tile of this workgroup: ws[chunk][tap][ci][n]  (Cq = K, Cp = N)
+  if (tap < 27) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ci = quad * 4 + c;
+      if (ci >= g.K) continue;
+#pragma unroll
+      for (int n = 0; n < kThinNP; ++n)
+        if (n < g.N) ws[(((size_t)chunk_id * 27 + tap) * g.K + ci) * g.N + n] = acc[n][c];
+    }
+  }
+}
+
+struct WgradThinPlan { bool ok; ConvTapGeom g; int nchunks; };
+
+WgradThinPlan plan_wgrad_thin(const ssbev_conv_dims* d) {
+  WgradThinPlan p;
+  p.ok = false;
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return p;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return p;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->tile_hint == 7) return p;
+  if (d->Cin > 32 || d->Cin < 16 || d->Cin % 4 != 0 || d->Cout > kThinNP) return p;
+  ConvTapGeom& g = p.g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo; g.K = d->Cin; g.N = d->Cout;
+  g.nseg = (g.W + kTapWseg - 1) / kTapWseg;
+  g.NG = g.B * g.D * g.H;
+  g.relu = 0; g.has_bias = 0;
+  if ((long)g.NG * g.nseg < 1024L * 16 && d->tile_hint != 9) return p;
+  long nranges = std::max(1L, 1024L / g.nseg);              // ~4 workgroups per CU (LDS 53 KB, light registers)
+  if (nranges > g.NG) nranges = g.NG;
+  g.gpc = (int)((g.NG + nranges - 1) / nranges);
+  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  p.nchunks = (int)(nranges * g.nseg);
+  p.ok = true;
+  return p;
+}
+
 // tile_hint 8 forces the generic gather kernels (A/B timing), 9 forces this kernel on small problems (tests)
 bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
@@ -1836,6 +1999,10 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
   {
+    const WgradThinPlan tp = plan_wgrad_thin(d);
+    if (tp.ok) return align256b((size_t)tp.nchunks * 27 * d->Cin * d->Cout * sizeof(float));
+  }
+  {
     const Wgrad1x1Plan p1 = plan_wgrad_1x1(d);
     if (p1.ok && d->tile_hint != 7) return align256b((size_t)p1.nchunks * p1.Cq * p1.Cp * sizeof(float));
   }
@@ -1860,6 +2027,17 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  {
+    const WgradThinPlan tp = plan_wgrad_thin(d);
+    if (tp.ok) {                                 // 32 -> (<= 4) heads: VALU reduction over the LDS ring
+      hipStream_t st = as_stream(stream);
+      float* partial = static_cast<float*>(ws);
+      const size_t lds = (size_t)(kTapRingF + 2 * kTapWseg * kThinNP) * sizeof(float);
+      hipLaunchKernelGGL(wgrad_thin_kernel, dim3(tp.nchunks), dim3(256), lds, st, x, gy, partial, tp.g);
+      launch_wgrad_reduce(partial, gw, tp.nchunks, 27, d->Cin, d->Cout, st);
+      return ssbev_launch_status();
+    }
+  }
   {
     const Wgrad1x1Plan p1 = plan_wgrad_1x1(d);
     if (p1.ok && d->tile_hint != 7) {
