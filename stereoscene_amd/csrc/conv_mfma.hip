@@ -1796,6 +1796,175 @@ WgradThinPlan plan_wgrad_thin(const ssbev_conv_dims* d) {
   return p;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward / data gradient of the same heads (32 input channels, <= 4 output channels; also the data gradient of the
+// 2 -> 32 layer, whose output side is the thin one): out[v][n] = sum_tap sum_k x[v + tap][k] * Weff[n][k][tap] as a VALU
+// dot product over the LDS ring.  Thread (voxel = tid / 8, channel quad = tid % 8): per tap one ds_read_b128 of x and one
+// of the weights per output channel (LDS-resident, 13.8 KB, broadcast across the voxels), then an xor-shuffle fold over the
+// 8 quads.  wt[(tap * NP + n) * 32 + k] = Weff[n][k][tap] (pack_thin_kernel; mode 0 forward, mode 1 data gradient).
+__global__ void __launch_bounds__(256)
+pack_thin_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * kThinNP * 32) return;
+  const int k = i & 31, n = (i >> 5) % kThinNP, tap = i / (32 * kThinNP);
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (n < N && k < K) v = mode == 0 ? w[((size_t)n * Cin + k) * 27 + tap] : w[((size_t)k * Cin + n) * 27 + (26 - tap)];
+  wt[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+conv_thin_kernel(const float* __restrict__ X, const float* __restrict__ wt, const float* __restrict__ bias,
+                 float* __restrict__ Y, ConvTapGeom g) {
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [3 planes][4 slots][34 voxels][32 channels], 16-byte swizzled
+  float* wl = tl + kTapRingF;                // [27 taps][NP][32 k]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 27 * kThinNP * 32; i += 256) wl[i] = wt[i];
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * kTapWseg;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;
+  int xoff[4], xmeta[4];
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int q = wave + n * 4;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ (u & 7)) << 2), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kTapPlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  auto stage_row = [&](int b, int d, int hp) {
+    const float* base = X + ((long)(b * g.D + d - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = ring + (meta >> 4) + (hp & 3) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+  const int v = tid >> 3, quad = tid & 7;
+  float bv[kThinNP];
+#pragma unroll
+  for (int n = 0; n < kThinNP; ++n) bv[n] = (g.has_bias && n < g.N) ? bias[n] : 0.0f;
+
+  bool fresh = true;
+  int h = g_begin % g.H, d, b;
+  {
+    const int bd = g_begin / g.H;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    if (fresh) {
+      stage_row(b, d, h); stage_row(b, d, h + 1); stage_row(b, d, h + 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h + 1 < g.H;
+    if (same_plane) stage_row(b, d, h + 3);
+    float acc[kThinNP];
+#pragma unroll
+    for (int n = 0; n < kThinNP; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* rowp = ring + kd * kTapPlaneF + ((h + kh) & 3) * kTapRowF;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int u = v + kw, tap = (kd * 3 + kh) * 3 + kw;
+          const float4 xq = *reinterpret_cast<const float4*>(rowp + u * 32 + ((quad ^ (u & 7)) << 2));
+#pragma unroll
+          for (int n = 0; n < kThinNP; ++n) {
+            if (n < g.N) {
+              const float4 wq = *reinterpret_cast<const float4*>(wl + (tap * kThinNP + n) * 32 + quad * 4);
+              acc[n] += xq.x * wq.x + xq.y * wq.y + xq.z * wq.z + xq.w * wq.w;
+            }
+          }
+        }
+      }
+    // fold the 8 channel quads of a voxel (adjacent lanes)
+#pragma unroll
+    for (int n = 0; n < kThinNP; ++n) {
+      acc[n] += __shfl_xor(acc[n], 1, 64);
+      acc[n] += __shfl_xor(acc[n], 2, 64);
+      acc[n] += __shfl_xor(acc[n], 4, 64);
+    }
+    const int wv = w0 + v;
+    if (quad == 0 && wv < g.W) {
+      float* dst = Y + (((long)(b * g.D + d) * g.H + h) * g.W + wv) * g.N;
+#pragma unroll
+      for (int n = 0; n < kThinNP; ++n)
+        if (n < g.N) {
+          float o = acc[n] + bv[n];
+          dst[n] = g.relu ? fmaxf(o, 0.0f) : o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fresh = !same_plane;
+    if (++h == g.H) {
+      h = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+}
+
+bool conv_thin_applicable(const ssbev_conv_dims* d, int mode) {
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->accumulate || d->tile_hint == 8) return false;
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  if (K > 32 || K < 16 || K % 4 != 0 || N > kThinNP) return false;
+  return d->tile_hint == 9 || (long)d->B * d->Do * d->Ho * ((d->Wo + kTapWseg - 1) / kTapWseg) >= 1024L * 16;
+}
+
+int launch_conv_thin(const float* x, const float* wt, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                     hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + kTapWseg - 1) / kTapWseg;
+  g.NG = g.B * g.D * g.H;
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  long nranges = std::max(1L, 1024L / g.nseg);
+  if (nranges > g.NG) nranges = g.NG;
+  g.gpc = (int)((g.NG + nranges - 1) / nranges);
+  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  const size_t lds = (size_t)(kTapRingF + 27 * kThinNP * 32) * sizeof(float);
+  auto kern = conv_thin_kernel;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nranges * g.nseg)), dim3(256), lds, st, x, wt, bias, y, g);
+  return ssbev_launch_status();
+}
+
 // tile_hint 8 forces the generic gather kernels (A/B timing), 9 forces this kernel on small problems (tests)
 bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
@@ -1946,6 +2115,11 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (conv_thin_applicable(d, mode)) {       // <= 4 output channels: LDS-resident [tap][n][k] table (conv_thin_kernel)
+    hipLaunchKernelGGL(pack_thin_kernel, dim3(cdiv(27 * kThinNP * 32, 256)), dim3(256), 0, as_stream(stream), w_src,
+                       w_packed, d->Cout, d->Cin, mode);
+    return ssbev_launch_status();
+  }
   if (conv_tap_applicable(d, mode)) {        // register-resident tap-split layout (see conv_tap_kernel)
     hipLaunchKernelGGL(pack_tap_kernel, dim3(cdiv(kTapPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed,
                        d->Cout, d->Cin, mode);
@@ -1969,6 +2143,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
                    const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
+  if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
   g.B = d->B; g.Cin = d->Cin; g.Cout = d->Cout; g.CinPad = pad8(d->Cin); g.CoutPad = pad32(d->Cout);
@@ -1984,6 +2159,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin
   g.B = d->B; g.Cin = d->Cout; g.Cout = d->Cin; g.CinPad = pad8(d->Cout); g.CoutPad = pad32(d->Cin);
