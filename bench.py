@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
     ap.add_argument("--cpu-sample", default="auto", choices=["auto", "small", "full", "none"])
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--ablation", default="full", choices=["full", "bev_only", "stereo_only"],
+                    help="BASELINE configs[4]: depth distribution from the MIE fusion | monocular DepthNet only | stereo volume only")
     return ap.parse_args()
 
 
@@ -103,6 +105,7 @@ def main():
     cfg = S.CONFIGS[args.config]
     torch.manual_seed(rank)
     model = model_zoo.build_detector(cfg)          # deterministic fill-by-key weights, gamma = alpha = 0.5
+    model.img_view_transformer.ablation = args.ablation
     model.train()
     reducer = FlatGradAllReduce(model, bucket_mb=64) if not args.forward_only else None
     smp = S.synthetic_sample(cfg, B=args.batch, tag=f"bench{rank}")
@@ -197,7 +200,8 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"{args.config}: stereo pair features 2x[B,640,48,160] -> 256x256x32 occupancy, "
                                       f"D={model.img_view_transformer.D}, fwd+bwd incl. 4 losses"
-                                      + (" (forward only)" if args.forward_only else ""),
+                                      + (" (forward only)" if args.forward_only else "")
+                                      + (f" (ablation: {args.ablation})" if args.ablation != "full" else ""),
                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": f"dp{world}", "train_mode": True},
                "roofline": roof,

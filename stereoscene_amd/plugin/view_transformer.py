@@ -360,15 +360,24 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
 
     Extra kwarg ``warp_align_corners`` selects the grid_sample convention of ``warp`` (VT:151-154):
     True = literal behaviour on torch >= 1.3, False = what torch 1.10.1 (README pin) executed.
+
+    Extra kwarg / attribute ``ablation`` (BASELINE configs[4]; the reference has no such switch, its forward is "full"):
+    "full" = stereo volume and monocular depth fused by the MIE block (VT:497-505); "bev_only" = the monocular DepthNet
+    distribution lifts the features (cost volume and MIE skipped); "stereo_only" = the softmax of the stereo cost volume
+    lifts them (MIE skipped).  All sub-modules are built in every mode, so state dicts stay interchangeable.
     """
+    ABLATIONS = ("full", "bev_only", "stereo_only")
 
     def __init__(self, loss_depth_weight, semkitti=False, imgseg=False, imgseg_class=20, lift_with_imgseg=False,
                  point_cloud_range=None, loss_seg_weight=1.0, loss_depth_type="bce", point_xyz_channel=0,
                  point_xyz_mode="cat", cam_channels=27, loss_depth_reg_weight=0.0, use_voxel_net=False,
                  grid_config=None, data_config=None, numC_input=512, numC_Trans=64, downsample=16,
                  accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False,
-                 warp_align_corners=True, **kwargs):
+                 warp_align_corners=True, ablation="full", **kwargs):
         super().__init__()
+        if ablation not in self.ABLATIONS:
+            raise ValueError(f"ablation must be one of {self.ABLATIONS}, got {ablation!r}")
+        self.ablation = ablation
         if imgseg or point_xyz_channel or use_voxel_net or vp_megvii:
             raise NotImplementedError("options unused by projects/configs/.../stereoscene.py are not built")
         self.grid_config, self.data_config = grid_config, data_config
@@ -488,12 +497,17 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         calib = input[16]
         # geometry first: its tiny host-side 3x3 inverses must not stall the queued device work
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
-        stereo = self.stereo_volume_net(x.squeeze(1), feature_right.squeeze(1), mlp_input, mlp_input_right,
-                                        calib)["single_channel"]
+        stereo = None
+        if self.ablation != "bev_only":
+            stereo = self.stereo_volume_net(x.squeeze(1), feature_right.squeeze(1), mlp_input, mlp_input_right,
+                                            calib)["single_channel"]
         B, N, C, H, W = x.shape
         y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
         depth_prob = self.get_depth_dist(y[:, :self.D])
         img_feat = y[:, self.D:self.D + self.numC_Trans]
-        depth_prob = self.volume_interaction(stereo, depth_prob)
+        if self.ablation == "full":
+            depth_prob = self.volume_interaction(stereo, depth_prob)
+        elif self.ablation == "stereo_only":
+            depth_prob = stereo
         bev_feat = F.lift_splat(depth_prob, img_feat, geom, self.bx, self.dx, self.nx)
         return bev_feat, depth_prob
