@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
     ap.add_argument("--cpu-sample", default="auto", choices=["auto", "small", "full", "none"])
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the BASELINE metric (default); bf16 = BASELINE configs[3]: Winograd-domain tensors and GEMMs "
+                         "of the wide conv layers in bf16 with fp32 accumulation, everything else fp32 (never the headline)")
     ap.add_argument("--ablation", default="full", choices=["full", "bev_only", "stereo_only"],
                     help="BASELINE configs[4]: depth distribution from the MIE fusion | monocular DepthNet only | stereo volume only")
     return ap.parse_args()
@@ -103,6 +106,7 @@ def main():
     from stereoscene_amd import functional as F, model_zoo, synthetic as S
     from stereoscene_amd.dp import FlatGradAllReduce
     cfg = S.CONFIGS[args.config]
+    F.set_precision(args.precision)
     torch.manual_seed(rank)
     model = model_zoo.build_detector(cfg)          # deterministic fill-by-key weights, gamma = alpha = 0.5
     model.img_view_transformer.ablation = args.ablation
@@ -196,12 +200,14 @@ def main():
         out = {"metric": "voxels/sec fwd+bwd, 256x256x32 grid D=192" if args.config == "kitti_d192" else
                f"voxels/sec fwd+bwd ({args.config})",
                "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.precision == "fp32" else "bf16 Winograd-domain GEMMs (fp32 accumulate) + f32 elsewhere",
                "data": "synthetic",
                "config": {"workload": f"{args.config}: stereo pair features 2x[B,640,48,160] -> 256x256x32 occupancy, "
                                       f"D={model.img_view_transformer.D}, fwd+bwd incl. 4 losses"
                                       + (" (forward only)" if args.forward_only else "")
-                                      + (f" (ablation: {args.ablation})" if args.ablation != "full" else ""),
+                                      + (f" (ablation: {args.ablation})" if args.ablation != "full" else "")
+                                      + (" (precision: bf16 mixed, configs[3])" if args.precision != "fp32" else ""),
                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": f"dp{world}", "train_mode": True},
                "roofline": roof,

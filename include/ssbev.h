@@ -267,6 +267,16 @@ int ssbev_wino_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* 
 int ssbev_wino2d_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* bf16 variants (BASELINE configs[3], "bf16 mixed precision, MFMA 3D-conv path"): identical transforms, but the
+ * transformed-domain tensor (V, M, Z) is stored as bf16 (uint16_t bit patterns, round-to-nearest-even) so that the
+ * frequency GEMMs run on the bf16 matrix pipe with fp32 accumulation and the streaming passes move half the bytes.
+ * Activations, gradients and weights on the caller's side stay fp32. */
+int ssbev_wino_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 /* Weight side: U = G w G^T (mode 0: U [NF][Cin][Cout] from torch-layout w [Cout][Cin][taps]; mode 1: the data-gradient
  * operand [NF][Cout][Cin] from the mirrored taps), and gw = G^T gU G for the weight gradient.  ndim = 3 (27 taps, NF = 64)
  * or 2 (9 taps, NF = 16). */

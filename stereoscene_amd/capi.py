@@ -108,6 +108,12 @@ SIGNATURES = {
     "ssbev_wino2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_softmax_axis_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_softmax_axis_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_occ_loss_num_sums": (C.c_int, []),

@@ -18,6 +18,15 @@ namespace {
 struct WinoGeom { int B, D, H, W, C; };
 __device__ const float kWinoZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
+// Storage type of the transformed-domain tensors (V, M, Z): float, or bf16 bit patterns (the `_bf16` entry points: half
+// the HBM traffic of the streaming passes, and the frequency GEMMs then run on the bf16 matrix pipe with fp32
+// accumulation; round-to-nearest-even on store via v_cvt_pk_bf16_f32).
+typedef unsigned short bf16_bits;
+__device__ __forceinline__ float fload(const float* p) { return *p; }
+__device__ __forceinline__ float fload(const bf16_bits* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void fstore(float* p, float v) { *p = v; }
+__device__ __forceinline__ void fstore(bf16_bits* p, float v) { *p = __builtin_bit_cast(bf16_bits, (__bf16)v); }
+
 // 1-D F(2,3) transforms, in place on 4 values with stride `s`
 __device__ __forceinline__ void bt4(float* v, int s) {        // B^T d
   const float d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s];
@@ -28,8 +37,9 @@ __device__ __forceinline__ void a4(float* v, int s) {         // A g : 2 -> 4 va
   v[0] = g0; v[s] = g0 + g1; v[2 * s] = g0 - g1; v[3 * s] = -g1;
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom g, long total) {
+wino_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -64,11 +74,12 @@ wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom g
   for (int p = 0; p < 16; ++p) bt4(v + p, 16);                                 // along d
   const long T = total / g.C;
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) V[((long)xi * T + tile) * g.C + c] = v[xi];
+  for (int xi = 0; xi < 64; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+wino_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -81,7 +92,7 @@ wino_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeom 
   const long T = total / g.C;
   float m[64];
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) m[xi] = M[((long)xi * T + tile) * g.C + c];
+  for (int xi = 0; xi < 64; ++xi) m[xi] = fload(M + ((long)xi * T + tile) * g.C + c);
   // A^T along w: 4 -> 2   (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3)
   float r1[32];
 #pragma unroll
@@ -112,8 +123,9 @@ wino_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeom 
     }
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z, WinoGeom g, long total) {
+wino_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -143,12 +155,13 @@ wino_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z, 
   for (int p = 0; p < 16; ++p) a4(v + p, 16);                                  // along d
   const long T = total / g.C;
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) Z[((long)xi * T + tile) * g.C + c] = v[xi];
+  for (int xi = 0; xi < 64; ++xi) fstore(Z + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
 // ---- 2-D variant, F(2x2, 3x3): 16 frequencies, tiles over (h, w); the D axis of the dims struct is a batch axis ----
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino2d_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom g, long total) {
+wino2d_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -174,11 +187,12 @@ wino2d_input_kernel(const float* __restrict__ x, float* __restrict__ V, WinoGeom
   for (int f = 0; f < 4; ++f) bt4(v + f, 4);
   const long T = total / g.C;
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) V[((long)xi * T + tile) * g.C + c] = v[xi];
+  for (int xi = 0; xi < 16; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino2d_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+wino2d_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -190,7 +204,7 @@ wino2d_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeo
   const long T = total / g.C;
   float m[16];
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) m[xi] = M[((long)xi * T + tile) * g.C + c];
+  for (int xi = 0; xi < 16; ++xi) m[xi] = fload(M + ((long)xi * T + tile) * g.C + c);
   float r[8];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -206,8 +220,9 @@ wino2d_output_kernel(const float* __restrict__ M, float* __restrict__ y, WinoGeo
   }
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
-wino2d_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z, WinoGeom g, long total) {
+wino2d_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -227,7 +242,7 @@ wino2d_output_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ Z
   for (int f = 0; f < 4; ++f) a4(v + f, 4);
   const long T = total / g.C;
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) Z[((long)xi * T + tile) * g.C + c] = v[xi];
+  for (int xi = 0; xi < 16; ++xi) fstore(Z + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
 bool wino2d_ok(const ssbev_wino_dims* d) {
@@ -583,8 +598,8 @@ bool wino_ok(const ssbev_wino_dims* d) {
 
 extern "C" {
 
-#define SSBEV_WINO_ENTRY(NAME, KERNEL)                                                                             \
-  int NAME(const float* src, float* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                       \
+#define SSBEV_WINO_ENTRY(NAME, KERNEL, TSRC, TDST)                                                                 \
+  int NAME(const TSRC* src, TDST* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                         \
     if (!wino_ok(d) || !src || !dst) return SSBEV_EINVAL;                                                          \
     const long total = (long)d->B * (d->D / 2) * (d->H / 2) * (d->W / 2) * d->C;                                   \
     const WinoGeom g{d->B, d->D, d->H, d->W, d->C};                                                                \
@@ -592,8 +607,8 @@ extern "C" {
     return ssbev_launch_status();                                                                                  \
   }
 
-#define SSBEV_WINO2D_ENTRY(NAME, KERNEL)                                                                           \
-  int NAME(const float* src, float* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                       \
+#define SSBEV_WINO2D_ENTRY(NAME, KERNEL, TSRC, TDST)                                                               \
+  int NAME(const TSRC* src, TDST* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                         \
     if (!wino2d_ok(d) || !src || !dst) return SSBEV_EINVAL;                                                        \
     const long total = (long)d->B * d->D * (d->H / 2) * (d->W / 2) * d->C;                                         \
     const WinoGeom g{d->B, d->D, d->H, d->W, d->C};                                                                \
@@ -674,12 +689,21 @@ int ssbev_wino_bgemm(const float* A, const float* Wp, float* Cm, int64_t T, int 
   return ssbev_launch_status();
 }
 
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform, wino2d_input_kernel)
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform, wino2d_output_kernel)
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint, wino2d_output_adjoint_kernel)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform, wino2d_input_kernel<float>, float, float)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform, wino2d_output_kernel<float>, float, float)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint, wino2d_output_adjoint_kernel<float>, float, float)
 
-SSBEV_WINO_ENTRY(ssbev_wino_input_transform, wino_input_kernel)
-SSBEV_WINO_ENTRY(ssbev_wino_output_transform, wino_output_kernel)
-SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint, wino_output_adjoint_kernel)
+SSBEV_WINO_ENTRY(ssbev_wino_input_transform, wino_input_kernel<float>, float, float)
+SSBEV_WINO_ENTRY(ssbev_wino_output_transform, wino_output_kernel<float>, float, float)
+SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint, wino_output_adjoint_kernel<float>, float, float)
+
+// bf16 storage of the transformed-domain tensor (uint16_t = bf16 bit pattern); activations / gradients stay fp32
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16, wino2d_input_kernel<bf16_bits>, float, uint16_t)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform_bf16, wino2d_output_kernel<bf16_bits>, uint16_t, float)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint_bf16, wino2d_output_adjoint_kernel<bf16_bits>, float, uint16_t)
+
+SSBEV_WINO_ENTRY(ssbev_wino_input_transform_bf16, wino_input_kernel<bf16_bits>, float, uint16_t)
+SSBEV_WINO_ENTRY(ssbev_wino_output_transform_bf16, wino_output_kernel<bf16_bits>, uint16_t, float)
+SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint_bf16, wino_output_adjoint_kernel<bf16_bits>, float, uint16_t)
 
 }  // extern "C"

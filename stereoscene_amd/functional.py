@@ -462,9 +462,23 @@ def _wino_g(device):
     return _WINO_G
 
 
-def _wino_call(name, src, dims, out_shape):
+# BASELINE configs[3] ("bf16 mixed precision, MFMA 3D-conv path"): "bf16" stores the Winograd-domain tensors of the wide
+# 3x3(x3) layers (70 % of the step's convolution FLOPs) as bf16 and runs their frequency GEMMs on the bf16 matrix pipe with
+# fp32 accumulation; weights, activations, gradients, normalisation and losses stay fp32.  Default "fp32" (the parity
+# contract of the headline metric); never switched implicitly.
+PRECISION = os.environ.get("SSBEV_PRECISION", "fp32")
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode!r}")
+    PRECISION = mode
+
+
+def _wino_call(name, src, dims, out_shape, dtype=torch.float32):
     lib = capi.load()
-    dst = torch.empty(out_shape, dtype=torch.float32, device=src.device)
+    dst = torch.empty(out_shape, dtype=dtype, device=src.device)
     capi.check(getattr(lib, name)(capi.ptr(src), capi.ptr(dst), C.byref(dims), capi.stream()), name)
     return dst
 
@@ -526,7 +540,8 @@ class _WinoConv(torch.autograd.Function):
         lib = capi.load()
         w = weight.detach().contiguous()
         fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
-        fused = three_d and WINO_DEPTH_FUSED
+        bf = PRECISION == "bf16"
+        fused = three_d and WINO_DEPTH_FUSED and not bf
         if not fused:
             U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
             capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0,
@@ -535,18 +550,23 @@ class _WinoConv(torch.autograd.Function):
             if fused:      # (h,w)-transformed tensors only (4x), the depth axis of F(2,3) inside the GEMM kernel
                 y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
                 V = None
+            elif bf:
+                V = _wino_call(pre + "input_transform_bf16", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin), torch.bfloat16)
+                M = torch.bmm(V, U.to(torch.bfloat16))
+                y = _wino_call(pre + "output_transform_bf16", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
             else:
                 V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM) else torch.bmm(V, U)
                 y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(xcl if fused else V, weight)
-        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused)
+        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf)
         return from_cl(y)
 
     @staticmethod
     def backward(ctx, gy):
         V, weight = ctx.saved_tensors            # (depth-fused path: V is the channels-last input, transformed below)
-        B, D, H, W, Cin, Cout, T, three_d, fl, fused = ctx.geom
+        B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf = ctx.geom
+        sfx, fdt = ("_bf16", torch.bfloat16) if bf else ("", torch.float32)
         nf = 64 if three_d else 16
         pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         gcl = to_cl(gy)
@@ -561,17 +581,17 @@ class _WinoConv(torch.autograd.Function):
             capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(Ut), Cout, Cin, 3 if three_d else 2, 1,
                                                        capi.stream()), "ssbev_wino_weight_transform")
             with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
-                Vg = _wino_call(pre + "input_transform", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
-                Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM) else torch.bmm(Vg, Ut)
+                Vg = _wino_call(pre + "input_transform" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
+                Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf) else torch.bmm(Vg, Ut.to(fdt))
                 del Vg
-                gxcl = _wino_call(pre + "output_transform", Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
+                gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
             with _span("conv_winograd_wgrad", fl, fl / (3.375 if three_d else 2.25), f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 if fused:
                     V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-                Z = _wino_call(pre + "output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout))
-                gU = torch.bmm(V.transpose(1, 2), Z)
+                Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
+                gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else torch.bmm(V.transpose(1, 2), Z)
             gw = torch.empty_like(w)
             capi.check(lib.ssbev_wino_weight_grad(capi.ptr(gU), capi.ptr(gw), Cout, Cin, 3 if three_d else 2,
                                                   capi.stream()), "ssbev_wino_weight_grad")

@@ -519,6 +519,40 @@ def test_winograd_conv3d_matches_aten(case, variant, monkeypatch):
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(1, 96, 96, 4, 6, 8, 3), (2, 128, 96, 6, 4, 4, 3), (1, 384, 192, 2, 4, 6, 3),
+                                  (2, 96, 128, 1, 6, 10, 2), (1, 640, 96, 1, 12, 40, 2)])
+def test_winograd_bf16_mode_error_budget(case):
+    """BASELINE configs[3]: Winograd-domain tensors stored as bf16, frequency GEMMs on the bf16 matrix pipe (fp32
+    accumulate).  Not a bit-parity mode: the gate is the error budget of bf16 operands (2^-9 relative per rounded
+    value, three roundings V / U / M): max-abs error relative to the tensor's max below 2e-2 and an L2 error below 1e-2,
+    for the forward, the data gradient and the weight gradient; inputs, outputs and gradients remain fp32 tensors."""
+    B, Cin, Cout, D, H, W, nd = case
+    shape = (B, Cin, D, H, W) if nd == 3 else (B, Cin, H, W)
+    k = (3,) * nd
+    x = S.hash_normal(f"wbf/x{case}", shape)
+    w = S.hash_uniform(f"wbf/w{case}", (Cout, Cin) + k, -1, 1) * (3.0 / (Cin * 3 ** nd)) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = (TF.conv3d if nd == 3 else TF.conv2d)(xc, wc, None, 1, 1)
+    go = S.hash_normal(f"wbf/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    F.set_precision("bf16")
+    try:
+        got = (F.conv3d if nd == 3 else F.conv2d)(xg, wg, None, 1, 1)
+        got.backward(go.to(DEV))
+    finally:
+        F.set_precision("fp32")
+    assert got.dtype == torch.float32 and xg.grad.dtype == torch.float32 and wg.grad.dtype == torch.float32
+    for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad), ("gw", wg.grad, wc.grad)):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        rel_max = (a - b).abs().max().item() / b.abs().max().item()
+        rel_l2 = ((a - b).norm() / b.norm()).item()
+        assert rel_max < 2e-2 and rel_l2 < 1e-2, (name, rel_max, rel_l2)
+        assert rel_l2 > 1e-5, (name, "bf16 mode did not engage", rel_l2)
+    with pytest.raises(ValueError):
+        F.set_precision("fp16")
+
+
 @pytest.mark.parametrize("case", [(2, 96, 128, 6, 10, True), (1, 640, 96, 12, 40, False), (1, 128, 100, 4, 8, True)])
 def test_winograd_conv2d_matches_aten(case):
     """2-D F(2x2, 3x3) path of the wide 3x3 conv2d layers (DepthNet): forward, data and weight gradient, bias."""
