@@ -127,6 +127,10 @@ typedef struct {
   int relu;            /* fused epilogue: y = max(y,0) after bias                        */
   int accumulate;      /* y += result (used for residual / split accumulations)          */
   int tile_hint;       /* 0 = library heuristic; MT*100+NT*10+QU forces a register tiling  */
+  int precision;       /* 0 = fp32 MFMA (exact fp32 products, the parity contract);
+                        * 1 = forward / data gradient round their operands to bf16 in registers (nearest even) and use
+                        *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[3]); tensors in memory
+                        *     stay fp32, the weight gradient kernels stay on the fp32 MFMA                          */
 } ssbev_conv_dims;
 
 /* weight packing: src is the torch layout  conv: [Cout,Cin,kd,kh,kw]  deconv: [Cin,Cout,kd,kh,kw]

@@ -38,7 +38,7 @@ class GwcDims(C.Structure):
 class ConvDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "Cin", "Cout", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "kd", "kh", "kw", "sd", "sh", "sw",
-        "pd", "ph", "pw", "dd", "dh", "dw", "transposed", "relu", "accumulate", "tile_hint")]
+        "pd", "ph", "pw", "dd", "dh", "dw", "transposed", "relu", "accumulate", "tile_hint", "precision")]
 
 
 class NormDims(C.Structure):

@@ -43,10 +43,27 @@ struct ConvGeom {
   int relu, accumulate;
   int hint;                            // 0 or MT*100+NT*10+QU
   int chunk_taps;                      // LDSB variant: taps staged in LDS per pass
+  int bf16;                            // operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (precision = 1)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// bf16 mode (ssbev_conv_dims.precision = 1, BASELINE configs[3]): tensors stay fp32 in memory; operands are rounded to
+// bf16 (nearest even, v_cvt_pk_bf16_f32) in registers and contracted with v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// one instruction covers the 16 input channels that take eight fp32 MFMAs.  Lane (l & 31, l >> 5) supplies k slots
+// 8 * (l >> 5) .. + 7 of both operands; any assignment of channels to slots is valid as long as A and B agree, and both
+// use [quad of k-step 2j | quad of k-step 2j + 1] of the fp32 layouts.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(const float4& a, const float4& b) {
+  bf16x8 r;
+  r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+  r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  return r;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // One wave computes an (MT*32 voxels) x (NT*32 channels) tile.  QU consecutive 8-channel k-steps are
@@ -56,7 +73,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // is read with ds_read_b128.  For the 32-channel cost-volume layers the 110 KB of weights do not fit the
 // 32 KB L1, so without this every wave streams them from L2 for each of its 64 voxels (as much L2 traffic
 // as the activations themselves); a 16-wave workgroup amortises one copy over 1024 voxels.
-template <int MT, int NT, int QU, int WPB = 4, bool LDSB = false, bool PIPE = false>
+template <int MT, int NT, int QU, int WPB = 4, bool LDSB = false, bool PIPE = false, bool BF16 = false>
 __global__ void __launch_bounds__(WPB * 64)
 conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                    float* __restrict__ y, ConvGeom g) {
@@ -196,9 +213,29 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
       }
     };
     auto mm_head = [&](const float4 (&av)[QU][MT], const float4 (&bv)[QU][NT]) {
-      acc[0][0] = mfma32(av[0][0].x, bv[0][0].x, acc[0][0]);
+      if constexpr (BF16)
+        acc[0][0] = mfma_bf16(to_bf16x8(av[0][0], av[QU > 1 ? 1 : 0][0]), to_bf16x8(bv[0][0], bv[QU > 1 ? 1 : 0][0]), acc[0][0]);
+      else
+        acc[0][0] = mfma32(av[0][0].x, bv[0][0].x, acc[0][0]);
     };
     auto mm_tail = [&](const float4 (&av)[QU][MT], const float4 (&bv)[QU][NT]) {
+      if constexpr (BF16) {
+        static_assert(!BF16 || !PIPE || QU % 2 == 0, "pipelined bf16 walk pairs the k-steps");
+#pragma unroll
+        for (int u = 0; u < QU; u += 2) {
+          bf16x8 ab[MT], bb[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) ab[mt] = to_bf16x8(av[u][mt], av[u + 1 < QU ? u + 1 : u][mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bb[nt] = to_bf16x8(bv[u][nt], bv[u + 1 < QU ? u + 1 : u][nt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              if (u + mt + nt != 0) acc[mt][nt] = mfma_bf16(ab[mt], bb[nt], acc[mt][nt]);
+        }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < QU; ++u) {
 #pragma unroll
@@ -288,9 +325,25 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
         acc[mt][nt] = mfma32(av[u][mt].COMP, bv[u][nt].COMP, acc[mt][nt]);
+      if constexpr (BF16) {       // k-steps in pairs: 16 channels per bf16 MFMA (an odd last step pairs with zeros)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < QU; u += 2) {
+          bf16x8 ab[MT], bb[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) ab[mt] = to_bf16x8(av[u][mt], u + 1 < QU ? av[u + 1 < QU ? u + 1 : u][mt] : z4);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bb[nt] = to_bf16x8(bv[u][nt], u + 1 < QU ? bv[u + 1 < QU ? u + 1 : u][nt] : z4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ab[mt], bb[nt], acc[mt][nt]);
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < QU; ++u) {
         SSBEV_GATHER_STEP(x) SSBEV_GATHER_STEP(y) SSBEV_GATHER_STEP(z) SSBEV_GATHER_STEP(w)
+      }
       }
 #undef SSBEV_GATHER_STEP
     }
@@ -583,6 +636,16 @@ int launch_gather(const float* x, const float* wp, const float* bias, float* y, 
   }
   dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
   constexpr bool PIPE = NT == 5;
+  if (g.bf16) {                    // k-steps are consumed in pairs: at least two per group whenever Cin allows
+    constexpr int QB = QU < 2 ? 2 : QU;
+    if ((g.CinPad >> 3) % QB == 0)
+      hipLaunchKernelGGL((conv_gather_kernel<MT, NT, QB, 4, false, PIPE, true>), grid, block, 0, st, x, wp, bias, y, g);
+    else if ((g.CinPad >> 3) % 2 == 0)
+      hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 2, 4, false, PIPE, true>), grid, block, 0, st, x, wp, bias, y, g);
+    else
+      hipLaunchKernelGGL((conv_gather_kernel<MT, NT, 1, 4, false, false, true>), grid, block, 0, st, x, wp, bias, y, g);
+    return ssbev_launch_status();
+  }
   if ((g.CinPad >> 3) % QU == 0)
     hipLaunchKernelGGL((conv_gather_kernel<MT, NT, QU, 4, false, PIPE>), grid, block, 0, st, x, wp, bias, y, g);
   else
@@ -610,7 +673,7 @@ int launch_gather_ldsb(const float* x, const float* wp, const float* bias, float
   ConvGeom gg = g;
   gg.chunk_taps = chunk;
   const size_t lds = per_tap * chunk;
-  auto kern = conv_gather_kernel<MT, 1, QU, WPB, true>;
+  auto kern = g.bf16 ? conv_gather_kernel<MT, 1, QU, WPB, true, false, true> : conv_gather_kernel<MT, 1, QU, WPB, true>;
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SSBEV_ELAUNCH;
@@ -1453,6 +1516,7 @@ pack_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, i
   wp[i] = v;
 }
 
+template <bool BF16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
                 float* __restrict__ Y, ConvTapGeom g) {
@@ -1464,11 +1528,23 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
   const int li = lane & 31, lk = lane >> 5;
 
   // weights of this wave's taps: A operands, resident for the whole kernel
-  float wr[7][16];
+  float wr[BF16 ? 1 : 7][16];
+  bf16x8 wb[BF16 ? 7 : 1][2];             // bf16 mode: two 16-channel operand groups per tap (56 VGPRs instead of 112)
 #pragma unroll
-  for (int tt = 0; tt < 7; ++tt)
+  for (int tt = 0; tt < 7; ++tt) {
+    float t16[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wr[tt][r] = wp[((wave * 7 + tt) * 16 + r) * 64 + lane];
+    for (int r = 0; r < 16; ++r) t16[r] = wp[((wave * 7 + tt) * 16 + r) * 64 + lane];
+    if constexpr (BF16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wb[tt][j] = to_bf16x8(make_float4(t16[8 * j], t16[8 * j + 1], t16[8 * j + 2], t16[8 * j + 3]),
+                              make_float4(t16[8 * j + 4], t16[8 * j + 5], t16[8 * j + 6], t16[8 * j + 7]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wr[tt][r] = t16[r];
+    }
+  }
   const int ntap = wave < 3 ? 7 : 6;
 
   unsigned chunk_id;
@@ -1564,8 +1640,15 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
     };
-    auto mm_head = [&](int tt, const float4 (&xv)[4]) { acc2[0] = mfma32(wr[tt][0], xv[0].x, acc2[0]); };
+    auto mm_head = [&](int tt, const float4 (&xv)[4]) {
+      if constexpr (BF16) acc2[0] = mfma_bf16(wb[tt][0], to_bf16x8(xv[0], xv[1]), acc2[0]);
+      else acc2[0] = mfma32(wr[tt][0], xv[0].x, acc2[0]);
+    };
     auto mm_tail = [&](int tt, const float4 (&xv)[4]) {
+      if constexpr (BF16) {
+        acc2[1] = mfma_bf16(wb[tt][1], to_bf16x8(xv[2], xv[3]), acc2[1]);
+        return;
+      }
 #pragma unroll
       for (int q = 1; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 0], xv[q].x, acc2[q & 1]);
 #pragma unroll
@@ -1998,7 +2081,7 @@ int launch_conv_tap(const float* x, const float* wp, const float* bias, float* y
   if (nranges < 1) nranges = 1;
   g.gpc = (int)((g.NG + nranges - 1) / nranges);
   nranges = (g.NG + g.gpc - 1) / g.gpc;
-  auto kern = conv_tap_kernel;
+  auto kern = d->precision == 1 ? conv_tap_kernel<true> : conv_tap_kernel<false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kTapLdsBytes) != hipSuccess)
     return SSBEV_ELAUNCH;
@@ -2152,7 +2235,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 1 : 0; g.relu = d->relu; g.accumulate = d->accumulate;
   g.hint = d->tile_hint >= 10 ? d->tile_hint : 0;       // hints below 10 select other kernel families
-  g.chunk_taps = 0;
+  g.chunk_taps = 0; g.bf16 = d->precision == 1;
   return dispatch_gather(x, w_packed, bias, y, g, as_stream(stream));
 }
 
@@ -2168,6 +2251,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
   g.form = d->transposed ? 0 : 1;   // grad of a conv gathers like a deconv and vice versa
   g.relu = 0; g.accumulate = d->accumulate; g.hint = d->tile_hint >= 10 ? d->tile_hint : 0; g.chunk_taps = 0;
+  g.bf16 = d->precision == 1;
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
   return dispatch_gather(gy, w_packed_t, nullptr, gx, g, as_stream(stream));
 }

@@ -341,7 +341,7 @@ def _conv_dims(xshape_cl, wshape, stride, padding, dilation, transposed, output_
         outs = [(i + 2 * p - dl * (k - 1) - 1) // s + 1
                 for i, s, p, dl, k in zip((Di, Hi, Wi), stride, padding, dilation, (kd, kh, kw))]
     d = capi.ConvDims(B, Cin, Cout, Di, Hi, Wi, outs[0], outs[1], outs[2], kd, kh, kw, *stride, *padding, *dilation,
-                      int(transposed), int(relu), int(accumulate), int(TILE_HINT))
+                      int(transposed), int(relu), int(accumulate), int(TILE_HINT), 1 if PRECISION == "bf16" else 0)
     return d
 
 

@@ -52,6 +52,6 @@ def test_workspace_queries_and_einval_on_host():
     assert lib.ssbev_voxel_index(None, None, None, C.byref(d), None) == capi.EINVAL
     g = capi.GwcDims(1, 64, 32, 8, 2, 8, 2.0, 1)   # down != 1 is not supported
     assert lib.ssbev_gwc_warp_fwd(None, None, None, None, C.byref(g), None) == capi.EINVAL
-    c = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0)
+    c = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0)
     assert lib.ssbev_conv_packed_weight_elems(C.byref(c)) >= 27 * 32 * 32      # (the tap-split layout pads to 28 taps)
     assert lib.ssbev_conv_bwd_weight_workspace(C.byref(c)) >= 27 * 32 * 32 * 4

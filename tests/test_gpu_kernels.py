@@ -553,6 +553,70 @@ def test_winograd_bf16_mode_error_budget(case):
         F.set_precision("fp16")
 
 
+BF16_DIRECT_CASES = [
+    # kind, Cin, Cout, (D, H, W), kernel, stride, pad, dil, tile hint
+    ("conv", 32, 32, (5, 6, 40), 3, 1, 1, 1, 9),        # tap-split LDS kernel, bf16 operands
+    ("conv", 24, 32, (4, 5, 33), 3, 1, 1, 1, 9),        # tap kernel, partial channel quads
+    ("conv", 40, 200, (5, 7, 12), 3, 1, 1, 1, 154),     # pipelined <1,5> (k-steps paired inside the pipeline)
+    ("conv", 40, 200, (5, 7, 12), 3, 1, 1, 1, 264),     # <2,6,4>
+    ("conv", 40, 200, (5, 7, 12), 3, 1, 1, 1, 221),     # QU = 1 request -> paired variant / odd CinPad/8 -> zero half
+    ("conv", 64, 96, (4, 6, 10), 3, 1, 1, 1, 8),        # library heuristic, generic gather
+    ("conv", 32, 64, (6, 8, 12), 3, 2, 1, 1, 0),        # stride 2 (form 0) and its parity-class data gradient
+    ("deconv", 64, 32, (3, 4, 6), 3, 2, 1, 1, 0),       # transposed k3 s2 op1
+    ("deconv", 128, 128, (2, 3, 4), 2, 2, 0, 1, 0),     # k = s deconv of the FPN
+    ("conv", 64, 48, (4, 6, 10), 1, 1, 0, 1, 0),        # 1x1x1
+    ("conv2d", 64, 64, (1, 12, 20), 3, 1, 6, 6, 0),     # dilated ASPP branch
+]
+
+
+@pytest.mark.parametrize("case", BF16_DIRECT_CASES)
+def test_direct_conv_bf16_mode_error_budget(case):
+    """ssbev_conv_dims.precision = 1: forward and data gradient of the direct kernels with bf16-rounded operands on
+    v_mfma_f32_32x32x16_bf16 (fp32 accumulate), against ATen fp32.  Gate = bf16 error budget (two operand roundings of
+    2^-9 relative, fp32 accumulation): relative L2 error < 6e-3, max-abs < 2e-2 of the tensor's max; the weight
+    gradient of the same call stays on the fp32 kernels (tight tolerance)."""
+    kind, Cin, Cout, (D, H, W), k, st, pad, dil, hint = case
+    nd = 2 if kind == "conv2d" else 3
+    xs = (2, Cin, H, W) if nd == 2 else (2, Cin, D, H, W)
+    ws = ((Cin, Cout) if kind == "deconv" else (Cout, Cin)) + (k,) * nd
+    x = S.hash_normal(f"dbf/x{case}", xs)
+    w = S.hash_uniform(f"dbf/w{case}", ws, -1, 1) * (3.0 / (Cin * k ** nd)) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if kind == "deconv":
+        op = 1 if (k == 3 and st == 2) else 0
+        want = TF.conv_transpose3d(xc, wc, None, st, pad, op)
+    elif nd == 2:
+        want = TF.conv2d(xc, wc, None, st, pad, dil)
+    else:
+        want = TF.conv3d(xc, wc, None, st, pad, dil)
+    go = S.hash_normal(f"dbf/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    F.set_precision("bf16")
+    F.TILE_HINT = hint
+    wino = F.WINOGRAD
+    F.WINOGRAD = False
+    try:
+        if kind == "deconv":
+            got = F.conv_transpose3d(xg, wg, None, st, pad, op)
+        elif nd == 2:
+            got = F.conv2d(xg, wg, None, st, pad, dil)
+        else:
+            got = F.conv3d(xg, wg, None, st, pad, dil)
+        got.backward(go.to(DEV))
+    finally:
+        F.set_precision("fp32")
+        F.TILE_HINT = 0
+        F.WINOGRAD = wino
+    for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad)):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        rel_max = (a - b).abs().max().item() / b.abs().max().item()
+        rel_l2 = ((a - b).norm() / b.norm()).item()
+        assert rel_max < 2e-2 and rel_l2 < 6e-3, (name, rel_max, rel_l2)
+        assert rel_l2 > 1e-5, (name, "bf16 operands did not engage", rel_l2)
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("case", [(2, 96, 128, 6, 10, True), (1, 640, 96, 12, 40, False), (1, 128, 100, 4, 8, True)])
 def test_winograd_conv2d_matches_aten(case):
     """2-D F(2x2, 3x3) path of the wide 3x3 conv2d layers (DepthNet): forward, data and weight gradient, bias."""
