@@ -254,6 +254,33 @@ int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, fl
                      const ssbev_dcn_dims* d, ssbev_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image branch (the step before a1/a5): operators of CustomEfficientNet (backbones/efficientnet.py:112-229,
+ * 275-519: InvertedResidual = expand 1x1 -> depthwise k x k -> SE -> linear 1x1) that are not dense contractions.
+ * Channels-last fp32, C % 4 == 0.
+ *   dwconv2d: depthwise k x k (k = 3 | 5, stride 1 | 2), y[b,ho,wo,c] = sum_ij x[b, ho*s - pad_t + i, wo*s - pad_l + j, c]
+ *             * w[i*k + j][c]; out-of-range taps read zero.  pad_t / pad_l and Ho / Wo are explicit, so mmcv's
+ *             Conv2dAdaptivePadding ("same": Ho = ceil(Hi/s), odd padding row/column at the bottom/right) is
+ *             pad_t = pad_total_h / 2, pad_l = pad_total_w / 2.  w / gw layout: [k*k][C] (torch [C,1,k,k] transposed).
+ *   swish:    y = x * sigmoid(x) (mmcv Swish) and its gradient.
+ *   chan_sum: out[b][c] = scale * sum_s a[b][s][c] * (bmul ? bmul[b][s][c] : 1) -- AdaptiveAvgPool2d(1) of mmdet's
+ *             SELayer (scale = 1/S) and the gate gradient of its rescale.
+ *   chan_scale: y[b][s][c] = x[b][s][c] * gate[b][c]; x = NULL: y = gate[b][c] * scale (gradient of the pool).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int B, C, Hi, Wi, Ho, Wo, k, stride, pad_t, pad_l; } ssbev_dw_dims;
+int ssbev_dwconv2d_fwd(const float* x, const float* w, float* y, const ssbev_dw_dims* d, ssbev_stream_t stream);
+int ssbev_dwconv2d_bwd_data(const float* gy, const float* w, float* gx, const ssbev_dw_dims* d, ssbev_stream_t stream);
+size_t ssbev_dwconv2d_bwd_weight_workspace(const ssbev_dw_dims* d);                      /* floats */
+int ssbev_dwconv2d_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_dw_dims* d, float* ws,
+                              size_t ws_elems, ssbev_stream_t stream);
+int ssbev_swish_fwd(const float* x, float* y, int64_t n, ssbev_stream_t stream);        /* n % 4 == 0 */
+int ssbev_swish_bwd(const float* x, const float* gy, float* gx, int64_t n, ssbev_stream_t stream);
+size_t ssbev_chan_sum_workspace(int B, int64_t S, int C);                                 /* floats */
+int ssbev_chan_sum(const float* a, const float* bmul, float* out, int B, int64_t S, int C, float scale, float* ws,
+                   size_t ws_elems, ssbev_stream_t stream);
+int ssbev_chan_scale(const float* x, const float* gate, float* y, int B, int64_t S, int C, float scale,
+                     ssbev_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Winograd F(2x2x2, 3x3x3) transforms for stride-1 3x3x3 "same" convolutions (even D, H, W; channels-last).
  * T = B * D/2 * H/2 * W/2 tiles, 64 frequencies.  The element-wise stage between them is 64 plain GEMMs
  * [T x Cin] x [Cin x Cout] (forward / data gradient) or [Cin x T] x [T x Cout] (weight gradient).

@@ -50,6 +50,10 @@ class DcnDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "G", "k", "pad", "dil")]
 
 
+class DwDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "Hi", "Wi", "Ho", "Wo", "k", "stride", "pad_t", "pad_l")]
+
+
 class WinoDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "D", "H", "W", "C")]
 
@@ -96,6 +100,15 @@ SIGNATURES = {
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_dcn_col2im": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_bn_update_running": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int64, _P]),
+    "ssbev_dwconv2d_fwd": (C.c_int, [_P, _P, _P, C.POINTER(DwDims), _P]),
+    "ssbev_dwconv2d_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(DwDims), _P]),
+    "ssbev_dwconv2d_bwd_weight_workspace": (C.c_size_t, [C.POINTER(DwDims)]),
+    "ssbev_dwconv2d_bwd_weight": (C.c_int, [_P, _P, _P, C.POINTER(DwDims), _P, C.c_size_t, _P]),
+    "ssbev_swish_fwd": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "ssbev_swish_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ssbev_chan_sum_workspace": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "ssbev_chan_sum": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "ssbev_chan_scale": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, _P]),
     "ssbev_wino_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

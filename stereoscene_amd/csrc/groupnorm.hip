@@ -11,6 +11,8 @@
 // BatchNorm in training mode is the same computation with G = C and (B, S) -> (1, B*S).
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int NT = 256;
@@ -31,8 +33,12 @@ __global__ void __launch_bounds__(NT)
 gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ y,
                   const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial,
                   GnGeom g) {
-  extern __shared__ float lds[];                       // [rows][C][2]
-  const int q = g.C >> 2;                              // float4 lanes per voxel
+  extern __shared__ float lds[];                       // [rows][Cs][2]
+  // channel slab of this block (blockIdx.z): up to NT float4 lanes = 1024 channels (the image branch's BatchNorms
+  // reach 3840 channels; everything on the voxel path fits one slab)
+  const int q0 = blockIdx.z * NT;                      // first float4 lane of the slab
+  const int q = min((g.C >> 2) - q0, NT);              // float4 lanes per voxel in this slab
+  const int Cs = q * 4;
   const int rows = NT / q > 0 ? NT / q : 1;            // voxels handled per block iteration
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -41,7 +47,7 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
   float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
   const int c4 = tid % q, r = tid / q;
   if (r < rows) {
-    const int c = c4 * 4;
+    const int c = (q0 + c4) * 4;
     const int cpg = g.C / g.G;
     float mu4[4] = {0.f, 0.f, 0.f, 0.f}, rs4[4] = {1.f, 1.f, 1.f, 1.f};      // this thread's channels never change
     if (MODE == 1) {
@@ -74,16 +80,16 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      lds[((size_t)r * g.C + c + k) * 2 + 0] = a0[k];
-      lds[((size_t)r * g.C + c + k) * 2 + 1] = a1[k];
+      lds[((size_t)r * Cs + c4 * 4 + k) * 2 + 0] = a0[k];
+      lds[((size_t)r * Cs + c4 * 4 + k) * 2 + 1] = a1[k];
     }
   }
   __syncthreads();
-  // fold the `rows` voxel lanes: thread t < 2*C sums column t
-  for (int t = tid; t < 2 * g.C; t += NT) {
+  // fold the `rows` voxel lanes: thread t < 2*Cs sums column t of the slab
+  for (int t = tid; t < 2 * Cs; t += NT) {
     float s = 0.0f;
-    for (int rr = 0; rr < rows; ++rr) s += lds[(size_t)rr * g.C * 2 + t];
-    partial[((size_t)(b * g.chunks + chunk) * g.C) * 2 + t] = s;
+    for (int rr = 0; rr < rows; ++rr) s += lds[(size_t)rr * Cs * 2 + t];
+    partial[((size_t)(b * g.chunks + chunk) * g.C + q0 * 4) * 2 + t] = s;
   }
 }
 
@@ -284,8 +290,7 @@ unsigned apply_blocks(long total4, int q) {
 }
 
 bool gn_ok(const ssbev_norm_dims* d) {
-  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0 && d->C <= 1024 &&
-         (d->C / 4) <= NT;
+  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0;
 }
 
 GnGeom make_geom(const ssbev_norm_dims* d) {
@@ -303,10 +308,12 @@ GnGeom make_geom(const ssbev_norm_dims* d) {
 }
 
 size_t lds_bytes(const GnGeom& g) {
-  const int q = g.C >> 2;
+  const int q = std::min(g.C >> 2, NT);               // widest slab; narrower ones need rows * q <= NT entries too
   const int rows = NT / q > 0 ? NT / q : 1;
-  return (size_t)rows * g.C * 2 * sizeof(float);
+  return (size_t)std::max(rows * q, NT) * 4 * 2 * sizeof(float);
 }
+
+unsigned gn_slabs(const GnGeom& g) { return cdiv((size_t)(g.C >> 2), NT); }
 
 // running statistics of a training-mode BatchNorm (nn.BatchNorm semantics: unbiased variance in the running buffer)
 __global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -340,7 +347,7 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
-    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
                        nullptr, partial, g);
     hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
   }
@@ -371,7 +378,7 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
-  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
+  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
   hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);

@@ -918,3 +918,165 @@ class _OccLossSums(torch.autograd.Function):
 
 def occ_loss_sums(logits, label_u8, class_weight):
     return _OccLossSums.apply(logits, label_u8, class_weight)
+
+
+# -------------------------------------------------------------------------------------------------
+# Image branch: depthwise conv with "same" padding, Swish, squeeze-excitation pieces
+# -------------------------------------------------------------------------------------------------
+
+def same_padding(size, k, stride):
+    """mmcv Conv2dAdaptivePadding (the conv_cfg of CustomEfficientNet, efficientnet.py:373): output = ceil(size/stride),
+    total padding max((out-1)*stride + k - size, 0), the odd element goes to the bottom/right.  Returns (out, before, after)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+class _DwConv2d(torch.autograd.Function):
+    """Depthwise k x k conv (groups = channels), TF-"same" padding; x logical [B,C,H,W], weight [C,1,k,k]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        xcl = to_cl(_f32(x, "dwconv2d"))
+        B, H, W, Cc = xcl.shape
+        k = weight.shape[-1]
+        Ho, pt, _ = same_padding(H, k, stride)
+        Wo, pl, _ = same_padding(W, k, stride)
+        d = capi.DwDims(B, Cc, H, W, Ho, Wo, k, stride, pt, pl)
+        wt = weight.detach().reshape(Cc, k * k).t().contiguous()
+        y = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32, device=x.device)
+        lib = capi.load()
+        with _span("dwconv", 2.0 * y.numel() * k * k, 4.0 * (xcl.numel() + y.numel()), f"dw fwd C={Cc} {H}x{W} k{k} s{stride}"):
+            capi.check(lib.ssbev_dwconv2d_fwd(capi.ptr(xcl), capi.ptr(wt), capi.ptr(y), C.byref(d), capi.stream()),
+                       "ssbev_dwconv2d_fwd")
+        ctx.save_for_backward(xcl, wt)
+        ctx.d = d
+        return from_cl(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xcl, wt = ctx.saved_tensors
+        d = ctx.d
+        gcl = to_cl(gy)
+        lib = capi.load()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gxcl = torch.empty_like(xcl)
+            with _span("dwconv", 2.0 * gcl.numel() * d.k * d.k, 4.0 * (xcl.numel() + gcl.numel()), f"dw dgrad C={d.C} k{d.k} s{d.stride}"):
+                capi.check(lib.ssbev_dwconv2d_bwd_data(capi.ptr(gcl), capi.ptr(wt), capi.ptr(gxcl), C.byref(d), capi.stream()),
+                           "ssbev_dwconv2d_bwd_data")
+            gx = from_cl(gxcl)
+        if ctx.needs_input_grad[1]:
+            n = lib.ssbev_dwconv2d_bwd_weight_workspace(C.byref(d))
+            ws = torch.empty(max(n, 4), dtype=torch.float32, device=gy.device)
+            gwt = torch.empty_like(wt)
+            with _span("dwconv", 2.0 * gcl.numel() * d.k * d.k, 4.0 * (xcl.numel() + gcl.numel()), f"dw wgrad C={d.C} k{d.k} s{d.stride}"):
+                capi.check(lib.ssbev_dwconv2d_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwt), C.byref(d), capi.ptr(ws),
+                                                         ws.numel(), capi.stream()), "ssbev_dwconv2d_bwd_weight")
+            gw = gwt.t().reshape(d.C, 1, d.k, d.k).contiguous()
+        return gx, gw, None
+
+
+def depthwise_conv2d_same(x, weight, stride=1):
+    return _DwConv2d.apply(x, weight, int(stride))
+
+
+class _Swish(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x, "swish")
+        ctx.cl = x.dim() >= 3
+        xc = to_cl(x) if ctx.cl else x.contiguous()       # no copy for the channels-last activations of the branch
+        n = xc.numel()
+        ctx.torch_path = n % 4 != 0
+        ctx.save_for_backward(xc)
+        if ctx.torch_path:
+            y = xc * torch.sigmoid(xc)
+        else:
+            y = torch.empty_like(xc)
+            capi.check(capi.load().ssbev_swish_fwd(capi.ptr(xc), capi.ptr(y), n, capi.stream()), "ssbev_swish_fwd")
+        return from_cl(y) if ctx.cl else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        g = to_cl(gy) if ctx.cl else gy.contiguous()
+        if ctx.torch_path:
+            s = torch.sigmoid(xc)
+            gx = g * (s + xc * s * (1 - s))
+        else:
+            gx = torch.empty_like(xc)
+            capi.check(capi.load().ssbev_swish_bwd(capi.ptr(xc), capi.ptr(g), capi.ptr(gx), xc.numel(), capi.stream()),
+                       "ssbev_swish_bwd")
+        return from_cl(gx) if ctx.cl else gx
+
+
+def swish(x):
+    """mmcv ``Swish``: x * sigmoid(x)."""
+    return _Swish.apply(x)
+
+
+def _chan_sum(a, bmul, B, S, Cc, scale):
+    lib = capi.load()
+    out = torch.empty(B, Cc, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(lib.ssbev_chan_sum_workspace(B, S, Cc), 4), dtype=torch.float32, device=a.device)
+    capi.check(lib.ssbev_chan_sum(capi.ptr(a), capi.ptr(bmul), capi.ptr(out), B, S, Cc, float(scale), capi.ptr(ws),
+                                  ws.numel(), capi.stream()), "ssbev_chan_sum")
+    return out
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) of mmdet's SELayer: logical [B,C,H,W] -> [B,C,1,1]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xcl = to_cl(_f32(x, "global_avg_pool"))
+        B, H, W, Cc = xcl.shape
+        ctx.shape = (B, H, W, Cc)
+        return _chan_sum(xcl, None, B, H * W, Cc, 1.0 / (H * W)).view(B, Cc, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, Cc = ctx.shape
+        gx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=g.device)
+        capi.check(capi.load().ssbev_chan_scale(None, capi.ptr(g.reshape(B, Cc).contiguous()), capi.ptr(gx), B, H * W, Cc,
+                                                1.0 / (H * W), capi.stream()), "ssbev_chan_scale")
+        return from_cl(gx)
+
+
+class _ChanScale(torch.autograd.Function):
+    """x * gate with gate [B,C,1,1] (the SE rescale, mmdet SELayer.forward)."""
+
+    @staticmethod
+    def forward(ctx, x, gate):
+        xcl = to_cl(_f32(x, "chan_scale"))
+        B, H, W, Cc = xcl.shape
+        gt = gate.reshape(B, Cc).contiguous()
+        y = torch.empty_like(xcl)
+        capi.check(capi.load().ssbev_chan_scale(capi.ptr(xcl), capi.ptr(gt), capi.ptr(y), B, H * W, Cc, 1.0, capi.stream()),
+                   "ssbev_chan_scale")
+        ctx.save_for_backward(xcl, gt)
+        return from_cl(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xcl, gt = ctx.saved_tensors
+        B, H, W, Cc = xcl.shape
+        gcl = to_cl(gy)
+        gx = ggate = None
+        if ctx.needs_input_grad[0]:
+            gxcl = torch.empty_like(xcl)
+            capi.check(capi.load().ssbev_chan_scale(capi.ptr(gcl), capi.ptr(gt), capi.ptr(gxcl), B, H * W, Cc, 1.0,
+                                                    capi.stream()), "ssbev_chan_scale")
+            gx = from_cl(gxcl)
+        if ctx.needs_input_grad[1]:
+            ggate = _chan_sum(gcl, xcl, B, H * W, Cc, 1.0).view(B, Cc, 1, 1)
+        return gx, ggate
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+def chan_scale(x, gate):
+    return _ChanScale.apply(x, gate)

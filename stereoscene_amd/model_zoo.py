@@ -3,13 +3,23 @@
 from . import synthetic as S
 
 
-def model_cfg(cfg, numC_Trans=128, warp_align_corners=True):
-    """Same structure and hyper-parameters as the reference config's ``model`` dict, minus the 2-D
-    image backbone/neck (outside the hot path), for the sizes in ``cfg`` (a synthetic.CFG_*)."""
+def image_branch_cfg(arch="b7"):
+    """``img_backbone`` / ``img_neck`` of the reference config (stereoscene.py:59-74), minus the checkpoint init."""
+    return dict(
+        img_backbone=dict(type="CustomEfficientNet", arch=arch, drop_path_rate=0.2, frozen_stages=0, norm_eval=False,
+                          out_indices=(2, 3, 4, 5, 6), with_cp=True),
+        img_neck=dict(type="SECONDFPN", in_channels=[48, 80, 224, 640, 2560], upsample_strides=[0.5, 1, 2, 4, 4],
+                      out_channels=[128, 128, 128, 128, 128]))
+
+
+def model_cfg(cfg, numC_Trans=128, warp_align_corners=True, image_branch=False):
+    """Same structure and hyper-parameters as the reference config's ``model`` dict for the sizes in ``cfg`` (a
+    synthetic.CFG_*).  ``image_branch=False`` (default, the benchmarked hot path a1-a16) leaves the 2-D
+    image backbone/neck out: the detector then takes the image-neck features in place of raw images."""
     norm_cfg = dict(type="GN", num_groups=32, requires_grad=True)
     channels = [128, 256, 512]
     return dict(
-        type="BEVDepthOccupancy",
+        type="BEVDepthOccupancy", **(image_branch_cfg() if image_branch else {}),
         img_view_transformer=dict(
             type="ViewTransformerLiftSplatShootVoxel", downsample=cfg["downsample"], numC_input=640,
             cam_channels=30, semkitti=False, loss_depth_weight=1.0, grid_config=S.grid_config(cfg),

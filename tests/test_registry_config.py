@@ -34,6 +34,7 @@ def test_plugin_fills_registries():
     from stereoscene_amd import plugin  # noqa: F401
     assert "ViewTransformerLiftSplatShootVoxel" in NECKS and "SECONDFPN3D" in NECKS
     assert "CustomResNet3D" in BACKBONES and "OccHead" in HEADS and "BEVDepthOccupancy" in DETECTORS
+    assert "CustomEfficientNet" in BACKBONES and "SECONDFPN" in NECKS
 
 
 @pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference checkout not present (GPU box)")
@@ -47,8 +48,12 @@ def test_reference_config_loads_unchanged_and_builds():
     vt = det.img_view_transformer
     assert vt.D == 112 and tuple(vt.frustum.shape) == (112, 48, 160, 3)
     assert [int(v) for v in vt.nx.tolist()] == [128, 128, 16]
-    n = sum(p.numel() for p in det.parameters())
+    n = sum(p.numel() for n_, p in det.named_parameters() if not n_.startswith(("img_backbone.", "img_neck.")))
     assert 88e6 < n < 92e6
+    # the image branch builds from the same unchanged config: EfficientNet-B7 + SECONDFPN
+    nb = sum(p.numel() for p in det.img_backbone.parameters())
+    assert 63e6 < nb < 65e6 and len(det.img_backbone.layers) == 7
+    assert [b[0].weight.shape[1 if i else 0] for i, b in enumerate(det.img_neck.deblocks)] == [128] * 5
 
 
 def test_state_dict_keys_match_reference_manifest():
