@@ -137,6 +137,58 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, float* __restrict__ me
   }
 }
 
+// Per-channel statistics (BatchNorm: one channel per group): one WAVE per (b, channel), lanes striding over the chunk
+// partials, butterfly sum.  The image branch runs ~170 BatchNorms per pass, most of them on maps of a few thousand
+// pixels where the workgroup-per-group kernels above (1024 threads, ten barriers) are pure latency.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd, GnGeom g) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= g.B * g.C) return;
+  const int b = i / g.C, c = i % g.C;
+  double a = 0.0, q = 0.0;
+  for (int chunk = lane; chunk < g.chunks; chunk += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+    a += p.x; q += p.y;
+  }
+  a = wave_sum_d(a); q = wave_sum_d(q);
+  if (lane == 0) {
+    const double n = (double)g.S, m = a / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)g.eps));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, float* __restrict__ coef,
+                            float* __restrict__ dgamma, float* __restrict__ dbeta, GnGeom g) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= g.C) return;
+  double tb = 0.0, ts = 0.0;
+  const double gm = gamma[c], n = (double)g.S;
+  for (int b = 0; b < g.B; ++b) {
+    double sb = 0.0, ss = 0.0;
+    for (int chunk = lane; chunk < g.chunks; chunk += 64) {
+      const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+      sb += p.x; ss += p.y;
+    }
+    sb = wave_sum_d(sb); ss = wave_sum_d(ss);
+    if (lane == 0) {
+      coef[(b * g.C + c) * 2 + 0] = (float)(gm * ss / n);
+      coef[(b * g.C + c) * 2 + 1] = (float)(gm * sb / n);
+    }
+    tb += sb; ts += ss;
+  }
+  if (lane == 0) { dbeta[c] = (float)tb; dgamma[c] = (float)ts; }
+}
+
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -349,7 +401,10 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   if (!d->stats_given) {
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
                        nullptr, partial, g);
-    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
+    if (g.G == g.C)
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, mean, rstd, g);
+    else
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
@@ -379,7 +434,10 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
-  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
+  if (g.G == g.C)
+    hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
+  else
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,

@@ -79,22 +79,23 @@ dw_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w, fl
 // Partial weight gradients: block (chunk of output pixels) x (64 channel quads); the 4 pixel lanes of a block are
 // folded through LDS in a fixed order and each chunk writes its own [k*k][C] slab (deterministic; folded by
 // dw_reduce_kernel).
-constexpr int kDwQuads = 64, kDwLanes = 4;
+// Thread layout: Q channel quads x L pixel lanes with Q * L <= 256 (Q = all quads when C <= 1024, else 64 per block), so
+// that narrow layers (C = 32: 8 quads x 32 lanes) keep every thread busy.
 template <int K>
 __global__ void __launch_bounds__(256)
 dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, DwGeom g,
-                     long npix, int pix_per_chunk) {
-  __shared__ float4 red[kDwLanes][kDwQuads];
-  const int ql = threadIdx.x & (kDwQuads - 1), pl = threadIdx.x >> 6;
-  const int quad = blockIdx.y * kDwQuads + ql;
-  const bool qok = quad < (g.C >> 2);
+                     long npix, int pix_per_chunk, int Q, int L) {
+  __shared__ float4 red[256];
+  const int ql = threadIdx.x % Q, pl = threadIdx.x / Q;
+  const int quad = blockIdx.y * Q + ql;
+  const bool qok = quad < (g.C >> 2) && pl < L;
   const int c = quad << 2;
   float4 acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   const long p0 = (long)blockIdx.x * pix_per_chunk, p1 = min(npix, p0 + pix_per_chunk);
   if (qok) {
-    for (long p = p0 + pl; p < p1; p += kDwLanes) {
+    for (long p = p0 + pl; p < p1; p += L) {
       long r = p;
       const int wo = (int)(r % g.Wo); r /= g.Wo;
       const int ho = (int)(r % g.Ho);
@@ -119,13 +120,12 @@ dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy, 
   float* dst = part + (long)blockIdx.x * (K * K) * g.C;
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
-    red[pl][ql] = acc[t];
+    red[threadIdx.x] = acc[t];
     __syncthreads();
     if (pl == 0 && qok) {
-      float4 s = red[0][ql];
-#pragma unroll
-      for (int l = 1; l < kDwLanes; ++l) {
-        const float4 v = red[l][ql];
+      float4 s = red[ql];
+      for (int l = 1; l < L; ++l) {
+        const float4 v = red[l * Q + ql];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       *reinterpret_cast<float4*>(dst + (long)t * g.C + c) = s;
@@ -134,13 +134,15 @@ dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy, 
   }
 }
 
+// one wave per output element, lanes striding over the chunk slabs (fixed butterfly order: deterministic)
 __global__ void __launch_bounds__(256)
 dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int n, int nchunks) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.0f;
-  for (int ch = 0; ch < nchunks; ++ch) s += part[(long)ch * n + i];
-  gw[i] = s;
+  for (int ch = lane; ch < nchunks; ch += 64) s += part[(long)ch * n + i];
+  s = wave_sum(s);
+  if (lane == 0) gw[i] = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -207,11 +209,12 @@ chan_sum_kernel(const float* __restrict__ a, const float* __restrict__ bmul, flo
 
 __global__ void __launch_bounds__(256)
 chan_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int nchunks, float scale) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.0f;
-  for (int ch = 0; ch < nchunks; ++ch) s += part[(long)ch * n + i];
-  out[i] = s * scale;
+  for (int ch = lane; ch < nchunks; ch += 64) s += part[(long)ch * n + i];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = s * scale;
 }
 
 // y[b][s][c] = x[b][s][c] * gate[b][c] (+ optionally add[b][s][c]); also the broadcast of the pool gradient (x = null:
@@ -243,9 +246,17 @@ bool dw_ok(const ssbev_dw_dims* d) {
 
 DwGeom dw_geom(const ssbev_dw_dims* d) { return DwGeom{d->B, d->C, d->Hi, d->Wi, d->Ho, d->Wo, d->k, d->stride, d->pad_t, d->pad_l}; }
 
+void dw_layout(const ssbev_dw_dims* d, int* Q, int* L, int* qblocks) {
+  const int quads = d->C >> 2;
+  *Q = quads <= 256 ? quads : 64;
+  *L = 256 / *Q;
+  *qblocks = (quads + *Q - 1) / *Q;
+}
+
 void dw_chunks(const ssbev_dw_dims* d, long* npix, int* ppc, int* nchunks) {
   *npix = (long)d->B * d->Ho * d->Wo;
-  const int qblocks = ((d->C >> 2) + kDwQuads - 1) / kDwQuads;
+  int Q, L, qblocks;
+  dw_layout(d, &Q, &L, &qblocks);
   long want = std::max(1L, 2048L / qblocks);                 // ~2k workgroups in total
   long per = std::max(64L, (*npix + want - 1) / want);
   *ppc = (int)per;
@@ -297,12 +308,14 @@ int ssbev_dwconv2d_bwd_weight(const float* x, const float* gy, float* gw, const 
   long npix; int ppc, nchunks;
   dw_chunks(d, &npix, &ppc, &nchunks);
   const DwGeom g = dw_geom(d);
-  const dim3 grid(nchunks, ((d->C >> 2) + kDwQuads - 1) / kDwQuads), block(256);
+  int Q, L, qblocks;
+  dw_layout(d, &Q, &L, &qblocks);
+  const dim3 grid(nchunks, qblocks), block(256);
   hipStream_t st = as_stream(stream);
-  if (d->k == 3) hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, grid, block, 0, st, x, gy, ws, g, npix, ppc);
-  else hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, grid, block, 0, st, x, gy, ws, g, npix, ppc);
+  if (d->k == 3) hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, grid, block, 0, st, x, gy, ws, g, npix, ppc, Q, L);
+  else hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, grid, block, 0, st, x, gy, ws, g, npix, ppc, Q, L);
   const int n = d->k * d->k * d->C;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, gw, n, nchunks);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, ws, gw, n, nchunks);
   return ssbev_launch_status();
 }
 
@@ -333,7 +346,7 @@ int ssbev_chan_sum(const float* a, const float* bmul, float* out, int B, int64_t
   chan_chunks(B, (long)S, C, &per, &nchunks);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(chan_sum_kernel, dim3(cdiv(C >> 2, 64), B, nchunks), dim3(256), 0, st, a, bmul, ws, (long)S, C, per);
-  hipLaunchKernelGGL(chan_fold_kernel, dim3(cdiv((size_t)B * C, 256)), dim3(256), 0, st, ws, out, B * C, nchunks, scale);
+  hipLaunchKernelGGL(chan_fold_kernel, dim3(cdiv((size_t)B * C, 4)), dim3(256), 0, st, ws, out, B * C, nchunks, scale);
   return ssbev_launch_status();
 }
 

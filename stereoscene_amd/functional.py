@@ -932,6 +932,18 @@ def same_padding(size, k, stride):
     return out, total // 2, total - total // 2
 
 
+def linear_cl(x, weight, bias=None):
+    """1x1 / stride-1 convolution of a channels-last map as the plain GEMM it is -- [pixels, Cin] x [Cin, Cout] on the
+    channels-last buffer, no layout change -- on rocBLAS (forward, data and weight gradient through autograd's mm).
+    Used by the image branch, whose pointwise convs range from 2 rows (SE gates) to 245 k rows x 32..3840 channels."""
+    xcl = to_cl(_f32(x, "linear_cl"))
+    shp = xcl.shape
+    w2 = weight.reshape(weight.shape[0], -1)
+    x2 = xcl.reshape(-1, shp[-1])
+    y = torch.addmm(bias, x2, w2.t()) if bias is not None else torch.mm(x2, w2.t())
+    return from_cl(y.view(*shp[:-1], w2.shape[0]))
+
+
 class _DwConv2d(torch.autograd.Function):
     """Depthwise k x k conv (groups = channels), TF-"same" padding; x logical [B,C,H,W], weight [C,1,k,k]."""
 

@@ -65,6 +65,8 @@ class SamePadConv2d(nn.Conv2d):
 
     def forward(self, x):
         k, s = self.kernel_size[0], self.stride[0]
+        if k == 1 and s == 1:
+            return F.linear_cl(x, self.weight, self.bias)      # pointwise conv = plain GEMM on the channels-last buffer
         if s == 1:
             return F.conv2d(x, self.weight, self.bias, 1, k // 2, 1)
         _, pt, pb = F.same_padding(x.shape[-2], k, s)
@@ -95,8 +97,9 @@ class ConvModule(nn.Module):
         bias = norm_cfg is None
         same = conv_cfg is not None and conv_cfg.get("type") == "Conv2dAdaptivePadding"
         if groups == 1:
-            self.conv = SamePadConv2d(in_channels, out_channels, kernel_size, stride, 0, bias=bias) if same else \
-                Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+            pointwise = kernel_size == 1 and stride == 1 and padding == 0
+            self.conv = SamePadConv2d(in_channels, out_channels, kernel_size, stride, 0, bias=bias) if (same or pointwise) \
+                else Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
         else:
             if not (same and groups == in_channels == out_channels):
                 raise NotImplementedError("grouped convs other than depthwise 'same' ones are not part of the branch")
