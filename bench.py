@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 (no sparsity), MI355X_MICROARCH.md
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 VOXELS_PER_SAMPLE = 256 * 256 * 32
 
@@ -172,15 +173,19 @@ def main():
             if t:
                 traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1p_pmc_traffic.json"
         tf = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0      # noqa: E731
+        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roof = {"bound": "mfma",
                 "kernel": "convolution forward + data gradient, every launch of the step: direct MFMA kernels (conv_gather_kernel"
                           "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 "
                           "layers, Winograd F(2,3)^3 / F(2,3)^2 pipelines (wino*_input_kernel -> 64 / 16 batched fp32 GEMMs -> wino*_output_kernel)",
                 "flop_convention": "achieved counts direct-convolution FLOPs (2*voxels*Cin*Cout*taps: what the operator computes, "
                                    "SURVEY 8(d)); the Winograd launches execute 3.375x (3-D) / 2.25x (2-D) fewer multiply-adds, see frac_executed",
-                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "frac_executed": executed / (fam_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if fam_n else 0.0,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "peak_source": "fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md" if args.precision == "fp32" else
+                               "dense bf16 MFMA, MI355X_MICROARCH.md (bf16 mode: operands rounded to bf16, fp32 storage keeps the "
+                               "kernels load-bound far below this peak)",
+                "frac": achieved / peak,
+                "frac_executed": executed / (fam_ms * 1e-3) / 1e12 / peak if fam_n else 0.0,
                 "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": g.get("bytes", 0.0) / max(g["launches"], 1),
                 "algorithmic_gflop_per_launch": fam_flops / 1e9 / max(fam_n, 1),

@@ -1,11 +1,12 @@
 """Image branch at the KITTI size: EfficientNet-B7 + SECONDFPN on two 384 x 1280 views, forward and
 forward+backward time, with the per-family HIP-event breakdown.  `python tools/image_branch_bench.py [--no-cp]`"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereoscene_amd import functional as F, model_zoo, synthetic as S  # noqa: E402
 from stereoscene_amd import plugin  # noqa: E402,F401
 from stereoscene_amd.registry import BACKBONES, NECKS  # noqa: E402

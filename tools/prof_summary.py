@@ -1,8 +1,38 @@
-"""Print a compact per-kernel summary of a rocprofv3 *_kernel_stats.csv (ms per step)."""
-import csv, sys
-path, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-rows = list(csv.DictReader(open(path)))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time: {tot/1e6/steps:.1f} ms/step over {steps:g} steps")
-for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
-    print(f"{float(r['TotalDurationNs'])/1e6/steps:9.2f} ms/step {int(r['Calls'])/steps:7.1f} calls/step  avg {float(r['AverageNs'])/1e3:9.1f} us  {float(r['Percentage']):6.2f}%  {r['Name'][:120]}")
+"""Compact summary of a rocprofv3 *_kernel_stats.csv: total, family roll-up and the top kernels (ms per step).
+usage: python tools/prof_summary.py <kernel_stats.csv> <steps> [top_n]"""
+import csv
+import re
+import sys
+
+FAMILIES = [
+    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_thin_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_thin_kernel"),
+    ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
+    ("rocBLAS / hipBLASLt GEMMs (Cijk_*: Winograd frequency GEMMs, BRI products, image-branch pointwise convs)", r"Cijk_"),
+    ("weight gradient, direct (wgrad_lds/wgrad_thin/wgrad_1x1/wgrad_cf/wgrad_kernel + reduce)", r"wgrad"),
+    ("GroupNorm / BatchNorm (gn_*, bn_*)", r"gn_|bn_"),
+    ("weight packing (pack_*)", r"pack_"),
+    ("cost volume, lift/splat, scatter prep, DCN, softmax, losses, trilinear, image-branch ops", r"gwc_|pool_|lift_|voxel_index|histogram|scan_|fill_kernel|canonicalise|dcn_|softmax_axis|occ_loss|trilinear|bri_|dw_|swish|chan_|adamw|sumsq"),
+]
+
+
+def main():
+    path, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"total kernel time: {tot / 1e6 / steps:.1f} ms/step over {steps:g} steps")
+    print("\nfamily roll-up (ms/step, kernel launches/step):")
+    left = list(rows)
+    for label, pat in FAMILIES:
+        hit = [r for r in left if re.search(pat, r["Name"])]
+        left = [r for r in left if not re.search(pat, r["Name"])]
+        print(f"  {sum(float(r['TotalDurationNs']) for r in hit) / 1e6 / steps:8.2f} ms {sum(int(r['Calls']) for r in hit) / steps:8.1f}  {label}")
+    print(f"  {sum(float(r['TotalDurationNs']) for r in left) / 1e6 / steps:8.2f} ms {sum(int(r['Calls']) for r in left) / steps:8.1f}  ATen elementwise / reductions / copies and everything else")
+    print()
+    for r in rows[:top]:
+        print(f"{float(r['TotalDurationNs']) / 1e6 / steps:9.2f} ms/step {int(r['Calls']) / steps:7.1f} calls/step  avg {float(r['AverageNs']) / 1e3:9.1f} us  "
+              f"{float(r['Percentage']):6.2f}%  {r['Name'][:130]}")
+
+
+if __name__ == "__main__":
+    main()
