@@ -254,6 +254,21 @@ int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, fl
                      const ssbev_dcn_dims* d, ssbev_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Data side: CreateDepthFromLiDAR (datasets/pipelines/occ_to_depth.py:216-303), the producer of the
+ * gt_depths slot of img_inputs.  points [N][3] fp32 (lidar frame), cam = 34 floats (host or device memory):
+ * inv(rots) 3x3 row major | trans 3 | intrins 4x4 row major | post_rots[:2,:2] | post_trans[:2].
+ * Writes uvd [N][3] (augmented pixel u, v and depth of every point), valid [N] (inside the image, depth > 0), the
+ * depth map [H][W] = depth of the NEAREST valid point per pixel (pixel = round-half-even(u, v)), 0 where none, and --
+ * when labels [N] and seg are given -- seg [H][W] = label of that nearest point.  Same operation order as the
+ * reference's torch expressions; ties on depth resolve to the lowest point index.  ws: ssbev_lidar_depth_workspace bytes.
+ * The 34 camera floats are copied synchronously (one implicit stream sync: this is a data-loading operator).
+ * ------------------------------------------------------------------------------------------ */
+size_t ssbev_lidar_depth_workspace(int H, int W);
+int ssbev_lidar_depth_map(const float* points, int n_points, const float* cam, const float* labels, float* uvd,
+                          unsigned char* valid, float* depth, float* seg, int H, int W, void* ws, size_t ws_bytes,
+                          ssbev_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Image branch (the step before a1/a5): operators of CustomEfficientNet (backbones/efficientnet.py:112-229,
  * 275-519: InvertedResidual = expand 1x1 -> depthwise k x k -> SE -> linear 1x1) that are not dense contractions.
  * Channels-last fp32, C % 4 == 0.
