@@ -263,6 +263,17 @@ int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, fl
  * reference's torch expressions; ties on depth resolve to the lowest point index.  ws: ssbev_lidar_depth_workspace bytes.
  * The 34 camera floats are copied synchronously (one implicit stream sync: this is a data-loading operator).
  * ------------------------------------------------------------------------------------------ */
+/* Image loading (loading_semkitti.py:101-131, 176-232: `img.resize(resize_dims)`, `img.crop(crop)`, flip, mmcv
+ * `imnormalize`, HWC -> CHW).  ssbev_resize_pil_u8 is byte-exact with Pillow's antialiased resize of 8-bit images: the
+ * caller passes libImaging's fixed-point coefficient tables (kk [out][ksize] int32 with 22 fractional bits, bounds
+ * [out][2] = first source index, tap count) for the horizontal and the vertical pass; tmp [Hs][Wd][C] is the 8-bit
+ * intermediate.  ssbev_crop_normalize_u8: dst [3][h][w] = (src[y0+y][x0+x'][c'] - mean[c]) * stdinv[c], x' mirrored when
+ * flip, c' = 2-c when swap_rb; pixels outside the source read 0 (PIL crop semantics); mean / stdinv are HOST pointers. */
+int ssbev_resize_pil_u8(const uint8_t* src, int Hs, int Ws, int C, const int32_t* kk_h, const int32_t* bounds_h, int ksize_h,
+                        const int32_t* kk_v, const int32_t* bounds_v, int ksize_v, uint8_t* tmp, uint8_t* dst, int Hd, int Wd,
+                        ssbev_stream_t stream);
+int ssbev_crop_normalize_u8(const uint8_t* src, int Hs, int Ws, float* dst, int x0, int y0, int w, int h, int flip,
+                            const float* mean, const float* stdinv, int swap_rb, ssbev_stream_t stream);
 size_t ssbev_lidar_depth_workspace(int H, int W);
 int ssbev_lidar_depth_map(const float* points, int n_points, const float* cam, const float* labels, float* uvd,
                           unsigned char* valid, float* depth, float* seg, int H, int W, void* ws, size_t ws_bytes,

@@ -50,6 +50,95 @@ def cameras():
     return views
 
 
+IMG_H, IMG_W, IN_SIZE = 47, 155, (48, 160)
+DATA_CONFIG = {"input_size": IN_SIZE, "resize": (0.0, 0.0), "rot": (0.0, 0.0), "flip": False, "crop_h": (0.0, 0.0),
+               "resize_test": 0.0}
+
+
+def stereo_images():
+    """Two deterministic RGB uint8 images (left, right)."""
+    return [(S.hash_uniform(f"img/{n}", (IMG_H, IMG_W, 3), 0.0, 256.0).floor().clamp(0, 255).to(torch.uint8).numpy())
+            for n in ("left", "right")]
+
+
+def stereo_meta():
+    """cam_intrinsic / lidar2cam / calib entries of `get_data_info` (semantic_kitti_lss_dataset.py:153-229) for a KITTI-like rig."""
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = 707.0912 * IMG_W / 1241.0
+    K[0, 2], K[1, 2] = 601.8873 * IMG_W / 1241.0, 183.1104 * IMG_W / 1241.0
+    K2 = K.copy()
+    K2[0, 3] = -0.54 * K[0, 0]
+    Tr = np.eye(4)
+    Tr[:3, :3] = [[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]]
+    Tr[:3, 3] = [0.0, -0.08, -0.27]
+    return dict(cam_intrinsic=[K, K2], lidar2cam=[Tr, Tr], calib=torch.tensor(K[0, 0] * 0.54))
+
+
+def loader_fixtures(out):
+    """LoadMultiViewImageFromFiles_SemanticKitti + LoadSemKittiAnnotation + bev_transform of the reference."""
+    import types
+    from PIL import Image
+
+    def imread(path, flag="unchanged"):                       # mmcv.imread: cv2 order (BGR)
+        with Image.open(path) as im:
+            return np.asarray(im.convert("RGB"))[..., ::-1].copy()
+
+    def imnormalize(img, mean, std, to_rgb=True):             # mmcv.image.photometric.imnormalize (published formula)
+        img = img.copy().astype(np.float32)
+        mean64 = np.float64(mean.reshape(1, -1))
+        stdinv = 1 / np.float64(std.reshape(1, -1))
+        if to_rgb:
+            img = img[..., ::-1]
+        return ((img - mean64.astype(np.float32)) * stdinv.astype(np.float32)).astype(np.float32)
+
+    sys.modules["mmcv"].imread = imread
+    MG._pkg("mmcv.image")
+    MG._mod("mmcv.image.photometric", imnormalize=imnormalize)
+    for name in ("torchvision", "pyquaternion", "scipy.ndimage.interpolation"):
+        pass
+    MG._mod("torchvision")
+    MG._mod("pyquaternion", Quaternion=object)
+    MG._pkg("mmdet3d.core")
+    MG._mod("mmdet3d.core.points", BasePoints=object, get_points_type=None)
+    MG._mod("mmdet3d.core.bbox", LiDARInstance3DBoxes=object)
+    MG._mod("mmdet.datasets.pipelines", LoadAnnotations=object, LoadImageFromFile=object)
+    import scipy.ndimage
+    if not hasattr(scipy.ndimage, "interpolation"):           # removed alias in recent scipy
+        scipy.ndimage.interpolation = types.SimpleNamespace(rotate=scipy.ndimage.rotate)
+    LS = importlib.import_module("projects.mmdet3d_plugin.datasets.pipelines.loading_semkitti")
+    imgs = stereo_images()
+    meta = stereo_meta()
+    with tempfile.TemporaryDirectory() as tmp:
+        names = []
+        for im, cam in zip(imgs, ("image_2", "image_3")):
+            d = os.path.join(tmp, "sequences", "00", cam)
+            os.makedirs(d)
+            Image.fromarray(im).save(os.path.join(d, "000123.png"))
+            names.append(os.path.join(d, "000123.png"))
+        for mode, is_train in (("test", False), ("train", True)):
+            step = LS.LoadMultiViewImageFromFiles_SemanticKitti(data_config=DATA_CONFIG, is_train=is_train, colorjitter=False,
+                                                                img_norm_cfg=dict(mean=[123.675, 116.28, 103.53],
+                                                                                  std=[58.395, 57.12, 57.375], to_rgb=True))
+            np.random.seed(0)
+            results = step(dict(img_filename=names, gt_occ=np.zeros((4, 4, 2), dtype=np.uint8), **meta))
+            ann = LS.LoadSemKittiAnnotation(bda_aug_conf=dict(rot_lim=(0, 0), scale_lim=(0.95, 1.05), flip_dx_ratio=0.5,
+                                                              flip_dy_ratio=0.5), is_train=is_train)
+            results = ann(results)
+            for k, name in enumerate(("left", "right")):
+                v = results["img_inputs"][k]
+                assert len(v) == 10
+                for j, key in enumerate(("img", "rot", "tran", "intrin", "post_rot", "post_tran", "bda", "depth", "cam2lidar", "calib")):
+                    out[f"load_{mode}_{name}_{key}"] = np.asarray(v[j])
+            print(mode, "img", tuple(results["img_inputs"][0][0].shape), "post_rot", results["img_inputs"][0][4].flatten().tolist())
+    # BEV augmentation of voxel labels (flip + 90-degree-free rotation), pure host logic of the reference
+    lab = (S.hash_uniform("bev/lab", (16, 16, 4), 0.0, 20.0).floor()).to(torch.uint8)
+    center = torch.tensor([25.6, 0.0, 1.2])
+    for tag, (rot, fx, fy) in dict(flipx=(0.0, True, False), flipxy=(0.0, True, True), rot=(30.0, False, True)).items():
+        v, m = LS.bev_transform(lab.clone(), rot, 1.0, fx, fy, center)
+        out[f"bev_{tag}_labels"] = v.numpy().astype(np.uint8)
+        out[f"bev_{tag}_mat"] = m.numpy()
+
+
 def main():
     # The pipeline runs inside torch DataLoader workers, which call torch.set_num_threads(1): only then is the CPU
     # index_put of occ_to_depth.py:299 sequential ("last write wins" = nearest point after the descending sort).  With
@@ -101,6 +190,11 @@ def main():
     print("points_occ", out["points_occ"].shape, "points_uv", out["points_uv"].shape, "seg pixels", sidx.numel())
     path = os.path.join(MG.OUT, "lidar_depth.npz")
     np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) / 1e3, "kB")
+    out2 = {}
+    loader_fixtures(out2)
+    path = os.path.join(MG.OUT, "image_loading.npz")
+    np.savez_compressed(path, **out2)
     print("wrote", path, os.path.getsize(path) / 1e3, "kB")
 
 

@@ -100,6 +100,8 @@ SIGNATURES = {
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_dcn_col2im": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(DcnDims), _P]),
     "ssbev_bn_update_running": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int64, _P]),
+    "ssbev_resize_pil_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "ssbev_crop_normalize_u8": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "ssbev_lidar_depth_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "ssbev_lidar_depth_map": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ssbev_dwconv2d_fwd": (C.c_int, [_P, _P, _P, C.POINTER(DwDims), _P]),

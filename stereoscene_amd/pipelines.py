@@ -9,6 +9,7 @@ Formats: velodyne ``.bin`` = float32 x, y, z, intensity; lidarseg ``.label`` = u
 preprocessed voxel labels ``*_1_1.npy`` = uint8 [256,256,32] (semantic_kitti_dataset.py:137-139).
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -150,3 +151,365 @@ class CreateDepthFromLiDAR:
         right = self._view(results, 1, bda_mat)
         results["img_inputs"] = [left, right]
         return results
+
+
+# -------------------------------------------------------------------------------------------------
+# Image loading: Pillow-exact resize + crop / flip / normalise on the GPU
+# -------------------------------------------------------------------------------------------------
+
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x):
+    x = np.abs(x)
+    a = -0.5
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+
+
+def pil_resample_tables(in_size, out_size):
+    """Fixed-point coefficient table of Pillow's antialiased bicubic resize along one axis (libImaging Resample.c,
+    `precompute_coeffs` + `normalize_coeffs_8bpc`): returns (kk int32 [out, ksize], bounds int32 [out, 2], ksize)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = _bicubic((np.arange(xmax) + xmin - center + 0.5) * ss)
+        tot = w.sum()
+        if tot != 0.0:
+            w = w / tot
+        fixed = np.where(w < 0, -0.5 + w * (1 << _PRECISION_BITS), 0.5 + w * (1 << _PRECISION_BITS))
+        kk[xx, :xmax] = np.trunc(fixed).astype(np.int32)
+        bounds[xx] = (xmin, xmax)
+    return kk, bounds, ksize
+
+
+_TABLE_CACHE = {}
+
+
+def _tables(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    if key not in _TABLE_CACHE:
+        kk, bounds, ksize = pil_resample_tables(in_size, out_size)
+        _TABLE_CACHE[key] = (torch.from_numpy(kk).to(device), torch.from_numpy(bounds).to(device), ksize)
+    return _TABLE_CACHE[key]
+
+
+def resize_u8(img, size):
+    """``PIL.Image.resize(size)`` (default bicubic, antialiased) of a uint8 [H, W, C] GPU tensor; ``size`` = (W, H) as in
+    PIL.  Byte-exact with Pillow (tests/test_pipelines.py)."""
+    lib = capi.load()
+    Hs, Ws, Cc = img.shape
+    Wd, Hd = int(size[0]), int(size[1])
+    img = img.contiguous()
+    dst = torch.empty(Hd, Wd, Cc, dtype=torch.uint8, device=img.device)
+    kh = bh = kv = bv = None
+    ksh = ksv = 0
+    if Wd != Ws:
+        kh, bh, ksh = _tables(Ws, Wd, img.device)
+    if Hd != Hs:
+        kv, bv, ksv = _tables(Hs, Hd, img.device)
+    tmp = torch.empty(Hs, Wd, Cc, dtype=torch.uint8, device=img.device) if (Wd != Ws and Hd != Hs) else None
+    capi.check(lib.ssbev_resize_pil_u8(capi.ptr(img), Hs, Ws, Cc, capi.ptr(kh), capi.ptr(bh), ksh, capi.ptr(kv), capi.ptr(bv),
+                                       ksv, capi.ptr(tmp), capi.ptr(dst), Hd, Wd, capi.stream()), "ssbev_resize_pil_u8")
+    return dst
+
+
+def crop_normalize(img, crop, flip, mean, std, swap_rb=False):
+    """``img.crop(crop)`` (+ FLIP_LEFT_RIGHT) + mmcv ``imnormalize`` + ``permute(2, 0, 1)``: uint8 [H, W, 3] -> float32
+    [3, h, w].  ``(x - float32(mean)) * float32(1 / float64(std))`` as mmcv/OpenCV compute it."""
+    lib = capi.load()
+    Hs, Ws, _ = img.shape
+    x0, y0, x1, y1 = (int(v) for v in crop)
+    w, h = x1 - x0, y1 - y0
+    out = torch.empty(3, h, w, dtype=torch.float32, device=img.device)
+    m = np.asarray(mean, dtype=np.float32)
+    si = (1.0 / np.asarray(std, dtype=np.float32).astype(np.float64)).astype(np.float32)
+    capi.check(lib.ssbev_crop_normalize_u8(capi.ptr(img.contiguous()), Hs, Ws, capi.ptr(out), x0, y0, w, h, int(bool(flip)),
+                                           m.ctypes.data_as(C.c_void_p), si.ctypes.data_as(C.c_void_p), int(bool(swap_rb)),
+                                           capi.stream()), "ssbev_crop_normalize_u8")
+    return out
+
+
+def read_image_rgb(path):
+    """PNG/JPEG -> uint8 [H, W, 3] in RGB order (upstream reads BGR with cv2 and swaps inside imnormalize: same pixels)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+@PIPELINES.register_module()
+class LoadMultiViewImageFromFiles_SemanticKitti:
+    """Pipeline step of stereoscene.py:140 (loading_semkitti.py:76-302): loads the stereo pair, applies the image-view
+    augmentation (resize / crop / flip; the same draw for both views), normalises, and assembles
+    ``results['img_inputs'] = [left, right]`` with each view = [img, rot, tran, intrin, post_rot, post_tran, depth,
+    cam2lidar, calib] (leading axis of 1).  Pixels are produced on the GPU (``resize_u8`` / ``crop_normalize``); the
+    augmentation draw and the 3x3 bookkeeping are host code, as upstream.  ``rot != 0`` and ``colorjitter`` are not built
+    (the config sets rot = (0, 0), colorjitter = False)."""
+
+    def __init__(self, data_config, is_train=False, colorjitter=False, img_norm_cfg=None, load_depth=False, device="cuda"):
+        if colorjitter or load_depth:
+            raise NotImplementedError("colorjitter / load_depth are off in stereoscene.py and not built")
+        self.is_train, self.data_config, self.img_norm_cfg, self.device = is_train, data_config, img_norm_cfg, device
+
+    @staticmethod
+    def get_rot(h):
+        return torch.Tensor([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]])
+
+    def sample_augmentation(self, H, W, flip=None, scale=None):
+        fH, fW = self.data_config["input_size"]
+        if self.is_train:
+            resize = float(fW) / float(W) + np.random.uniform(*self.data_config["resize"])
+            resize_dims = (int(W * resize), int(H * resize))
+            newW, newH = resize_dims
+            crop_h = int((1 - np.random.uniform(*self.data_config["crop_h"])) * newH) - fH
+            crop_w = int(np.random.uniform(0, max(0, newW - fW)))
+            crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
+            flip = self.data_config["flip"] and np.random.choice([0, 1])
+            rotate = np.random.uniform(*self.data_config["rot"])
+        else:
+            resize = float(fW) / float(W) + self.data_config.get("resize_test", 0.0)
+            if scale is not None:
+                resize = scale
+            resize_dims = (int(W * resize), int(H * resize))
+            newW, newH = resize_dims
+            crop_h = int((1 - np.mean(self.data_config["crop_h"])) * newH) - fH
+            crop_w = int(max(0, newW - fW) / 2)
+            crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
+            flip = False if flip is None else flip
+            rotate = 0
+        return resize, resize_dims, crop, flip, rotate
+
+    def img_transform(self, img, post_rot, post_tran, resize, resize_dims, crop, flip, rotate):
+        """img: uint8 [H, W, 3] on the GPU -> normalised float [3, fH, fW]; post_rot / post_tran as loading_semkitti.py:109-125."""
+        if rotate != 0:
+            raise NotImplementedError("image rotation is off in stereoscene.py (rot = (0, 0)) and not built")
+        cfg = self.img_norm_cfg or dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+        out = crop_normalize(resize_u8(img, resize_dims), crop, flip, cfg["mean"], cfg["std"], swap_rb=False)
+        post_rot = post_rot * resize
+        post_tran = post_tran - torch.Tensor(crop[:2])
+        if flip:
+            A = torch.Tensor([[-1, 0], [0, 1]])
+            b = torch.Tensor([crop[2] - crop[0], 0])
+            post_rot = A.matmul(post_rot)
+            post_tran = A.matmul(post_tran) + b
+        A = self.get_rot(rotate / 180 * np.pi)
+        b = torch.Tensor([crop[2] - crop[0], crop[3] - crop[1]]) / 2
+        b = A.matmul(-b) + b
+        post_rot = A.matmul(post_rot)
+        post_tran = A.matmul(post_tran) + b
+        return out, post_rot, post_tran
+
+    def _view(self, results, k, augs):
+        raw = torch.from_numpy(np.array(read_image_rgb(results["img_filename"][k]))).to(self.device)
+        resize, resize_dims, crop, flip, rotate = augs
+        img, post_rot2, post_tran2 = self.img_transform(raw, torch.eye(2), torch.zeros(2), resize, resize_dims, crop, flip, rotate)
+        post_tran, post_rot = torch.zeros(3), torch.eye(3)
+        post_tran[:2] = post_tran2
+        post_rot[:2, :2] = post_rot2
+        intrin = torch.Tensor(results["cam_intrinsic"][k])
+        cam2lidar = torch.Tensor(results["lidar2cam"][k]).inverse()
+        res = [img, cam2lidar[:3, :3], cam2lidar[:3, 3], intrin, post_rot, post_tran, torch.zeros(1), cam2lidar,
+               results["calib"]]
+        return [x[None] if torch.is_tensor(x) else torch.as_tensor(x)[None] for x in res]
+
+    def get_inputs(self, results, flip=None, scale=None):
+        assert len(results["img_filename"]) == 2
+        from PIL import Image
+        with Image.open(results["img_filename"][1]) as im:          # the draw uses the right image's size (:189-190)
+            W, H = im.size
+        augs = self.sample_augmentation(H=H, W=W, flip=flip, scale=scale)
+        right = self._view(results, 1, augs)
+        left = self._view(results, 0, augs)
+        return [left, right]
+
+    def __call__(self, results):
+        results["img_inputs"] = self.get_inputs(results)
+        return results
+
+
+def bev_transform(voxel_labels, rotate_angle, scale_ratio, flip_dx, flip_dy, transform_center):
+    """BEV augmentation of the voxel labels and its 4x4 matrix about the centre of the point-cloud range
+    (loading_semkitti.py:304-356): ``denorm @ flip_x @ flip_y @ rot @ norm``; labels rotated with nearest-neighbour
+    resampling (fill 255) and flipped.  ``scale_ratio`` is drawn but unused upstream."""
+    trans_norm, trans_denorm = torch.eye(4), torch.eye(4)
+    trans_norm[:3, -1] = -transform_center
+    trans_denorm[:3, -1] = transform_center
+    ang = torch.tensor(rotate_angle / 180 * np.pi)
+    s, c = torch.sin(ang), torch.cos(ang)
+    rot_mat = torch.Tensor([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    flip_mat = torch.eye(4)
+    if flip_dx:
+        flip_mat = flip_mat @ torch.diag(torch.Tensor([-1, 1, 1, 1]))
+    if flip_dy:
+        flip_mat = flip_mat @ torch.diag(torch.Tensor([1, -1, 1, 1]))
+    bda_mat = trans_denorm @ flip_mat @ rot_mat @ trans_norm
+    lab = voxel_labels.numpy().astype(np.uint8)
+    if not np.isclose(rotate_angle, 0):
+        import scipy.ndimage
+        scipy.ndimage.rotate(lab, rotate_angle, output=lab, mode="constant", order=0, cval=255, axes=(0, 1), reshape=False)
+    if flip_dy:
+        lab = lab[:, ::-1]
+    if flip_dx:
+        lab = lab[::-1]
+    return torch.from_numpy(lab.copy()).long(), bda_mat
+
+
+@PIPELINES.register_module()
+class LoadSemKittiAnnotation:
+    """Pipeline step of stereoscene.py:142 (loading_semkitti.py:358-402): turns ``results['gt_occ']`` into a tensor,
+    optionally applies the BEV augmentation, and inserts the BEV matrix as slot 6 of both views' ``img_inputs``."""
+
+    def __init__(self, bda_aug_conf, is_train=True, apply_bda=False, point_cloud_range=(0, -25.6, -2, 51.2, 25.6, 4.4)):
+        self.bda_aug_conf, self.is_train, self.apply_bda = bda_aug_conf, is_train, apply_bda
+        self.point_cloud_range = torch.tensor(point_cloud_range)
+        self.transform_center = (self.point_cloud_range[:3] + self.point_cloud_range[3:]) / 2
+
+    def sample_bda_augmentation(self):
+        rotate_bda = np.random.uniform(*self.bda_aug_conf["rot_lim"])
+        scale_bda = np.random.uniform(*self.bda_aug_conf["scale_lim"])
+        flip_dx = np.random.uniform() < self.bda_aug_conf["flip_dx_ratio"]
+        flip_dy = np.random.uniform() < self.bda_aug_conf["flip_dy_ratio"]
+        return rotate_bda, scale_bda, flip_dx, flip_dy
+
+    def __call__(self, results):
+        g = results["gt_occ"]
+        gt_occ = [torch.tensor(x) for x in g] if type(g) is list else torch.tensor(g)
+        if self.apply_bda:
+            if self.is_train:
+                gt_occ, bda_rot = bev_transform(gt_occ, *self.sample_bda_augmentation(), self.transform_center)
+            else:
+                bda_rot = torch.eye(4)
+        else:
+            bda_rot = torch.eye(3)
+        views = []
+        for v in results["img_inputs"]:
+            imgs, rots, trans, intrins, post_rots, post_trans, gt_depths, sensor2sensors, calib = v
+            views.append([imgs, rots, trans, intrins, post_rots, post_trans, bda_rot, gt_depths, sensor2sensors, calib])
+        results["img_inputs"] = tuple(views)
+        results["gt_occ"] = gt_occ
+        return results
+
+
+# -------------------------------------------------------------------------------------------------
+# dataset: SemanticKITTI stereo + voxel labels (semantic_kitti_dataset.py:85-160, semantic_kitti_lss_dataset.py:153-229)
+# -------------------------------------------------------------------------------------------------
+DATASETS = Registry("dataset")
+
+SPLITS = {"train": ["00", "01", "02", "03", "04", "05", "06", "07", "09", "10"], "val": ["08"],
+          "test": ["11", "12", "13", "14", "15", "16", "17", "18", "19", "20", "21"]}
+
+
+def read_calib_file(filepath):
+    """Raw ``key: numbers`` table of a calib.txt (semantic_kitti_lss_dataset.py:212-222)."""
+    data = {}
+    with open(filepath, "r") as f:
+        for line in f:
+            line = line.rstrip()
+            if not line:
+                continue
+            key, value = line.split(":", 1)
+            try:
+                data[key] = np.array([float(x) for x in value.split()])
+            except ValueError:
+                pass
+    return data
+
+
+def dynamic_baseline(calib_info):
+    """Stereo baseline from the rectified projection matrices (semantic_kitti_lss_dataset.py:223-227)."""
+    P3 = np.reshape(calib_info["P3"], [3, 4])
+    P2 = np.reshape(calib_info["P2"], [3, 4])
+    return P3[0, 3] / (-P3[0, 0]) - P2[0, 3] / (-P2[0, 0])
+
+
+class Compose:
+    def __init__(self, steps):
+        self.steps = [PIPELINES.build(s) if isinstance(s, dict) else s for s in steps]
+
+    def __call__(self, results):
+        for s in self.steps:
+            results = s(results)
+            if results is None:
+                return None
+        return results
+
+
+@DATASETS.register_module()
+class CustomSemanticKITTILssDataset:
+    """Index of <data_root>/dataset/sequences/<seq>/{image_2,image_3,voxels,calib.txt} + <ann_file>/<seq>/<id>_1_1.npy and
+    the per-sample dict the pipeline starts from (``get_data_info``); ``__getitem__`` runs the pipeline."""
+
+    def __init__(self, data_root, ann_file, pipeline, split="train", camera_used=("left", "right"), occ_size=(256, 256, 32),
+                 pc_range=(0, -25.6, -2, 51.2, 25.6, 4.4), test_mode=False, sequences=None, **kwargs):
+        self.data_root, self.ann_file, self.split, self.test_mode = data_root, ann_file, split, test_mode
+        self.sequences = list(sequences) if sequences is not None else SPLITS[split]
+        self.camera_map = {"left": "2", "right": "3"}
+        self.camera_used = [self.camera_map[c] for c in camera_used]
+        self.occ_size, self.pc_range = list(occ_size), list(pc_range)
+        self.pipeline = Compose(pipeline) if pipeline is not None else None
+        self.data_infos = self.load_annotations(ann_file)
+
+    def load_annotations(self, ann_file):
+        import glob
+        scans = []
+        for sequence in self.sequences:
+            base = os.path.join(self.data_root, "dataset", "sequences", sequence)
+            if not os.path.exists(os.path.join(base, "calib.txt")):
+                continue
+            calib = read_calib(os.path.join(base, "calib.txt"))
+            P2, P3, Tr = calib["P2"], calib["P3"], calib["Tr"]
+            for id_path in sorted(glob.glob(os.path.join(base, "voxels", "*.bin"))):
+                img_id = os.path.basename(id_path).split(".")[0]
+                voxel_path = os.path.join(ann_file, sequence, img_id + "_1_1.npy")
+                scans.append(dict(img_2_path=os.path.join(base, "image_2", img_id + ".png"),
+                                  img_3_path=os.path.join(base, "image_3", img_id + ".png"), sequence=sequence, frame_id=img_id,
+                                  P2=P2, P3=P3, T_velo_2_cam=Tr, proj_matrix_2=P2 @ Tr, proj_matrix_3=P3 @ Tr,
+                                  voxel_path=voxel_path if os.path.exists(voxel_path) else None,
+                                  calib_path=os.path.join(base, "calib.txt")))
+        return scans
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def get_ann_info(self, index):
+        p = self.data_infos[index]["voxel_path"]
+        return None if p is None else np.load(p)
+
+    def get_data_info(self, index):
+        info = self.data_infos[index]
+        calib_info = read_calib_file(info["calib_path"])
+        calib = np.reshape(calib_info["P2"], [3, 4])[0, 0] * dynamic_baseline(calib_info)
+        return dict(occ_size=np.array(self.occ_size), pc_range=np.array(self.pc_range),
+                    img_filename=[info[f"img_{c}_path"] for c in self.camera_used],
+                    lidar2img=[info[f"proj_matrix_{c}"] for c in self.camera_used],
+                    cam_intrinsic=[info[f"P{c}"] for c in self.camera_used],
+                    lidar2cam=[info["T_velo_2_cam"] for _ in self.camera_used], calib=calib,
+                    sequence=info["sequence"], frame_id=info["frame_id"], gt_occ=self.get_ann_info(index))
+
+    def __getitem__(self, index):
+        d = self.get_data_info(index)
+        return d if self.pipeline is None else self.pipeline(d)
+
+
+def collate(samples, device="cuda"):
+    """Batch of pipeline outputs -> the detector's call signature: ``img_inputs = (left10, right10)`` with a leading
+    batch axis on every entry (what mmcv's collate + scatter produce upstream), ``gt_occ`` [B, X, Y, Z] int64."""
+    views = []
+    for k in range(2):
+        cols = []
+        for j in range(10):
+            items = [torch.as_tensor(s["img_inputs"][k][j]) for s in samples]
+            if j == 9:                                              # calib: one scalar per sample
+                cols.append(torch.stack([t.reshape(()).float() for t in items]).to(device))
+            else:
+                cols.append(torch.stack([t.float() for t in items]).to(device))
+        views.append(tuple(cols))
+    gt = torch.stack([torch.as_tensor(s["gt_occ"]).long() for s in samples]).to(device)
+    return dict(img_inputs=tuple(views), gt_occ=gt)

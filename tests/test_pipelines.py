@@ -103,3 +103,187 @@ def test_create_depth_from_lidar_on_hip_matches_reference(tmp_path):
     # empty scan: all-zero maps, no launch on zero points
     uvd, valid, depth, s2 = P.lidar_depth_map(torch.zeros(0, 3, device="cuda"), None, *cameras()[0][1:6], H, W)
     assert uvd.shape == (0, 3) and depth.abs().sum().item() == 0 and s2 is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# image loading / annotation loading
+# ---------------------------------------------------------------------------------------------------------------------
+from oracle.make_golden_data import DATA_CONFIG, stereo_images, stereo_meta  # noqa: E402
+
+
+def test_pillow_resize_restatements_are_byte_exact():
+    """Both restatements of libImaging's fixed-point bicubic resize (the oracle's scalar one and the product's table
+    builder, emulated here with integer numpy) against Pillow itself, up- and down-scaling."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for (Hs, Ws, Hd, Wd) in [(37, 124, 39, 128), (60, 200, 30, 77), (50, 80, 50, 96), (64, 64, 100, 64), (47, 155, 48, 160)]:
+        img = rng.integers(0, 256, (Hs, Ws, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((Wd, Hd)))
+        assert np.array_equal(DR.pil_resize_u8(img, (Wd, Hd)), ref)
+        cur = img.astype(np.int64)
+        for axis, (n_in, n_out) in ((1, (Ws, Wd)), (0, (Hs, Hd))):
+            if n_in == n_out:
+                continue
+            kk, bounds, ksize = P.pil_resample_tables(n_in, n_out)
+            src = np.moveaxis(cur, axis, 0)
+            out = np.stack([np.clip(((1 << 21) + np.tensordot(kk[o, :bounds[o, 1]].astype(np.int64),
+                                                               src[bounds[o, 0]:bounds[o, 0] + bounds[o, 1]], axes=(0, 0))) >> 22,
+                                    0, 255) for o in range(n_out)])
+            cur = np.moveaxis(out, 0, axis)
+        assert np.array_equal(cur.astype(np.uint8), ref)
+
+
+def test_oracle_image_loading_matches_reference_loader():
+    g = load_golden("image_loading")
+    imgs, meta = stereo_images(), stereo_meta()
+    for mode, is_train in (("test", False), ("train", True)):
+        for k, name in enumerate(("left", "right")):
+            img, rot, tran, post_rot, post_tran = DR.load_view(imgs[k], meta["lidar2cam"][k], meta["cam_intrinsic"][k], DATA_CONFIG,
+                                                               is_train)
+            pre = f"load_{mode}_{name}_"
+            assert np.abs(img.numpy() - g[pre + "img"][0]).max() < 1e-5
+            assert np.abs(rot.numpy() - g[pre + "rot"][0]).max() < 1e-6 and np.abs(tran.numpy() - g[pre + "tran"][0]).max() < 1e-6
+            assert np.abs(post_rot.numpy() - g[pre + "post_rot"][0]).max() < 1e-6
+            assert np.abs(post_tran.numpy() - g[pre + "post_tran"][0]).max() < 1e-5
+            assert np.array_equal(g[pre + "bda"], np.eye(3, dtype=np.float32))          # apply_bda=False: identity in slot 6
+
+
+def test_bev_transform_and_annotation_loader_host_logic():
+    from stereoscene_amd import synthetic as S
+    g = load_golden("image_loading")
+    lab = (S.hash_uniform("bev/lab", (16, 16, 4), 0.0, 20.0).floor()).to(torch.uint8)
+    center = torch.tensor([25.6, 0.0, 1.2])
+    for tag, (rot, fx, fy) in dict(flipx=(0.0, True, False), flipxy=(0.0, True, True), rot=(30.0, False, True)).items():
+        v, m = P.bev_transform(lab.clone(), rot, 1.0, fx, fy, center)
+        assert np.array_equal(v.numpy().astype(np.uint8), g[f"bev_{tag}_labels"]) and v.dtype == torch.int64
+        assert np.abs(m.numpy() - g[f"bev_{tag}_mat"]).max() < 1e-5
+    step = P.PIPELINES.build(dict(type="LoadSemKittiAnnotation", bda_aug_conf=dict(rot_lim=(0, 0), scale_lim=(0.95, 1.05),
+                                                                                  flip_dx_ratio=0.5, flip_dy_ratio=0.5)))
+    views = [[torch.zeros(1)] * 9, [torch.ones(1)] * 9]
+    res = step(dict(gt_occ=np.zeros((4, 4, 2), dtype=np.uint8), img_inputs=views))
+    assert len(res["img_inputs"]) == 2 and all(len(v) == 10 for v in res["img_inputs"])
+    assert torch.equal(res["img_inputs"][0][6], torch.eye(3)) and res["gt_occ"].shape == (4, 4, 2)
+    with pytest.raises(NotImplementedError):
+        P.PIPELINES.build(dict(type="LoadMultiViewImageFromFiles_SemanticKitti", data_config=DATA_CONFIG, colorjitter=True))
+
+
+@pytest.mark.gpu
+def test_image_loader_on_hip_matches_reference(tmp_path):
+    from PIL import Image
+    g = load_golden("image_loading")
+    imgs, meta = stereo_images(), stereo_meta()
+    names = []
+    for im, cam in zip(imgs, ("image_2", "image_3")):
+        d = tmp_path / "sequences" / "00" / cam
+        os.makedirs(d)
+        Image.fromarray(im).save(str(d / "000123.png"))
+        names.append(str(d / "000123.png"))
+    # the resize kernels alone: byte-exact with Pillow
+    for (Wd, Hd) in [(160, 48), (77, 30), (155, 60), (200, 47)]:
+        got = P.resize_u8(torch.from_numpy(imgs[0]).cuda(), (Wd, Hd)).cpu().numpy()
+        assert np.array_equal(got, np.asarray(Image.fromarray(imgs[0]).resize((Wd, Hd)))), (Wd, Hd)
+    for mode, is_train in (("test", False), ("train", True)):
+        step = P.PIPELINES.build(dict(type="LoadMultiViewImageFromFiles_SemanticKitti", data_config=DATA_CONFIG, is_train=is_train,
+                                      img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)))
+        np.random.seed(0)
+        res = step(dict(img_filename=names, **meta))
+        for k, name in enumerate(("left", "right")):
+            v = res["img_inputs"][k]
+            assert len(v) == 9
+            for j, key in enumerate(("img", "rot", "tran", "intrin", "post_rot", "post_tran", "depth", "cam2lidar", "calib")):
+                want = g[f"load_{mode}_{name}_{key}"]
+                got = v[j].detach().cpu().numpy()
+                assert got.shape == want.shape, (key, got.shape, want.shape)
+                assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() < 1e-5, (mode, name, key)
+    # flip path of crop_normalize against numpy
+    r = P.resize_u8(torch.from_numpy(imgs[1]).cuda(), (160, 48))
+    out = P.crop_normalize(r, (3, -2, 150, 40), True, [1.0, 2.0, 3.0], [2.0, 4.0, 8.0]).cpu().numpy()
+    ref = np.zeros((42, 147, 3), dtype=np.float32)
+    ref[2:] = r.cpu().numpy()[0:40, 3:150].astype(np.float32)
+    ref = ((ref[:, ::-1] - np.array([1.0, 2.0, 3.0], dtype=np.float32)) * np.array([0.5, 0.25, 0.125], dtype=np.float32))
+    assert np.abs(out - ref.transpose(2, 0, 1)).max() < 1e-6
+
+
+def _write_mini_kitti(root, n_frames, img_hw, occ_size):
+    """Synthetic SemanticKITTI-shaped tree: images, calib.txt, voxel ids, preprocessed labels, velodyne scans + labels."""
+    from PIL import Image
+    from stereoscene_amd import synthetic as S
+    seq = os.path.join(root, "kitti", "dataset", "sequences", "00")
+    for d in ("image_2", "image_3", "voxels"):
+        os.makedirs(os.path.join(seq, d))
+    os.makedirs(os.path.join(root, "labels", "00"))
+    os.makedirs(os.path.join(root, "velodyne", "00", "velodyne"))
+    os.makedirs(os.path.join(root, "lidarseg", "00", "labels"))
+    Hh, Ww = img_hw
+    fx = 707.0912 * Ww / 1241.0
+    P2 = [fx, 0, 601.8873 * Ww / 1241.0, 4.5, 0, fx, 183.1104 * Ww / 1241.0, 0.2, 0, 0, 1, 0.003]
+    P3 = list(P2)
+    P3[3] = P2[3] - 0.54 * fx
+    Tr = [0, -1, 0, 0.0, 0, 0, -1, -0.08, 1, 0, 0, -0.27]
+    with open(os.path.join(seq, "calib.txt"), "w") as f:
+        for k, v in (("P0", P2), ("P1", P2), ("P2", P2), ("P3", P3), ("Tr", Tr)):
+            f.write(f"{k}: " + " ".join(repr(float(x)) for x in v) + "\n")
+    pts, raw = scene()
+    for i in range(n_frames):
+        fid = f"{i:06d}"
+        for cam in ("image_2", "image_3"):
+            im = S.hash_uniform(f"mini/{cam}/{fid}", (Hh, Ww, 3), 0.0, 256.0).floor().clamp(0, 255).to(torch.uint8).numpy()
+            Image.fromarray(im).save(os.path.join(seq, cam, fid + ".png"))
+        open(os.path.join(seq, "voxels", fid + ".bin"), "wb").close()
+        lab = (S.hash_uniform(f"mini/lab/{fid}", tuple(occ_size), 0.0, 20.0).floor()).to(torch.uint8).numpy()
+        lab[::7, ::5] = 255
+        np.save(os.path.join(root, "labels", "00", fid + "_1_1.npy"), lab)
+        pts.tofile(os.path.join(root, "velodyne", "00", "velodyne", fid + ".bin"))
+        raw.tofile(os.path.join(root, "lidarseg", "00", "labels", fid + ".label"))
+    return fx, P2, P3
+
+
+def test_dataset_index_and_sample_dict(tmp_path):
+    fx, P2, P3 = _write_mini_kitti(str(tmp_path), 2, (62, 155), (32, 32, 8))
+    ds = P.DATASETS.build(dict(type="CustomSemanticKITTILssDataset", data_root=str(tmp_path / "kitti"),
+                               ann_file=str(tmp_path / "labels"), pipeline=None, split="train", occ_size=(32, 32, 8)))
+    assert len(ds) == 2 and ds.data_infos[1]["frame_id"] == "000001"
+    d = ds.get_data_info(0)
+    assert [os.path.basename(os.path.dirname(p)) for p in d["img_filename"]] == ["image_2", "image_3"]
+    assert d["cam_intrinsic"][1][0, 3] == P3[3] and d["lidar2cam"][0].shape == (4, 4) and d["gt_occ"].shape == (32, 32, 8)
+    assert np.allclose(d["lidar2img"][0], d["cam_intrinsic"][0] @ d["lidar2cam"][0])
+    base = P.dynamic_baseline(P.read_calib_file(ds.data_infos[0]["calib_path"]))
+    assert abs(base - 0.54) < 1e-12 and abs(d["calib"] - fx * 0.54) < 1e-9           # P3[0,3]/(-fx) - P2[0,3]/(-fx)
+    assert P.DATASETS.build(dict(type="CustomSemanticKITTILssDataset", data_root=str(tmp_path / "kitti"),
+                                 ann_file=str(tmp_path / "labels"), pipeline=None, split="val")).__len__() == 0
+
+
+@pytest.mark.gpu
+def test_files_to_losses_end_to_end(tmp_path):
+    """Disk -> dataset -> LoadMultiViewImage -> LoadSemKittiAnnotation -> CreateDepthFromLiDAR -> collate -> detector with
+    the image branch -> losses -> backward: every data-side and model-side piece of the build in one pass."""
+    from stereoscene_amd import model_zoo, plugin, synthetic as S  # noqa: F401  (plugin fills the registries)
+    from stereoscene_amd.registry import DETECTORS
+    cfg = S.CFG_T
+    _write_mini_kitti(str(tmp_path), 2, (62, 155), cfg["occ_size"])
+    data_config = {"input_size": cfg["input_size"], "resize": (0.0, 0.0), "rot": (0.0, 0.0), "flip": False, "crop_h": (0.0, 0.0),
+                   "resize_test": 0.0}
+    pipeline = [
+        dict(type="LoadMultiViewImageFromFiles_SemanticKitti", is_train=True, colorjitter=False, data_config=data_config,
+             img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)),
+        dict(type="LoadSemKittiAnnotation", bda_aug_conf=dict(rot_lim=(0, 0), scale_lim=(0.95, 1.05), flip_dx_ratio=0.5,
+                                                              flip_dy_ratio=0.5), is_train=True),
+        dict(type="CreateDepthFromLiDAR", point_cloud_range=list(cfg["pc_range"]), grid_size=list(cfg["occ_size"]),
+             lidar_root=str(tmp_path / "velodyne"), lidarseg_root=str(tmp_path / "lidarseg")),
+    ]
+    ds = P.DATASETS.build(dict(type="CustomSemanticKITTILssDataset", data_root=str(tmp_path / "kitti"),
+                               ann_file=str(tmp_path / "labels"), pipeline=pipeline, split="train", occ_size=cfg["occ_size"],
+                               pc_range=cfg["pc_range"]))
+    batch = P.collate([ds[0], ds[1]])
+    left, right = batch["img_inputs"]
+    assert left[0].shape == (2, 1, 3) + tuple(cfg["input_size"]) and left[7].shape == (2, 1) + tuple(cfg["input_size"])
+    assert left[9].shape == (2,) and (left[7] > 0).sum().item() > 100 and batch["gt_occ"].shape == (2,) + tuple(cfg["occ_size"])
+    mc = model_zoo.model_cfg(cfg, image_branch=True)
+    model = DETECTORS.build(mc)
+    S.fill_state_dict_(model)
+    model = model.cuda().train()
+    losses = model.forward_train(img_inputs=batch["img_inputs"], gt_occ=batch["gt_occ"])
+    total = sum(v for k, v in losses.items() if k.startswith("loss"))
+    total.backward()
+    assert torch.isfinite(total) and float(losses["loss_depth"]) > 0
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
