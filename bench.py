@@ -162,7 +162,7 @@ def main():
         zero = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
         g, wino = ks.get("conv_gather", zero), ks.get("conv_winograd", zero)
         fam_flops, fam_ms, fam_n = g["flops"] + wino["flops"], g["ms"] + wino["ms"], g["launches"] + wino["launches"]
-        executed = g["flops"] + wino["bytes"]       # Winograd spans carry their executed GEMM FLOPs (F(2,3)^3: /3.375, F(2,3)^2: /2.25)
+        executed = g["flops"] + wino["bytes"]       # Winograd spans carry their executed GEMM FLOPs (F(2x4x4): /6, F(2,3)^3: /3.375, F(2,3)^2: /2.25)
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_n else 0.0
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "r1p_pmc_traffic.json")
@@ -176,10 +176,11 @@ def main():
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roof = {"bound": "mfma",
                 "kernel": "convolution forward + data gradient, every launch of the step: direct MFMA kernels (conv_gather_kernel"
-                          "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 "
-                          "layers, Winograd F(2,3)^3 / F(2,3)^2 pipelines (wino*_input_kernel -> 64 / 16 batched fp32 GEMMs -> wino*_output_kernel)",
+                          "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 / 3x3 "
+                          "layers, Winograd pipelines (wino43_input_kernel -> 144 batched fp32 GEMMs -> wino43_output_kernel with "
+                          "F(2x4x4,3x3x3) tiles; F(2,3)^2 with 16 GEMMs for the 2-D layers)",
                 "flop_convention": "achieved counts direct-convolution FLOPs (2*voxels*Cin*Cout*taps: what the operator computes, "
-                                   "SURVEY 8(d)); the Winograd launches execute 3.375x (3-D) / 2.25x (2-D) fewer multiply-adds, see frac_executed",
+                                   "SURVEY 8(d)); the Winograd launches execute 6x (3-D, F(2x4x4)) / 2.25x (2-D, F(2x2)) fewer multiply-adds, see frac_executed",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "peak_source": "fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md" if args.precision == "fp32" else
                                "dense bf16 MFMA, MI355X_MICROARCH.md (bf16 mode: operands rounded to bf16, fp32 storage keeps the "

@@ -334,6 +334,25 @@ int ssbev_wino_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_win
 int ssbev_wino2d_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* F(2x4x4, 3x3x3) / F(4x4, 3x3): 4-wide tiles along h and w (Lavin & Gray's F(4,3)), 2-deep along d.  144 (2-D: 36)
+ * frequencies, xi = (a*6 + e)*6 + f; T = B * D/2 * H/4 * W/4 (2-D: B * D * H/4 * W/4); needs H % 4 == W % 4 == 0
+ * (3-D: D % 2 == 0).  Transformed domain 4.5x (2.25x) the activation instead of 8x (4x), GEMM stage 6x (4x) fewer
+ * multiply-adds than the direct convolution.  Same roles as the ssbev_wino_* functions above; `_bf16` = bf16 storage of
+ * the transformed-domain tensor. */
+int ssbev_wino43_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_2d_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino43_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream);
+int ssbev_wino43_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream);
 /* Weight side: U = G w G^T (mode 0: U [NF][Cin][Cout] from torch-layout w [Cout][Cin][taps]; mode 1: the data-gradient
  * operand [NF][Cout][Cin] from the mirrored taps), and gw = G^T gU G for the weight gradient.  ndim = 3 (27 taps, NF = 64)
  * or 2 (9 taps, NF = 16). */

@@ -125,6 +125,20 @@ SIGNATURES = {
     "ssbev_wino2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_weight_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ssbev_wino43_weight_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

@@ -330,6 +330,249 @@ wino_weight_grad_kernel(const float* __restrict__ gU, float* __restrict__ gw, in
   for (int t = 0; t < TAPS; ++t) gw[((size_t)co * Cin + ci) * TAPS + t] = g[t];
 }
 
+// ---- F(4,3) along h and w, F(2,3) along d: "F(2x4x4, 3x3x3)" and its 2-D sibling F(4x4, 3x3) -------------------------
+// The F(2,3)^3 pipeline above is bound by the 8x larger transformed tensors.  With 4-wide tiles along h and w the
+// transformed domain is only 4.5x (2-D: 2.25x) the activation and the GEMM stage does 6x (2-D: 4x) fewer multiply-adds
+// than the direct convolution: per 2x4x4 = 32 outputs, 4*6*6 = 144 frequencies.  Lavin & Gray's F(4,3) matrices; the
+// transforms involve the constants 2, 4, 5, 8 and 1/4 .. 1/24, so fp32 results carry ~1e-6 .. 1e-5 relative error against
+// the direct kernel (tests: 2e-4 gate; the 1e-3 logits contract holds with margin).
+//   V / M / Z: [NF][T][C], frequency index xi = (a * 6 + e) * 6 + f  (a: d-axis F(2,3), e: h, f: w);
+//   T = B * D/2 * H/4 * W/4 (3-D) or B * D * H/4 * W/4 (2-D, NF = 36, D a batch axis).
+__device__ __forceinline__ void bt6(float* v, int s) {        // B^T d, 6 -> 6
+  const float d0 = v[0], d1 = v[s], d2 = v[2 * s], d3 = v[3 * s], d4 = v[4 * s], d5 = v[5 * s];
+  v[0] = 4.0f * d0 - 5.0f * d2 + d4;
+  v[s] = -4.0f * d1 - 4.0f * d2 + d3 + d4;
+  v[2 * s] = 4.0f * d1 - 4.0f * d2 - d3 + d4;
+  v[3 * s] = -2.0f * d1 - d2 + 2.0f * d3 + d4;
+  v[4 * s] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
+  v[5 * s] = 4.0f * d1 - 5.0f * d3 + d5;
+}
+__device__ __forceinline__ void at6(const float* m, int s, float* o, int so) {     // A^T m, 6 -> 4
+  const float m0 = m[0], m1 = m[s], m2 = m[2 * s], m3 = m[3 * s], m4 = m[4 * s], m5 = m[5 * s];
+  const float p = m1 + m2, q = m1 - m2, r = m3 + m4, t = m3 - m4;
+  o[0] = m0 + p + r;
+  o[so] = q + 2.0f * t;
+  o[2 * so] = p + 4.0f * r;
+  o[3 * so] = q + 8.0f * t + m5;
+}
+__device__ __forceinline__ void a6(const float* g, int s, float* o, int so) {      // A g, 4 -> 6 (adjoint of at6)
+  const float g0 = g[0], g1 = g[s], g2 = g[2 * s], g3 = g[3 * s];
+  o[0] = g0;
+  o[so] = g0 + g1 + g2 + g3;
+  o[2 * so] = g0 - g1 + g2 - g3;
+  o[3 * so] = g0 + 2.0f * g1 + 4.0f * g2 + 8.0f * g3;
+  o[4 * so] = g0 - 2.0f * g1 + 4.0f * g2 - 8.0f * g3;
+  o[5 * so] = g3;
+}
+__device__ __forceinline__ void g6(const float* g, int s, float* o, int so) {      // G g, 3 -> 6
+  const float g0 = g[0], g1 = g[s], g2 = g[2 * s];
+  o[0] = 0.25f * g0;
+  o[so] = -(g0 + g1 + g2) * (1.0f / 6.0f);
+  o[2 * so] = -(g0 - g1 + g2) * (1.0f / 6.0f);
+  o[3 * so] = g0 * (1.0f / 24.0f) + g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+  o[4 * so] = g0 * (1.0f / 24.0f) - g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+  o[5 * so] = g2;
+}
+__device__ __forceinline__ void gt6(const float* u, int s, float* o, int so) {     // G^T u, 6 -> 3
+  const float u0 = u[0], u1 = u[s], u2 = u[2 * s], u3 = u[3 * s], u4 = u[4 * s], u5 = u[5 * s];
+  o[0] = 0.25f * u0 - (u1 + u2) * (1.0f / 6.0f) + (u3 + u4) * (1.0f / 24.0f);
+  o[so] = (u2 - u1) * (1.0f / 6.0f) + (u3 - u4) * (1.0f / 12.0f);
+  o[2 * so] = -(u1 + u2) * (1.0f / 6.0f) + (u3 + u4) * (1.0f / 6.0f) + u5;
+}
+
+// decode (tile, channel); TD = tiles along d are 2 deep (3-D) or every plane is its own "tile" (2-D)
+template <bool THREE_D>
+__device__ __forceinline__ void tile43(long t, const WinoGeom& g, int& b_or_bd, int& td, int& th, int& tw) {
+  tw = (int)(t % (g.W / 4)); t /= g.W / 4;
+  th = (int)(t % (g.H / 4)); t /= g.H / 4;
+  if (THREE_D) { td = (int)(t % (g.D / 2)); b_or_bd = (int)(t / (g.D / 2)); }
+  else { td = 0; b_or_bd = (int)t; }
+}
+
+template <bool THREE_D, typename TF>
+__global__ void __launch_bounds__(256)
+wino43_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
+  constexpr int NA = THREE_D ? 4 : 1, NF = NA * 36;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  const long tile = i / g.C;
+  int b, td, th, tw;
+  tile43<THREE_D>(tile, g, b, td, th, tw);
+  float v[NF];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const int d = THREE_D ? 2 * td - 1 + a : 0;
+    const long plane = THREE_D ? (long)b * g.D + d : (long)b;
+    const bool dok = !THREE_D || (d >= 0 && d < g.D);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int h = 4 * th - 1 + e;
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        const int w = 4 * tw - 1 + f;
+        const bool ok = dok && h >= 0 && h < g.H && w >= 0 && w < g.W;
+        v[(a * 6 + e) * 6 + f] = ok ? x[((plane * g.H + h) * g.W + w) * g.C + c] : 0.0f;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NA * 6; ++p) bt6(v + p * 6, 1);                            // along w
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) bt6(v + a * 36 + f, 6);                          // along h
+  if (THREE_D) {
+#pragma unroll
+    for (int p = 0; p < 36; ++p) bt4(v + p, 36);                                 // along d (F(2,3))
+  }
+  const long T = total / g.C;
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
+}
+
+template <bool THREE_D, typename TF>
+__global__ void __launch_bounds__(256)
+wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+  constexpr int NA = THREE_D ? 4 : 1, NF = NA * 36;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  const long tile = i / g.C;
+  int b, td, th, tw;
+  tile43<THREE_D>(tile, g, b, td, th, tw);
+  const long T = total / g.C;
+  float m[NF];
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) m[xi] = fload(M + ((long)xi * T + tile) * g.C + c);
+  float r1[NA * 6 * 4];                              // [a][e][4] after w
+#pragma unroll
+  for (int p = 0; p < NA * 6; ++p) at6(m + p * 6, 1, r1 + p * 4, 1);
+  float r2[NA * 4 * 4];                              // [a][4][4] after h
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) at6(r1 + a * 24 + f, 4, r2 + a * 16 + f, 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (THREE_D) {
+        const float m0 = r2[0 * 16 + e * 4 + f], m1 = r2[1 * 16 + e * 4 + f], m2 = r2[2 * 16 + e * 4 + f], m3 = r2[3 * 16 + e * 4 + f];
+        const long base = ((((long)b * g.D + 2 * td) * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c;
+        y[base] = m0 + m1 + m2;
+        y[base + (long)g.H * g.W * g.C] = m1 - m2 - m3;
+      } else {
+        y[(((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c] = r2[e * 4 + f];
+      }
+    }
+}
+
+template <bool THREE_D, typename TF>
+__global__ void __launch_bounds__(256)
+wino43_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
+  constexpr int NA = THREE_D ? 4 : 1, NG = THREE_D ? 2 : 1, NF = NA * 36;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % g.C);
+  const long tile = i / g.C;
+  int b, td, th, tw;
+  tile43<THREE_D>(tile, g, b, td, th, tw);
+  float gin[NG * 16];
+#pragma unroll
+  for (int a = 0; a < NG; ++a) {
+    const long plane = THREE_D ? (long)b * g.D + 2 * td + a : (long)b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) gin[(a * 4 + e) * 4 + f] = gy[((plane * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c];
+  }
+  float r1[NG * 4 * 6];                              // [a][4][6] after w
+#pragma unroll
+  for (int p = 0; p < NG * 4; ++p) a6(gin + p * 4, 1, r1 + p * 6, 1);
+  float v[NF];                                       // [a'][6][6]; 3-D: filled at a' = 0, 1 then expanded along d
+#pragma unroll
+  for (int a = 0; a < NG; ++a)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) a6(r1 + a * 24 + f, 6, v + a * 36 + f, 6);
+  if (THREE_D) {
+#pragma unroll
+    for (int p = 0; p < 36; ++p) a4(v + p, 36);                                  // along d: 2 -> 4
+  }
+  const long T = total / g.C;
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) fstore(Z + ((long)xi * T + tile) * g.C + c, v[xi]);
+}
+
+// weights: w [Cout][Cin][taps] -> U [NF][Cin][Cout] (mode 0) or [NF][Cout][Cin] with mirrored taps (mode 1)
+template <bool THREE_D>
+__global__ void __launch_bounds__(256)
+wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int mode) {
+  constexpr int ND_ = THREE_D ? 3 : 1, TAPS = ND_ * 9, NA = THREE_D ? 4 : 1, NF = NA * 36;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * Cin) return;
+  const int co = mode == 0 ? i % Cout : i / Cin, ci = mode == 0 ? i / Cout : i % Cin;
+  float g[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) g[t] = w[((size_t)co * Cin + ci) * TAPS + (mode == 0 ? t : TAPS - 1 - t)];
+  float a1[ND_ * 3 * 6];                             // [kd][kh][6] after w
+#pragma unroll
+  for (int p = 0; p < ND_ * 3; ++p) g6(g + p * 3, 1, a1 + p * 6, 1);
+  float a2[ND_ * 36];                                // [kd][6][6] after h
+#pragma unroll
+  for (int d = 0; d < ND_; ++d)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) g6(a1 + d * 18 + f, 6, a2 + d * 36 + f, 6);
+  float u[NF];
+  if (THREE_D) {
+#pragma unroll
+    for (int p = 0; p < 36; ++p) g4(a2 + p, 36, u + p, 36);                      // along d: 3 -> 4
+  } else {
+#pragma unroll
+    for (int p = 0; p < 36; ++p) u[p] = a2[p];
+  }
+  const size_t plane = (size_t)Cout * Cin;
+  const size_t pos = mode == 0 ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) U[xi * plane + pos] = u[xi];
+}
+
+template <bool THREE_D>
+__global__ void __launch_bounds__(256)
+wino43_weight_grad_kernel(const float* __restrict__ gU, float* __restrict__ gw, int Cout, int Cin) {
+  constexpr int ND_ = THREE_D ? 3 : 1, TAPS = ND_ * 9, NA = THREE_D ? 4 : 1, NF = NA * 36;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * Cin) return;
+  const int co = i % Cout, ci = i / Cout;
+  const size_t plane = (size_t)Cout * Cin;
+  float u[NF];
+#pragma unroll
+  for (int xi = 0; xi < NF; ++xi) u[xi] = gU[xi * plane + (size_t)ci * Cout + co];
+  float a1[NA * 6 * 3];                              // [a][6][3] after w
+#pragma unroll
+  for (int p = 0; p < NA * 6; ++p) gt6(u + p * 6, 1, a1 + p * 3, 1);
+  float a2[NA * 9];                                  // [a][3][3] after h
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) gt6(a1 + a * 18 + f, 3, a2 + a * 9 + f, 3);
+  float g[TAPS];
+  if (THREE_D) {
+#pragma unroll
+    for (int p = 0; p < 9; ++p) gt3(a2 + p, 9, g + p, 9);                        // along d: 4 -> 3
+  } else {
+#pragma unroll
+    for (int p = 0; p < 9; ++p) g[p] = a2[p];
+  }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) gw[((size_t)co * Cin + ci) * TAPS + t] = g[t];
+}
+
+bool wino43_ok(const ssbev_wino_dims* d, bool three_d) {
+  return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->H % 4 == 0 && d->W % 4 == 0 &&
+         (!three_d || d->D % 2 == 0);
+}
+
 // ---- depth-fused frequency GEMM -------------------------------------------------------------------------------------
 // The plain pipeline materialises the 3-D transformed input V (8x the activation) and the 3-D transformed output M (8x)
 // in HBM and is bound by exactly that traffic.  This kernel works on tensors transformed over (h, w) only (4x):
@@ -696,6 +939,45 @@ SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint, wino2d_output_adjoint_kernel<flo
 SSBEV_WINO_ENTRY(ssbev_wino_input_transform, wino_input_kernel<float>, float, float)
 SSBEV_WINO_ENTRY(ssbev_wino_output_transform, wino_output_kernel<float>, float, float)
 SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint, wino_output_adjoint_kernel<float>, float, float)
+
+#define SSBEV_WINO43_ENTRY(NAME, KERNEL, THREE_D, TF, TSRC, TDST)                                                   \
+  int NAME(const TSRC* src, TDST* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                         \
+    if (!wino43_ok(d, THREE_D) || !src || !dst) return SSBEV_EINVAL;                                                \
+    const long total = (long)d->B * (THREE_D ? d->D / 2 : d->D) * (d->H / 4) * (d->W / 4) * d->C;                  \
+    const WinoGeom g{d->B, d->D, d->H, d->W, d->C};                                                                \
+    hipLaunchKernelGGL((KERNEL<THREE_D, TF>), dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, \
+                       total);                                                                                     \
+    return ssbev_launch_status();                                                                                  \
+  }
+
+SSBEV_WINO43_ENTRY(ssbev_wino43_input_transform, wino43_input_kernel, true, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_output_transform, wino43_output_kernel, true, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_output_adjoint, wino43_output_adjoint_kernel, true, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_input_transform, wino43_input_kernel, false, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_output_transform, wino43_output_kernel, false, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_output_adjoint, wino43_output_adjoint_kernel, false, float, float, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_input_transform_bf16, wino43_input_kernel, true, bf16_bits, float, uint16_t)
+SSBEV_WINO43_ENTRY(ssbev_wino43_output_transform_bf16, wino43_output_kernel, true, bf16_bits, uint16_t, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_output_adjoint_bf16, wino43_output_adjoint_kernel, true, bf16_bits, float, uint16_t)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_input_transform_bf16, wino43_input_kernel, false, bf16_bits, float, uint16_t)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_output_transform_bf16, wino43_output_kernel, false, bf16_bits, uint16_t, float)
+SSBEV_WINO43_ENTRY(ssbev_wino43_2d_output_adjoint_bf16, wino43_output_adjoint_kernel, false, bf16_bits, float, uint16_t)
+
+int ssbev_wino43_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream) {
+  if (!w || !U || Cout <= 0 || Cin <= 0 || (ndim != 2 && ndim != 3) || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  const dim3 grid(cdiv((size_t)Cout * Cin, 256)), block(256);
+  if (ndim == 3) hipLaunchKernelGGL(wino43_weight_kernel<true>, grid, block, 0, as_stream(stream), w, U, Cout, Cin, mode);
+  else hipLaunchKernelGGL(wino43_weight_kernel<false>, grid, block, 0, as_stream(stream), w, U, Cout, Cin, mode);
+  return ssbev_launch_status();
+}
+
+int ssbev_wino43_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream) {
+  if (!gU || !gw || Cout <= 0 || Cin <= 0 || (ndim != 2 && ndim != 3)) return SSBEV_EINVAL;
+  const dim3 grid(cdiv((size_t)Cout * Cin, 256)), block(256);
+  if (ndim == 3) hipLaunchKernelGGL(wino43_weight_grad_kernel<true>, grid, block, 0, as_stream(stream), gU, gw, Cout, Cin);
+  else hipLaunchKernelGGL(wino43_weight_grad_kernel<false>, grid, block, 0, as_stream(stream), gU, gw, Cout, Cin);
+  return ssbev_launch_status();
+}
 
 // bf16 storage of the transformed-domain tensor (uint16_t = bf16 bit pattern); activations / gradients stay fp32
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16, wino2d_input_kernel<bf16_bits>, float, uint16_t)

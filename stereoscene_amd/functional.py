@@ -524,29 +524,52 @@ def _wino_depth_fused(xcl, w, B, D, H, W, K, N, mode):
     return _wino_call("ssbev_wino2d_output_transform", Mo, capi.WinoDims(B, D, H, W, N), (B, D, H, W, N))
 
 
+# F(4,3) tiles along h and w (F(2,3) along d): 4.5x / 2.25x transformed domain instead of 8x / 4x and 6x / 4x fewer
+# multiply-adds instead of 3.375x / 2.25x; used whenever H and W are multiples of 4 (SSBEV_WINO_F43=0: F(2,3) everywhere)
+WINO_F43 = os.environ.get("SSBEV_WINO_F43", "1") != "0"
+# ... and for the 2-D layers (DepthNet, 640 channels on the 48x160 map) only on request: there F(4,3)^2 saves ~1 ms per step
+# but its rounding error (reduction over 640 channels of values scaled by the 4 / 5 / 8 entries) more than doubles the
+# gradient noise of the DepthNet parameters in the full-step parity test (L2 1.1 % vs 0.45 %), for no accuracy budget left
+WINO_F43_2D = os.environ.get("SSBEV_WINO_F43_2D", "0") != "0"
+
+
 class _WinoConv(torch.autograd.Function):
-    """3x3(x3) / stride 1 / pad 1 convolution as Winograd F(2,3)^n: HIP transforms + 4^n plain GEMMs (2.25x / 3.375x fewer
-    MACs).  x logical [B,Cin,D,H,W] channels-last, weight [Cout,Cin,kd,3,3] with kd = 3 (3-D, even D,H,W) or kd = 1
-    (2-D over (H,W), even H,W; D is a batch axis)."""
+    """3x3(x3) / stride 1 / pad 1 convolution in the Winograd domain: HIP transforms + NF plain GEMMs.  x logical
+    [B,Cin,D,H,W] channels-last, weight [Cout,Cin,kd,3,3] with kd = 3 (3-D, even D) or kd = 1 (2-D over (H,W); D is a
+    batch axis).  Tiles: F(4,3) along h and w when both are multiples of 4 (NF = 144 / 36), else F(2,3) (NF = 64 / 16)."""
+
+    @staticmethod
+    def _plan(three_d, D, H, W, bf):
+        # bf16 mode stays on F(2,3): its +-1 transforms add no error of their own, while the F(4,3) matrices amplify the
+        # bf16 rounding of V / M by their 4 / 5 / 8 entries (measured: 11 % max error against 1 % for F(2,3))
+        f43 = WINO_F43 and (three_d or WINO_F43_2D) and not bf and H % 4 == 0 and W % 4 == 0 and \
+            not (three_d and (WINO_DEPTH_FUSED or WINO_OWN_GEMM))
+        if f43:
+            pre = "ssbev_wino43_" if three_d else "ssbev_wino43_2d_"
+            nf, th, reduction = (144, 4, 6.0) if three_d else (36, 4, 4.0)
+        else:
+            pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
+            nf, th, reduction = (64, 2, 3.375) if three_d else (16, 2, 2.25)
+        return f43, pre, nf, th, reduction
 
     @staticmethod
     def forward(ctx, x, weight):
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout, three_d = weight.shape[0], weight.shape[2] == 3
-        nf = 64 if three_d else 16
-        T = B * (D // 2 if three_d else D) * (H // 2) * (W // 2)
-        pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
+        bf = PRECISION == "bf16"
+        f43, pre, nf, th, red = _WinoConv._plan(three_d, D, H, W, bf)
+        T = B * (D // 2 if three_d else D) * (H // th) * (W // th)
         lib = capi.load()
         w = weight.detach().contiguous()
         fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
-        bf = PRECISION == "bf16"
-        fused = three_d and WINO_DEPTH_FUSED and not bf
+        fused = three_d and WINO_DEPTH_FUSED and not bf and not f43
+        wt = lib.ssbev_wino43_weight_transform if f43 else lib.ssbev_wino_weight_transform
         if not fused:
             U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
-            capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0,
-                                                       capi.stream()), "ssbev_wino_weight_transform")
-        with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino fwd {Cin}->{Cout} {D}x{H}x{W}"):
+            capi.check(wt(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0, capi.stream()), "ssbev_wino_weight_transform")
+        tag = f"wino{'43' if f43 else ''} fwd {Cin}->{Cout} {D}x{H}x{W}"
+        with _span("conv_winograd", fl, fl / red, tag):
             if fused:      # (h,w)-transformed tensors only (4x), the depth axis of F(2,3) inside the GEMM kernel
                 y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
                 V = None
@@ -556,45 +579,46 @@ class _WinoConv(torch.autograd.Function):
                 y = _wino_call(pre + "output_transform_bf16", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
             else:
                 V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-                M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM) else torch.bmm(V, U)
+                M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM and not f43) else torch.bmm(V, U)
                 y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(xcl if fused else V, weight)
-        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf)
+        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red)
         return from_cl(y)
 
     @staticmethod
     def backward(ctx, gy):
         V, weight = ctx.saved_tensors            # (depth-fused path: V is the channels-last input, transformed below)
-        B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf = ctx.geom
+        B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red = ctx.geom
         sfx, fdt = ("_bf16", torch.bfloat16) if bf else ("", torch.float32)
-        nf = 64 if three_d else 16
-        pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
         gcl = to_cl(gy)
         lib = capi.load()
         w = weight.detach().contiguous()
+        nd = 3 if three_d else 2
         gx = gw = None
+        vtag = "43" if f43 else ""
         if ctx.needs_input_grad[0] and fused:
-            with _span("conv_winograd", fl, fl / 3.375, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            with _span("conv_winograd", fl, fl / red, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 gx = from_cl(_wino_depth_fused(gcl, w, B, D, H, W, Cout, Cin, 1))
         elif ctx.needs_input_grad[0]:
             Ut = torch.empty(nf, Cout, Cin, dtype=torch.float32, device=gy.device)
-            capi.check(lib.ssbev_wino_weight_transform(capi.ptr(w), capi.ptr(Ut), Cout, Cin, 3 if three_d else 2, 1,
-                                                       capi.stream()), "ssbev_wino_weight_transform")
-            with _span("conv_winograd", fl, fl / (3.375 if three_d else 2.25), f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            wt = lib.ssbev_wino43_weight_transform if f43 else lib.ssbev_wino_weight_transform
+            capi.check(wt(capi.ptr(w), capi.ptr(Ut), Cout, Cin, nd, 1, capi.stream()), "ssbev_wino_weight_transform")
+            with _span("conv_winograd", fl, fl / red, f"wino{vtag} dgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 Vg = _wino_call(pre + "input_transform" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
-                Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf) else torch.bmm(Vg, Ut.to(fdt))
+                Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf and not f43) \
+                    else torch.bmm(Vg, Ut.to(fdt))
                 del Vg
                 gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
-            with _span("conv_winograd_wgrad", fl, fl / (3.375 if three_d else 2.25), f"wino wgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            with _span("conv_winograd_wgrad", fl, fl / red, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 if fused:
                     V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
                 gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else torch.bmm(V.transpose(1, 2), Z)
             gw = torch.empty_like(w)
-            capi.check(lib.ssbev_wino_weight_grad(capi.ptr(gU), capi.ptr(gw), Cout, Cin, 3 if three_d else 2,
-                                                  capi.stream()), "ssbev_wino_weight_grad")
+            wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
+            capi.check(wg(capi.ptr(gU), capi.ptr(gw), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
         return gx, gw
 
 

@@ -510,6 +510,7 @@ def test_winograd_conv3d_matches_aten(case, variant, monkeypatch):
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     assert F.WINOGRAD and F.wino_conv3d_applicable(xg, wg, (1, 1, 1), (1, 1, 1), (1, 1, 1))
     # frequency stage: rocBLAS batched GEMM (default) / own LDS-streaming MFMA GEMM / depth-fused MFMA GEMM kernel
+    monkeypatch.setattr(F, "WINO_F43", False)                   # this test pins the F(2,3)^3 kernels (exact +-1 transforms)
     monkeypatch.setattr(F, "WINO_DEPTH_FUSED", variant == "depth_fused")
     monkeypatch.setattr(F, "WINO_OWN_GEMM", variant == "own_gemm")
     got = F.conv3d(xg, wg, None, 1, 1)
@@ -537,11 +538,14 @@ def test_winograd_bf16_mode_error_budget(case):
     want.backward(go)
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     F.set_precision("bf16")
+    f43 = F.WINO_F43
+    F.WINO_F43 = False                                          # F(2,3) transforms (the F(4,3) ones: test_winograd_f43_tiles)
     try:
         got = (F.conv3d if nd == 3 else F.conv2d)(xg, wg, None, 1, 1)
         got.backward(go.to(DEV))
     finally:
         F.set_precision("fp32")
+        F.WINO_F43 = f43
     assert got.dtype == torch.float32 and xg.grad.dtype == torch.float32 and wg.grad.dtype == torch.float32
     for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad), ("gw", wg.grad, wc.grad)):
         a, b = a.detach().cpu().double(), b.detach().double()
@@ -551,6 +555,39 @@ def test_winograd_bf16_mode_error_budget(case):
         assert rel_l2 > 1e-5, (name, "bf16 mode did not engage", rel_l2)
     with pytest.raises(ValueError):
         F.set_precision("fp16")
+
+
+@pytest.mark.parametrize("case", [(2, 128, 96, 6, 4, 4, 3), (1, 96, 96, 4, 8, 12, 3), (1, 384, 192, 2, 4, 8, 3), (1, 100, 128, 8, 12, 4, 3),
+                                  (1, 64, 64, 6, 8, 8, 3), (1, 640, 96, 1, 12, 40, 2), (2, 128, 100, 1, 4, 8, 2), (1, 96, 128, 1, 48, 16, 2)])
+def test_winograd_f43_tiles(case, monkeypatch):
+    """F(4,3) tiles along h and w (F(2,3) along d), the default fp32 Winograd path on grids whose H and W are multiples
+    of 4: forward, data and weight gradient against ATen.  The F(4,3) transforms are not +-1 matrices (constants 2..8 and
+    1/4..1/24), so the fp32 gate is 2e-4 of the tensor's max (measured errors are ~1e-5).  The bf16 mode must NOT take this
+    path (the same constants amplify the bf16 rounding of the transformed tensors to ~10 %)."""
+    precision = "fp32"
+    monkeypatch.setattr(F, "WINO_F43_2D", True)             # the 2-D variant is opt-in (see functional.WINO_F43_2D)
+    B, Cin, Cout, D, H, W, nd = case
+    shape = (B, Cin, D, H, W) if nd == 3 else (B, Cin, H, W)
+    x = S.hash_normal(f"w43/x{case}", shape)
+    w = S.hash_uniform(f"w43/w{case}", (Cout, Cin) + (3,) * nd, -1, 1) * (3.0 / (Cin * 3 ** nd)) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = (TF.conv3d if nd == 3 else TF.conv2d)(xc, wc, None, 1, 1)
+    go = S.hash_normal(f"w43/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert F.WINO_F43 and F._WinoConv._plan(nd == 3, D, H, W, False)[0] and not F._WinoConv._plan(nd == 3, D, H, W, True)[0]
+    F.set_precision(precision)
+    try:
+        got = (F.conv3d if nd == 3 else F.conv2d)(xg, wg, None, 1, 1)
+        got.backward(go.to(DEV))
+    finally:
+        F.set_precision("fp32")
+    tol_max, tol_l2 = (2e-4, 1e-4) if precision == "fp32" else (3e-2, 1.5e-2)
+    for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad), ("gw", wg.grad, wc.grad)):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        rel_max = (a - b).abs().max().item() / b.abs().max().item()
+        rel_l2 = ((a - b).norm() / b.norm()).item()
+        assert rel_max < tol_max and rel_l2 < tol_l2, (name, rel_max, rel_l2)
 
 
 BF16_DIRECT_CASES = [
@@ -618,8 +655,9 @@ def test_direct_conv_bf16_mode_error_budget(case):
 
 
 @pytest.mark.parametrize("case", [(2, 96, 128, 6, 10, True), (1, 640, 96, 12, 40, False), (1, 128, 100, 4, 8, True)])
-def test_winograd_conv2d_matches_aten(case):
+def test_winograd_conv2d_matches_aten(case, monkeypatch):
     """2-D F(2x2, 3x3) path of the wide 3x3 conv2d layers (DepthNet): forward, data and weight gradient, bias."""
+    monkeypatch.setattr(F, "WINO_F43", False)
     B, Cin, Cout, H, W, has_bias = case
     x = S.hash_normal(f"wino2/x{case}", (B, Cin, H, W))
     w = S.hash_uniform(f"wino2/w{case}", (Cout, Cin, 3, 3), -1, 1) * (3.0 / (Cin * 9)) ** 0.5
