@@ -351,6 +351,11 @@ int ssbev_wino43_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_w
 int ssbev_wino43_2d_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_2d_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_2d_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* F(4x4x4, 3x3x3): F(4,3) along d as well (D % 4 == 0): 216 frequencies per 64 outputs, T = B * D/4 * H/4 * W/4, 8x fewer
+ * multiply-adds, 3.375x transformed domain.  Weight functions below: ndim = 4 selects this variant (3 = F(2x4x4), 2 = 2-D). */
+int ssbev_wino444_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino444_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino444_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream);
 int ssbev_wino43_weight_grad(const float* gU, float* gw, int Cout, int Cin, int ndim, ssbev_stream_t stream);
 /* Weight side: U = G w G^T (mode 0: U [NF][Cin][Cout] from torch-layout w [Cout][Cin][taps]; mode 1: the data-gradient

@@ -137,6 +137,9 @@ SIGNATURES = {
     "ssbev_wino43_2d_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino444_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino444_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino444_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_weight_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino43_weight_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

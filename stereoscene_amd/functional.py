@@ -531,6 +531,10 @@ WINO_F43 = os.environ.get("SSBEV_WINO_F43", "1") != "0"
 # but its rounding error (reduction over 640 channels of values scaled by the 4 / 5 / 8 entries) more than doubles the
 # gradient noise of the DepthNet parameters in the full-step parity test (L2 1.1 % vs 0.45 %), for no accuracy budget left
 WINO_F43_2D = os.environ.get("SSBEV_WINO_F43_2D", "0") != "0"
+# F(4,3) along d as well (F(4x4x4): 216 GEMMs, 8x fewer multiply-adds, 3.375x transformed domain) when D % 4 == 0: opt-in.
+# Measured 106.3 vs 108.8 ms/step, but the third non-+-1 axis brings the gradient noise of the full-step parity test back
+# to 1.1 % (tools/grad_l2_probe.py), so the default keeps F(2,3) along d.
+WINO_F444 = os.environ.get("SSBEV_WINO_F444", "0") != "0"
 
 
 class _WinoConv(torch.autograd.Function):
@@ -544,13 +548,15 @@ class _WinoConv(torch.autograd.Function):
         # bf16 rounding of V / M by their 4 / 5 / 8 entries (measured: 11 % max error against 1 % for F(2,3))
         f43 = WINO_F43 and (three_d or WINO_F43_2D) and not bf and H % 4 == 0 and W % 4 == 0 and \
             not (three_d and (WINO_DEPTH_FUSED or WINO_OWN_GEMM))
+        if f43 and three_d and WINO_F444 and D % 4 == 0:
+            return 4, "ssbev_wino444_", 216, 4, 8.0
         if f43:
             pre = "ssbev_wino43_" if three_d else "ssbev_wino43_2d_"
             nf, th, reduction = (144, 4, 6.0) if three_d else (36, 4, 4.0)
         else:
             pre = "ssbev_wino_" if three_d else "ssbev_wino2d_"
             nf, th, reduction = (64, 2, 3.375) if three_d else (16, 2, 2.25)
-        return f43, pre, nf, th, reduction
+        return (1 if f43 else 0), pre, nf, th, reduction
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -559,16 +565,17 @@ class _WinoConv(torch.autograd.Function):
         Cout, three_d = weight.shape[0], weight.shape[2] == 3
         bf = PRECISION == "bf16"
         f43, pre, nf, th, red = _WinoConv._plan(three_d, D, H, W, bf)
-        T = B * (D // 2 if three_d else D) * (H // th) * (W // th)
+        T = B * (D // (4 if f43 == 4 else 2) if three_d else D) * (H // th) * (W // th)
         lib = capi.load()
         w = weight.detach().contiguous()
         fl = 2.0 * B * D * H * W * Cin * Cout * (27 if three_d else 9)
         fused = three_d and WINO_DEPTH_FUSED and not bf and not f43
         wt = lib.ssbev_wino43_weight_transform if f43 else lib.ssbev_wino_weight_transform
+        wdim = 4 if f43 == 4 else (3 if three_d else 2)
         if not fused:
             U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
-            capi.check(wt(capi.ptr(w), capi.ptr(U), Cout, Cin, 3 if three_d else 2, 0, capi.stream()), "ssbev_wino_weight_transform")
-        tag = f"wino{'43' if f43 else ''} fwd {Cin}->{Cout} {D}x{H}x{W}"
+            capi.check(wt(capi.ptr(w), capi.ptr(U), Cout, Cin, wdim, 0, capi.stream()), "ssbev_wino_weight_transform")
+        tag = f"wino{ {0: '', 1: '43', 4: '444'}[f43]} fwd {Cin}->{Cout} {D}x{H}x{W}"
         with _span("conv_winograd", fl, fl / red, tag):
             if fused:      # (h,w)-transformed tensors only (4x), the depth axis of F(2,3) inside the GEMM kernel
                 y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
@@ -593,9 +600,9 @@ class _WinoConv(torch.autograd.Function):
         gcl = to_cl(gy)
         lib = capi.load()
         w = weight.detach().contiguous()
-        nd = 3 if three_d else 2
+        nd = 4 if f43 == 4 else (3 if three_d else 2)
         gx = gw = None
-        vtag = "43" if f43 else ""
+        vtag = {0: "", 1: "43", 4: "444"}[f43]
         if ctx.needs_input_grad[0] and fused:
             with _span("conv_winograd", fl, fl / red, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
                 gx = from_cl(_wino_depth_fused(gcl, w, B, D, H, W, Cout, Cin, 1))

@@ -558,7 +558,7 @@ def test_winograd_bf16_mode_error_budget(case):
 
 
 @pytest.mark.parametrize("case", [(2, 128, 96, 6, 4, 4, 3), (1, 96, 96, 4, 8, 12, 3), (1, 384, 192, 2, 4, 8, 3), (1, 100, 128, 8, 12, 4, 3),
-                                  (1, 64, 64, 6, 8, 8, 3), (1, 640, 96, 1, 12, 40, 2), (2, 128, 100, 1, 4, 8, 2), (1, 96, 128, 1, 48, 16, 2)])
+                                  (1, 64, 64, 6, 8, 8, 3), (1, 128, 128, 16, 8, 8, 3), (2, 512, 256, 4, 4, 8, 3), (1, 640, 96, 1, 12, 40, 2), (2, 128, 100, 1, 4, 8, 2), (1, 96, 128, 1, 48, 16, 2)])
 def test_winograd_f43_tiles(case, monkeypatch):
     """F(4,3) tiles along h and w (F(2,3) along d), the default fp32 Winograd path on grids whose H and W are multiples
     of 4: forward, data and weight gradient against ATen.  The F(4,3) transforms are not +-1 matrices (constants 2..8 and
@@ -566,6 +566,7 @@ def test_winograd_f43_tiles(case, monkeypatch):
     path (the same constants amplify the bf16 rounding of the transformed tensors to ~10 %)."""
     precision = "fp32"
     monkeypatch.setattr(F, "WINO_F43_2D", True)             # the 2-D variant is opt-in (see functional.WINO_F43_2D)
+    monkeypatch.setattr(F, "WINO_F444", True)               # D % 4 == 0 cases exercise F(4x4x4), the others F(2x4x4)
     B, Cin, Cout, D, H, W, nd = case
     shape = (B, Cin, D, H, W) if nd == 3 else (B, Cin, H, W)
     x = S.hash_normal(f"w43/x{case}", shape)
@@ -576,6 +577,7 @@ def test_winograd_f43_tiles(case, monkeypatch):
     want.backward(go)
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     assert F.WINO_F43 and F._WinoConv._plan(nd == 3, D, H, W, False)[0] and not F._WinoConv._plan(nd == 3, D, H, W, True)[0]
+    assert F._WinoConv._plan(nd == 3, D, H, W, False)[0] == (4 if (nd == 3 and D % 4 == 0 and F.WINO_F444) else 1)
     F.set_precision(precision)
     try:
         got = (F.conv3d if nd == 3 else F.conv2d)(xg, wg, None, 1, 1)
