@@ -2,7 +2,8 @@
 //
 // Design (MI355X-first, not a translation of BEVFusion's bev_pool CUDA op):
 //   * the scatter is turned into a GATHER over a CSR table (voxel -> ascending point list) that
-//     is built on the device with a histogram / scan / fill / per-segment canonicalisation;
+//     is built on the device with a histogram / scan (segment starts) and one stable radix sort of
+//     (voxel id, point id) pairs (hipCUB's device-wide LSD sort: the only library primitive in this file);
 //     no float atomics anywhere, sums are sequential fp32 in a fixed order => bit-reproducible
 //     and bit-identical to the CPU oracle;
 //   * one wavefront owns one voxel and streams its C channels with 8-byte lanes (C=128 ->
@@ -10,6 +11,8 @@
 //     [B,nx,ny,nz,C] output write (134 MB at the KITTI config), everything else stays in L2;
 //   * Lift (depth x feature outer product, 755 MB at D=192) is fused in: never materialised.
 #include "common.h"
+
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -136,60 +139,23 @@ __global__ void scan_write_kernel(const int32_t* __restrict__ counts, int nv, co
   (void)n_total_slot;
 }
 
-__global__ void fill_kernel(const int32_t* __restrict__ vox, int n, const int32_t* __restrict__ starts,
-                            int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Canonical CSR order by ONE stable radix sort: key = voxel id (dropped points get key nv and sort behind every voxel),
+// value = point id.  The ids enter in ascending order and an LSD radix sort is stable, so each voxel's run comes out in
+// ascending point id -- the sequential-sum order of the CPU oracle -- with no per-voxel work at all (the previous
+// atomic fill + per-voxel rank sort spent 0.77 ms on the long lists of the near-camera voxels; this is ~0.1 ms).
+__global__ void sort_keys_kernel(const int32_t* __restrict__ vox, int n, int nv, uint32_t* __restrict__ keys,
+                                 int32_t* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int v = vox[i];
-  if (v < 0) return;
-  const int pos = atomicAdd(&cursor[v], 1);
-  tmp[starts[v] + pos] = i;
+  keys[i] = v < 0 ? (uint32_t)nv : (uint32_t)v;
+  ids[i] = i;
 }
 
-// Put every voxel's point list into ascending order (the atomic fill order is arbitrary).
-// One wave per 64 voxels: short lists by a per-lane insertion sort, long ones by a wave-wide
-// rank sort (point ids are unique, so rank = number of smaller ids).
-constexpr int SHORT_SEG = 12;
-__global__ void canonicalise_kernel(const int32_t* __restrict__ starts, const int32_t* __restrict__ tmp,
-                                    int32_t* __restrict__ order, int nv) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int v = wave * 64 + lane;
-  int s = 0, n = 0;
-  if (v < nv) {
-    s = starts[v];
-    n = starts[v + 1] - s;
-  }
-  if (n > 0 && n <= SHORT_SEG) {
-    int e[SHORT_SEG];
-#pragma unroll
-    for (int i = 0; i < SHORT_SEG; ++i) e[i] = (i < n) ? tmp[s + i] : INT32_MAX;
-    // odd-even transposition network on a fixed-size register array (no dynamic indexing)
-#pragma unroll
-    for (int r = 0; r < SHORT_SEG; ++r) {
-#pragma unroll
-      for (int i = (r & 1); i + 1 < SHORT_SEG; i += 2) {
-        const int a = e[i], b = e[i + 1];
-        e[i] = min(a, b);
-        e[i + 1] = max(a, b);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < SHORT_SEG; ++i)
-      if (i < n) order[s + i] = e[i];
-  }
-  unsigned long long longs = __ballot(n > SHORT_SEG);
-  while (longs) {
-    const int src = __ffsll((long long)longs) - 1;
-    longs &= longs - 1;
-    const int ls = __shfl(s, src, 64), ln = __shfl(n, src, 64);
-    for (int i = lane; i < ln; i += 64) {
-      const int e = tmp[ls + i];
-      int r = 0;
-      for (int j = 0; j < ln; ++j) r += (tmp[ls + j] < e) ? 1 : 0;
-      order[ls + r] = e;
-    }
-  }
+int key_bits(int nv) {
+  int b = 1;
+  while ((1ll << b) <= (long long)nv) ++b;
+  return b;
 }
 
 // ---------------------------------------------------------------- gather-sum kernels
@@ -357,13 +323,16 @@ int ssbev_coords_to_vox(const int32_t* coords, int n, int32_t* vox, const ssbev_
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// upper bound of hipcub::DeviceRadixSort::SortPairs' temporary storage for n (uint32, int32) pairs (alternate key / value
+// buffers + digit histograms / look-back state); the exact size is queried at run time and checked against it
+static size_t sort_scratch_bound(size_t n) { return align256(n * 8) + ((size_t)8 << 20); }
 
 size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d) {
   if (!pool_dims_ok(d) || n_points < 0) return 0;
   const size_t nv = (size_t)d->B * d->nx * d->ny * d->nz;
   const size_t ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
-  // counts[nv] | cursor[nv] | tile_sums[ntiles] | tmp[n_points]
-  return align256(nv * 4) * 2 + align256(ntiles * 4) + align256((size_t)n_points * 4 + 4);
+  // counts[nv] | tile_sums[ntiles] | keys_in[n] | keys_out[n] | ids_in[n] | radix-sort scratch
+  return align256(nv * 4) + align256(ntiles * 4) + 3 * align256((size_t)n_points * 4 + 4) + sort_scratch_bound(n_points);
 }
 
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
@@ -375,18 +344,29 @@ int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_
   const int ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
   char* base = static_cast<char*>(ws);
   int32_t* counts = reinterpret_cast<int32_t*>(base);
-  int32_t* cursor = reinterpret_cast<int32_t*>(base + align256((size_t)nv * 4));
-  int32_t* tiles = reinterpret_cast<int32_t*>(base + 2 * align256((size_t)nv * 4));
-  int32_t* tmp = reinterpret_cast<int32_t*>(base + 2 * align256((size_t)nv * 4) + align256((size_t)ntiles * 4));
-  if (hipMemsetAsync(base, 0, 2 * align256((size_t)nv * 4), st) != hipSuccess) return SSBEV_ELAUNCH;
+  int32_t* tiles = reinterpret_cast<int32_t*>(base + align256((size_t)nv * 4));
+  char* p = base + align256((size_t)nv * 4) + align256((size_t)ntiles * 4);
+  const size_t nb = align256((size_t)n_points * 4 + 4);
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(p);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(p + nb);
+  int32_t* ids_in = reinterpret_cast<int32_t*>(p + 2 * nb);
+  void* scratch = p + 3 * nb;
+  const size_t scratch_avail = ws_bytes - (size_t)(p + 3 * nb - base);
+  if (hipMemsetAsync(base, 0, align256((size_t)nv * 4), st) != hipSuccess) return SSBEV_ELAUNCH;
   if (n_points)
     hipLaunchKernelGGL(histogram_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, counts);
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles);
   hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_T), 0, st, tiles, ntiles);
   hipLaunchKernelGGL(scan_write_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles, starts, nv);
   if (n_points) {
-    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, starts, cursor, tmp);
-    hipLaunchKernelGGL(canonicalise_kernel, dim3(cdiv((size_t)nv, 256)), dim3(256), 0, st, starts, tmp, order, nv);
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, nv, keys_in, ids_in);
+    size_t need = 0;
+    const int bits = key_bits(nv);
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_in, keys_out, ids_in, order, n_points, 0, bits, st) != hipSuccess)
+      return SSBEV_ELAUNCH;
+    if (need > scratch_avail) return SSBEV_EWORKSPACE;
+    if (hipcub::DeviceRadixSort::SortPairs(scratch, need, keys_in, keys_out, ids_in, order, n_points, 0, bits, st) != hipSuccess)
+      return SSBEV_ELAUNCH;
   }
   return ssbev_launch_status();
 }
