@@ -118,17 +118,24 @@ dcn_coord_grad_kernel(const float* __restrict__ x, const float* __restrict__ off
   }
 }
 
-// Input gradient.  Every sample adds to four corner pixels (unordered fp32 atomics, as in mmcv).  Sent straight to
-// L2 that is 4 x 9 atomics per output pixel and channel (177 M per DepthNet step: 2.2 ms).  A workgroup therefore owns a
-// TH x TW tile of output pixels and a 32-channel slice, accumulates into an LDS window that covers the tile plus a
-// reach of R pixels (ds_add_f32; samples that land outside the window -- offsets larger than R -- go to global
-// memory directly), and flushes the window with one global atomic per touched element: ~9x fewer L2 atomics.
+// Input gradient.  Every sample adds to four corner pixels (unordered fp32 atomics in mmcv).  Sent straight to L2 that is
+// 4 x 9 atomics per output pixel and channel (177 M per DepthNet step: 2.2 ms).  A workgroup therefore owns a TH x TW tile
+// of output pixels and a 32-channel slice and accumulates into an LDS window that covers the tile plus a reach of R
+// pixels (samples that land outside the window -- offsets larger than R -- go to global memory directly); the window
+// is flushed with one global atomic per touched element (~9x fewer L2 atomics).
+// LDS float atomics are NOT used for the window: ds_add_f32 retires ~0.4 lanes per clock on gfx950 (PMC: 155 LDS-busy
+// cycles per wave instruction, 0.85 ms for this kernel).  Instead every (tap, corner) phase is made collision-free by a
+// claim round: the threads of a pixel store their pixel id into an owner map (plain ds_write), and after a barrier
+// only the pixels that still own their target add with plain 16-byte read-modify-writes; losers (two pixels of the tile
+// whose offsets send the same corner to the same window position -- rare, offsets vary smoothly) retry.  36 phases of a
+// few LDS instructions and barriers each.
 constexpr int kDcnTH = 4, kDcnTW = 16, kDcnR = 3, kDcnCC = 32;
-constexpr int kDcnWH = kDcnTH + 2 * kDcnR + 1, kDcnWW = kDcnTW + 2 * kDcnR + 1, kDcnPitch = kDcnCC + 1;
+constexpr int kDcnWH = kDcnTH + 2 * kDcnR + 1, kDcnWW = kDcnTW + 2 * kDcnR + 1, kDcnPitch = kDcnCC + 4;
 
 __global__ void __launch_bounds__(256)
 dcn_input_grad_kernel(const float* __restrict__ off, const float* __restrict__ gcols, float* __restrict__ gx, DcnGeom g) {
-  __shared__ float win[kDcnWH * kDcnWW * kDcnPitch];
+  __shared__ __align__(16) float win[kDcnWH * kDcnWW * kDcnPitch];
+  __shared__ int owner[kDcnWH * kDcnWW];
   const int tiles_w = (g.W + kDcnTW - 1) / kDcnTW;
   const int th = blockIdx.x / tiles_w, tw = blockIdx.x % tiles_w;
   const int c0 = blockIdx.y * kDcnCC;
@@ -141,34 +148,53 @@ dcn_input_grad_kernel(const float* __restrict__ off, const float* __restrict__ g
   float* gxb = gx + b * (long)g.H * g.W * g.C;
   const int px = threadIdx.x >> 2, qsub = threadIdx.x & 3;            // 64 pixels x 4 threads, 8 channels each
   const int oh = th * kDcnTH + px / kDcnTW, ow = tw * kDcnTW + px % kDcnTW;
-  if (oh < g.H && ow < g.W) {
-    const long pix = (b * g.H + oh) * g.W + ow;
-    const int c = c0 + qsub * 8;
-    if (c < g.C) {
-      const int grp = c / Cg, cg = c - grp * Cg;
-      for (int tap = 0; tap < K; ++tap) {
-        const Sample s = make_sample(off, pix, oh, ow, tap, g);
-        if (!s.inside) continue;
+  const int c = c0 + qsub * 8;
+  const bool live = oh < g.H && ow < g.W && c < g.C;
+  const long pix = live ? (b * g.H + oh) * g.W + ow : 0;
+  const int grp = live ? c / Cg : 0, cg = c - grp * Cg;
+  for (int tap = 0; tap < K; ++tap) {
+    Sample s;
+    s.inside = false;
+    float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      s = make_sample(off, pix, oh, ow, tap, g);
+      if (s.inside) {
         const float* gp = gcols + (((long)grp * BHW + pix) * K + tap) * Cg + cg;
         const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
-        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        const float wgt[4] = {(1.f - s.lh) * (1.f - s.lw), (1.f - s.lh) * s.lw, s.lh * (1.f - s.lw), s.lh * s.lw};
-        const bool okc[4] = {s.ok00, s.ok01, s.ok10, s.ok11};
+        gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gb.x; gv[5] = gb.y; gv[6] = gb.z; gv[7] = gb.w;
+      }
+    }
+    const bool use = live && s.inside;
+    const float wgt[4] = {(1.f - s.lh) * (1.f - s.lw), (1.f - s.lh) * s.lw, s.lh * (1.f - s.lw), s.lh * s.lw};
+    const bool okc[4] = {s.ok00, s.ok01, s.ok10, s.ok11};
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          if (!okc[k4]) continue;
-          const int hc = s.h0 + (k4 >> 1), wc = s.w0 + (k4 & 1);
-          const int wh = hc - h_lo, wwc = wc - w_lo;
-          if (wh >= 0 && wh < kDcnWH && wwc >= 0 && wwc < kDcnWW) {
-            float* dst = win + (wh * kDcnWW + wwc) * kDcnPitch + qsub * 8;
+    for (int k4 = 0; k4 < 4; ++k4) {
+      int pos = -1;
+      if (use && okc[k4]) {
+        const int hc = s.h0 + (k4 >> 1), wc = s.w0 + (k4 & 1);
+        const int wh = hc - h_lo, wwc = wc - w_lo;
+        if (wh >= 0 && wh < kDcnWH && wwc >= 0 && wwc < kDcnWW) {
+          pos = wh * kDcnWW + wwc;
+        } else {                                           // beyond the reach of the window: straight to L2
+          float* dst = gxb + ((long)hc * g.W + wc) * g.C + c;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(dst + e, wgt[k4] * gv[e]);
-          } else {
-            float* dst = gxb + ((long)hc * g.W + wc) * g.C + c;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, wgt[k4] * gv[e]);
-          }
+          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, wgt[k4] * gv[e]);
         }
+      }
+      bool pending = pos >= 0;
+      while (__syncthreads_or(pending ? 1 : 0)) {
+        if (pending) owner[pos] = px;
+        __syncthreads();
+        if (pending && owner[pos] == px) {
+          float4* d = reinterpret_cast<float4*>(win + pos * kDcnPitch + qsub * 8);
+          float4 a0 = d[0], a1 = d[1];
+          const float w = wgt[k4];
+          a0.x += w * gv[0]; a0.y += w * gv[1]; a0.z += w * gv[2]; a0.w += w * gv[3];
+          a1.x += w * gv[4]; a1.y += w * gv[5]; a1.z += w * gv[6]; a1.w += w * gv[7];
+          d[0] = a0; d[1] = a1;
+          pending = false;
+        }
+        __syncthreads();
       }
     }
   }

@@ -1,5 +1,5 @@
 """Compact summary of a rocprofv3 *_kernel_stats.csv: total, family roll-up and the top kernels (ms per step).
-usage: python tools/prof_summary.py <kernel_stats.csv> <steps> [top_n]"""
+usage: python tools/prof_summary.py <kernel_stats.csv> <steps> [top_n] [name-regex: list only matching kernels]"""
 import csv
 import re
 import sys
@@ -19,6 +19,12 @@ def main():
     path, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     rows = list(csv.DictReader(open(path)))
+    if len(sys.argv) > 4:
+        for r in rows:
+            if re.search(sys.argv[4], r["Name"]):
+                print(f"{float(r['TotalDurationNs']) / 1e6 / steps:9.3f} ms/step {int(r['Calls']) / steps:7.1f} calls/step  avg "
+                      f"{float(r['AverageNs']) / 1e3:9.1f} us  {r['Name'][:110]}")
+        return
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"total kernel time: {tot / 1e6 / steps:.1f} ms/step over {steps:g} steps")
     print("\nfamily roll-up (ms/step, kernel launches/step):")
