@@ -424,14 +424,42 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """F.conv3d replacement (groups=1): the MFMA implicit-GEMM kernels, or Winograd F(2x2x2,3x3x3) for the wide
     stride-1 3x3x3 layers."""
     st, pd, dl = _triple(stride, 3), _triple(padding, 3), _triple(dilation, 3)
+    if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == (1, 1, 1)
+            and st == (1, 1, 1) and pd == (0, 0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
+        return linear_cl(x, weight, bias)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x, weight, st, pd, dl):
         y = _WinoConv.apply(x, weight)
         return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
     return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0))
 
 
+# Layers that are plain GEMMs in the channels-last layout go to rocBLAS (forward, data and weight gradient through
+# autograd's mm): wide pointwise convolutions ([pixels, Cin] x [Cin, Cout]) and the kernel == stride transposed
+# convolutions of the FPN ([voxels, Cin] x [Cin, k^3 * Cout] followed by a depth-to-space copy).  The hand-written
+# kernels stay on everything with spatial taps.  SSBEV_GEMM_LAYERS=0 keeps these layers on the MFMA conv kernels.
+GEMM_LAYERS = os.environ.get("SSBEV_GEMM_LAYERS", "1") != "0"
+GEMM_MIN_CIN = int(os.environ.get("SSBEV_GEMM_MIN_CIN", "512"))       # pointwise convs narrower than this stay on the HIP kernels
+
+
+def _deconv_k_eq_s_gemm(x, weight, bias, k):
+    xcl = to_cl(_f32(x, "deconv_gemm"))
+    B, D, H, W, Ci = xcl.shape
+    Co = weight.shape[1]
+    kd, kh, kw = k
+    w2 = weight.permute(0, 2, 3, 4, 1).reshape(Ci, kd * kh * kw * Co)
+    g = torch.mm(xcl.reshape(-1, Ci), w2).view(B, D, H, W, kd, kh, kw, Co)
+    y = g.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D * kd, H * kh, W * kw, Co)
+    if bias is not None:
+        y = y + bias
+    return from_cl(y)
+
+
 def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0):
     """F.conv_transpose3d replacement (weight [Cin, Cout, kd, kh, kw])."""
+    st, pd, op = _triple(stride, 3), _triple(padding, 3), _triple(output_padding, 3)
+    if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == tuple(st)
+            and pd == (0, 0, 0) and op == (0, 0, 0) and weight.shape[0] >= 128):
+        return _deconv_k_eq_s_gemm(x, weight, bias, tuple(st))
     return _ConvNd.apply(x, weight, bias, _triple(stride, 3), _triple(padding, 3), (1, 1, 1), True,
                          _triple(output_padding, 3))
 
@@ -440,6 +468,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """F.conv2d replacement: a depth-1 volume through the same kernels (groups=1); wide 3x3 stride-1 layers via
     Winograd F(2x2,3x3)."""
     s, p, dl = _triple(stride, 2), _triple(padding, 2), _triple(dilation, 2)
+    if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == (1, 1)
+            and s == (1, 1) and p == (0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
+        return linear_cl(x, weight, bias)           # wide pointwise conv = plain GEMM on the channels-last buffer
     x5, w5 = x.unsqueeze(2), weight.unsqueeze(2)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x5, w5, (1,) + s, (0,) + p, (1,) + dl):
         y = _WinoConv.apply(x5, w5).squeeze(2)
