@@ -178,7 +178,9 @@ def main():
                 "kernel": "convolution forward + data gradient, every launch of the step: direct MFMA kernels (conv_gather_kernel"
                           "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 / 3x3 "
                           "layers, Winograd pipelines (wino43_input_kernel -> 144 batched fp32 GEMMs -> wino43_output_kernel with "
-                          "F(2x4x4,3x3x3) tiles; F(2,3)^2 with 16 GEMMs for the 2-D layers)",
+                          "F(2x4x4,3x3x3) tiles; F(2,3)^2 with 16 GEMMs for the 2-D layers).  Layers that are plain GEMMs in the "
+                          "channels-last layout (pointwise convs with >= 512 input channels, kernel == stride deconvs) run on "
+                          "rocBLAS and are not part of this family",
                 "flop_convention": "achieved counts direct-convolution FLOPs (2*voxels*Cin*Cout*taps: what the operator computes, "
                                    "SURVEY 8(d)); the Winograd launches execute 6x (3-D, F(2x4x4)) / 2.25x (2-D, F(2x2)) fewer multiply-adds, see frac_executed",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
