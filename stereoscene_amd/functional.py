@@ -464,6 +464,28 @@ def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0
                          _triple(output_padding, 3))
 
 
+# A 3x3 convolution with dilation d and padding d only couples pixels of the same residue class modulo d: it is d*d
+# independent ordinary 3x3 / pad 1 convolutions on the (H/d) x (W/d) sub-grids.  The ASPP branches of DepthNet (640 -> 640,
+# dilation 6 / 12 / 18 on the 48 x 160 map) are therefore sent through the Winograd path as a batch of d*d small images
+# (space-to-batch / batch-to-space are two tensor copies of 20 MB): 2.25x fewer multiply-adds than the direct dilated
+# kernel.  Only when zero-padding the map to multiples of 2d costs < 35 % extra pixels (not for d = 18 at 48 x 160).
+DILATED_POLYPHASE = os.environ.get("SSBEV_DILATED_POLYPHASE", "1") != "0"
+POLYPHASE_MAX_PAD = float(os.environ.get("SSBEV_POLYPHASE_MAX_PAD", "1.35"))
+
+
+def _dilated_polyphase(x, weight, d):
+    B, Cc, H, W = x.shape
+    Hp, Wp = -(-H // (2 * d)) * 2 * d, -(-W // (2 * d)) * 2 * d
+    if Hp * Wp > POLYPHASE_MAX_PAD * H * W:
+        return None
+    xp = torch.nn.functional.pad(x, [0, Wp - W, 0, Hp - H]) if (Hp != H or Wp != W) else x
+    xs = xp.reshape(B, Cc, Hp // d, d, Wp // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, Cc, Hp // d, Wp // d)
+    ys = conv2d(xs, weight, None, 1, 1, 1)
+    Co = weight.shape[0]
+    y = ys.reshape(B, d, d, Co, Hp // d, Wp // d).permute(0, 3, 4, 1, 5, 2).reshape(B, Co, Hp, Wp)
+    return y[:, :, :H, :W]
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """F.conv2d replacement: a depth-1 volume through the same kernels (groups=1); wide 3x3 stride-1 layers via
     Winograd F(2x2,3x3)."""
@@ -471,6 +493,11 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == (1, 1)
             and s == (1, 1) and p == (0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
         return linear_cl(x, weight, bias)           # wide pointwise conv = plain GEMM on the channels-last buffer
+    if (DILATED_POLYPHASE and WINOGRAD and TILE_HINT == 0 and x.is_cuda and tuple(weight.shape[2:]) == (3, 3) and s == (1, 1)
+            and dl[0] == dl[1] and dl[0] > 1 and p == dl and min(weight.shape[0], weight.shape[1]) >= 64):
+        y = _dilated_polyphase(x, weight, dl[0])
+        if y is not None:
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
     x5, w5 = x.unsqueeze(2), weight.unsqueeze(2)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x5, w5, (1,) + s, (0,) + p, (1,) + dl):
         y = _WinoConv.apply(x5, w5).squeeze(2)

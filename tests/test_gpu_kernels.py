@@ -675,3 +675,26 @@ def test_winograd_conv2d_matches_aten(case, monkeypatch):
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 64, 96, 12, 40, 6), (2, 128, 64, 24, 20, 12), (1, 640, 64, 48, 160, 6), (1, 64, 64, 12, 40, 18)])
+def test_dilated_conv_polyphase_winograd(case):
+    """3x3 / dilation d / padding d conv2d as d*d ordinary 3x3 convolutions on the residue-class sub-grids (Winograd path)
+    against ATen's dilated convolution: forward, data and weight gradient; the last case (padding would cost > 35 % extra
+    pixels) stays on the direct dilated kernel."""
+    B, Cin, Cout, H, W, d = case
+    x = S.hash_normal(f"dil/x{case}", (B, Cin, H, W))
+    w = S.hash_uniform(f"dil/w{case}", (Cout, Cin, 3, 3), -1, 1) * (3.0 / (Cin * 9)) ** 0.5
+    b = S.hash_uniform(f"dil/b{case}", (Cout,), -0.5, 0.5)
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv2d(xc, wc, b, 1, d, d)
+    go = S.hash_normal(f"dil/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert (F._dilated_polyphase(xg.detach(), wg.detach(), d) is None) == (d == 18)
+    got = F.conv2d(xg, wg, b.to(DEV), 1, d, d)
+    got.backward(go.to(DEV))
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
