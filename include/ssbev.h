@@ -167,6 +167,17 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
                         const float* mean, const float* rstd, float* gx, float* gresidual,
                         float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws,
                         size_t ws_bytes, ssbev_stream_t stream);
+/* Variants that carry the fused ReLU's sign pattern as a bit mask instead of re-reading y in backward (2 of the 8 tensor
+ * passes of a normalisation with ReLU): relu_mask has ssbev_groupnorm_mask_words(d) 64-bit words; with T = float4 index of
+ * an element quadruple, word (T / 64) * 4 + k, bit T % 64 = [component k of y is > 0].  Written by _fwd_mask when
+ * d->relu = 1 (ignored otherwise), read by _bwd_mask. */
+size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d);
+int ssbev_groupnorm_fwd_mask(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                             float* mean, float* rstd, uint64_t* relu_mask, const ssbev_norm_dims* d, void* ws,
+                             size_t ws_bytes, ssbev_stream_t stream);
+int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* relu_mask, const float* gamma,
+                             const float* mean, const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
+                             const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 upsample (align_corners=False) of channels-last volumes, forward and gather-form

@@ -95,6 +95,9 @@ SIGNATURES = {
     "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd": (C.c_int, [_P] * 7 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_mask_words": (C.c_size_t, [C.POINTER(NormDims)]),
+    "ssbev_groupnorm_fwd_mask": (C.c_int, [_P] * 8 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_bwd_mask": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),

@@ -31,8 +31,8 @@ struct GnGeom {
 template <int MODE>
 __global__ void __launch_bounds__(NT)
 gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ y,
-                  const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial,
-                  GnGeom g) {
+                  const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
+                  const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g) {
   extern __shared__ float lds[];                       // [rows][Cs][2]
   // channel slab of this block (blockIdx.z): up to NT float4 lanes = 1024 channels (the image branch's BatchNorms
   // reach 3840 channels; everything on the voxel path fits one slab)
@@ -66,7 +66,13 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
       } else {
         const float4 gv = *reinterpret_cast<const float4*>(gy + off);
         float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-        if (g.relu) {
+        if (g.relu && mask) {                   // 1 bit per element instead of re-reading y (see gn_apply_fwd_kernel)
+          const size_t i4 = off >> 2;
+          const unsigned long long* mw = mask + (i4 >> 6) * 4;
+          const int sh = (int)(i4 & 63);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+        } else if (g.relu) {
           const float4 yv = *reinterpret_cast<const float4*>(y + off);
           gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
           gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
@@ -193,7 +199,7 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const float* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    float* __restrict__ y, GnGeom g, long total4) {
+                    float* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;            // see gn_apply_bwd_kernel
@@ -225,6 +231,16 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
     for (int k = 0; k < 4; ++k) {
       float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
       v[k] = g.relu ? fmaxf(o, 0.0f) : o;
+    }
+    if (mask) {
+      // ReLU mask for the backward pass: word (i / 64) * 4 + k holds bit (i % 64) = [component k of float4 i is > 0].  The 64
+      // lanes of a wave own 64 consecutive float4s (block offsets and the grid stride are multiples of 256), so one ballot
+      // per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long bal = __ballot(v[k] > 0.0f);
+        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
+      }
     }
     reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -285,8 +301,8 @@ gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restric
 __global__ void __launch_bounds__(NT)
 gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    const float* __restrict__ coef, float* __restrict__ gx, float* __restrict__ gres, GnGeom g,
-                    long total4) {
+                    const float* __restrict__ coef, float* __restrict__ gx, float* __restrict__ gres,
+                    const unsigned long long* __restrict__ mask, GnGeom g, long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
   // the launch makes `stride` a multiple of q whenever it can: a thread then always owns the same four channels and
@@ -315,7 +331,12 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 gv = reinterpret_cast<const float4*>(gy)[i];
     float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    if (g.relu) {
+    if (g.relu && mask) {
+      const unsigned long long* mw = mask + (i >> 6) * 4;
+      const int sh = (int)(i & 63);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+    } else if (g.relu) {
       const float4 yv = reinterpret_cast<const float4*>(y)[i];
       gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
       gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
@@ -388,9 +409,15 @@ size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d) {
   return ((size_t)g.B * g.chunks * g.C * 2 + (size_t)g.B * g.G * 2 + 64) * sizeof(float);
 }
 
-int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                        float* mean, float* rstd, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
-                        ssbev_stream_t stream) {
+size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d) {
+  if (!gn_ok(d)) return 0;
+  const size_t total4 = (size_t)d->B * d->S * (d->C / 4);
+  return ((total4 + 63) / 64) * 4;
+}
+
+static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                              float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
+                              size_t ws_bytes, ssbev_stream_t stream) {
   if (!gn_ok(d) || !x || !gamma || !beta || !y || !mean || !rstd || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
   const GnGeom g = make_geom(d);
@@ -400,7 +427,7 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
-                       nullptr, partial, g);
+                       nullptr, nullptr, partial, g);
     if (g.G == g.C)
       hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, mean, rstd, g);
     else
@@ -408,9 +435,23 @@ int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, c
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
-  hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y, g,
-                     total4);
+  hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                     d->relu ? mask : nullptr, g, total4);
   return ssbev_launch_status();
+}
+
+int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                        float* mean, float* rstd, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
+                        ssbev_stream_t stream) {
+  return groupnorm_fwd_impl(x, gamma, beta, residual, y, mean, rstd, nullptr, d, ws, ws_bytes, stream);
+}
+
+int ssbev_groupnorm_fwd_mask(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                             float* mean, float* rstd, uint64_t* relu_mask, const ssbev_norm_dims* d, void* ws,
+                             size_t ws_bytes, ssbev_stream_t stream) {
+  if (d && d->relu && !relu_mask) return SSBEV_EINVAL;
+  return groupnorm_fwd_impl(x, gamma, beta, residual, y, mean, rstd, reinterpret_cast<unsigned long long*>(relu_mask), d, ws,
+                            ws_bytes, stream);
 }
 
 int ssbev_bn_update_running(const float* mean, const float* rstd, float* running_mean, float* running_var, int C,
@@ -421,11 +462,12 @@ int ssbev_bn_update_running(const float* mean, const float* rstd, float* running
   return ssbev_launch_status();
 }
 
-int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* mean,
-                        const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
-                        const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, const unsigned long long* mask,
+                              const float* gamma, const float* mean, const float* rstd, float* gx, float* gresidual,
+                              float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
+                              ssbev_stream_t stream) {
   if (!gn_ok(d) || !gy || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !ws) return SSBEV_EINVAL;
-  if (d->relu && !y) return SSBEV_EINVAL;
+  if (d->relu && !y && !mask) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
@@ -433,7 +475,8 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
-  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mean, rstd, partial, g);
+  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mask, mean, rstd,
+                     partial, g);
   if (g.G == g.C)
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
@@ -441,8 +484,21 @@ int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const f
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
-                     gresidual, g, total4);
+                     gresidual, mask, g, total4);
   return ssbev_launch_status();
+}
+
+int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* mean,
+                        const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
+                        const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return groupnorm_bwd_impl(gy, x, y, nullptr, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, ws_bytes, stream);
+}
+
+int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* relu_mask, const float* gamma,
+                             const float* mean, const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
+                             const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return groupnorm_bwd_impl(gy, x, nullptr, reinterpret_cast<const unsigned long long*>(relu_mask), gamma, mean, rstd, gx,
+                            gresidual, ggamma, gbeta, d, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -755,6 +755,10 @@ def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
 # -------------------------------------------------------------------------------------------------
 
 
+# The fused ReLU's sign pattern travels to backward as a bit mask (1/32 of the tensor) instead of y being re-read twice
+GN_RELU_MASK = os.environ.get("SSBEV_GN_RELU_MASK", "1") != "0"
+
+
 class _GroupNorm(torch.autograd.Function):
     """GroupNorm on a channels-last volume with optional fused residual add and ReLU."""
 
@@ -775,11 +779,19 @@ class _GroupNorm(torch.autograd.Function):
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
         w, b = weight.detach().contiguous(), bias.detach().contiguous()
         nb = 4.0 * xcl.numel() * (3 + (residual is not None) - 2 * given)      # stats read + apply read/write
+        use_mask = bool(relu) and GN_RELU_MASK and not given and any(ctx.needs_input_grad[:4])
+        mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if use_mask else None
         with _span("groupnorm", 0.0, nb, f"fwd   N C={Cch} G={groups} S={S} res={int(residual is not None)}"):
-            capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
-                                               capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
-                                               capi.stream()), "ssbev_groupnorm_fwd")
-        ctx.save_for_backward(xcl, y if relu else None, w, mean, rstd)
+            if use_mask:
+                capi.check(lib.ssbev_groupnorm_fwd_mask(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
+                                                        capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask), C.byref(d), capi.ptr(ws),
+                                                        ws.numel(), capi.stream()), "ssbev_groupnorm_fwd_mask")
+            else:
+                capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
+                                                   capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
+                                                   capi.stream()), "ssbev_groupnorm_fwd")
+        ctx.save_for_backward(xcl, (mask if use_mask else y) if relu else None, w, mean, rstd)
+        ctx.use_mask = use_mask
         ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given)
         ctx.mark_non_differentiable(mean, rstd)
         return from_cl(y), mean, rstd
@@ -798,12 +810,13 @@ class _GroupNorm(torch.autograd.Function):
         gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
-        nb = 4.0 * xcl.numel() * (5 + relu + has_res)      # stats: x, gy (, y); apply: x, gy (, y) -> gx (, gres)
+        # stats: x, gy (, y); apply: x, gy (, y) -> gx (, gres); the ReLU bit mask replaces both y reads
+        nb = 4.0 * xcl.numel() * (5 + (relu and not ctx.use_mask) + has_res)
         with _span("groupnorm", 0.0, nb, f"bwd   N C={Cch} G={groups} S={S} res={int(has_res)}"):
-            capi.check(lib.ssbev_groupnorm_bwd(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
-                                               capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
-                                               C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                       "ssbev_groupnorm_bwd")
+            fn = lib.ssbev_groupnorm_bwd_mask if ctx.use_mask else lib.ssbev_groupnorm_bwd
+            capi.check(fn(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
+                          capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
+                          C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_groupnorm_bwd")
         return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None
 
 
