@@ -285,5 +285,81 @@ def test_files_to_losses_end_to_end(tmp_path):
     losses = model.forward_train(img_inputs=batch["img_inputs"], gt_occ=batch["gt_occ"])
     total = sum(v for k, v in losses.items() if k.startswith("loss"))
     total.backward()
-    assert torch.isfinite(total) and float(losses["loss_depth"]) > 0
+    assert torch.isfinite(total) and float(losses["loss_depth"].detach()) > 0
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.gpu
+def test_training_loop_from_files_with_runner(tmp_path):
+    """The whole stack in one loop: files -> dataset -> DistributedGroupSampler -> pipeline steps (GPU resize / z-buffer) ->
+    collate -> detector (hot path only, image-neck features synthesised from the loaded images by a fixed projection) ->
+    fused AdamW + clip -> EpochBasedRunner hooks (step LR, checkpoint rotation, evaluation with save_best, resume)."""
+    from stereoscene_amd import evaluate as E, model_zoo, plugin, runner as R, synthetic as S, train as T  # noqa: F401
+    cfg = S.CFG_T
+    _write_mini_kitti(str(tmp_path), 4, (62, 155), cfg["occ_size"])
+    data_config = {"input_size": cfg["input_size"], "resize": (0.0, 0.0), "rot": (0.0, 0.0), "flip": False, "crop_h": (0.0, 0.0),
+                   "resize_test": 0.0}
+    pipeline = [
+        dict(type="LoadMultiViewImageFromFiles_SemanticKitti", is_train=True, data_config=data_config),
+        dict(type="LoadSemKittiAnnotation", bda_aug_conf=dict(rot_lim=(0, 0), scale_lim=(0.95, 1.05), flip_dx_ratio=0.5,
+                                                              flip_dy_ratio=0.5), is_train=True),
+        dict(type="CreateDepthFromLiDAR", point_cloud_range=list(cfg["pc_range"]), grid_size=list(cfg["occ_size"]),
+             lidar_root=str(tmp_path / "velodyne"), lidarseg_root=str(tmp_path / "lidarseg")),
+    ]
+    ds = P.DATASETS.build(dict(type="CustomSemanticKITTILssDataset", data_root=str(tmp_path / "kitti"),
+                               ann_file=str(tmp_path / "labels"), pipeline=pipeline, split="train", occ_size=cfg["occ_size"],
+                               pc_range=cfg["pc_range"]))
+    assert len(ds) == 4
+    model = model_zoo.build_detector(cfg).train()
+    torch.manual_seed(0)
+    proj = torch.randn(640, 3 * 8 * 8, device="cuda") * 0.2          # stand-in image branch: 8x8 patch embedding -> 640 ch
+
+    def to_batch(indices):
+        b = P.collate([ds[i] for i in indices])
+        views = []
+        for v in b["img_inputs"]:
+            img = v[0][:, 0]                                                         # [B,3,H,W]
+            patches = torch.nn.functional.unfold(img, 8, stride=8)                   # [B, 192, fH*fW]
+            feat = torch.einsum("ck,bkn->bcn", proj, patches).reshape(img.shape[0], 1, 640, img.shape[2] // 8, img.shape[3] // 8)
+            views.append((feat.contiguous(),) + tuple(v[1:]))
+        return dict(img_inputs=tuple(views), gt_occ=b["gt_occ"])
+
+    sampler = R.DistributedGroupSampler(ds, samples_per_gpu=2, num_replicas=1, rank=0, seed=0)
+
+    class Loader:
+        def __iter__(self):
+            idx = list(iter(sampler))
+            for i in range(0, len(idx), 2):
+                yield to_batch(idx[i:i + 2])
+
+    opt = T.FlatAdamW(model, lr=2e-3, weight_decay=0.01, max_grad_norm=5.0)
+
+    def step_fn(batch):
+        return {k: float(v.detach()) for k, v in T.train_step(model, opt, batch["img_inputs"], batch["gt_occ"]).items()
+                if k.startswith("loss")}
+
+    def eval_fn():
+        scores = E.evaluate(model, [to_batch([0, 1])])
+        model.train()
+        return scores
+
+    def set_lr(lr):
+        opt.lr = lr
+
+    def make(max_epochs):
+        return R.EpochBasedRunner(step_fn, set_lr, lambda: dict(state_dict=model.state_dict(), optimizer=opt.state_dict()),
+                                  lambda ck: (model.load_state_dict(ck["state_dict"]), opt.load_state_dict(ck["optimizer"])),
+                                  str(tmp_path / "work"), base_lr=2e-3, lr_step=(3, 5), max_epochs=max_epochs, eval_fn=eval_fn,
+                                  eval_interval=2, log=lambda r: None)
+    run = make(4)
+    hist = run.run(Loader(), sampler)
+    tot = [sum(v for k, v in h.items() if k.startswith("loss")) for h in hist]
+    assert len(hist) == 4 and all(np.isfinite(tot)) and tot[-1] < tot[0], tot
+    assert abs(hist[3]["lr"] - 2e-4) < 1e-12 and "semkitti_combined_IoU" in hist[1]["eval"]
+    files = sorted(os.listdir(tmp_path / "work"))
+    assert "epoch_4.pth" in files and "epoch_3.pth" in files and "epoch_2.pth" not in files and any(f.startswith("best_") for f in files)
+    run2 = make(5)
+    meta = run2.resume()
+    assert meta["epoch"] == 4 and opt.step_count == 8
+    hist2 = run2.run(Loader(), sampler)
+    assert [h["epoch"] for h in hist2] == [5] and np.isfinite(sum(v for k, v in hist2[0].items() if k.startswith("loss")))
