@@ -354,6 +354,7 @@ def test_training_loop_from_files_with_runner(tmp_path):
     run = make(4)
     hist = run.run(Loader(), sampler)
     tot = [sum(v for k, v in h.items() if k.startswith("loss")) for h in hist]
+    print("epoch loss totals:", [round(t, 3) for t in tot])
     assert len(hist) == 4 and all(np.isfinite(tot)) and tot[-1] < tot[0], tot
     assert abs(hist[3]["lr"] - 2e-4) < 1e-12 and "semkitti_combined_IoU" in hist[1]["eval"]
     files = sorted(os.listdir(tmp_path / "work"))
