@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int MAX_CPG = 8;
 constexpr int KCHUNK = 16;
 
 struct XTap { int x0; float w0, w1; };
