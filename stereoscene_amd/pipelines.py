@@ -513,3 +513,38 @@ def collate(samples, device="cuda"):
         views.append(tuple(cols))
     gt = torch.stack([torch.as_tensor(s["gt_occ"]).long() for s in samples]).to(device)
     return dict(img_inputs=tuple(views), gt_occ=gt)
+
+
+@PIPELINES.register_module()
+class OccDefaultFormatBundle3D:
+    """Formatting step of stereoscene.py:144 / :153 (datasets/pipelines/formating.py:50-89): ``gt_occ``, ``points_occ`` and
+    ``points_uv`` become tensors.  mmcv's DataContainer wrapping (a hint for its collate / scatter) has no counterpart
+    here: ``collate`` below stacks plain tensors."""
+
+    def __init__(self, class_names=None, with_gt=True, with_label=True, **kwargs):
+        self.class_names, self.with_gt, self.with_label = class_names, with_gt, with_label
+
+    def __call__(self, results):
+        if results.get("gt_occ") is not None:
+            g = results["gt_occ"]
+            results["gt_occ"] = tuple(torch.as_tensor(x) for x in g) if type(g) is list else torch.as_tensor(g)
+        for k in ("points_occ", "points_uv"):
+            if k in results:
+                results[k] = torch.as_tensor(results[k])
+        return results
+
+
+@PIPELINES.register_module()
+class Collect3D:
+    """mmdet3d ``Collect3D`` as used at stereoscene.py:145-146 / :154-155: keeps ``keys`` and gathers the available
+    ``meta_keys`` into ``img_metas`` (a plain dict)."""
+
+    def __init__(self, keys, meta_keys=("pc_range", "occ_size", "sequence", "frame_id", "img_filename")):
+        self.keys, self.meta_keys = list(keys), list(meta_keys)
+
+    def __call__(self, results):
+        data = {"img_metas": {k: results[k] for k in self.meta_keys if k in results}}
+        for k in self.keys:
+            if k in results:
+                data[k] = results[k]
+        return data

@@ -364,3 +364,27 @@ def test_training_loop_from_files_with_runner(tmp_path):
     assert meta["epoch"] == 4 and opt.step_count == 8
     hist2 = run2.run(Loader(), sampler)
     assert [h["epoch"] for h in hist2] == [5] and np.isfinite(sum(v for k, v in hist2[0].items() if k.startswith("loss")))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/projects/configs/occupancy/semantickitti/stereoscene.py"),
+                    reason="reference checkout not present (GPU box)")
+def test_reference_config_pipelines_build_unchanged():
+    """train_pipeline / test_pipeline / data.train of the reference's own config build from the registries as they are
+    (host logic: no file is read, no kernel launched)."""
+    from stereoscene_amd.registry import Config
+    cfg = Config.fromfile("/root/reference/projects/configs/occupancy/semantickitti/stereoscene.py")
+    train = P.Compose(cfg.train_pipeline)
+    test = P.Compose(cfg.test_pipeline)
+    assert [type(s).__name__ for s in train.steps] == ["LoadMultiViewImageFromFiles_SemanticKitti", "LoadSemKittiAnnotation",
+                                                       "CreateDepthFromLiDAR", "OccDefaultFormatBundle3D", "Collect3D"]
+    assert [type(s).__name__ for s in test.steps] == ["LoadMultiViewImageFromFiles_SemanticKitti", "LoadSemKittiAnnotation",
+                                                      "OccDefaultFormatBundle3D", "Collect3D"]
+    assert train.steps[0].is_train and not test.steps[0].is_train and train.steps[0].data_config["input_size"] == (384, 1280)
+    out = train.steps[4](train.steps[3](dict(gt_occ=np.zeros((2, 2, 2), dtype=np.uint8), points_occ=np.zeros((3, 4)), img_inputs=1,
+                                             pc_range=[0], sequence="00", other=5)))
+    assert set(out) == {"img_metas", "img_inputs", "gt_occ", "points_occ"} and torch.is_tensor(out["gt_occ"])
+    assert out["img_metas"] == {"pc_range": [0], "sequence": "00"}
+    dcfg = dict(cfg.data.train)
+    assert dcfg["type"] == "CustomSemanticKITTILssDataset"
+    ds = P.DATASETS.build({**dcfg, "data_root": "/nonexistent", "ann_file": "/nonexistent"})
+    assert len(ds) == 0 and [type(s).__name__ for s in ds.pipeline.steps][-1] == "Collect3D"
