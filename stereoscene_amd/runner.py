@@ -163,3 +163,30 @@ class EpochBasedRunner:
             self.history.append(rec)
             self.log(rec)
         return self.history
+
+
+def runner_kwargs_from_config(cfg):
+    """The hook configuration of a reference config (stereoscene.py:203-225) as ``EpochBasedRunner`` keyword arguments:
+    ``optimizer.lr``, ``lr_config(policy='step', step=[...])``, ``checkpoint_config``, ``evaluation``, ``runner.max_epochs``."""
+    lr_cfg = dict(cfg.get("lr_config", {}))
+    if lr_cfg.get("policy", "step") != "step":
+        raise NotImplementedError(f"lr policy {lr_cfg.get('policy')!r}: the hot-path configs use 'step'")
+    ck, ev, rn = dict(cfg.get("checkpoint_config", {})), dict(cfg.get("evaluation", {})), dict(cfg.get("runner", {}))
+    if rn.get("type", "EpochBasedRunner") != "EpochBasedRunner":
+        raise NotImplementedError(rn.get("type"))
+    return dict(base_lr=cfg["optimizer"]["lr"], lr_step=tuple(lr_cfg.get("step", ())), lr_gamma=lr_cfg.get("gamma", 0.1),
+                max_epochs=rn.get("max_epochs", 1), ckpt_interval=ck.get("interval", 1), max_keep_ckpts=ck.get("max_keep_ckpts", -1),
+                eval_interval=ev.get("interval", 1), save_best=ev.get("save_best"), rule=ev.get("rule", "greater"))
+
+
+def optimizer_from_config(model, cfg, reducer=None):
+    """``optimizer = dict(type='AdamW', lr, weight_decay)`` + ``optimizer_config.grad_clip.max_norm`` -> train.FlatAdamW."""
+    from .train import FlatAdamW
+    opt = dict(cfg["optimizer"])
+    if opt.pop("type") != "AdamW":
+        raise NotImplementedError("the hot-path configs train with AdamW")
+    clip = (cfg.get("optimizer_config") or {}).get("grad_clip") or {}
+    if clip and clip.get("norm_type", 2) != 2:
+        raise NotImplementedError("only the 2-norm clip is fused")
+    return FlatAdamW(model, lr=opt["lr"], weight_decay=opt.get("weight_decay", 0.01), betas=tuple(opt.get("betas", (0.9, 0.999))),
+                     eps=opt.get("eps", 1e-8), max_grad_norm=float(clip.get("max_norm", 0.0)), reducer=reducer)

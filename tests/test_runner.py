@@ -71,3 +71,16 @@ def test_runner_hooks_checkpoint_rotation_best_and_resume(tmp_path):
     assert [h["epoch"] for h in hist2] == [6, 7, 8] and abs(hist2[0]["lr"] - 1e-6) < 1e-18
     assert run2.best_score == 15.0 and os.path.basename(run2.best_ckpt).endswith("epoch_8.pth")
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("epoch_")) == ["epoch_7.pth", "epoch_8.pth"]
+
+
+def test_runner_kwargs_from_the_reference_config():
+    import pytest
+    from stereoscene_amd.registry import Config
+    path = "/root/reference/projects/configs/occupancy/semantickitti/stereoscene.py"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present (GPU box)")
+    cfg = Config.fromfile(path)
+    kw = R.runner_kwargs_from_config(cfg)
+    assert kw == dict(base_lr=1e-4, lr_step=(20, 25), lr_gamma=0.1, max_epochs=30, ckpt_interval=1, max_keep_ckpts=2,
+                      eval_interval=2, save_best="semkitti_combined_IoU", rule="greater")
+    assert cfg.optimizer["type"] == "AdamW" and cfg.optimizer_config["grad_clip"]["max_norm"] == 5
