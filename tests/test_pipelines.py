@@ -332,7 +332,9 @@ def test_training_loop_from_files_with_runner(tmp_path):
             for i in range(0, len(idx), 2):
                 yield to_batch(idx[i:i + 2])
 
-    opt = T.FlatAdamW(model, lr=2e-3, weight_decay=0.01, max_grad_norm=5.0)
+    opt = R.optimizer_from_config(model, dict(optimizer=dict(type="AdamW", lr=2e-3, weight_decay=0.01),
+                                              optimizer_config=dict(grad_clip=dict(max_norm=5, norm_type=2))))
+    assert isinstance(opt, T.FlatAdamW) and opt.max_grad_norm == 5.0 and opt.wd == 0.01
 
     def step_fn(batch):
         return {k: float(v.detach()) for k, v in T.train_step(model, opt, batch["img_inputs"], batch["gt_occ"]).items()
