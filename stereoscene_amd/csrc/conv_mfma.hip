@@ -86,7 +86,9 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
   int par_d = 0, par_h = 0, par_w = 0;
   int Dc = g.Do, Hc = g.Ho, Wc = g.Wo;   // extent of the enumerated (per-class) output grid
   if (g.form == 1) {
-    int cls = blockIdx.z;
+    // heaviest parity class first: class (1,1,1) of a k3 s2 problem walks 8 taps, class (0,0,0) one; workgroups are
+    // dispatched in blockIdx order, so the light classes fill the tail of the heavy ones instead of the other way round
+    int cls = (int)gridDim.z - 1 - (int)blockIdx.z;
     par_w = cls % g.sw; cls /= g.sw;
     par_h = cls % g.sh; cls /= g.sh;
     par_d = cls;
