@@ -16,6 +16,7 @@ LAYERS = [
     ("cost deconv 64->32", 64, 32, (96, 24, 80), 3, 2, 1, True, 1),
     ("vox 128->128 k3 @128x128x16", 128, 128, (128, 128, 16), 3, 1, 1, False, 0),
     ("vox 128->256 k3s2", 128, 256, (128, 128, 16), 3, 2, 1, False, 0),
+    ("vox 256->512 k3s2", 256, 512, (64, 64, 8), 3, 2, 1, False, 0),
     ("vox 256->256 k3 @64x64x8", 256, 256, (64, 64, 8), 3, 1, 1, False, 0),
     ("vox 512->512 k3 @32x32x4", 512, 512, (32, 32, 4), 3, 1, 1, False, 0),
     ("head 384->192 k3", 384, 192, (128, 128, 16), 3, 1, 1, False, 0),
