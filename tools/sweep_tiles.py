@@ -19,7 +19,8 @@ for name, ci, co, (D, H, W), k, s, p, tr, op in LAYERS:
     y = f(); go = torch.randn_like(y)
     flops = 2.0 * (y.numel() // co) * co * ci * k ** 3 if not tr else 2.0 * (x.numel() // ci) * ci * co * k ** 3
     row = {}
-    for mt, nt in (((2, 4), (2, 2), (2, 3), (2, 6), (1, 6), (1, 3), (1, 2)) if len(sys.argv) > 1 else ((4, 1), (2, 1), (1, 1), (2, 4), (2, 2), (1, 2))):
+    wide = len(sys.argv) > 1 and not (len(sys.argv) > 2 and sys.argv[2] == "narrow")
+    for mt, nt in (((2, 4), (2, 2), (2, 3), (2, 6), (1, 6), (1, 3), (1, 2)) if wide else ((4, 1), (2, 1), (1, 1), (2, 4), (2, 2), (1, 2))):
         for qu in (1, 2, 4):
             F.TILE_HINT = mt * 100 + nt * 10 + qu
             try:
