@@ -593,6 +593,7 @@ WINO_F43_2D = os.environ.get("SSBEV_WINO_F43_2D", "0") != "0"
 # Measured 106.3 vs 108.8 ms/step, but the third non-+-1 axis brings the gradient noise of the full-step parity test back
 # to 1.1 % (tools/grad_l2_probe.py), so the default keeps F(2,3) along d.
 WINO_F444 = os.environ.get("SSBEV_WINO_F444", "0") != "0"
+WINO_F444_MIN_CIN = int(os.environ.get("SSBEV_WINO_F444_MIN_CIN", "0"))     # with F444 on: only layers at least this wide
 
 
 class _WinoConv(torch.autograd.Function):
@@ -601,12 +602,12 @@ class _WinoConv(torch.autograd.Function):
     batch axis).  Tiles: F(4,3) along h and w when both are multiples of 4 (NF = 144 / 36), else F(2,3) (NF = 64 / 16)."""
 
     @staticmethod
-    def _plan(three_d, D, H, W, bf):
+    def _plan(three_d, D, H, W, bf, cin=1 << 30):
         # bf16 mode stays on F(2,3): its +-1 transforms add no error of their own, while the F(4,3) matrices amplify the
         # bf16 rounding of V / M by their 4 / 5 / 8 entries (measured: 11 % max error against 1 % for F(2,3))
         f43 = WINO_F43 and (three_d or WINO_F43_2D) and not bf and H % 4 == 0 and W % 4 == 0 and \
             not (three_d and (WINO_DEPTH_FUSED or WINO_OWN_GEMM))
-        if f43 and three_d and WINO_F444 and D % 4 == 0:
+        if f43 and three_d and WINO_F444 and D % 4 == 0 and cin >= WINO_F444_MIN_CIN:
             return 4, "ssbev_wino444_", 216, 4, 8.0
         if f43:
             pre = "ssbev_wino43_" if three_d else "ssbev_wino43_2d_"
@@ -622,7 +623,7 @@ class _WinoConv(torch.autograd.Function):
         B, D, H, W, Cin = xcl.shape
         Cout, three_d = weight.shape[0], weight.shape[2] == 3
         bf = PRECISION == "bf16"
-        f43, pre, nf, th, red = _WinoConv._plan(three_d, D, H, W, bf)
+        f43, pre, nf, th, red = _WinoConv._plan(three_d, D, H, W, bf, Cin)
         T = B * (D // (4 if f43 == 4 else 2) if three_d else D) * (H // th) * (W // th)
         lib = capi.load()
         w = weight.detach().contiguous()

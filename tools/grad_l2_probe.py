@@ -23,8 +23,9 @@ oin = [smp["x_l"], *smp["geo_l"], mlp_l, smp["x_r"], *smp["geo_r"], mlp_r, smp["
 ocfg = dict(D=model.img_view_transformer.D, numC_Trans=128, warp_align_corners=True, downsample=S.CFG_T["downsample"], dbound=S.CFG_T["dbound"])
 want, aux = O.forward_train(sd, oin, smp["gt_depths"], smp["gt_occ"], ocfg, train=True, stats_out={})
 sum(want.values()).backward()
-for f43, f2d in ((True, True), (True, False), (False, False)):
-    F.WINO_F43, F.WINO_F43_2D = f43, f2d
+import os
+for f43, f2d, f444 in ((True, False, False), (True, False, True)):
+    F.WINO_F43, F.WINO_F43_2D, F.WINO_F444 = f43, f2d, f444
     model, _, _ = run()
     rows = []
     for name, p in model.named_parameters():
@@ -33,4 +34,4 @@ for f43, f2d in ((True, True), (True, False), (False, False)):
         if ref.abs().max().item() < 1e-8: continue
         rows.append((((p.grad.cpu() - ref).norm() / ref.norm()).item(), name))
     rows.sort(reverse=True)
-    print(("F43" if f43 else "F23") + ("+2d" if f2d else ""), [(round(a, 5), n.split("img_view_transformer.")[-1]) for a, n in rows[:5]])
+    print(("F43" if f43 else "F23") + ("+2d" if f2d else "") + (f"+F444(cin>={F.WINO_F444_MIN_CIN})" if f444 else ""), [(round(a, 5), n.split("img_view_transformer.")[-1]) for a, n in rows[:5]])
