@@ -1731,6 +1731,220 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_taph_kernel: the same layers with Winograd F(2,3) along h folded into the tap walk (fp32, even H).
+// conv_tap_kernel runs at ~70 % of the fp32 matrix pipe, so only fewer multiply-adds make these layers faster.  A pair
+// of output rows (h0, h0+1) needs the four input rows h0-1 .. h0+2:
+//     V0 = x0 - x2   V1 = x1 + x2   V2 = x2 - x1   V3 = x1 - x3        (one v_fma per operand float, sign = +-1)
+//     M_f = sum over (kd, kw, k) U_f[n][k][kd][kw] * V_f               U = G w along kh (pack_taph_kernel)
+//     y(h0) = M0 + M1 + M2          y(h0+1) = M1 - M2 - M3
+// i.e. 4 x 9 weight matrices per row pair instead of 2 x 27: 1.5x fewer MFMAs and 3x fewer LDS operand reads.
+// Eight waves: wave = (frequency f, channel half kg); each keeps its nine 32 x 16 U_f slices in 72 VGPRs, reads TWO
+// ring rows per (kd, kw) and owns one 32 x 32 accumulator.  The ring holds 6 row slots x 3 planes (rows h0..h0+3 in
+// use, h0+4 / h0+5 in flight); the eight partial tiles meet in LDS, where the output transform is three adds.
+constexpr int kTwSlots = 6, kTwPlaneF = kTwSlots * kTapRowF, kTwRingF = 3 * kTwPlaneF;
+constexpr int kTwRedF = 8 * 16 * 64;
+constexpr size_t kTwLdsBytes = (size_t)(kTwRingF + 2 * kTwRedF) * sizeof(float);
+constexpr int kTwPackedElems = 8 * 9 * 8 * 64;
+
+// w_packed[((wave * 9 + c) * 8 + r) * 64 + lane] = U_f[n = lane & 31][k][kd = c / 3][kw = c % 3],  f = wave & 3,
+// k = 16 (wave >> 2) + 8 (r >> 2) + 4 (lane >> 5) + (r & 3); Weff as in pack_tap_kernel (mode 1: roles swapped, mirrored)
+__global__ void __launch_bounds__(256)
+pack_taph_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kTwPackedElems) return;
+  const int lane = i & 63, r = (i >> 6) & 7, wc = i >> 9;
+  const int c = wc % 9, wave = wc / 9, f = wave & 3, kg = wave >> 2;
+  const int kd = c / 3, kw = c % 3;
+  const int n = lane & 31, k = 16 * kg + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (n < N && k < K) {
+    float t[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int tap = kd * 9 + kh * 3 + kw;
+      t[kh] = mode == 0 ? w[((size_t)n * Cin + k) * 27 + tap] : w[((size_t)k * Cin + n) * 27 + (26 - tap)];
+    }
+    v = f == 0 ? t[0] : f == 1 ? 0.5f * ((t[0] + t[2]) + t[1]) : f == 2 ? 0.5f * ((t[0] + t[2]) - t[1]) : t[2];
+  }
+  wp[i] = v;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                 float* __restrict__ Y, ConvTapGeom g) {      // g.NG / g.gpc count row PAIRS here
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [3 planes][6 slots][34 voxels][32 channels], 16-byte swizzled
+  float* red2 = tl + kTwRingF;               // 2 x [8 waves][16 rows][64 lanes]: double-buffered, one barrier per pair
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int f = wave & 3, kg = wave >> 2;
+
+  float wr[9][8];
+#pragma unroll
+  for (int c = 0; c < 9; ++c)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wr[c][r] = wp[((wave * 9 + c) * 8 + r) * 64 + lane];
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * kTapWseg;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  const int H2 = g.H >> 1;
+
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 staging entries per (plane, row), see conv_tap_kernel
+  int xoff[2], xmeta[2];
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int q = wave + n * 8;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ (u & 7)) << 2), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kTwPlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  auto stage_row = [&](int b, int d, int hp) {                  // padded row hp = input row hp - 1 -> slot hp % 6
+    const float* base = X + ((long)(b * g.D + d - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = ring + (meta >> 4) + (hp % kTwSlots) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+
+  const int ra = f == 0 ? 0 : (f == 2 ? 2 : 1);
+  const int rb = f == 3 ? 3 : (f == 2 ? 1 : 2);
+  const float sgn = f == 1 ? 1.0f : -1.0f;
+  const int j_out = wave >> 2, rg = wave & 3;
+  const int nb = 8 * rg + 4 * lk;            // first of the 4 output channels this lane stores (row h0 + j_out)
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
+  }
+
+  bool fresh = true;
+  int h2 = g_begin % H2, d, b;
+  {
+    const int bd = g_begin / H2;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = 2 * h2;
+    if (fresh) {
+      stage_row(b, d, h0); stage_row(b, d, h0 + 1); stage_row(b, d, h0 + 2); stage_row(b, d, h0 + 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
+    if (same_plane) { stage_row(b, d, h0 + 4); stage_row(b, d, h0 + 5); }
+
+    const int offA = ((h0 + ra) % kTwSlots) * kTapRowF, offB = ((h0 + rb) % kTwSlots) * kTapRowF;
+    float* red = red2 + (G & 1) * kTwRedF;
+    f32x16 acc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.0f;
+    float4 va[2], vb[2];
+    auto fetch = [&](int c, float4 (&v)[2]) {
+      const int u = li + c % 3;
+      const float* colp = ring + (c / 3) * kTwPlaneF + u * 32;
+      const int sw = u & 7;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = ((2 * (2 * kg + q) + lk) ^ sw) << 2;
+        const float4 xa = *reinterpret_cast<const float4*>(colp + offA + o);
+        const float4 xb = *reinterpret_cast<const float4*>(colp + offB + o);
+        v[q] = make_float4(fmaf(sgn, xb.x, xa.x), fmaf(sgn, xb.y, xa.y), fmaf(sgn, xb.z, xa.z), fmaf(sgn, xb.w, xa.w));
+      }
+    };
+    auto mm_head = [&](int c, const float4 (&v)[2]) { acc2[0] = mfma32(wr[c][0], v[0].x, acc2[0]); };
+    auto mm_tail = [&](int c, const float4 (&v)[2]) {
+      acc2[1] = mfma32(wr[c][4], v[1].x, acc2[1]);
+      acc2[0] = mfma32(wr[c][1], v[0].y, acc2[0]);
+      acc2[1] = mfma32(wr[c][5], v[1].y, acc2[1]);
+      acc2[0] = mfma32(wr[c][2], v[0].z, acc2[0]);
+      acc2[1] = mfma32(wr[c][6], v[1].z, acc2[1]);
+      acc2[0] = mfma32(wr[c][3], v[0].w, acc2[0]);
+      acc2[1] = mfma32(wr[c][7], v[1].w, acc2[1]);
+    };
+    fetch(0, va);
+#pragma unroll
+    for (int c = 0; c < 9; c += 2) {
+      mm_head(c, va);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 9) fetch(c + 1, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_tail(c, va);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 9) {
+        mm_head(c + 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < 9) fetch(c + 2, va);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_tail(c + 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * rg + i;
+        float m[4];
+#pragma unroll
+        for (int ff = 0; ff < 4; ++ff) m[ff] = red[(ff * 16 + r) * 64 + lane] + red[((ff + 4) * 16 + r) * 64 + lane];
+        o[i] = (j_out == 0 ? (m[0] + m[1]) + m[2] : (m[1] - m[2]) - m[3]) + bv[i];
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      const int wv = w0 + li;
+      if (wv < g.W) {
+        float* dst = Y + (((long)(b * g.D + d) * g.H + h0 + j_out) * g.W + wv) * g.N + nb;
+        if ((g.N & 3) == 0) {
+          if (nb < g.N) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < g.N) dst[i] = o[i];
+        }
+      }
+    }
+    fresh = !same_plane;                     // no second barrier: the next pair publishes into the other half of red2
+    if (++h2 == H2) {
+      h2 = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3x3 stride-1 "heads" with 32 input channels and <= 4 output channels (classif3_2 / redir2:
 // 32 -> 1).  On the MFMA kernel such a layer costs as much as a full 32 -> 32 one (31 of 32 tile columns are padding).
 // Here it is a VALU reduction over the LDS ring of conv_tap_kernel:
@@ -2070,10 +2284,51 @@ bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
   if (d->Cin > 32 || d->Cout > 32) return false;
   const int K = mode == 0 ? d->Cin : d->Cout;
   if (K % 4 != 0) return false;
-  if (K < 16 && d->tile_hint != 9) return false;     // few input channels: the generic kernel has little to fetch
+  if (K < 16 && d->tile_hint != 9 && d->tile_hint != 6) return false;     // few input channels: the generic kernel has little to fetch
   // worth it only when the volume fills the chip with row walks: >= 1024 (segment, row-range) workgroups of >= 16 rows
   // (tile_hint 9 forces it on any size: tests)
-  return d->tile_hint == 9 || (long)d->B * d->Do * d->Ho * ((d->Wo + kTapWseg - 1) / kTapWseg) >= 1024L * 16;
+  return d->tile_hint == 9 || d->tile_hint == 6 ||
+         (long)d->B * d->Do * d->Ho * ((d->Wo + kTapWseg - 1) / kTapWseg) >= 1024L * 16;
+}
+
+// F(2,3)-along-h variant: fp32, even H.  tile_hint 6 keeps the plain tap kernel (tests / A-B timing)
+bool conv_taph_applicable(const ssbev_conv_dims* d, int mode) {
+  return conv_tap_applicable(d, mode) && d->Ho % 2 == 0 && d->precision == 0 && d->tile_hint != 6;
+}
+
+int launch_conv_taph(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                     hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + kTapWseg - 1) / kTapWseg;
+  g.NG = g.B * g.D * (g.H / 2);              // row pairs
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  // one 512-thread workgroup per CU (141 KB of LDS); whole rounds of 256 workgroups, >= 12 row pairs each
+  long nranges = 256 / g.nseg;
+  for (long rounds = 8; rounds >= 1; --rounds) {
+    const long nr = (256 * rounds) / g.nseg;
+    if ((g.NG + nr - 1) / nr >= 12) { nranges = nr; break; }
+  }
+  if (nranges < 1) nranges = 1;
+  g.gpc = (int)((g.NG + nranges - 1) / nranges);
+  // a chunk that crosses a depth plane restages its whole ring (4 rows x 3 planes, latency exposed): prefer a chunk
+  // length that divides the pairs of a plane
+  const int H2 = g.H / 2;
+  if (g.gpc < H2) {
+    for (int c = g.gpc; c >= (g.gpc * 3 + 3) / 4 && c >= 1; --c)
+      if (H2 % c == 0) { g.gpc = c; break; }
+  } else {
+    g.gpc = (g.gpc / H2) * H2;
+  }
+  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kTwLdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(conv_taph_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(512), kTwLdsBytes, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
 }
 
 int launch_conv_tap(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
@@ -2206,7 +2461,7 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
   const size_t generic = taps * (a > b ? a : b);
-  return generic > (size_t)kTapPackedElems ? generic : (size_t)kTapPackedElems;
+  return generic > (size_t)kTwPackedElems ? generic : (size_t)kTwPackedElems;
 }
 
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
@@ -2215,6 +2470,11 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   if (conv_thin_applicable(d, mode)) {       // <= 4 output channels: LDS-resident [tap][n][k] table (conv_thin_kernel)
     hipLaunchKernelGGL(pack_thin_kernel, dim3(cdiv(27 * kThinNP * 32, 256)), dim3(256), 0, as_stream(stream), w_src,
                        w_packed, d->Cout, d->Cin, mode);
+    return ssbev_launch_status();
+  }
+  if (conv_taph_applicable(d, mode)) {       // Winograd-along-h variant of the tap kernel: U = G w per (kd, kw)
+    hipLaunchKernelGGL(pack_taph_kernel, dim3(cdiv(kTwPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed,
+                       d->Cout, d->Cin, mode);
     return ssbev_launch_status();
   }
   if (conv_tap_applicable(d, mode)) {        // register-resident tap-split layout (see conv_tap_kernel)
@@ -2241,6 +2501,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
+  if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
   g.B = d->B; g.Cin = d->Cin; g.Cout = d->Cout; g.CinPad = pad8(d->Cin); g.CoutPad = pad32(d->Cout);
@@ -2257,6 +2518,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
+  if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin
   g.B = d->B; g.Cin = d->Cout; g.Cout = d->Cin; g.CinPad = pad8(d->Cout); g.CoutPad = pad32(d->Cin);

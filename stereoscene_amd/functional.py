@@ -325,7 +325,7 @@ def _triple(v, n):
     return v if len(v) == n else (v[0],) * n
 
 
-TILE_HINT = 0   # tuning hook (tools/probe_conv.py): forwarded to ssbev_conv_dims.tile_hint
+TILE_HINT = int(os.environ.get("SSBEV_TILE_HINT", "0"))   # tuning hook (tools/probe_conv.py, A/B runs): forwarded to ssbev_conv_dims.tile_hint
 
 
 def _conv_dims(xshape_cl, wshape, stride, padding, dilation, transposed, output_padding, relu=0, accumulate=0):

@@ -449,11 +449,15 @@ def test_deform_conv_hip_sampling_matches_tensor_op_formulation(cfg):
 @pytest.mark.parametrize("case", [(1, 32, 32, 5, 6, 40, True), (2, 4, 32, 4, 5, 33, False), (1, 32, 1, 3, 7, 64, True),
                                   (1, 32, 20, 6, 9, 96, False), (1, 2, 32, 4, 4, 32, True), (1, 32, 32, 9, 3, 160, False),
                                   (1, 32, 4, 4, 6, 70, True), (2, 20, 3, 4, 5, 33, False), (1, 16, 2, 3, 4, 32, True),
-                                  (1, 4, 24, 5, 4, 45, False)])
-def test_conv_tap_split_lds_kernel(case):
-    """The register-weights / LDS-rows kernel of the <= 32-channel 3x3x3 layers (forced with tile hint 9) against ATen,
-    forward and data gradient; the weight gradient of the same call runs on its usual kernels.  Cases with <= 4 channels
-    on the output side of a pass take the thin VALU kernels (conv_thin_kernel / wgrad_thin_kernel) instead."""
+                                  (1, 4, 24, 5, 4, 45, False), (2, 32, 32, 4, 8, 40, True), (1, 24, 32, 3, 12, 33, False),
+                                  (1, 32, 20, 2, 2, 64, True)])
+@pytest.mark.parametrize("hint", [9, 6])
+def test_conv_tap_split_lds_kernel(case, hint):
+    """The register-weights / LDS-rows kernels of the <= 32-channel 3x3x3 layers (forced with a tile hint) against ATen,
+    forward and data gradient; the weight gradient of the same call runs on its usual kernels.  Hint 9: the library's
+    choice -- conv_taph_kernel (Winograd F(2,3) along h inside the tap walk) when H is even, conv_tap_kernel otherwise;
+    hint 6: always conv_tap_kernel.  Cases with <= 4 channels on the output side of a pass take the thin VALU kernels
+    (conv_thin_kernel / wgrad_thin_kernel) instead."""
     B, Cin, Cout, D, H, W, has_bias = case
     x = S.hash_normal(f"tap/x{case}", (B, Cin, D, H, W))
     w = S.hash_uniform(f"tap/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
@@ -462,7 +466,7 @@ def test_conv_tap_split_lds_kernel(case):
     want = TF.conv3d(xc, wc, b, 1, 1)
     go = S.hash_normal(f"tap/go{case}", tuple(want.shape))
     want.backward(go)
-    F.TILE_HINT = 9
+    F.TILE_HINT = hint
     try:
         xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
         got = F.conv3d(xg, wg, b.to(DEV) if has_bias else None, 1, 1)

@@ -1,0 +1,26 @@
+"""GPU probe: conv_taph_kernel (F(2,3) along h) against conv_tap_kernel (tile hint 6) on the 32 -> 32 cost-volume layer."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stereoscene_amd import functional as F
+
+D, H, W = 192, 48, 160
+x = torch.randn(1, 32, D, H, W, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+w = torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.03
+ref = None
+for hint in (6, 0, 6, 0):
+    F.TILE_HINT = hint
+    with torch.no_grad():
+        y = F.conv3d(x, w, None, 1, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            y = F.conv3d(x, w, None, 1, 1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+    if ref is None:
+        ref = y
+    fl = 2.0 * D * H * W * 27 * 32 * 32
+    print(f"hint {hint}: {dt * 1e3:.3f} ms  {fl / dt / 1e12:.1f} TF/s (operator)  maxdiff {(y - ref).abs().max().item():.2e} "
+          f"of {ref.abs().max().item():.2f}")
+F.TILE_HINT = 0
