@@ -1085,7 +1085,7 @@ struct WgradLdsGeom {
 constexpr int kWgLdsMaxX = 8, kWgLdsMaxG = 4;    // global->LDS wave instructions (Q rows, P rows) per wave and step
 __device__ const float kWgZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int MQB, int MPB, int KDB, int KSPLIT, int S>
+template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false>
 __global__ void __launch_bounds__(64 * MQB * MPB * KDB * KSPLIT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, float* __restrict__ ws, WgradLdsGeom g) {
   constexpr int NW = MQB * MPB * KDB * KSPLIT, CQ = 32 * MQB, CP = 32 * MPB, MAXX = kWgLdsMaxX, MAXG = kWgLdsMaxG;
@@ -1162,9 +1162,13 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
     gmeta[n] = __builtin_amdgcn_readfirstlane(meta);
   }
 
-  f32x16 acc[3][3];
+  // WINO (stride 1, even RG): F(2,3) along h over PAIRS of P rows -- per k-step 4 x 3 products V_f (from four Q rows)
+  // x Z_f (from two P rows) instead of 2 x 9, accumulated per frequency; the epilogue applies G^T (see conv_taph_kernel)
+  static_assert(!WINO || S == 1, "the Winograd variant is stride 1");
+  constexpr int NF = WINO ? 4 : 3;
+  f32x16 acc[NF][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NF; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -1232,6 +1236,50 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
       const float* gyb = gl + cur * g.RG * grow_f + e * 32 + li + (lk + 2 * ks0) * CP;
       const float* xb = xl + z * xplane_f + a * 32 + li + (lk + 2 * ks0) * S * CQ;
       int s0 = (S * h0) % g.nslot;
+      if constexpr (WINO) {
+        for (int rr = 0; rr < g.RG; rr += 2) {
+          int s1 = s0 + 1; if (s1 >= g.nslot) s1 -= g.nslot;
+          int s2 = s1 + 1; if (s2 >= g.nslot) s2 -= g.nslot;
+          int s3 = s2 + 1; if (s3 >= g.nslot) s3 -= g.nslot;
+          const float* q0 = xb + s0 * xrow_f;
+          const float* q1 = xb + s1 * xrow_f;
+          const float* q2 = xb + s2 * xrow_f;
+          const float* q3 = xb + s3 * xrow_f;
+          const float* pg0 = gyb + rr * grow_f;
+          const float* pg1 = pg0 + grow_f;
+          float c[4];
+          {
+            const float x0 = q0[0], x1 = q1[0], x2 = q2[0], x3 = q3[0];
+            c[0] = x0 - x2; c[1] = x1 + x2; c[2] = x2 - x1; c[3] = x1 - x3;
+          }
+          float n1[4] = {q0[CQ], q1[CQ], q2[CQ], q3[CQ]};
+          float n2[4] = {q0[2 * CQ], q1[2 * CQ], q2[2 * CQ], q3[2 * CQ]};
+          float g0 = pg0[0], g1 = pg1[0];
+          for (int ks = 0; ks < nks; ++ks) {
+            const float v1[4] = {n1[0] - n1[2], n1[1] + n1[2], n1[2] - n1[1], n1[1] - n1[3]};
+            const float v2[4] = {n2[0] - n2[2], n2[1] + n2[2], n2[2] - n2[1], n2[1] - n2[3]};
+            const float z[4] = {g0, g0 + g1, g0 - g1, -g1};
+            acc[0][0] = mfma32(c[0], z[0], acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            n1[0] = q0[3 * CQ]; n1[1] = q1[3 * CQ]; n1[2] = q2[3 * CQ]; n1[3] = q3[3 * CQ];
+            n2[0] = q0[4 * CQ]; n2[1] = q1[4 * CQ]; n2[2] = q2[4 * CQ]; n2[3] = q3[4 * CQ];
+            g0 = pg0[2 * CP]; g1 = pg1[2 * CP];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 1; f < 4; ++f) acc[f][0] = mfma32(c[f], z[f], acc[f][0]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f][1] = mfma32(v1[f], z[f], acc[f][1]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f][2] = mfma32(v2[f], z[f], acc[f][2]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) c[f] = v2[f];
+            q0 += 2 * CQ; q1 += 2 * CQ; q2 += 2 * CQ; q3 += 2 * CQ; pg0 += 2 * CP; pg1 += 2 * CP;
+          }
+          s0 += 2;
+          if (s0 >= g.nslot) s0 -= g.nslot;
+        }
+      } else
       for (int rr = 0; rr < g.RG; ++rr) {
         int s1 = s0 + 1; if (s1 >= g.nslot) s1 -= g.nslot;
         int s2 = s1 + 1; if (s2 >= g.nslot) s2 -= g.nslot;
@@ -1352,7 +1400,14 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = qt * CQ + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = acc[i][j][r];
+          float v;
+          if constexpr (WINO) {      // gw = G^T dU along kh
+            const float hs = 0.5f * (acc[1][j][r] + acc[2][j][r]);
+            v = i == 0 ? acc[0][j][r] + hs : i == 1 ? 0.5f * (acc[1][j][r] - acc[2][j][r]) : hs + acc[NF - 1][j][r];
+          } else {
+            v = acc[i][j][r];
+          }
+          if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = v;
         }
       }
   }
@@ -1418,6 +1473,9 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   p.ksplit = p.cfg == 1 ? 4 : (p.cfg == 2 ? 2 : 1);
   const long tiles = (long)cdiv(g.Cq, CQ) * cdiv(g.Cp, CP) * (g.kd / KDB);
   double best = 1e30;
+  // cfg 1 has a Winograd-along-h variant that needs whole row pairs per step (even RG, 2/3 of the MFMAs): first look
+  // for such a plan, then for any
+  for (int pass = 0; pass < 2 && !p.ok; ++pass)
   for (int Wseg = 4 * p.ksplit; Wseg <= g.Wp && Wseg <= 80; Wseg += 4 * p.ksplit) {
     if (g.Wp % Wseg) continue;
     const int ncol = S * Wseg + 2;
@@ -1434,6 +1492,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
     while (RG > 1 && (!fits(RG) || lds_of(RG) > kWgLdsMaxBytes)) RG /= 2;
     const size_t lds = lds_of(RG);
     if (!fits(RG) || lds > kWgLdsMaxBytes || g.Hp % RG) continue;
+    if (pass == 0 && p.cfg == 1 && RG % 2 != 0) continue;
     const int nseg = g.Wp / Wseg, nrg = g.Hp / RG;
     const long NG = (long)g.B * g.Dp * nrg;
     const long resident = 512;                       // two workgroups per CU
@@ -1461,10 +1520,10 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   return p;
 }
 
-template <int MQB, int MPB, int KDB, int KSPLIT, int S>
+template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false>
 int launch_wgrad_lds(const float* P, const float* Q, float* ws, const WgradLdsPlan& p, hipStream_t st) {
   const WgradLdsGeom& g = p.g;
-  auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S>;
+  auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S, WINO>;
   dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB * KSPLIT);
   const size_t lds = p.lds_bytes + 1024;                                            // +1 KB: prefetch slack
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1480,7 +1539,9 @@ int run_wgrad_lds(const float* x, const float* gy, float* ws, const ssbev_conv_d
   const float* Q = d->transposed ? gy : x;
   switch (p.cfg) {
     case 0: return launch_wgrad_lds<2, 2, 1, 1, 1>(P, Q, ws, p, st);
-    case 1: return launch_wgrad_lds<1, 1, 1, 4, 1>(P, Q, ws, p, st);
+    case 1:   // <= 32 x 32 channels: F(2,3) along h over row pairs when the step holds whole pairs (tile_hint 6: plain)
+      if (p.g.RG % 2 == 0 && d->tile_hint != 6) return launch_wgrad_lds<1, 1, 1, 4, 1, true>(P, Q, ws, p, st);
+      return launch_wgrad_lds<1, 1, 1, 4, 1>(P, Q, ws, p, st);
     case 2: return launch_wgrad_lds<1, 2, 1, 2, 2>(P, Q, ws, p, st);
     default: return launch_wgrad_lds<2, 2, 1, 1, 2>(P, Q, ws, p, st);
   }

@@ -450,7 +450,7 @@ def test_deform_conv_hip_sampling_matches_tensor_op_formulation(cfg):
                                   (1, 32, 20, 6, 9, 96, False), (1, 2, 32, 4, 4, 32, True), (1, 32, 32, 9, 3, 160, False),
                                   (1, 32, 4, 4, 6, 70, True), (2, 20, 3, 4, 5, 33, False), (1, 16, 2, 3, 4, 32, True),
                                   (1, 4, 24, 5, 4, 45, False), (2, 32, 32, 4, 8, 40, True), (1, 24, 32, 3, 12, 33, False),
-                                  (1, 32, 20, 2, 2, 64, True)])
+                                  (1, 32, 20, 2, 2, 64, True), (1, 32, 32, 3, 8, 64, False), (2, 28, 32, 2, 12, 32, True)])
 @pytest.mark.parametrize("hint", [9, 6])
 def test_conv_tap_split_lds_kernel(case, hint):
     """The register-weights / LDS-rows kernels of the <= 32-channel 3x3x3 layers (forced with a tile hint) against ATen,

@@ -24,3 +24,24 @@ for hint in (6, 0, 6, 0):
     print(f"hint {hint}: {dt * 1e3:.3f} ms  {fl / dt / 1e12:.1f} TF/s (operator)  maxdiff {(y - ref).abs().max().item():.2e} "
           f"of {ref.abs().max().item():.2f}")
 F.TILE_HINT = 0
+
+# weight gradient of the same layer: wgrad_lds_kernel<..., WINO> against the plain variant (tile hint 6)
+xg = x.detach()
+wq = w.clone().requires_grad_(True)
+go = torch.randn(1, 32, D, H, W, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+gref = None
+for hint in (6, 0, 6, 0):
+    F.TILE_HINT = hint
+    def run():
+        wq.grad = None
+        F.conv3d(xg, wq, None, 1, 1).backward(go)
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    if gref is None:
+        gref = wq.grad.clone()
+    print(f"fwd+wgrad hint {hint}: {dt * 1e3:.3f} ms  maxdiff {(wq.grad - gref).abs().max().item():.2e} of {gref.abs().max().item():.1f}")
+F.TILE_HINT = 0
