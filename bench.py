@@ -139,7 +139,7 @@ def main():
         step()
     # HIP events around every launch of the dominant kernel family (two event records per launch cost ~10 us of
     # queue time: timing every family as tools/layer_table.py does adds 2.5 ms to a step)
-    fams = {"conv_gather", "conv_winograd"}
+    fams = {"conv_gather", "conv_winograd", "conv_tap_h"}
     if os.environ.get("SSBEV_TIME_WGRAD"):
         fams |= {"conv_wgrad", "conv_winograd_wgrad"}
     timer = F.KernelTimer(families=fams)
@@ -178,9 +178,12 @@ def main():
     if rank == 0:
         ks = timer.summary()
         zero = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
-        g, wino = ks.get("conv_gather", zero), ks.get("conv_winograd", zero)
-        fam_flops, fam_ms, fam_n = g["flops"] + wino["flops"], g["ms"] + wino["ms"], g["launches"] + wino["launches"]
-        executed = g["flops"] + wino["bytes"]       # Winograd spans carry their executed GEMM FLOPs (F(2x4x4): /6, F(2,3)^3: /3.375, F(2,3)^2: /2.25)
+        g, wino, taph = ks.get("conv_gather", zero), ks.get("conv_winograd", zero), ks.get("conv_tap_h", zero)
+        fam_flops = g["flops"] + wino["flops"] + taph["flops"]
+        fam_ms, fam_n = g["ms"] + wino["ms"] + taph["ms"], g["launches"] + wino["launches"] + taph["launches"]
+        # Winograd spans carry their executed GEMM FLOPs (F(2x4x4): /6, F(2,3)^3: /3.375, F(2,3)^2: /2.25); conv_taph_kernel
+        # (F(2,3) along h inside the direct kernel) executes 2/3 of the operator's multiply-adds
+        executed = g["flops"] + wino["bytes"] + taph["flops"] / 1.5
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_n else 0.0
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "r1v_pmc_traffic.json")
@@ -194,13 +197,14 @@ def main():
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roof = {"bound": "mfma",
                 "kernel": "convolution forward + data gradient, every launch of the step: direct MFMA kernels (conv_gather_kernel"
-                          "<MT,NT,QU>, conv_tap_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 / 3x3 "
+                          "<MT,NT,QU>, conv_tap_kernel / conv_taph_kernel; v_mfma_f32_32x32x2_f32 implicit GEMM) and, for the wide stride-1 3x3x3 / 3x3 "
                           "layers, Winograd pipelines (wino43_input_kernel -> 144 batched fp32 GEMMs -> wino43_output_kernel with "
                           "F(2x4x4,3x3x3) tiles; F(2,3)^2 with 16 GEMMs for the 2-D layers).  Layers that are plain GEMMs in the "
                           "channels-last layout (pointwise convs with >= 512 input channels, kernel == stride deconvs) run on "
                           "rocBLAS and are not part of this family",
                 "flop_convention": "achieved counts direct-convolution FLOPs (2*voxels*Cin*Cout*taps: what the operator computes, "
-                                   "SURVEY 8(d)); the Winograd launches execute 6x (3-D, F(2x4x4)) / 2.25x (2-D, F(2x2)) fewer multiply-adds, see frac_executed",
+                                   "SURVEY 8(d)); the Winograd launches execute 6x (3-D, F(2x4x4)) / 2.25x (2-D, F(2x2)) fewer multiply-adds and "
+                                   "conv_taph_kernel (<= 32-channel 3x3x3 layers, F(2,3) along h in-kernel) 1.5x fewer, see frac_executed",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "peak_source": "fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md" if args.precision == "fp32" else
                                "dense bf16 MFMA, MI355X_MICROARCH.md (bf16 mode: operands rounded to bf16, fp32 storage keeps the "
@@ -208,7 +212,7 @@ def main():
                 "frac": achieved / peak,
                 "frac_executed": executed / (fam_ms * 1e-3) / 1e12 / peak if fam_n else 0.0,
                 "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": g.get("bytes", 0.0) / max(g["launches"], 1),
+                "algorithmic_bytes_per_launch": (g.get("bytes", 0.0) + taph.get("bytes", 0.0)) / max(g["launches"] + taph["launches"], 1),
                 "algorithmic_gflop_per_launch": fam_flops / 1e9 / max(fam_n, 1),
                 "avg_launch_ms": fam_ms / max(fam_n, 1),
                 "launches_per_step": fam_n / max(args.steps, 1),
@@ -216,13 +220,16 @@ def main():
                 "ms_per_step_in_kernel": fam_ms / max(args.steps, 1),
                 "direct": {"launches_per_step": g["launches"] / args.steps, "ms_per_step": g["ms"] / args.steps,
                            "gflop_per_step": g["flops"] / 1e9 / args.steps, "tflops": tf(g)},
+                "direct_winograd_h": {"launches_per_step": taph["launches"] / args.steps, "ms_per_step": taph["ms"] / args.steps,
+                                      "direct_conv_gflop_per_step": taph["flops"] / 1e9 / args.steps,
+                                      "effective_tflops": tf(taph), "executed_tflops": tf(taph) / 1.5},
                 "winograd": {"launches_per_step": wino["launches"] / args.steps, "ms_per_step": wino["ms"] / args.steps,
                              "direct_conv_gflop_per_step": wino["flops"] / 1e9 / args.steps,
                              "executed_gemm_gflop_per_step": wino["bytes"] / 1e9 / args.steps,
                              "effective_tflops": tf(wino),
                              "executed_tflops": wino["bytes"] / (wino["ms"] * 1e-3) / 1e12 if wino["ms"] > 0 else 0.0},
                 "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": tf(v)}
-                                  for k, v in ks.items() if k not in ("conv_gather", "conv_winograd")}}
+                                  for k, v in ks.items() if k not in ("conv_gather", "conv_winograd", "conv_tap_h")}}
         out = {"metric": "voxels/sec fwd+bwd, 256x256x32 grid D=192" if args.config == "kitti_d192" else
                f"voxels/sec fwd+bwd ({args.config})",
                "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -136,6 +136,10 @@ typedef struct {
 /* weight packing: src is the torch layout  conv: [Cout,Cin,kd,kh,kw]  deconv: [Cin,Cout,kd,kh,kw]
  * mode 0: forward operand;  mode 1: operand of the data-gradient (channels swapped, taps flipped) */
 size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d);
+/* which kernel family ssbev_conv_fwd (mode 0) / ssbev_conv_bwd_data (mode 1) dispatches this problem to -- for FLOP
+ * accounting in profilers (bench.py): 0 = generic gather kernels, 1 = conv_tap_kernel, 2 = conv_taph_kernel (Winograd
+ * F(2,3) along h inside the kernel: executes 2/3 of the operator's multiply-adds), 3 = conv_thin_kernel; < 0 = error */
+int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode);
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream);
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ssbev_gwc_warp_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(GwcDims), _P]),
     "ssbev_gwc_warp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P]),
     "ssbev_conv_packed_weight_elems": (C.c_size_t, [C.POINTER(ConvDims)]),
+    "ssbev_conv_kernel_class": (C.c_int, [C.POINTER(ConvDims), C.c_int]),
     "ssbev_conv_pack_weight": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),
     "ssbev_conv_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), _P]),
     "ssbev_conv_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),

@@ -2516,6 +2516,14 @@ void launch_wgrad(const float* P, const float* Qt, float* ws, const WgradGeom& g
 
 extern "C" {
 
+int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
+  if (!conv_dims_ok(d) || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (conv_thin_applicable(d, mode)) return 3;
+  if (conv_taph_applicable(d, mode)) return 2;
+  if (conv_tap_applicable(d, mode)) return 1;
+  return 0;
+}
+
 size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
   // big enough for either role assignment (forward or data-gradient operand)

@@ -93,6 +93,14 @@ def _conv_tag(d, role):
             f"k{d.kd}{d.kh}{d.kw} s{d.sd}{d.sh}{d.sw} d{d.dd}{d.dh}{d.dw}")
 
 
+def _conv_family(lib, d, mode):
+    """Span family of a direct conv launch: the <= 32-channel layers on conv_taph_kernel execute 2/3 of the operator's
+    multiply-adds (F(2,3) along h), which bench.py's executed-FLOP figure accounts for."""
+    if KERNEL_TIMER is None:
+        return "conv_gather"
+    return "conv_tap_h" if lib.ssbev_conv_kernel_class(C.byref(d), mode) == 2 else "conv_gather"
+
+
 def conv_bytes(d):
     """Algorithmic bytes of one conv problem: every input, weight and output element touched once."""
     taps = d.kd * d.kh * d.kw
@@ -370,7 +378,7 @@ class _ConvNd(torch.autograd.Function):
         wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
-        with _span("conv_gather", conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd")):
+        with _span(_conv_family(lib, d, 0), conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd")):
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
                                           capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
@@ -396,7 +404,7 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _packed(w5, d, 1)
             gxcl = torch.empty_like(xcl)
-            with _span("conv_gather", conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad")):
+            with _span(_conv_family(lib, d, 1), conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad")):
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
                                                    capi.stream()), "ssbev_conv_bwd_data")
             if kpad:

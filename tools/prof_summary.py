@@ -5,7 +5,7 @@ import re
 import sys
 
 FAMILIES = [
-    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_thin_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_thin_kernel"),
+    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_thin_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_thin_kernel"),
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
     ("rocBLAS / hipBLASLt GEMMs (Cijk_*: Winograd frequency GEMMs, BRI products, image-branch pointwise convs)", r"Cijk_"),
     ("weight gradient, direct (wgrad_lds/wgrad_thin/wgrad_1x1/wgrad_cf/wgrad_kernel + reduce)", r"wgrad"),
