@@ -2367,23 +2367,22 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
   g.NG = g.B * g.D * (g.H / 2);              // row pairs
   g.relu = mode == 0 ? d->relu : 0;
   g.has_bias = (mode == 0 && bias) ? 1 : 0;
-  // one 512-thread workgroup per CU (141 KB of LDS); whole rounds of 256 workgroups, >= 12 row pairs each
-  long nranges = 256 / g.nseg;
-  for (long rounds = 8; rounds >= 1; --rounds) {
-    const long nr = (256 * rounds) / g.nseg;
-    if ((g.NG + nr - 1) / nr >= 12) { nranges = nr; break; }
-  }
-  if (nranges < 1) nranges = 1;
-  g.gpc = (int)((g.NG + nranges - 1) / nranges);
-  // a chunk that crosses a depth plane restages its whole ring (4 rows x 3 planes, latency exposed): prefer a chunk
-  // length that divides the pairs of a plane
+  // One 512-thread workgroup per CU (141 KB of LDS).  Chunk length (row pairs per workgroup) by a small cost model fitted on
+  // the 192 x 48 x 160 layer (tools/taph_gpc_probe.py): whole rounds of 256 workgroups matter most (the last round's idle
+  // CUs: 12 pairs -> 7.5 rounds 0.580 ms, 18 pairs -> 5.0 rounds 0.537 ms), then the start-up of a chunk (weights + first
+  // four rows, ~0.6 pair) and the ring restage at every depth-plane crossing (~0.3 pair)
   const int H2 = g.H / 2;
-  if (g.gpc < H2) {
-    for (int c = g.gpc; c >= (g.gpc * 3 + 3) / 4 && c >= 1; --c)
-      if (H2 % c == 0) { g.gpc = c; break; }
-  } else {
-    g.gpc = (g.gpc / H2) * H2;
+  double best = 1e30;
+  g.gpc = 1;
+  for (int c = 1; c <= g.NG && c <= 96; ++c) {
+    const long blocks = (long)((g.NG + c - 1) / c) * g.nseg;
+    const long rounds = (blocks + 255) / 256;
+    const double crossings = H2 % c == 0 ? 0.0 : (c % H2 == 0 ? c / H2 - 1 : (double)c / H2);
+    const double cost = rounds * (c + 0.6 + 0.3 * crossings);
+    if (cost < best) { best = cost; g.gpc = c; }
   }
+  long nranges;
+  if (const char* e = getenv("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kTwLdsBytes) != hipSuccess)
