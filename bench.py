@@ -186,13 +186,13 @@ def main():
         executed = g["flops"] + wino["bytes"] + taph["flops"] / 1.5
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_n else 0.0
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r1v_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r1y_pmc_traffic.json")
         if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
             # command (committed summary; PMC collection cannot run inside the timed process)
             t = json.load(open(tfile))["kernels"].get("conv_fwd_dgrad")
             if t:
-                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1v_pmc_traffic.json"
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r1y_pmc_traffic.json"
         tf = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0      # noqa: E731
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roof = {"bound": "mfma",

@@ -7,9 +7,9 @@ streaming kernels of this path (gwc_warp_fwd writes 188.7 MB, pool_gather 134.2 
 it is doubled."""
 import collections, csv, json, sys
 
-FAMILIES = [("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_thin_kernel")),
+FAMILIES = [("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
-            ("conv_tap_kernel", ("conv_tap_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
+            ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
             ("gwc_warp_fwd", ("gwc_warp_fwd_kernel",)), ("pool_gather", ("pool_gather_kernel",)),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
             ("wino_input_kernel", ("wino_input_kernel", "wino43_input_kernel")),
