@@ -1478,6 +1478,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   for (int pass = 0; pass < 2 && !p.ok; ++pass)
   for (int Wseg = 4 * p.ksplit; Wseg <= g.Wp && Wseg <= 80; Wseg += 4 * p.ksplit) {
     if (g.Wp % Wseg) continue;
+    if (const char* e = getenv("SSBEV_WGL_WSEG")) { if (atoi(e) > 0 && atoi(e) != Wseg) continue; }   // tuning hook
     const int ncol = S * Wseg + 2;
     // rows per step: aim at >= 16 MFMA k-steps per wave and barrier, within the staging lists and LDS
     int RG = 1;
@@ -1517,6 +1518,9 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
       }
     }
   }
+  if (getenv("SSBEV_WGL_DEBUG") && p.ok)
+    fprintf(stderr, "wgrad_lds plan: cfg %d Cq %d Cp %d grid %dx%dx%d -> Wseg %d RG %d nslot %d gpc %d nranges %d nchunks %d lds %zu\n",
+            p.cfg, g.Cq, g.Cp, g.Dp, g.Hp, g.Wp, g.Wseg, g.RG, g.nslot, g.gpc, g.nranges, p.nchunks, p.lds_bytes);
   return p;
 }
 
