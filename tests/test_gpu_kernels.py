@@ -478,6 +478,31 @@ def test_conv_tap_split_lds_kernel(case, hint):
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
 
 
+def test_conv_tap_winograd_h_full_size_agrees_with_plain_tap_kernels():
+    """BASELINE-size check of the in-kernel F(2,3)-along-h kernels (conv_taph_kernel, wgrad_lds_kernel<..., WINO>): the
+    32 -> 32 cost-volume layer at 192 x 48 x 160 (kitti_d192, too large for the CPU reference in a test) against the plain
+    tap kernels (tile hint 6, themselves pinned to ATen at small sizes above) -- forward, data gradient, weight gradient."""
+    D, H, W = 192, 48, 160
+    x = S.hash_normal("taph/x", (1, 32, D, H, W)).to(DEV)
+    w = (S.hash_uniform("taph/w", (32, 32, 3, 3, 3), -1, 1) * (3.0 / (32 * 27)) ** 0.5).to(DEV)
+    b = S.hash_uniform("taph/b", (32,), -0.5, 0.5).to(DEV)
+    go = S.hash_normal("taph/go", (1, 32, D, H, W)).to(DEV)
+    res = []
+    for hint in (6, 0):
+        F.TILE_HINT = hint
+        try:
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = F.conv3d(xg, wg, b, 1, 1)
+            y.backward(go)
+            res.append((y.detach(), xg.grad, wg.grad))
+        finally:
+            F.TILE_HINT = 0
+    for a, r, tol in zip(res[1], res[0], (2e-5, 2e-5, 5e-5)):
+        assert torch.isfinite(a).all()
+        assert maxdiff(a, r) < tol * max(1.0, r.abs().max().item())
+    assert maxdiff(res[1][0], res[0][0]) > 0.0          # the two paths really are different kernels
+
+
 @pytest.mark.parametrize("hint", [154, 144, 314, 264, 234, 164, 134, 152, 261])
 def test_conv_wide_and_odd_register_tilings(hint):
     """The <1,5> (software-pipelined), <2,6>, <2,3>, <1,6>, <1,3>, <1,4>, <3,1> tilings forced through the tile hint on a
