@@ -1,5 +1,7 @@
+"""GPU probe: conv_taph_kernel on the 32 -> 32 cost-volume layer; SSBEV_TAPH_GPC overrides the chunk length (row pairs per
+workgroup) that launch_conv_taph's cost model would pick."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stereoscene_amd import functional as F
 D, H, W = 192, 48, 160
