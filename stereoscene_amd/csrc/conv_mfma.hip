@@ -1085,7 +1085,7 @@ struct WgradLdsGeom {
 constexpr int kWgLdsMaxX = 8, kWgLdsMaxG = 4;    // global->LDS wave instructions (Q rows, P rows) per wave and step
 __device__ const float kWgZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false>
+template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false, int NKS = 0>
 __global__ void __launch_bounds__(64 * MQB * MPB * KDB * KSPLIT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, float* __restrict__ ws, WgradLdsGeom g) {
   constexpr int NW = MQB * MPB * KDB * KSPLIT, CQ = 32 * MQB, CP = 32 * MPB, MAXX = kWgLdsMaxX, MAXG = kWgLdsMaxG;
@@ -1255,15 +1255,17 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
           float n1[4] = {q0[CQ], q1[CQ], q2[CQ], q3[CQ]};
           float n2[4] = {q0[2 * CQ], q1[2 * CQ], q2[2 * CQ], q3[2 * CQ]};
           float g0 = pg0[0], g1 = pg1[0];
-          for (int ks = 0; ks < nks; ++ks) {
+          // NKS > 0: compile-time trip count (Wseg / 2 / KSPLIT), fully unrolled -- LDS offsets become immediates
+          auto kstep = [&](int ks) {
             const float v1[4] = {n1[0] - n1[2], n1[1] + n1[2], n1[2] - n1[1], n1[1] - n1[3]};
             const float v2[4] = {n2[0] - n2[2], n2[1] + n2[2], n2[2] - n2[1], n2[1] - n2[3]};
             const float z[4] = {g0, g0 + g1, g0 - g1, -g1};
             acc[0][0] = mfma32(c[0], z[0], acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
-            n1[0] = q0[3 * CQ]; n1[1] = q1[3 * CQ]; n1[2] = q2[3 * CQ]; n1[3] = q3[3 * CQ];
-            n2[0] = q0[4 * CQ]; n2[1] = q1[4 * CQ]; n2[2] = q2[4 * CQ]; n2[3] = q3[4 * CQ];
-            g0 = pg0[2 * CP]; g1 = pg1[2 * CP];
+            const int oq = 2 * ks * CQ, op = 2 * ks * CP;
+            n1[0] = q0[oq + 3 * CQ]; n1[1] = q1[oq + 3 * CQ]; n1[2] = q2[oq + 3 * CQ]; n1[3] = q3[oq + 3 * CQ];
+            n2[0] = q0[oq + 4 * CQ]; n2[1] = q1[oq + 4 * CQ]; n2[2] = q2[oq + 4 * CQ]; n2[3] = q3[oq + 4 * CQ];
+            g0 = pg0[op + 2 * CP]; g1 = pg1[op + 2 * CP];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 1; f < 4; ++f) acc[f][0] = mfma32(c[f], z[f], acc[f][0]);
@@ -1274,7 +1276,12 @@ wgrad_lds_kernel(const float* __restrict__ Pg, const float* __restrict__ Qg, flo
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < 4; ++f) c[f] = v2[f];
-            q0 += 2 * CQ; q1 += 2 * CQ; q2 += 2 * CQ; q3 += 2 * CQ; pg0 += 2 * CP; pg1 += 2 * CP;
+          };
+          if constexpr (NKS > 0) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) kstep(ks);
+          } else {
+            for (int ks = 0; ks < nks; ++ks) kstep(ks);
           }
           s0 += 2;
           if (s0 >= g.nslot) s0 -= g.nslot;
@@ -1524,10 +1531,10 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   return p;
 }
 
-template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false>
+template <int MQB, int MPB, int KDB, int KSPLIT, int S, bool WINO = false, int NKS = 0>
 int launch_wgrad_lds(const float* P, const float* Q, float* ws, const WgradLdsPlan& p, hipStream_t st) {
   const WgradLdsGeom& g = p.g;
-  auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S, WINO>;
+  auto kern = wgrad_lds_kernel<MQB, MPB, KDB, KSPLIT, S, WINO, NKS>;
   dim3 grid(p.nchunks, cdiv(g.Cq, 32 * MQB) * cdiv(g.Cp, 32 * MPB), g.kd / KDB), block(64 * MQB * MPB * KDB * KSPLIT);
   const size_t lds = p.lds_bytes + 1024;                                            // +1 KB: prefetch slack
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1543,8 +1550,11 @@ int run_wgrad_lds(const float* x, const float* gy, float* ws, const ssbev_conv_d
   const float* Q = d->transposed ? gy : x;
   switch (p.cfg) {
     case 0: return launch_wgrad_lds<2, 2, 1, 1, 1>(P, Q, ws, p, st);
-    case 1:   // <= 32 x 32 channels: F(2,3) along h over row pairs when the step holds whole pairs (tile_hint 6: plain)
-      if (p.g.RG % 2 == 0 && d->tile_hint != 6) return launch_wgrad_lds<1, 1, 1, 4, 1, true>(P, Q, ws, p, st);
+    case 1:   // <= 32 x 32 channels: F(2,3) along h over row pairs when the step holds whole pairs (tile_hint 6: plain; 5: run-time k-step count instead of the unrolled NKS = 4 instance)
+      if (p.g.RG % 2 == 0 && d->tile_hint != 6) {
+        if (p.g.Wseg == 32 && d->tile_hint != 5) return launch_wgrad_lds<1, 1, 1, 4, 1, true, 4>(P, Q, ws, p, st);
+        return launch_wgrad_lds<1, 1, 1, 4, 1, true>(P, Q, ws, p, st);
+      }
       return launch_wgrad_lds<1, 1, 1, 4, 1>(P, Q, ws, p, st);
     case 2: return launch_wgrad_lds<1, 2, 1, 2, 2>(P, Q, ws, p, st);
     default: return launch_wgrad_lds<2, 2, 1, 1, 2>(P, Q, ws, p, st);

@@ -488,7 +488,7 @@ def test_conv_tap_winograd_h_full_size_agrees_with_plain_tap_kernels():
     b = S.hash_uniform("taph/b", (32,), -0.5, 0.5).to(DEV)
     go = S.hash_normal("taph/go", (1, 32, D, H, W)).to(DEV)
     res = []
-    for hint in (6, 0):
+    for hint in (6, 0, 5):          # 5: the weight-gradient variant with a run-time k-step count
         F.TILE_HINT = hint
         try:
             xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -497,9 +497,10 @@ def test_conv_tap_winograd_h_full_size_agrees_with_plain_tap_kernels():
             res.append((y.detach(), xg.grad, wg.grad))
         finally:
             F.TILE_HINT = 0
-    for a, r, tol in zip(res[1], res[0], (2e-5, 2e-5, 5e-5)):
-        assert torch.isfinite(a).all()
-        assert maxdiff(a, r) < tol * max(1.0, r.abs().max().item())
+    for got in res[1:]:
+        for a, r, tol in zip(got, res[0], (2e-5, 2e-5, 5e-5)):
+            assert torch.isfinite(a).all()
+            assert maxdiff(a, r) < tol * max(1.0, r.abs().max().item())
     assert maxdiff(res[1][0], res[0][0]) > 0.0          # the two paths really are different kernels
 
 
