@@ -1,12 +1,21 @@
 """Data-parallel gradient exchange for the hot path: one process per GPU, RCCL over xGMI
 (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests).
 
-The reference wraps the model in MMDistributedDataParallel (mmdet_train.py:75-79) = bucketed
-all-reduce(mean) of gradients overlapped with backward, broadcast_buffers=False.  This is the same
-exchange, laid out for MI355X: all gradients live in ONE flat fp32 buffer (after a step ``param.grad``
-are views into it), cut into a few large buckets in reverse-forward order; a bucket's all-reduce is
-launched from the autograd hook of its last-arriving parameter, so the exchange overlaps the remaining
-backward.  xGMI is point-to-point (7 links/GPU): few, large messages.
+The reference wraps the model in MMDistributedDataParallel (mmdet_train.py:70-79, launched by
+tools/dist_train.sh:9-19) = bucketed all-reduce(mean) of gradients overlapped with backward,
+broadcast_buffers=False.  This is the same exchange, laid out for MI355X: all gradients live in ONE flat
+fp32 buffer (after a step ``param.grad`` are views into it), cut into a few large buckets in reverse-forward
+order; a bucket's exchange is launched from the autograd hook of its last-arriving parameter, so it overlaps
+the remaining backward.  xGMI is point-to-point (7 links/GPU): few, large messages.
+
+Exchange per bucket (``exchange=``, env SSBEV_DP_EXCHANGE):
+  * "rs_ag" (default on RCCL): in-place reduce-scatter(AVG) of the bucket into this rank's
+    1/world slice, then in-place all-gather of the slices -- every GPU sends a distinct slice to each peer over
+    its own xGMI link instead of pushing the whole bucket around one ring.  Bucket boundaries are multiples of
+    ``world`` elements so the slices tile the bucket exactly.
+  * "all_reduce": one all-reduce(AVG) per bucket (what gloo runs, with SUM + a scale pass: gloo has no AVG /
+    reduce-scatter).
+The 1/world of the mean is folded into the reduction (ReduceOp.AVG); there is no separate scaling pass on RCCL.
 
 Gradients are moved into the flat buffer per BUCKET, not per parameter: during backward ``param.grad`` is
 None, so autograd simply hands over the tensor our kernels produced (no ``grad += new`` launch per
@@ -14,37 +23,55 @@ parameter -- ~300 five-microsecond kernels per step on this model); when the las
 arrived, one multi-tensor copy packs the bucket and re-points ``param.grad`` at the flat views.
 (A parameter used twice in one graph accumulates into its view after packing; with world_size > 1 such
 a parameter must not be split from its second use by a bucket boundary.  The hot path has none.)
+
+Parameters that received no gradient in a step (sub-modules switched off by an ablation mode) get a zeroed
+slice for the exchange and are listed in ``no_grad_ranges``: the fused optimizer skips those ranges, like
+torch.optim.AdamW skips ``grad is None``.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, module, bucket_mb=64, process_group=None, average=True):
+    def __init__(self, module, bucket_mb=64, process_group=None, average=True, exchange=None):
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
+        self.rank = dist.get_rank(process_group) if self.active else 0
         self.average = average
+        backend = dist.get_backend(process_group) if self.active else "none"
+        self.native_avg = backend == "nccl"                   # RCCL: AVG + reduce-scatter available
+        exchange = exchange or os.environ.get("SSBEV_DP_EXCHANGE", "rs_ag")
+        if exchange not in ("rs_ag", "all_reduce"):
+            raise ValueError(f"exchange must be 'rs_ag' or 'all_reduce', got {exchange!r}")
+        self.exchange = exchange if self.native_avg else "all_reduce"
         params = [p for p in module.parameters() if p.requires_grad]
         # gradients become ready roughly in reverse registration order (head -> ... -> stereo net)
         self.params = list(reversed(params))
-        total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         cap = max(1, int(bucket_mb * (1 << 20) // 4))
-        self.buckets, self._bucket_of, self._pending = [], {}, []
+        align = max(self.world, 1)
+        self.buckets, self._bucket_of = [], {}
+        self._offsets = {}
         off, start, count = 0, 0, 0
         for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._offsets[p] = off
             self._bucket_of[p] = len(self.buckets)
-            off += n
+            off += p.numel()
             count += 1
             if off - start >= cap:
+                off = -(-off // align) * align               # pad: the bucket splits into `world` equal slices
                 self.buckets.append((start, off, count))
                 start, count = off, 0
         if count:
+            off = -(-off // align) * align
             self.buckets.append((start, off, count))
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p in self.params:
+            o = self._offsets[p]
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
         self._views = {p: p.grad for p in self.params}
         self._members = [[] for _ in self.buckets]
         for p in self.params:
@@ -53,6 +80,8 @@ class FlatGradAllReduce:
         self._packed = [False] * len(self.buckets)
         self._seen = set()
         self._handles = []
+        self.no_grad_ranges = []          # [(start, end)] element ranges of the flat buffer without a gradient this step
+        self.bytes_exchanged = 0
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _pack(self, b):
@@ -62,6 +91,8 @@ class FlatGradAllReduce:
             view = self._views[p]
             if p.grad is None:
                 view.zero_()                       # no gradient reached this parameter in this step
+                o = self._offsets[p]
+                self.no_grad_ranges.append((o, o + p.numel()))
             elif p.grad.data_ptr() != view.data_ptr():
                 dst.append(view)
                 src.append(p.grad.detach().reshape(view.shape))
@@ -69,6 +100,22 @@ class FlatGradAllReduce:
         if dst:
             torch._foreach_copy_(dst, src)
         self._packed[b] = True
+
+    def _exchange(self, b, async_op):
+        """Launch the exchange of bucket b; returns the work handles (in issue order)."""
+        s, e, _ = self.buckets[b]
+        buf = self.flat[s:e]
+        self.bytes_exchanged += buf.numel() * 4
+        if self.exchange == "rs_ag":
+            n = (e - s) // self.world
+            mine = buf[self.rank * n:(self.rank + 1) * n]
+            op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+            h1 = dist.reduce_scatter_tensor(mine, buf, op=op, group=self.group, async_op=async_op)
+            h2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op)
+            return [h1, h2] if async_op else []
+        op = dist.ReduceOp.AVG if (self.average and self.native_avg) else dist.ReduceOp.SUM
+        h = dist.all_reduce(buf, op=op, group=self.group, async_op=async_op)
+        return [h] if async_op else []
 
     def _on_grad(self, p):
         if p in self._seen:                        # second use of a shared parameter: already counted
@@ -79,8 +126,7 @@ class FlatGradAllReduce:
         if self._arrived[b] == self.buckets[b][2]:
             self._pack(b)
             if self.active:
-                s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+                self._handles += self._exchange(b, async_op=True)
 
     def zero_grad(self):
         for p in self.params:
@@ -88,23 +134,38 @@ class FlatGradAllReduce:
         self._arrived = [0] * len(self.buckets)
         self._packed = [False] * len(self.buckets)
         self._seen.clear()
+        self.no_grad_ranges = []
+        self.bytes_exchanged = 0
 
     def finish(self):
         """Wait for the in-flight buckets (call after backward()); returns bytes exchanged per rank."""
         for h in self._handles:
             h.wait()
         # buckets with a parameter that received no gradient never completed: pack (and reduce) them now
-        for b, (s, e, c) in enumerate(self.buckets):
+        late = []
+        for b in range(len(self.buckets)):
             if not self._packed[b]:
                 self._pack(b)
                 if self.active:
-                    dist.all_reduce(self.flat[s:e], group=self.group)
-        if self.active and self.average and self.world > 1:
-            self.flat.div_(self.world)
+                    self._exchange(b, async_op=False)
+                    late.append(b)
+        if self.active and self.average and self.world > 1 and not self.native_avg:
+            self.flat.div_(self.world)             # gloo (CPU tests): SUM + scale
         self._handles = []
         self._arrived = [0] * len(self.buckets)
         self._seen.clear()
-        return self.flat.numel() * 4
+        return self.bytes_exchanged if self.active else 0
+
+    def live_ranges(self):
+        """Complement of ``no_grad_ranges`` in [0, flat.numel()): the element ranges the optimizer should update."""
+        out, pos = [], 0
+        for s, e in sorted(self.no_grad_ranges):
+            if s > pos:
+                out.append((pos, s))
+            pos = max(pos, e)
+        if pos < self.flat.numel():
+            out.append((pos, self.flat.numel()))
+        return out
 
     def remove(self):
         for h in self._hooks:

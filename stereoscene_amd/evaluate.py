@@ -14,17 +14,43 @@ CLASS_NAMES = ["unlabeled"] + KITTI_CLASS_NAMES[1:]
 
 
 @torch.no_grad()
-def evaluate(model, samples, device="cuda"):
+def evaluate(model, samples, device="cuda", dataset_len=None, sampler=None):
     """``samples`` yields dicts with ``img_inputs`` (left10, right10) and ``gt_occ`` [B,X,Y,Z].
-    Returns the reference's ``eval_results`` dict (percent, 2 decimals, + 'semkitti_combined_IoU')."""
+    Returns the reference's ``eval_results`` dict (percent, 2 decimals, + 'semkitti_combined_IoU').
+
+    Distributed evaluation: ``runner.DistributedSampler`` tiles the index list up to a multiple of the world size, so the
+    last ranks see duplicates of the first samples.  The reference drops them (``collect_results_cpu`` keeps
+    ``ordered_results[:len(dataset)]``, apis/test.py); pass the ``sampler`` (or ``dataset_len`` + the process group's
+    rank / world size) and the padded tail is skipped before the counts are accumulated.
+    The module's train / eval mode is restored on exit (the runner has no model handle to do it)."""
+    was_training = model.training
     model.eval()
+    rank, world = 0, 1
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    if sampler is not None:
+        dataset_len, rank, world = sampler.n, sampler.rank, sampler.num_replicas
+    per_rank = -(-dataset_len // world) if dataset_len is not None else None
     acc = torch.zeros(3 + 3 * len(CLASS_NAMES), dtype=torch.float64, device=device)
-    for s in samples:
-        gt = s["gt_occ"].to(device)
-        out = model.simple_test(None, s["img_inputs"], gt_occ=gt)
-        pred = out["output_voxels"].argmax(dim=1)
-        tp, fp, fn, tpc, fpc, fnc = ssc_counts(pred, gt, len(CLASS_NAMES), recompute_mask=True)
-        acc += torch.cat([torch.stack([tp, fp, fn]).double(), tpc.double(), fpc.double(), fnc.double()])
+    try:
+        seen = 0                      # samples of this rank's block consumed so far
+        for s in samples:
+            gt = s["gt_occ"].to(device)
+            out = model.simple_test(None, s["img_inputs"], gt_occ=gt)
+            pred = out["output_voxels"].argmax(dim=1)
+            nb = gt.shape[0]
+            if per_rank is not None:
+                # global position of sample i of this batch in the tiled index list = rank * per_rank + seen + i
+                keep = [i for i in range(nb) if rank * per_rank + seen + i < dataset_len]
+                seen += nb
+                if not keep:
+                    continue
+                if len(keep) < nb:
+                    pred, gt = pred[keep], gt[keep]
+            tp, fp, fn, tpc, fpc, fnc = ssc_counts(pred, gt, len(CLASS_NAMES), recompute_mask=True)
+            acc += torch.cat([torch.stack([tp, fp, fn]).double(), tpc.double(), fpc.double(), fnc.double()])
+    finally:
+        model.train(was_training)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(acc)
     return scores_from_counts(acc.cpu().numpy())
@@ -70,7 +96,7 @@ def load_checkpoint(model, path_or_state, strict=False):
     hot-path modules.  Parameter names are the reference's (tests/test_layout.py checks the key set against the
     reference-generated manifest), so this is a filtered ``load_state_dict``: keys of the image backbone / neck (outside the
     path) are reported, not loaded.  Returns (missing, unexpected_outside_path)."""
-    state = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, os.PathLike)) else path_or_state
+    state = torch.load(path_or_state, map_location="cpu", weights_only=True) if isinstance(path_or_state, (str, os.PathLike)) else path_or_state
     state = state.get("state_dict", state)
     own = model.state_dict()
     inside = {k: v for k, v in state.items() if k in own}

@@ -23,44 +23,54 @@ from . import capi
 
 
 class KernelTimer:
-    """Collects (kernel family, algorithmic flops, start event, end event) per C-ABI launch."""
+    """Collects (kernel family, algorithmic flops, algorithmic bytes, executed flops) per C-ABI launch.  Families in
+    ``families`` (None = all) are additionally bracketed by HIP events on the launch stream; the others are only
+    COUNTED (no event traffic), which is what bench.py's whole-step roofline floor needs."""
 
     def __init__(self, families=None):
         self.records = []
+        self.counts = {}              # family -> dict(launches, flops, bytes, executed): every span, timed or not
         self.families = families      # None = every instrumented family; a set restricts the event traffic
 
-    def span(self, family, flops, nbytes=0.0, tag=None):
+    def span(self, family, flops, nbytes=0.0, tag=None, executed=None):
+        c = self.counts.setdefault(family, dict(launches=0, flops=0.0, bytes=0.0, executed=0.0))
+        c["launches"] += 1
+        c["flops"] += flops
+        c["bytes"] += nbytes
+        c["executed"] += flops if executed is None else executed
         if self.families is not None and family not in self.families:
             return _NOSPAN
-        return _Span(self, family, flops, nbytes, tag)
+        return _Span(self, family, flops, nbytes, tag, flops if executed is None else executed)
 
     def by_tag(self):
         """{(family, tag): dict(launches, flops, ms)} -- the per-layer table of tools/layer_table.py."""
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, nbytes, a, b, tag in self.records:
-            d = out.setdefault((fam, tag), dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        for fam, flops, nbytes, a, b, tag, ex in self.records:
+            d = out.setdefault((fam, tag), dict(launches=0, flops=0.0, bytes=0.0, ms=0.0, executed=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
+            d["executed"] += ex
             d["ms"] += a.elapsed_time(b)
         return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, nbytes, a, b, _tag in self.records:
-            d = out.setdefault(fam, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        for fam, flops, nbytes, a, b, _tag, ex in self.records:
+            d = out.setdefault(fam, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0, executed=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
+            d["executed"] += ex
             d["ms"] += a.elapsed_time(b)
         return out
 
 
 class _Span:
-    def __init__(self, timer, family, flops, nbytes, tag=None):
-        self.t, self.family, self.flops, self.nbytes, self.tag = timer, family, flops, nbytes, tag
+    def __init__(self, timer, family, flops, nbytes, tag=None, executed=0.0):
+        self.t, self.family, self.flops, self.nbytes, self.tag, self.executed = timer, family, flops, nbytes, tag, executed
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -69,7 +79,7 @@ class _Span:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.records.append((self.family, self.flops, self.nbytes, self.a, self.b, self.tag))
+        self.t.records.append((self.family, self.flops, self.nbytes, self.a, self.b, self.tag, self.executed))
 
 
 class _NoSpan:
@@ -84,8 +94,8 @@ KERNEL_TIMER = None
 _NOSPAN = _NoSpan()
 
 
-def _span(family, flops, nbytes=0.0, tag=None):
-    return KERNEL_TIMER.span(family, flops, nbytes, tag) if KERNEL_TIMER is not None else _NOSPAN
+def _span(family, flops, nbytes=0.0, tag=None, executed=None):
+    return KERNEL_TIMER.span(family, flops, nbytes, tag, executed) if KERNEL_TIMER is not None else _NOSPAN
 
 
 def _conv_tag(d, role):
@@ -99,6 +109,10 @@ def _conv_family(lib, d, mode):
     if KERNEL_TIMER is None:
         return "conv_gather"
     return "conv_tap_h" if lib.ssbev_conv_kernel_class(C.byref(d), mode) == 2 else "conv_gather"
+
+
+# conv_taph_kernel runs F(2,3) along h inside the direct kernel: 2/3 of the operator's multiply-adds are executed
+_EXEC_DIV = {"conv_gather": 1.0, "conv_tap_h": 1.5}
 
 
 def conv_bytes(d):
@@ -243,9 +257,12 @@ class _LiftSplat(torch.autograd.Function):
         d = _pool_dims(B, N * D * H * W, Cch, nx, ny, nz)
         l = capi.LiftDims(N, D, H * W)
         out = torch.empty(B, nx, ny, nz, Cch, dtype=torch.float32, device=depth.device)
-        capi.check(lib.ssbev_lift_splat_fwd(capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(starts), capi.ptr(order),
-                                            capi.ptr(out), C.byref(d), C.byref(l), capi.stream()),
-                   "ssbev_lift_splat_fwd")
+        # algorithmic bytes: depth + features + the int32 voxel table in, the BEV volume out
+        nby = 4.0 * (depth.numel() + feat_cl.numel() + order.numel() + starts.numel() + out.numel())
+        with _span("lift_splat", 2.0 * depth.numel() * Cch, nby, f"fwd   lift_splat D={D} HW={H * W} C={Cch} grid={nx}x{ny}x{nz}"):
+            capi.check(lib.ssbev_lift_splat_fwd(capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(starts), capi.ptr(order),
+                                                capi.ptr(out), C.byref(d), C.byref(l), capi.stream()),
+                       "ssbev_lift_splat_fwd")
         ctx.save_for_backward(depth, feat_cl, vox)
         ctx.meta = (B, N, grid)
         return from_cl(out)                                       # logical [B, C, X, Y, Z]
@@ -262,9 +279,11 @@ class _LiftSplat(torch.autograd.Function):
         l = capi.LiftDims(N, D, H * W)
         gd = torch.empty_like(depth)
         gf = torch.empty_like(feat_cl)
-        capi.check(lib.ssbev_lift_splat_bwd(capi.ptr(g), capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(vox),
-                                            capi.ptr(gd), capi.ptr(gf), C.byref(d), C.byref(l), capi.stream()),
-                   "ssbev_lift_splat_bwd")
+        nby = 4.0 * (g.numel() + 2 * depth.numel() + 2 * feat_cl.numel() + vox.numel())
+        with _span("lift_splat", 4.0 * depth.numel() * Cch, nby, f"bwd   lift_splat D={D} HW={H * W} C={Cch}"):
+            capi.check(lib.ssbev_lift_splat_bwd(capi.ptr(g), capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(vox),
+                                                capi.ptr(gd), capi.ptr(gf), C.byref(d), C.byref(l), capi.stream()),
+                       "ssbev_lift_splat_bwd")
         return gd, from_cl(gf), None, None, None, None, None, None
 
 
@@ -294,8 +313,10 @@ class _GwcWarp(torch.autograd.Function):
         cal = calib.to(device=left.device, dtype=torch.float32).contiguous()
         d = capi.GwcDims(B, Cch, groups, ndisp, H, W, 1.0, int(bool(align_corners)))
         vol = torch.empty(B, ndisp, H, W, groups, dtype=torch.float32, device=left.device)
-        capi.check(lib.ssbev_gwc_warp_fwd(capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(vol), C.byref(d),
-                                          capi.stream()), "ssbev_gwc_warp_fwd")
+        nby = 4.0 * (l.numel() + r.numel() + vol.numel())        # read both feature maps, write the volume
+        with _span("gwc_warp_fwd", 8.0 * vol.numel() * (Cch // groups), nby, f"fwd   gwc_warp D={ndisp} {H}x{W} G={groups}"):
+            capi.check(lib.ssbev_gwc_warp_fwd(capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(vol), C.byref(d),
+                                              capi.stream()), "ssbev_gwc_warp_fwd")
         ctx.save_for_backward(l, r, cal)
         ctx.meta = (ndisp, groups, int(bool(align_corners)))
         return from_cl(vol)                                       # logical [B, G, D, H, W]
@@ -310,8 +331,10 @@ class _GwcWarp(torch.autograd.Function):
         d = capi.GwcDims(B, Cch, groups, ndisp, H, W, 1.0, ac)
         gl = torch.empty_like(l)
         gr = torch.empty_like(r)
-        capi.check(lib.ssbev_gwc_warp_bwd(capi.ptr(g), capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(gl),
-                                          capi.ptr(gr), C.byref(d), capi.stream()), "ssbev_gwc_warp_bwd")
+        nby = 4.0 * (g.numel() + 2 * l.numel() + 2 * r.numel())  # the gradient volume ONCE + both maps in, both gradients out
+        with _span("gwc_warp_bwd", 16.0 * g.numel() * (Cch // groups), nby, f"bwd   gwc_warp D={ndisp} {H}x{W} G={groups}"):
+            capi.check(lib.ssbev_gwc_warp_bwd(capi.ptr(g), capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(gl),
+                                              capi.ptr(gr), C.byref(d), capi.stream()), "ssbev_gwc_warp_bwd")
         return from_cl(gl), from_cl(gr), None, None, None, None
 
 
@@ -378,7 +401,8 @@ class _ConvNd(torch.autograd.Function):
         wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
-        with _span(_conv_family(lib, d, 0), conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd")):
+        fam = _conv_family(lib, d, 0)
+        with _span(fam, conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd"), conv_flops(d) / _EXEC_DIV[fam]):
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
                                           capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
@@ -404,7 +428,8 @@ class _ConvNd(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _packed(w5, d, 1)
             gxcl = torch.empty_like(xcl)
-            with _span(_conv_family(lib, d, 1), conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad")):
+            fam = _conv_family(lib, d, 1)
+            with _span(fam, conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad"), conv_flops(d) / _EXEC_DIV[fam]):
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
                                                    capi.stream()), "ssbev_conv_bwd_data")
             if kpad:
@@ -455,7 +480,11 @@ def _deconv_k_eq_s_gemm(x, weight, bias, k):
     Co = weight.shape[1]
     kd, kh, kw = k
     w2 = weight.permute(0, 2, 3, 4, 1).reshape(Ci, kd * kh * kw * Co)
-    g = torch.mm(xcl.reshape(-1, Ci), w2).view(B, D, H, W, kd, kh, kw, Co)
+    fl = 2.0 * B * D * H * W * Ci * kd * kh * kw * Co
+    nby = 4.0 * (xcl.numel() + w2.numel() + B * D * H * W * kd * kh * kw * Co)
+    mult = 3.0 if (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) else 1.0
+    with _span("gemm_lib", fl * mult, nby * mult, f"fwd   deconv k=s {Ci}->{Co} k{kd}{kh}{kw}"):
+        g = torch.mm(xcl.reshape(-1, Ci), w2).view(B, D, H, W, kd, kh, kw, Co)
     y = g.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D * kd, H * kh, W * kw, Co)
     if bias is not None:
         y = y + bias
@@ -643,7 +672,8 @@ class _WinoConv(torch.autograd.Function):
             U = torch.empty(nf, Cin, Cout, dtype=torch.float32, device=x.device)
             capi.check(wt(capi.ptr(w), capi.ptr(U), Cout, Cin, wdim, 0, capi.stream()), "ssbev_wino_weight_transform")
         tag = f"wino{ {0: '', 1: '43', 4: '444'}[f43]} fwd {Cin}->{Cout} {D}x{H}x{W}"
-        with _span("conv_winograd", fl, fl / red, tag):
+        nby = 4.0 * (B * D * H * W * (Cin + Cout) + (27 if three_d else 9) * Cin * Cout)
+        with _span("conv_winograd", fl, nby, tag, fl / red):
             if fused:      # (h,w)-transformed tensors only (4x), the depth axis of F(2,3) inside the GEMM kernel
                 y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
                 V = None
@@ -670,14 +700,15 @@ class _WinoConv(torch.autograd.Function):
         nd = 4 if f43 == 4 else (3 if three_d else 2)
         gx = gw = None
         vtag = {0: "", 1: "43", 4: "444"}[f43]
+        nby = 4.0 * (B * D * H * W * (Cin + Cout) + (27 if three_d else 9) * Cin * Cout)
         if ctx.needs_input_grad[0] and fused:
-            with _span("conv_winograd", fl, fl / red, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            with _span("conv_winograd", fl, nby, f"wino dgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
                 gx = from_cl(_wino_depth_fused(gcl, w, B, D, H, W, Cout, Cin, 1))
         elif ctx.needs_input_grad[0]:
             Ut = torch.empty(nf, Cout, Cin, dtype=torch.float32, device=gy.device)
             wt = lib.ssbev_wino43_weight_transform if f43 else lib.ssbev_wino_weight_transform
             capi.check(wt(capi.ptr(w), capi.ptr(Ut), Cout, Cin, nd, 1, capi.stream()), "ssbev_wino_weight_transform")
-            with _span("conv_winograd", fl, fl / red, f"wino{vtag} dgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            with _span("conv_winograd", fl, nby, f"wino{vtag} dgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
                 Vg = _wino_call(pre + "input_transform" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
                 Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf and not f43) \
                     else torch.bmm(Vg, Ut.to(fdt))
@@ -685,7 +716,7 @@ class _WinoConv(torch.autograd.Function):
                 gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
-            with _span("conv_winograd_wgrad", fl, fl / red, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}"):
+            with _span("conv_winograd_wgrad", fl, nby, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
                 if fused:
                     V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
@@ -729,8 +760,9 @@ class _DcnIm2col(torch.autograd.Function):
         B, H, W, Cch = xcl.shape
         d = capi.DcnDims(B, Cch, H, W, groups, k, pad, dil)
         cols = torch.empty(groups, B * H * W, k * k * (Cch // groups), dtype=torch.float32, device=x.device)
-        capi.check(lib.ssbev_dcn_im2col(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(cols), C.byref(d), capi.stream()),
-                   "ssbev_dcn_im2col")
+        with _span("dcn_sample", 0.0, 4.0 * (xcl.numel() + ocl.numel() + cols.numel()), "fwd   dcn_im2col"):
+            capi.check(lib.ssbev_dcn_im2col(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(cols), C.byref(d), capi.stream()),
+                       "ssbev_dcn_im2col")
         ctx.save_for_backward(xcl, ocl)
         ctx.d = d
         return cols
@@ -740,8 +772,9 @@ class _DcnIm2col(torch.autograd.Function):
         lib = capi.load()
         xcl, ocl = ctx.saved_tensors
         gx, goff = torch.empty_like(xcl), torch.empty_like(ocl)
-        capi.check(lib.ssbev_dcn_col2im(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(gcols.contiguous()), capi.ptr(gx),
-                                        capi.ptr(goff), C.byref(ctx.d), capi.stream()), "ssbev_dcn_col2im")
+        with _span("dcn_sample", 0.0, 4.0 * (2 * xcl.numel() + 2 * ocl.numel() + gcols.numel()), "bwd   dcn_col2im"):
+            capi.check(lib.ssbev_dcn_col2im(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(gcols.contiguous()), capi.ptr(gx),
+                                            capi.ptr(goff), C.byref(ctx.d), capi.stream()), "ssbev_dcn_col2im")
         return from_cl(gx), from_cl(goff), None, None, None, None
 
 
@@ -869,8 +902,9 @@ class _SoftmaxAxis(torch.autograd.Function):
         Cn = x.shape[dim]
         inner = x.numel() // (outer * Cn)
         y = torch.empty_like(x)
-        capi.check(lib.ssbev_softmax_axis_fwd(capi.ptr(x), capi.ptr(y), outer, Cn, inner, capi.stream()),
-                   "ssbev_softmax_axis_fwd")
+        with _span("softmax", 0.0, 8.0 * x.numel(), "fwd   softmax_axis"):
+            capi.check(lib.ssbev_softmax_axis_fwd(capi.ptr(x), capi.ptr(y), outer, Cn, inner, capi.stream()),
+                       "ssbev_softmax_axis_fwd")
         ctx.save_for_backward(y)
         ctx.meta = (outer, Cn, inner)
         return y
@@ -882,8 +916,9 @@ class _SoftmaxAxis(torch.autograd.Function):
         outer, Cn, inner = ctx.meta
         gy = gy.contiguous()
         gx = torch.empty_like(y)
-        capi.check(lib.ssbev_softmax_axis_bwd(capi.ptr(y), capi.ptr(gy), capi.ptr(gx), outer, Cn, inner, capi.stream()),
-                   "ssbev_softmax_axis_bwd")
+        with _span("softmax", 0.0, 12.0 * y.numel(), "bwd   softmax_axis"):
+            capi.check(lib.ssbev_softmax_axis_bwd(capi.ptr(y), capi.ptr(gy), capi.ptr(gx), outer, Cn, inner, capi.stream()),
+                       "ssbev_softmax_axis_bwd")
         return gx, None
 
 
@@ -909,8 +944,9 @@ class _Trilinear2x(torch.autograd.Function):
         B, D, H, W, Cch = xcl.shape
         d = capi.UpsampleDims(B, D, H, W, Cch)
         y = torch.empty(B, 2 * D, 2 * H, 2 * W, Cch, dtype=torch.float32, device=x.device)
-        capi.check(lib.ssbev_trilinear2x_fwd(capi.ptr(xcl), capi.ptr(y), C.byref(d), capi.stream()),
-                   "ssbev_trilinear2x_fwd")
+        with _span("trilinear", 0.0, 4.0 * (xcl.numel() + y.numel()), "fwd   trilinear2x"):
+            capi.check(lib.ssbev_trilinear2x_fwd(capi.ptr(xcl), capi.ptr(y), C.byref(d), capi.stream()),
+                       "ssbev_trilinear2x_fwd")
         ctx.dims = (B, D, H, W, Cch)
         return from_cl(y)
 
@@ -921,8 +957,9 @@ class _Trilinear2x(torch.autograd.Function):
         gcl = to_cl(gy)
         d = capi.UpsampleDims(B, D, H, W, Cch)
         gx = torch.empty(B, D, H, W, Cch, dtype=torch.float32, device=gy.device)
-        capi.check(lib.ssbev_trilinear2x_bwd(capi.ptr(gcl), capi.ptr(gx), C.byref(d), capi.stream()),
-                   "ssbev_trilinear2x_bwd")
+        with _span("trilinear", 0.0, 4.0 * (gcl.numel() + gx.numel()), "bwd   trilinear2x"):
+            capi.check(lib.ssbev_trilinear2x_bwd(capi.ptr(gcl), capi.ptr(gx), C.byref(d), capi.stream()),
+                       "ssbev_trilinear2x_bwd")
         return from_cl(gx)
 
 
@@ -958,8 +995,9 @@ class _BriAttention(torch.autograd.Function):
         d = capi.AttnDims(B, T, Dh)
         out = torch.empty_like(q)
         lse = torch.empty(B, T, dtype=torch.float32, device=q.device)
-        capi.check(lib.ssbev_bri_attention_fwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
-                                               capi.ptr(lse), C.byref(d), capi.stream()), "ssbev_bri_attention_fwd")
+        with _span("bri_flash", 4.0 * B * T * T * Dh, 16.0 * q.numel(), f"fwd   bri T={T} Dh={Dh}"):
+            capi.check(lib.ssbev_bri_attention_fwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
+                                                   capi.ptr(lse), C.byref(d), capi.stream()), "ssbev_bri_attention_fwd")
         ctx.save_for_backward(q, k, v, conf, out, lse)
         return out
 
@@ -973,10 +1011,12 @@ class _BriAttention(torch.autograd.Function):
         gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         gc = torch.empty_like(conf)
         ws = _ws(lib.ssbev_bri_attention_workspace(C.byref(d)), q.device)
-        capi.check(lib.ssbev_bri_attention_bwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
-                                               capi.ptr(lse), capi.ptr(g), capi.ptr(gq), capi.ptr(gk), capi.ptr(gv),
-                                               capi.ptr(gc), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                   "ssbev_bri_attention_bwd")
+        # operator FLOPs of the backward: dV, dP, dQ, dK products (4 x 2*T*T*Dh); the flash kernels recompute S twice more
+        with _span("bri_flash", 8.0 * B * T * T * Dh, 32.0 * q.numel(), f"bwd   bri T={T} Dh={Dh}", 14.0 * B * T * T * Dh):
+            capi.check(lib.ssbev_bri_attention_bwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
+                                                   capi.ptr(lse), capi.ptr(g), capi.ptr(gq), capi.ptr(gk), capi.ptr(gv),
+                                                   capi.ptr(gc), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_bri_attention_bwd")
         return gq, gk, gv, gc
 
 
@@ -1004,8 +1044,9 @@ class _OccLossSums(torch.autograd.Function):
         cw = class_weight.to(device=logits.device, dtype=torch.float32).contiguous()
         lab = label_u8.contiguous()
         ws = _ws(lib.ssbev_occ_loss_workspace(C.byref(d)), logits.device)
-        capi.check(lib.ssbev_occ_loss_fwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(sums), C.byref(d),
-                                          capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_fwd")
+        with _span("occ_loss", 0.0, 4.0 * xcl.numel() + lab.numel(), "fwd   occ_loss"):
+            capi.check(lib.ssbev_occ_loss_fwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(sums), C.byref(d),
+                                              capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_fwd")
         ctx.save_for_backward(xcl, lab, cw)
         nc = Cch
         diff = torch.cat((sums[0:1], sums[3:3 + 2 * nc]))
@@ -1022,8 +1063,9 @@ class _OccLossSums(torch.autograd.Function):
         coef = gdiff.to(torch.float32).contiguous()
         gx = torch.empty_like(xcl)
         ws = _ws(lib.ssbev_occ_loss_bwd_workspace(C.byref(d)), xcl.device)
-        capi.check(lib.ssbev_occ_loss_bwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(coef), capi.ptr(gx),
-                                          C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_bwd")
+        with _span("occ_loss", 0.0, 8.0 * xcl.numel() + lab.numel(), "bwd   occ_loss"):
+            capi.check(lib.ssbev_occ_loss_bwd(capi.ptr(xcl), capi.ptr(lab), capi.ptr(cw), capi.ptr(coef), capi.ptr(gx),
+                                              C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_occ_loss_bwd")
         return from_cl(gx), None, None
 
 
@@ -1051,7 +1093,11 @@ def linear_cl(x, weight, bias=None):
     shp = xcl.shape
     w2 = weight.reshape(weight.shape[0], -1)
     x2 = xcl.reshape(-1, shp[-1])
-    y = torch.addmm(bias, x2, w2.t()) if bias is not None else torch.mm(x2, w2.t())
+    fl = 2.0 * x2.shape[0] * x2.shape[1] * w2.shape[0]
+    nby = 4.0 * (x2.numel() + w2.numel() + x2.shape[0] * w2.shape[0])
+    mult = 3.0 if (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) else 1.0
+    with _span("gemm_lib", fl * mult, nby * mult, f"fwd   linear_cl {x2.shape[1]}->{w2.shape[0]} rows={x2.shape[0]}"):
+        y = torch.addmm(bias, x2, w2.t()) if bias is not None else torch.mm(x2, w2.t())
     return from_cl(y.view(*shp[:-1], w2.shape[0]))
 
 

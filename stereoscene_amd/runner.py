@@ -119,6 +119,8 @@ class EpochBasedRunner:
 
     def resume(self, path=None):
         path = path or os.path.join(self.work_dir, "latest.pth")
+        # weights_only=False: the checkpoint holds the optimizer's python scalars next to tensors, and it is a file this
+        # runner wrote itself (never load a checkpoint from an untrusted source this way)
         ck = torch.load(path, map_location="cpu", weights_only=False)
         meta = ck.pop("meta")
         self.epoch, self.iter = meta["epoch"], meta["iter"]
@@ -156,10 +158,12 @@ class EpochBasedRunner:
                 self.iter += 1
             self.epoch += 1
             rec = dict(epoch=self.epoch, lr=lr, **{k: v / max(n, 1) for k, v in sums.items()})
-            if self.ckpt_interval and self.epoch % self.ckpt_interval == 0:
-                self.save_checkpoint()
+            # evaluation first: the epoch checkpoint / latest.pth then carry this epoch's best_score / best_ckpt, so a
+            # resume() never overwrites a better 'best_*' file with a worse one
             if self.eval_fn is not None and self.eval_interval and self.epoch % self.eval_interval == 0:
                 rec["eval"] = self._evaluate()
+            if self.ckpt_interval and self.epoch % self.ckpt_interval == 0:
+                self.save_checkpoint()
             self.history.append(rec)
             self.log(rec)
         return self.history

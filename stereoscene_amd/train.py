@@ -23,13 +23,12 @@ class FlatAdamW:
         n = self.reducer.flat.numel()
         dev = self.reducer.flat.device
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        off = 0
+        self.flat_p.zero_()
         with torch.no_grad():
             for p in params:
-                k = p.numel()
+                off, k = self.reducer._offsets[p], p.numel()     # same offsets as the flat gradient buffer (bucket padding)
                 self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + k].view_as(p)
-                off += k
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -56,8 +55,12 @@ class FlatAdamW:
             norm_ptr = capi.ptr(self.norm)
         cfg = capi.AdamWCfg(self.lr, self.betas[0], self.betas[1], self.eps, self.wd, float(self.max_grad_norm or 0.0),
                             self.step_count)
-        capi.check(lib.ssbev_adamw_step(capi.ptr(self.flat_p), capi.ptr(g), capi.ptr(self.m), capi.ptr(self.v), n,
-                                        C.byref(cfg), norm_ptr, capi.stream()), "ssbev_adamw_step")
+        # parameters without a gradient this step (ablation modes) are skipped like torch.optim.AdamW skips grad None:
+        # no weight decay, no moment decay.  Normally one range = one launch.
+        for s, e in self.reducer.live_ranges():
+            at = lambda t: C.c_void_p(t.data_ptr() + 4 * s)      # noqa: E731
+            capi.check(lib.ssbev_adamw_step(at(self.flat_p), at(g), at(self.m), at(self.v), e - s,
+                                            C.byref(cfg), norm_ptr, capi.stream()), "ssbev_adamw_step")
         return self.norm
 
     def state_dict(self):

@@ -77,3 +77,92 @@ def test_forward_is_bit_deterministic_at_full_size():
     assert a.shape == (1, 20, 256, 256, 32)
     assert torch.equal(a, b)
     assert torch.isfinite(a).all()
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# Assembled path at the BASELINE sizes against the CPU oracle (north-star gates: fp32 logits within 1e-3, depth
+# distribution within 1e-4).  The oracle's full-size forward takes ~10 s on the GPU box's host with 32 threads.
+# -------------------------------------------------------------------------------------------------------------------
+def _oracle_inputs(smp):
+    mlp_l, mlp_r = O.get_mlp_input(*smp["geo_l"]), O.get_mlp_input(*smp["geo_r"])
+    return [smp["x_l"], *smp["geo_l"], mlp_l, smp["x_r"], *smp["geo_r"], mlp_r, smp["calib"]]
+
+
+def _ocfg(cfg, D, ac):
+    return dict(D=D, numC_Trans=128, warp_align_corners=ac, downsample=cfg["downsample"], dbound=cfg["dbound"])
+
+
+def _coarse_outputs(model, inputs):
+    voxel_feats, _, depth = model.extract_feat(None, img=inputs)
+    return model.pts_bbox_head(voxel_feats=voxel_feats)["output_voxels"][0], depth
+
+
+@pytest.mark.parametrize("name,ac", [("kitti_d192", True), ("kitti_d192", False), ("kitti_d112", True)])
+def test_full_size_forward_logits_vs_oracle(name, ac):
+    """kitti_d192 / kitti_d112 forward (eval mode, fill-by-key weights, both `warp` modes at the BASELINE size): coarse
+    logits [1,20,128,128,16] <= 1e-3 max-abs, depth_prob <= 1e-4, BEV volume <= 1e-3 of its scale vs the oracle."""
+    import torch
+    cfg = S.CONFIGS[name]
+    model = model_zoo.build_detector(cfg, warp_align_corners=ac).eval()
+    smp = S.synthetic_sample(cfg, B=1, tag="fs" + name)
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    with torch.no_grad():
+        logits, depth = _coarse_outputs(model, inputs)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))       # ATen CPU gets slower beyond ~32 threads on the 256-thread host
+    try:
+        with torch.no_grad():
+            _, aux = O.forward_train(sd, _oracle_inputs(smp), smp["gt_depths"], smp["gt_occ"],
+                                     _ocfg(cfg, model.img_view_transformer.D, ac), train=False)
+    finally:
+        torch.set_num_threads(nt)
+    assert logits.shape == aux["logits"].shape == (1, 20, 128, 128, 16)
+    e_depth = (depth.cpu() - aux["depth_prob"]).abs().max().item()
+    e_logit = (logits.cpu() - aux["logits"]).abs().max().item()
+    agree = (logits.cpu().argmax(1) == aux["logits"].argmax(1)).float().mean().item()
+    print(f"{name} ac={ac}: depth_prob max-abs {e_depth:.2e}, logits max-abs {e_logit:.2e} "
+          f"(scale {aux['logits'].abs().max().item():.2f}), argmax agreement {agree:.6f}")
+    assert e_depth < 1e-4
+    assert e_logit < 1e-3
+    assert agree > 0.9999
+
+
+def test_full_size_step_fwd_bwd_vs_oracle_kitti_d112():
+    """One fwd+bwd step at the reference's own config (D=112, 256x256x32 grid), train mode (batch-stat BN, dropout off):
+    4 losses and every parameter gradient against the oracle's autograd."""
+    import torch
+    cfg = S.CFG_K112
+    model = model_zoo.build_detector(cfg).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    smp = S.synthetic_sample(cfg, B=1, tag="fsstep")
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    losses = model.forward_train(img_inputs=inputs, gt_occ=smp["gt_occ"].to(DEV))
+    sum(v for k, v in losses.items() if k.startswith("loss")).backward()
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    sd = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd0.items()}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))
+    try:
+        want, _ = O.forward_train(sd, _oracle_inputs(smp), smp["gt_depths"], smp["gt_occ"],
+                                  _ocfg(cfg, model.img_view_transformer.D, True), train=True, stats_out={})
+        sum(want.values()).backward()
+    finally:
+        torch.set_num_threads(nt)
+    for k, v in want.items():
+        assert abs(float(losses[k]) - float(v)) < 1e-4 * max(1.0, abs(float(v))), (k, float(losses[k]), float(v))
+    worst, checked = (0.0, None), 0
+    for name, p in model.named_parameters():
+        if name not in trainable or p.grad is None or sd[name].grad is None:
+            continue
+        ref = sd[name].grad
+        if ref.abs().max().item() < 1e-8:
+            continue
+        l2 = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
+        worst = max(worst, (l2, name))
+        checked += 1
+    print(f"kitti_d112 step: {checked} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
+    assert checked > 150 and worst[0] < 1e-2, worst

@@ -446,6 +446,28 @@ def test_deform_conv_hip_sampling_matches_tensor_op_formulation(cfg):
         assert maxdiff(a, b) < 5e-5 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 48, 4, 12, 20, 1, 1), (1, 64, 64, 1, 9, 14, 1, 1), (1, 32, 32, 4, 10, 12, 2, 2),
+                                 (1, 640, 640, 4, 6, 20, 1, 1)])
+def test_deform_conv_vs_oracle(cfg):
+    """F.deform_conv2d (HIP sampling + MFMA group contraction) against the ORACLE's DCNv1 restatement
+    (oracle.path_ref.deform_conv2d, mmcv-full 1.4.0 semantics) under CPU autograd: output and the gradients with respect
+    to input, offsets and weight.  Offsets of a few pixels so that border / outside / fractional taps all occur; the last
+    case is DepthNet's own 640-channel, 4-group layer (BD:490-498) on a small map."""
+    B, Cin, Cout, G, H, W, pad, dil = cfg
+    x = S.hash_normal(f"dcno/x{cfg}", (B, Cin, H, W))
+    off = S.hash_normal(f"dcno/off{cfg}", (B, 18, H, W), 1.5)
+    w = S.hash_normal(f"dcno/w{cfg}", (Cout, Cin // G, 3, 3), (1.0 / (9 * Cin // G)) ** 0.5)
+    go = S.hash_normal(f"dcno/go{cfg}", (B, Cout, H, W))
+    xc, oc, wc = (t.clone().requires_grad_(True) for t in (x, off, w))
+    want = O.deform_conv2d(xc, oc, wc, 1, pad, dil, G, 1)
+    want.backward(go)
+    xg, og, wg = (t.to(DEV).requires_grad_(True) for t in (x, off, w))
+    got = F.deform_conv2d(xg, og, wg, G, pad, dil)
+    got.backward(go.to(DEV))
+    for a, b, what in ((got, want, "out"), (xg.grad, xc.grad, "gx"), (og.grad, oc.grad, "goff"), (wg.grad, wc.grad, "gw")):
+        assert maxdiff(a, b) < 5e-5 * max(1.0, b.abs().max().item()), what
+
+
 @pytest.mark.parametrize("case", [(1, 32, 32, 5, 6, 40, True), (2, 4, 32, 4, 5, 33, False), (1, 32, 1, 3, 7, 64, True),
                                   (1, 32, 20, 6, 9, 96, False), (1, 2, 32, 4, 4, 32, True), (1, 32, 32, 9, 3, 160, False),
                                   (1, 32, 4, 4, 6, 70, True), (2, 20, 3, 4, 5, 33, False), (1, 16, 2, 3, 4, 32, True),
