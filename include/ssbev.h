@@ -103,6 +103,13 @@ int ssbev_gwc_warp_fwd(const float* left, const float* right, const float* calib
 int ssbev_gwc_warp_bwd(const float* grad_vol, const float* left, const float* right,
                        const float* calib, float* grad_left, float* grad_right,
                        const ssbev_gwc_dims* d, ssbev_stream_t stream);
+/* Same gradients from ONE read of grad_vol (both views in one launch; plane chunks write partial rows into the
+ * caller-owned workspace and are summed in chunk order: deterministic, no atomics).  Falls back to the two-launch
+ * kernels above for shapes it does not cover (G % 4 != 0, 64 % G != 0, rows wider than its register plan). */
+size_t ssbev_gwc_warp_bwd_workspace(const ssbev_gwc_dims* d);
+int ssbev_gwc_warp_bwd_fused(const float* grad_vol, const float* left, const float* right,
+                             const float* calib, float* grad_left, float* grad_right,
+                             const ssbev_gwc_dims* d, void* workspace, size_t ws_bytes, ssbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense N-d convolution family on MFMA (implicit GEMM, no im2col), channels-last fp32.

@@ -86,6 +86,8 @@ SIGNATURES = {
     "ssbev_lift_splat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
     "ssbev_gwc_warp_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(GwcDims), _P]),
     "ssbev_gwc_warp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P]),
+    "ssbev_gwc_warp_bwd_workspace": (C.c_size_t, [C.POINTER(GwcDims)]),
+    "ssbev_gwc_warp_bwd_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P, C.c_size_t, _P]),
     "ssbev_conv_packed_weight_elems": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_kernel_class": (C.c_int, [C.POINTER(ConvDims), C.c_int]),
     "ssbev_conv_pack_weight": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),

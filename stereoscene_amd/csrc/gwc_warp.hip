@@ -12,9 +12,18 @@
 // written as W*G contiguous floats (channels-last volume) => the kernel is a pure streaming
 // write of the 189 MB volume (D=192), its only HBM-sized traffic.  The 2-channel group
 // reduction happens inside one lane (no cross-lane traffic needed for cpg=2..8).
+//
+// What makes it a streaming kernel (r2): the disparity tap x0(k) = floor(ix(k)) ~ calib/4/(k+1) takes only ~25 distinct
+// values over the 192 metric depths (x0 = 0 for every k >= 98, x0 = 1 for 49..97, ...), so the raw correlations
+// cost[.][x0], cost[.][x0+1] of a (pixel, group) are computed ONCE per run of planes with the same x0 and every plane of
+// the run is just out = wx0(k) * m0 + wx1(k) * m1: two VALU ops and one 16-byte store per four outputs (a lane owns four
+// consecutive groups, a wave stores 1 KB per instruction).  The per-plane LDS reads and the 2 x 2 x CPG multiply-adds of
+// the first version (113 us, 1.7 TB/s) only happen at the ~40 run starts.  Plane chunks are short where x0 changes at
+// every plane (k < 16) and long behind, so that the workgroups carry equal work.
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -120,6 +129,92 @@ gwc_warp_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ri
   }
 }
 
+// ---- forward, four groups per lane --------------------------------------------------------------------------------
+constexpr int MAX_CHUNKS = 48;
+struct PlaneChunks { int n; int start[MAX_CHUNKS + 1]; };   // chunk c covers planes [start[c], start[c+1])
+constexpr int FWD_MAXLEN = 32;                              // longest chunk (taps staged in LDS)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int CPG, bool NT>
+__global__ void __launch_bounds__(512)
+gwc_warp_fwd4_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                     const float* __restrict__ calib, float* __restrict__ vol, PlaneChunks chunks, int B, int C, int G,
+                     int D, int H, int W, float down, int align_corners) {
+  extern __shared__ __align__(16) float lds[];
+  const int stride = C + 4;
+  float* Rrow = lds;                                       // [W][stride]
+  XTap* taps = reinterpret_cast<XTap*>(lds + W * stride);  // [FWD_MAXLEN]
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1];
+  const float* Lrow_g = left + ((size_t)b * H + h) * W * C;
+  stage_row(right + ((size_t)b * H + h) * W * C, Rrow, W, C, stride);
+  if ((int)threadIdx.x < k_end - k_begin)
+    taps[threadIdx.x] = depth_tap(calib[b], k_begin + threadIdx.x, D, down, align_corners);
+  __syncthreads();
+
+  const float inv_cpg = 1.0f / (float)CPG;
+  const int G4 = G >> 2;
+  const size_t plane = (size_t)H * W * G;
+  for (int item = threadIdx.x; item < W * G4; item += blockDim.x) {
+    const int w = item / G4, g4 = (item - w * G4) << 2;
+    float l[4][2][CPG], wy[4][2];
+    int cy[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int y0;
+      float w0, w1;
+      group_tap(g4 + j, G, align_corners, &y0, &w0, &w1);
+      const bool ok0 = y0 >= 0 && y0 < G, ok1 = y0 + 1 >= 0 && y0 + 1 < G;
+      cy[j][0] = ok0 ? y0 * CPG : 0;
+      cy[j][1] = ok1 ? (y0 + 1) * CPG : 0;
+      wy[j][0] = ok0 ? w0 : 0.0f;
+      wy[j][1] = ok1 ? w1 : 0.0f;
+#pragma unroll
+      for (int c = 0; c < CPG; ++c) {
+        l[j][0][c] = ok0 ? Lrow_g[w * C + cy[j][0] + c] : 0.0f;
+        l[j][1][c] = ok1 ? Lrow_g[w * C + cy[j][1] + c] : 0.0f;
+      }
+    }
+    float m[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j][0] = m[j][1] = 0.0f;
+    int cur = INT32_MIN;
+    float* dst = vol + ((((size_t)b * D + k_begin) * H + h) * W + w) * G + g4;
+    for (int k = k_begin; k < k_end; ++k) {
+      const XTap t = taps[k - k_begin];
+      if (t.x0 != cur) {          // wave-uniform: a new run of planes that share their two disparity taps
+        cur = t.x0;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          const int d = cur + tx;
+          const bool valid = d >= 0 && d < D && w >= d;   // w >= d: the reference volume is zero left of the disparity
+          const float* r = Rrow + (valid ? (w - d) : 0) * stride;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+              c0 += l[j][0][c] * r[cy[j][0] + c];
+              c1 += l[j][1][c] * r[cy[j][1] + c];
+            }
+            m[j][tx] = valid ? wy[j][0] * (c0 * inv_cpg) + wy[j][1] * (c1 * inv_cpg) : 0.0f;
+          }
+        }
+      }
+      v4f o;
+      o.x = t.w0 * m[0][0] + t.w1 * m[0][1];
+      o.y = t.w0 * m[1][0] + t.w1 * m[1][1];
+      o.z = t.w0 * m[2][0] + t.w1 * m[2][1];
+      o.w = t.w0 * m[3][0] + t.w1 * m[3][1];
+      if (NT) __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));   // streaming write: keep it out of L2 / MALL
+      else *reinterpret_cast<v4f*>(dst) = o;
+      dst += plane;
+    }
+  }
+}
+
 // Backward.  For a source group g' the output groups that read it are those g with y0(g) == g'
 // (weight wy0(g)) or y0(g)+1 == g' (weight wy1(g)); y0 is monotone in g so there are at most a few.
 //   S(k, w)      = sum_{(g, wy)} wy * gvol[k, w, g]
@@ -217,6 +312,197 @@ gwc_warp_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ ot
   }
 }
 
+// ---- backward, ONE launch for both views: the gradient volume is read once ---------------------------------------
+// Same run structure as the forward.  A workgroup owns (batch, row, plane chunk) and alternates two phases:
+//   A (streaming): thread = (pixel, quad of output groups) reads gvol[k, w, g..g+3] as one 16-byte load per plane and
+//     folds the run's planes into T[tx] = sum_k wx_tx(k) * gvol[k] -- two FMAs per value, nothing else;
+//   B (run end):   the quads go to LDS (S[tx][w][g]); thread = (pixel, SOURCE group s) rebuilds
+//     gcost[s][d](w) = sum_{g: y-tap of g hits s} wy * S[tx][w][g] and accumulates, in registers,
+//       gL[w , s, :] += gcost[s][d](w)      * R[w - d, s, :]          (w >= d)
+//       gR[w , s, :] += gcost[s][d](w + d)  * L[w + d, s, :]          (w + d < W)
+//     with both feature rows resident in LDS.  Every output element has one owner: no atomics, fixed order.
+// Chunks write partial rows; gwc_partial_reduce_kernel sums them in chunk order (deterministic).
+template <int CPG> struct BwdCfg { static constexpr int MAXI = CPG >= 8 ? 2 : (CPG == 4 ? 4 : 8); };
+constexpr int BWD_MAXQ = 2;
+constexpr int BWD_MAXTHREADS = 768;     // 12 waves = 3 per SIMD: 170 VGPRs each
+
+template <int CPG>
+__global__ void __launch_bounds__(BWD_MAXTHREADS)
+gwc_warp_bwd2_kernel(const float* __restrict__ gvol, const float* __restrict__ left, const float* __restrict__ right,
+                     const float* __restrict__ calib, float* __restrict__ part_l, float* __restrict__ part_r,
+                     PlaneChunks chunks, int B, int C, int G, int D, int H, int W, float down, int align_corners) {
+  constexpr int MAXI = BwdCfg<CPG>::MAXI;
+  extern __shared__ __align__(16) float lds[];
+  const int stride = C + 4;
+  float* Lrow = lds;                                         // [W][stride]
+  float* Rrow = Lrow + W * stride;                           // [W][stride]
+  float* S = Rrow + W * stride;                              // [2][W][G]
+  XTap* taps = reinterpret_cast<XTap*>(S + 2 * W * G);       // [chunk length <= D]
+  int* src_g = reinterpret_cast<int*>(taps + D);             // [G][MAX_SRC]
+  float* src_w = reinterpret_cast<float*>(src_g + G * MAX_SRC);
+  int* src_n = reinterpret_cast<int*>(src_w + G * MAX_SRC);  // [G]
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  stage_row(left + ((size_t)b * H + h) * W * C, Lrow, W, C, stride);
+  stage_row(right + ((size_t)b * H + h) * W * C, Rrow, W, C, stride);
+  for (int k = tid; k < k_end - k_begin; k += nthr) taps[k] = depth_tap(calib[b], k_begin + k, D, down, align_corners);
+  for (int gs = tid; gs < G; gs += nthr) {
+    int n = 0;
+    for (int g = 0; g < G; ++g) {
+      int y0;
+      float w0, w1;
+      group_tap(g, G, align_corners, &y0, &w0, &w1);
+      if (y0 == gs && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w0; ++n; }
+      if (y0 + 1 == gs && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w1; ++n; }
+    }
+    src_n[gs] = n;
+  }
+  __syncthreads();
+
+  // phase-B identity of this thread: source group s is the same for all of its items (nthr % G == 0)
+  const int s = tid % G, w_first = tid / G, w_step = nthr / G;
+  int sg[MAX_SRC];
+  float sw[MAX_SRC];
+  {
+    const int n = src_n[s];
+#pragma unroll
+    for (int i = 0; i < MAX_SRC; ++i) {
+      sg[i] = i < n ? src_g[s * MAX_SRC + i] : 0;
+      sw[i] = i < n ? src_w[s * MAX_SRC + i] : 0.0f;
+    }
+  }
+  const int nsrc = src_n[s];
+  float accL[MAXI][CPG], accR[MAXI][CPG];
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) accL[it][c] = accR[it][c] = 0.0f;
+
+  const int nq = W * (G >> 2);                               // quads per plane row
+  const size_t plane = (size_t)H * W * G;
+  const float* grow = gvol + (((size_t)b * D) * H + h) * W * G;
+  int k = k_begin;
+  while (k < k_end) {
+    const int x0 = taps[k - k_begin].x0;
+    int ke = k + 1;
+    while (ke < k_end && taps[ke - k_begin].x0 == x0) ++ke;
+    // ---- phase A: stream the planes [k, ke) of this run
+    v4f T0[BWD_MAXQ], T1[BWD_MAXQ];
+#pragma unroll
+    for (int it = 0; it < BWD_MAXQ; ++it) T0[it] = T1[it] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+    for (int kk = k; kk < ke; ++kk) {
+      const XTap t = taps[kk - k_begin];
+      const v4f* gk = reinterpret_cast<const v4f*>(grow + (size_t)kk * plane);
+#pragma unroll
+      for (int it = 0; it < BWD_MAXQ; ++it) {
+        const int q = tid + it * nthr;
+        if (q < nq) {
+          const v4f gv = __builtin_nontemporal_load(gk + q);
+          T0[it] += t.w0 * gv;
+          T1[it] += t.w1 * gv;
+        }
+      }
+    }
+    // ---- phase B: contract the run against the feature rows
+#pragma unroll
+    for (int it = 0; it < BWD_MAXQ; ++it) {
+      const int q = tid + it * nthr;
+      if (q < nq) {
+        reinterpret_cast<v4f*>(S)[q] = T0[it];
+        reinterpret_cast<v4f*>(S + W * G)[q] = T1[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx) {
+      const int d = x0 + tx;
+      if (d < 0 || d >= D) continue;
+      const float* Sx = S + tx * W * G;
+#pragma unroll
+      for (int it = 0; it < MAXI; ++it) {
+        const int w = w_first + it * w_step;
+        if (w >= W) break;
+        if (w >= d) {
+          float gc = 0.0f;
+#pragma unroll
+          for (int i = 0; i < MAX_SRC; ++i)
+            if (i < nsrc) gc += sw[i] * Sx[w * G + sg[i]];
+          const float* r = Rrow + (w - d) * stride + s * CPG;
+#pragma unroll
+          for (int c = 0; c < CPG; ++c) accL[it][c] += gc * r[c];
+        }
+        if (w + d < W) {
+          float gc = 0.0f;
+#pragma unroll
+          for (int i = 0; i < MAX_SRC; ++i)
+            if (i < nsrc) gc += sw[i] * Sx[(w + d) * G + sg[i]];
+          const float* l = Lrow + (w + d) * stride + s * CPG;
+#pragma unroll
+          for (int c = 0; c < CPG; ++c) accR[it][c] += gc * l[c];
+        }
+      }
+    }
+    __syncthreads();
+    k = ke;
+  }
+  const float inv_cpg = 1.0f / (float)CPG;
+  const size_t slab = (size_t)B * H * W * C;
+  float* pl = part_l + blockIdx.y * slab + ((size_t)b * H + h) * W * C;
+  float* pr = part_r + blockIdx.y * slab + ((size_t)b * H + h) * W * C;
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int w = w_first + it * w_step;
+    if (w >= W) break;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+      pl[(size_t)w * C + s * CPG + c] = accL[it][c] * inv_cpg;
+      pr[(size_t)w * C + s * CPG + c] = accR[it][c] * inv_cpg;
+    }
+  }
+}
+
+// out[i] = sum over chunks (ascending) of part[chunk][i]; n4 float4 elements per slab
+__global__ void gwc_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  v4f acc = reinterpret_cast<const v4f*>(part)[i];
+  for (int c = 1; c < nchunks; ++c) acc += reinterpret_cast<const v4f*>(part)[(size_t)c * n4 + i];
+  reinterpret_cast<v4f*>(out)[i] = acc;
+}
+
+// Plane chunks of (roughly) equal cost.  Cost model: one unit per plane plus `run_cost` units per run start, with the run
+// starts distributed like the changes of x0(k) ~ X / (k + 1), X ~ D / 2 (KITTI: calib / 4 = 98 for D = 192): one per
+// plane while X / (k+1)^2 >= 1, X / (k+1)^2 per plane behind.  The true taps depend on calib (device memory); this only
+// balances the workgroups, any partition is correct.
+PlaneChunks make_chunks(int D, int n, float run_cost, int maxlen) {
+  PlaneChunks ch;
+  n = std::max(1, std::min(n, std::min(D, MAX_CHUNKS)));
+  const float X = 0.5f * (float)D;
+  for (;; ++n) {
+    double total = 0.0;
+    for (int k = 0; k < D; ++k) total += 1.0 + run_cost * std::min(1.0, (double)X / ((double)(k + 1) * (k + 1)));
+    ch.n = n;
+    ch.start[0] = 0;
+    double acc = 0.0;
+    int c = 1;
+    for (int k = 0; k < D && c < n; ++k) {
+      acc += 1.0 + run_cost * std::min(1.0, (double)X / ((double)(k + 1) * (k + 1)));
+      // chunk c starts behind plane k once the prefix reaches c/n of the total; keep >= 1 plane per remaining chunk
+      while (c < n && (acc >= total * c / n || D - (k + 1) <= n - c)) {
+        ch.start[c] = std::min(std::max(k + 1, ch.start[c - 1] + 1), D - (n - c));
+        ++c;
+      }
+    }
+    ch.start[n] = D;
+    int longest = 0;
+    for (int i = 0; i < n; ++i) longest = std::max(longest, ch.start[i + 1] - ch.start[i]);
+    if (longest <= maxlen || n >= std::min(D, MAX_CHUNKS)) return ch;
+  }
+}
+
 bool gwc_dims_ok(const ssbev_gwc_dims* d) {
   if (!d || d->B <= 0 || d->C <= 0 || d->G <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return false;
   if (d->C % d->G != 0 || d->C % 4 != 0 || d->down != 1.0f) return false;
@@ -229,9 +515,33 @@ size_t bwd_lds_bytes(const ssbev_gwc_dims* d) {
   return (size_t)d->W * (d->C + 4) * 4 + d->D * sizeof(XTap) + (size_t)d->G * MAX_SRC * 8 + d->G * 4;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// ---- forward: fwd4 (four groups per lane, run-cached correlations) when G % 4 == 0, else the per-plane kernel
 template <int CPG>
 int launch_fwd(const float* l, const float* r, const float* calib, float* vol, const ssbev_gwc_dims* d,
                hipStream_t st) {
+  static const int variant = env_int("SSBEV_GWC_FWD", 2);          // 1 = per-plane kernel (r1), 2 = fwd4
+  if (variant != 1 && d->G % 4 == 0) {
+    static const int threads = env_int("SSBEV_GWC_FWD_THREADS", 256);
+    static const int wg_target = env_int("SSBEV_GWC_FWD_WGS", 768);
+    static const int nt = env_int("SSBEV_GWC_FWD_NT", 1);
+    const PlaneChunks ch = make_chunks(d->D, (int)cdiv(wg_target, d->B * d->H), 8.0f, FWD_MAXLEN);
+    const size_t lds = (size_t)d->W * (d->C + 4) * 4 + FWD_MAXLEN * sizeof(XTap);
+    if (lds <= 160 * 1024) {
+      auto kern = nt ? gwc_warp_fwd4_kernel<CPG, true> : gwc_warp_fwd4_kernel<CPG, false>;
+      if (lds > 64 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+              hipSuccess)
+        return SSBEV_ELAUNCH;
+      hipLaunchKernelGGL(kern, dim3(d->B * d->H, ch.n), dim3(std::min(512, std::max(64, threads))), lds, st, l, r, calib,
+                         vol, ch, d->B, d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners);
+      return ssbev_launch_status();
+    }
+  }
   const size_t lds = fwd_lds_bytes(d);
   if (lds > 160 * 1024) return SSBEV_EINVAL;
   auto kern = gwc_warp_fwd_kernel<CPG>;
@@ -267,6 +577,64 @@ int launch_bwd(const float* gvol, const float* l, const float* r, const float* c
   return ssbev_launch_status();
 }
 
+// ---- fused backward (one read of the gradient volume) ------------------------------------------------------------
+struct Bwd2Plan { bool ok; int threads; PlaneChunks ch; size_t lds; };
+
+template <int CPG>
+Bwd2Plan plan_bwd2(const ssbev_gwc_dims* d) {
+  Bwd2Plan p;
+  p.ok = false;
+  if (d->G % 4 != 0 || d->G > 64 || 64 % d->G != 0) return p;
+  const int items = d->W * d->G;
+  int threads = (int)cdiv(cdiv(items, BwdCfg<CPG>::MAXI), 64) * 64;
+  threads = std::max(threads, (int)cdiv(cdiv(items / 4, BWD_MAXQ), 64) * 64);
+  threads = std::max(threads, 256);
+  if (threads > BWD_MAXTHREADS) return p;
+  p.threads = threads;
+  p.lds = (size_t)2 * d->W * (d->C + 4) * 4 + (size_t)2 * d->W * d->G * 4 + (size_t)d->D * sizeof(XTap) +
+          (size_t)d->G * MAX_SRC * 8 + (size_t)d->G * 4;
+  if (p.lds > 160 * 1024) return p;
+  static const int wg_target = env_int("SSBEV_GWC_BWD_WGS", 256);     // one workgroup per CU (LDS-bound occupancy)
+  const int rows = d->B * d->H;
+  p.ch = make_chunks(d->D, std::max(1, wg_target / rows), 4.0f, d->D);
+  p.ok = true;
+  return p;
+}
+
+template <int CPG>
+int launch_bwd2(const float* gvol, const float* l, const float* r, const float* calib, float* gl, float* gr,
+                const ssbev_gwc_dims* d, void* ws, size_t ws_bytes, hipStream_t st) {
+  const Bwd2Plan p = plan_bwd2<CPG>(d);
+  if (!p.ok) return launch_bwd<CPG>(gvol, l, r, calib, gl, gr, d, st);
+  const size_t slab = (size_t)d->B * d->H * d->W * d->C;
+  float *pl = gl, *pr = gr;
+  if (p.ch.n > 1) {
+    if (!ws || ws_bytes < 2 * p.ch.n * slab * sizeof(float)) return SSBEV_EWORKSPACE;
+    pl = static_cast<float*>(ws);
+    pr = pl + p.ch.n * slab;
+  }
+  auto kern = gwc_warp_bwd2_kernel<CPG>;
+  if (p.lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
+          hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(d->B * d->H, p.ch.n), dim3(p.threads), p.lds, st, gvol, l, r, calib, pl, pr, p.ch, d->B,
+                     d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners);
+  if (p.ch.n > 1) {
+    const size_t n4 = slab / 4;
+    hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, pl, gl, p.ch.n, n4);
+    hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, pr, gr, p.ch.n, n4);
+  }
+  return ssbev_launch_status();
+}
+
+template <int CPG>
+size_t bwd2_workspace(const ssbev_gwc_dims* d) {
+  const Bwd2Plan p = plan_bwd2<CPG>(d);
+  if (!p.ok || p.ch.n <= 1) return 0;
+  return (size_t)2 * p.ch.n * d->B * d->H * d->W * d->C * sizeof(float);
+}
+
 }  // namespace
 
 extern "C" {
@@ -293,6 +661,29 @@ int ssbev_gwc_warp_bwd(const float* grad_vol, const float* left, const float* ri
     case 2: return launch_bwd<2>(grad_vol, left, right, calib, grad_left, grad_right, d, st);
     case 4: return launch_bwd<4>(grad_vol, left, right, calib, grad_left, grad_right, d, st);
     default: return launch_bwd<8>(grad_vol, left, right, calib, grad_left, grad_right, d, st);
+  }
+}
+
+size_t ssbev_gwc_warp_bwd_workspace(const ssbev_gwc_dims* d) {
+  if (!gwc_dims_ok(d)) return 0;
+  switch (d->C / d->G) {
+    case 1: return bwd2_workspace<1>(d);
+    case 2: return bwd2_workspace<2>(d);
+    case 4: return bwd2_workspace<4>(d);
+    default: return bwd2_workspace<8>(d);
+  }
+}
+
+int ssbev_gwc_warp_bwd_fused(const float* grad_vol, const float* left, const float* right, const float* calib,
+                             float* grad_left, float* grad_right, const ssbev_gwc_dims* d, void* ws, size_t ws_bytes,
+                             ssbev_stream_t stream) {
+  if (!gwc_dims_ok(d) || !grad_vol || !left || !right || !calib || !grad_left || !grad_right) return SSBEV_EINVAL;
+  hipStream_t st = as_stream(stream);
+  switch (d->C / d->G) {
+    case 1: return launch_bwd2<1>(grad_vol, left, right, calib, grad_left, grad_right, d, ws, ws_bytes, st);
+    case 2: return launch_bwd2<2>(grad_vol, left, right, calib, grad_left, grad_right, d, ws, ws_bytes, st);
+    case 4: return launch_bwd2<4>(grad_vol, left, right, calib, grad_left, grad_right, d, ws, ws_bytes, st);
+    default: return launch_bwd2<8>(grad_vol, left, right, calib, grad_left, grad_right, d, ws, ws_bytes, st);
   }
 }
 

@@ -333,8 +333,10 @@ class _GwcWarp(torch.autograd.Function):
         gr = torch.empty_like(r)
         nby = 4.0 * (g.numel() + 2 * l.numel() + 2 * r.numel())  # the gradient volume ONCE + both maps in, both gradients out
         with _span("gwc_warp_bwd", 16.0 * g.numel() * (Cch // groups), nby, f"bwd   gwc_warp D={ndisp} {H}x{W} G={groups}"):
-            capi.check(lib.ssbev_gwc_warp_bwd(capi.ptr(g), capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(gl),
-                                              capi.ptr(gr), C.byref(d), capi.stream()), "ssbev_gwc_warp_bwd")
+            ws = _ws(lib.ssbev_gwc_warp_bwd_workspace(C.byref(d)), g.device)
+            capi.check(lib.ssbev_gwc_warp_bwd_fused(capi.ptr(g), capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(gl),
+                                                    capi.ptr(gr), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_gwc_warp_bwd_fused")
         return from_cl(gl), from_cl(gr), None, None, None, None
 
 

@@ -119,7 +119,12 @@ def test_gwc_warp_golden(ac):
 
 
 @pytest.mark.parametrize("ac", [True, False])
-@pytest.mark.parametrize("B,C,G,H,W,D", [(2, 64, 32, 3, 40, 48), (1, 64, 32, 2, 160, 192), (1, 32, 8, 2, 24, 16)])
+@pytest.mark.parametrize("B,C,G,H,W,D", [(2, 64, 32, 3, 40, 48), (1, 64, 32, 2, 160, 192), (1, 32, 8, 2, 24, 16),
+                                         (2, 32, 32, 2, 17, 5),       # cpg 1, ragged width, fewer planes than chunks
+                                         (1, 64, 8, 1, 33, 40),       # cpg 8
+                                         (1, 24, 6, 2, 20, 12),       # G % 4 != 0: per-plane forward / two-launch backward
+                                         (1, 64, 16, 1, 512, 24),     # row wider than the fused backward's register plan
+                                         (2, 64, 32, 1, 160, 1)])     # a single plane
 def test_gwc_warp_fwd_bwd_vs_oracle(ac, B, C, G, H, W, D):
     L = S.hash_normal("gw/L", (B, C, H, W))
     R = S.hash_normal("gw/R", (B, C, H, W))
@@ -138,6 +143,25 @@ def test_gwc_warp_fwd_bwd_vs_oracle(ac, B, C, G, H, W, D):
     s = max(1.0, Lc.grad.abs().max().item())
     assert maxdiff(Lg.grad, Lc.grad) < 2e-5 * s
     assert maxdiff(Rg.grad, Rc.grad) < 2e-5 * s
+
+
+def test_gwc_warp_nan_calib_and_determinism():
+    """A NaN calibration samples nothing (grid_sample of a NaN coordinate: zero taps) in that batch element only; the
+    plane-chunked backward (partial rows summed in chunk order) is bit-reproducible."""
+    B, C, G, H, W, D = 2, 64, 32, 2, 40, 48
+    L = S.hash_normal("gwn/L", (B, C, H, W)).to(DEV).requires_grad_(True)
+    R = S.hash_normal("gwn/R", (B, C, H, W)).to(DEV).requires_grad_(True)
+    calib = torch.tensor([float("nan"), 97.3], device=DEV)
+    vol = F.gwc_warp(L, R, calib, D, G, True)
+    assert torch.count_nonzero(vol[0]) == 0 and torch.isfinite(vol).all() and torch.count_nonzero(vol[1]) > 0
+    go = S.hash_normal("gwn/go", tuple(vol.shape)).to(DEV)
+    grads = []
+    for _ in range(2):
+        L.grad = R.grad = None
+        vol.backward(go, retain_graph=True)
+        grads.append((L.grad.clone(), R.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert torch.count_nonzero(grads[0][0][0]) == 0 and torch.isfinite(grads[0][0]).all()
 
 
 # ------------------------------------------------------------------------------------ convolutions
