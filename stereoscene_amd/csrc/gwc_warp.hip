@@ -136,29 +136,35 @@ constexpr int FWD_MAXLEN = 32;                              // longest chunk (ta
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int CPG, bool NT>
+template <int CPG, bool NT, bool STAGE>
 __global__ void __launch_bounds__(512)
 gwc_warp_fwd4_kernel(const float* __restrict__ left, const float* __restrict__ right,
                      const float* __restrict__ calib, float* __restrict__ vol, PlaneChunks chunks, int B, int C, int G,
-                     int D, int H, int W, float down, int align_corners) {
+                     int D, int H, int W, float down, int align_corners, int rows_per_wg) {
   extern __shared__ __align__(16) float lds[];
-  const int stride = C + 4;
-  float* Rrow = lds;                                       // [W][stride]
-  XTap* taps = reinterpret_cast<XTap*>(lds + W * stride);  // [FWD_MAXLEN]
-  const int bh = blockIdx.x;
-  const int b = bh / H, h = bh - b * H;
+  // STAGE: one row per workgroup, the right-view row staged in LDS (+4-float pad).  !STAGE: rows_per_wg consecutive rows
+  // per workgroup, the right view read straight from L2 at the (rare) run starts -- no staging, no LDS footprint, and
+  // rows_per_wg * W * G contiguous floats written per plane.
+  const int stride = STAGE ? C + 4 : C;
+  XTap* taps = reinterpret_cast<XTap*>(STAGE ? lds + W * stride : lds);  // [FWD_MAXLEN]
+  const int row0 = blockIdx.x * rows_per_wg;                             // first (b, h) row of this workgroup
+  const int nrows = min(rows_per_wg, B * H - row0);
   const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1];
-  const float* Lrow_g = left + ((size_t)b * H + h) * W * C;
-  stage_row(right + ((size_t)b * H + h) * W * C, Rrow, W, C, stride);
+  if (STAGE) stage_row(right + (size_t)row0 * W * C, lds, W, C, stride);
+  // calib is per batch element: a workgroup's rows must share it (rows_per_wg divides H, checked by the launcher)
   if ((int)threadIdx.x < k_end - k_begin)
-    taps[threadIdx.x] = depth_tap(calib[b], k_begin + threadIdx.x, D, down, align_corners);
+    taps[threadIdx.x] = depth_tap(calib[row0 / H], k_begin + threadIdx.x, D, down, align_corners);
   __syncthreads();
 
   const float inv_cpg = 1.0f / (float)CPG;
   const int G4 = G >> 2;
   const size_t plane = (size_t)H * W * G;
-  for (int item = threadIdx.x; item < W * G4; item += blockDim.x) {
-    const int w = item / G4, g4 = (item - w * G4) << 2;
+  for (int item = threadIdx.x; item < nrows * W * G4; item += blockDim.x) {
+    const int rr = item / (W * G4), wi = item - rr * (W * G4);
+    const int w = wi / G4, g4 = (wi - w * G4) << 2;
+    const int row = row0 + rr, b = row / H, h = row - b * H;
+    const float* Lrow_g = left + (size_t)row * W * C;
+    const float* Rrow = STAGE ? lds : right + (size_t)row * W * C;
     float l[4][2][CPG], wy[4][2];
     int cy[4][2];
 #pragma unroll
@@ -326,7 +332,7 @@ template <int CPG> struct BwdCfg { static constexpr int MAXI = CPG >= 8 ? 2 : (C
 constexpr int BWD_MAXQ = 2;
 constexpr int BWD_MAXTHREADS = 768;     // 12 waves = 3 per SIMD: 170 VGPRs each
 
-template <int CPG>
+template <int CPG, int UNR, bool NT>
 __global__ void __launch_bounds__(BWD_MAXTHREADS)
 gwc_warp_bwd2_kernel(const float* __restrict__ gvol, const float* __restrict__ left, const float* __restrict__ right,
                      const float* __restrict__ calib, float* __restrict__ part_l, float* __restrict__ part_r,
@@ -392,17 +398,26 @@ gwc_warp_bwd2_kernel(const float* __restrict__ gvol, const float* __restrict__ l
     v4f T0[BWD_MAXQ], T1[BWD_MAXQ];
 #pragma unroll
     for (int it = 0; it < BWD_MAXQ; ++it) T0[it] = T1[it] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
-    for (int kk = k; kk < ke; ++kk) {
-      const XTap t = taps[kk - k_begin];
-      const v4f* gk = reinterpret_cast<const v4f*>(grow + (size_t)kk * plane);
+    for (int kk = k; kk < ke; kk += UNR) {
+      v4f gv[UNR][BWD_MAXQ];
 #pragma unroll
-      for (int it = 0; it < BWD_MAXQ; ++it) {
-        const int q = tid + it * nthr;
-        if (q < nq) {
-          const v4f gv = __builtin_nontemporal_load(gk + q);
-          T0[it] += t.w0 * gv;
-          T1[it] += t.w1 * gv;
+      for (int u = 0; u < UNR; ++u) {
+        const v4f* gk = reinterpret_cast<const v4f*>(grow + (size_t)min(kk + u, ke - 1) * plane);
+#pragma unroll
+        for (int it = 0; it < BWD_MAXQ; ++it) {
+          const int q = min(tid + it * nthr, nq - 1);
+          gv[u][it] = NT ? __builtin_nontemporal_load(gk + q) : gk[q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (kk + u < ke) {
+          const XTap t = taps[kk + u - k_begin];
+#pragma unroll
+          for (int it = 0; it < BWD_MAXQ; ++it) {
+            T0[it] += t.w0 * gv[u][it];
+            T1[it] += t.w1 * gv[u][it];
+          }
         }
       }
     }
@@ -529,16 +544,22 @@ int launch_fwd(const float* l, const float* r, const float* calib, float* vol, c
     static const int threads = env_int("SSBEV_GWC_FWD_THREADS", 256);
     static const int wg_target = env_int("SSBEV_GWC_FWD_WGS", 768);
     static const int nt = env_int("SSBEV_GWC_FWD_NT", 1);
-    const PlaneChunks ch = make_chunks(d->D, (int)cdiv(wg_target, d->B * d->H), 8.0f, FWD_MAXLEN);
-    const size_t lds = (size_t)d->W * (d->C + 4) * 4 + FWD_MAXLEN * sizeof(XTap);
+    static const float run_cost = (float)env_int("SSBEV_GWC_FWD_RUNCOST", 4);
+    static const int rows_env = env_int("SSBEV_GWC_FWD_ROWS", 0);        // 0 = LDS-staged row per workgroup; n = n rows, unstaged
+    int rows = rows_env;
+    while (rows > 1 && d->H % rows != 0) --rows;                         // a workgroup's rows share one batch element
+    const int nrow_groups = rows > 0 ? d->B * d->H / rows : d->B * d->H;
+    const PlaneChunks ch = make_chunks(d->D, (int)cdiv(wg_target, nrow_groups), run_cost, FWD_MAXLEN);
+    const size_t lds = (rows > 0 ? 0 : (size_t)d->W * (d->C + 4) * 4) + FWD_MAXLEN * sizeof(XTap);
     if (lds <= 160 * 1024) {
-      auto kern = nt ? gwc_warp_fwd4_kernel<CPG, true> : gwc_warp_fwd4_kernel<CPG, false>;
+      auto kern = rows > 0 ? (nt ? gwc_warp_fwd4_kernel<CPG, true, false> : gwc_warp_fwd4_kernel<CPG, false, false>)
+                           : (nt ? gwc_warp_fwd4_kernel<CPG, true, true> : gwc_warp_fwd4_kernel<CPG, false, true>);
       if (lds > 64 * 1024 &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
               hipSuccess)
         return SSBEV_ELAUNCH;
-      hipLaunchKernelGGL(kern, dim3(d->B * d->H, ch.n), dim3(std::min(512, std::max(64, threads))), lds, st, l, r, calib,
-                         vol, ch, d->B, d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners);
+      hipLaunchKernelGGL(kern, dim3(nrow_groups, ch.n), dim3(std::min(512, std::max(64, threads))), lds, st, l, r, calib,
+                         vol, ch, d->B, d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners, std::max(rows, 1));
       return ssbev_launch_status();
     }
   }
@@ -596,7 +617,8 @@ Bwd2Plan plan_bwd2(const ssbev_gwc_dims* d) {
   if (p.lds > 160 * 1024) return p;
   static const int wg_target = env_int("SSBEV_GWC_BWD_WGS", 256);     // one workgroup per CU (LDS-bound occupancy)
   const int rows = d->B * d->H;
-  p.ch = make_chunks(d->D, std::max(1, wg_target / rows), 4.0f, d->D);
+  static const float run_cost = (float)env_int("SSBEV_GWC_BWD_RUNCOST", 5);
+  p.ch = make_chunks(d->D, std::max(1, wg_target / rows), run_cost, d->D);
   p.ok = true;
   return p;
 }
@@ -613,7 +635,9 @@ int launch_bwd2(const float* gvol, const float* l, const float* r, const float* 
     pl = static_cast<float*>(ws);
     pr = pl + p.ch.n * slab;
   }
-  auto kern = gwc_warp_bwd2_kernel<CPG>;
+  static const int unr = env_int("SSBEV_GWC_BWD_UNR", 2), nt = env_int("SSBEV_GWC_BWD_NT", 0);
+  auto kern = unr >= 4 ? (nt ? gwc_warp_bwd2_kernel<CPG, 4, true> : gwc_warp_bwd2_kernel<CPG, 4, false>)
+                       : (nt ? gwc_warp_bwd2_kernel<CPG, 2, true> : gwc_warp_bwd2_kernel<CPG, 2, false>);
   if (p.lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
           hipSuccess)

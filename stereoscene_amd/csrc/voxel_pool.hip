@@ -239,7 +239,9 @@ pool_gather2_kernel(const float* __restrict__ depth, const float* __restrict__ f
     if (v >= nv) break;
     const int s = __builtin_amdgcn_readlane(st, i), e = __builtin_amdgcn_readlane(st, i + 1);
     const int b = v / vox_per_batch;
-    for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+    for (int cb = 0; cb < C; cb += 64 * VEC) {        // wave-uniform loop: every lane takes part in the broadcasts below
+      const int c0 = cb + lane * VEC;
+      const bool active = c0 < C;
       float acc[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
@@ -261,7 +263,7 @@ pool_gather2_kernel(const float* __restrict__ depth, const float* __restrict__ f
             const int jj = min(j0 + u, cnt - 1);          // wave-uniform; the clamped tail re-reads the last row (unused)
             const int r = __builtin_amdgcn_readlane(row, jj);
             ww[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), jj));
-            const float* src = feat + (size_t)r * C + c0;
+            const float* src = feat + (size_t)r * C + (active ? c0 : 0);
             if (VEC == 4) {
               const float4 t = *reinterpret_cast<const float4*>(src);
               f[u][0] = t.x; f[u][1 % VEC] = t.y; f[u][2 % VEC] = t.z; f[u][3 % VEC] = t.w;
@@ -281,6 +283,7 @@ pool_gather2_kernel(const float* __restrict__ depth, const float* __restrict__ f
           }
         }
       }
+      if (!active) continue;
       float* dst = out + (size_t)v * C + c0;
       if (VEC == 4) {
         *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
@@ -290,6 +293,79 @@ pool_gather2_kernel(const float* __restrict__ depth, const float* __restrict__ f
         dst[0] = acc[0];
       }
     }
+  }
+}
+
+// Third layout, used when C == 64 * NV4 (the path's C = 128 -> NV4 = 2): FOUR voxels per wave side by side, 16 lanes each,
+// a lane owning 4 * NV4 consecutive channels (a 16-lane group reads one feature row as a contiguous 256 * NV4-byte run).
+// The per-voxel latency chains (bounds -> order[] -> depth[] / rows -> sums) of four voxels overlap inside one wave, which is
+// what the occupancy-limited gather2 (one voxel at a time per wave, 92 us) lacked.  Same sums, same order => bit-exact.
+template <bool FUSED, int NV4>
+__global__ void __launch_bounds__(256)
+pool_gather3_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                    float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
+  constexpr int C = 64 * NV4, U = 8;
+  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
+  const int v = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+  const bool vok = v < nv;
+  const int s = vok ? starts[v] : 0, e = vok ? starts[v + 1] : 0;
+  const int b = vok ? v / vox_per_batch : 0;
+  float4 acc[NV4];
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int p_next = (s + gl < e) ? order[s + gl] : 0;
+  for (int base = s; base < e; base += 16) {            // trip count differs between the four groups of a wave
+    const int cnt = min(16, e - base);
+    const int p = p_next;
+    // the next block's point ids travel while this block's rows are summed (long near-camera lists: the serial chain
+    // per 16 points is the two feature-row batches, not order[] -> rows)
+    p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
+    int row = p;
+    float wgt = 1.0f;
+    if (FUSED) {
+      const int q = p - b * P;
+      const int n = q / (D * HW);
+      row = (b * N + n) * HW + (q % HW);
+      wgt = gl < cnt ? depth[p] : 0.0f;
+    }
+    for (int j0 = 0; j0 < cnt; j0 += U) {
+      float4 f[U][NV4];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = gbase + min(j0 + u, cnt - 1);     // a lane of this group (all of them are active here)
+        const int r = __shfl(row, jj, 64);
+        ww[u] = __shfl(wgt, jj, 64);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u < cnt) {
+#pragma unroll
+          for (int k = 0; k < NV4; ++k) {
+            if (FUSED) {
+              acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
+              acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
+              acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
+              acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
+            } else {
+              acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
+              acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
+              acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
+              acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (vok) {
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
   }
 }
 
@@ -386,30 +462,39 @@ lift_splat_bwd2_kernel(const float* __restrict__ gout, const float* __restrict__
     const int vl = lane < cnt ? vox[pl] : -1;
     const float wl = lane < cnt ? depth[pl] : 0.0f;
     float dotl = 0.0f;                                   // lane j ends up with the dot of plane d0 + j
-    for (int j0 = 0; j0 < cnt; j0 += SLOTS * UNR) {
+    // only ~27 % of the frustum points fall inside the grid: walk the KEPT planes of this block (ballot + bit scan, all
+    // wave-uniform scalar work), SLOTS * UNR of them per batch; dropped planes keep a zero dot
+    unsigned long long mask = __ballot(vl >= 0);
+    while (mask) {
+      int jsel[UNR];
       float4 g[UNR];
       float w[UNR];
-      int vv[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        // plane of this lane's slot in step u (wave-uniform base, slot-dependent offset): broadcast through bpermute
-        const int j = j0 + u * SLOTS + slot;
-        vv[u] = __shfl(vl, min(j, 63), 64);
-        w[u] = __shfl(wl, min(j, 63), 64);
-        if (j >= cnt) vv[u] = -1;
-        g[u] = vv[u] >= 0 ? *reinterpret_cast<const float4*>(gout + (size_t)vv[u] * C + 4 * ls) : make_float4(0, 0, 0, 0);
+        int mine = -1;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+          const int j = mask ? (int)__builtin_ctzll(mask) : -1;
+          mask &= mask - 1;                              // (0 & anything) stays 0
+          if (sl == slot) mine = j;
+        }
+        jsel[u] = mine;
+        const int vv = __shfl(vl, max(mine, 0), 64);
+        w[u] = __shfl(wl, max(mine, 0), 64);
+        g[u] = mine >= 0 ? *reinterpret_cast<const float4*>(gout + (size_t)vv * C + 4 * ls) : make_float4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         float dot = g[u].x * f.x + g[u].y * f.y + g[u].z * f.z + g[u].w * f.w;
 #pragma unroll
         for (int off = LPS / 2; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-        acc.x += w[u] * g[u].x; acc.y += w[u] * g[u].y; acc.z += w[u] * g[u].z; acc.w += w[u] * g[u].w;
-        // hand the dot of plane j to lane j: every lane of slot `sl` holds dot(plane j0 + u*SLOTS + sl)
+        if (jsel[u] >= 0) { acc.x += w[u] * g[u].x; acc.y += w[u] * g[u].y; acc.z += w[u] * g[u].z; acc.w += w[u] * g[u].w; }
+        // hand the dot of plane j to lane j
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
           const float dsl = __shfl(dot, sl * LPS, 64);
-          if (lane == j0 + u * SLOTS + sl) dotl = dsl;
+          const int jl = __shfl(jsel[u], sl * LPS, 64);
+          if (lane == jl) dotl = dsl;
         }
       }
     }
@@ -444,7 +529,20 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
                   const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st) {
   const int nv = d->B * d->nx * d->ny * d->nz;
   const int vpb = d->nx * d->ny * d->nz;
-  static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 2;   // 1 = r1 kernel
+  static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 3;   // 1 = r1 kernel, 2 = one voxel per wave at a time, 3 = four side by side
+  if (variant == 3 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+    dim3 grid3(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block3(256);
+    if (d->C == 64)
+      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 1>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else if (d->C == 128)
+      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 2>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else
+      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 4>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    return ssbev_launch_status();
+  }
   if (variant != 1) {
     dim3 grid2(cdiv((size_t)cdiv(nv, POOL_VPW) * 64, 256)), block2(256);
     if (d->C % 256 == 0)

@@ -41,6 +41,11 @@ def main():
     vol = torch.empty(B, D, H, W, G, device=dev)
     d = capi.GwcDims(B, Cc, G, D, H, W, 1.0, 1)
     st = capi.stream()
+    report("reference: torch fill_", timed(lambda: vol.fill_(1.0)), 4.0 * vol.numel())
+    src = torch.randn_like(vol)
+    report("reference: torch sum (read)", timed(lambda: src.sum()), 4.0 * vol.numel())
+    report("reference: torch copy_", timed(lambda: vol.copy_(src)), 8.0 * vol.numel())
+    del src
     report("gwc_warp_fwd", timed(lambda: capi.check(lib.ssbev_gwc_warp_fwd(capi.ptr(l), capi.ptr(r), capi.ptr(cal), capi.ptr(vol),
                                                                         C.byref(d), st), "fwd")),
            4.0 * (l.numel() + r.numel() + vol.numel()))
