@@ -395,6 +395,20 @@ int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_win
  * streamed through LDS once, U in the ssbev_wino_dgemm_pack layout. */
 int ssbev_wino_bgemm(const float* A, const float* Wp, float* Cm, int64_t T, int K, int N, ssbev_stream_t stream);
 
+/* Depth-fused Winograd contraction (csrc/winograd_fused.hip): F(4,3) x F(4,3) over (h, w) in memory (P / Mo / Z are
+ * [36][B*D*(H/4)*(W/4)][C], the 2-D transforms above with D as a batch axis), F(2,3) along d in registers around the MFMAs.
+ * The default realisation of the wide stride-1 3x3x3 layers (resnet3d.py:18-32, second_fpn_3d.py:53-69, occhead.py:100-107):
+ * forward / data gradient = ssbev_wino43_2d_input_transform -> ssbev_wino43_df_gemm -> ssbev_wino43_2d_output_transform,
+ * weight gradient = ssbev_wino43_2d_output_adjoint(gy) + ssbev_wino43_df_wgrad(P saved by the forward).
+ * d = (B, D, H, W, C = K).  Supported when H % 4 == W % 4 == 0, D even, K % 32 == 0. */
+int ssbev_wino43_df_supported(const ssbev_wino_dims* d, int N);
+size_t ssbev_wino43_df_packed_elems(int Cout, int Cin);
+int ssbev_wino43_df_pack(const float* w, float* Wp, int Cout, int Cin, int mode, ssbev_stream_t stream);
+int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream);
+size_t ssbev_wino43_df_wgrad_workspace(const ssbev_wino_dims* d, int N);
+int ssbev_wino43_df_wgrad(const float* P, const float* Z, float* gw, const ssbev_wino_dims* d, int N, void* workspace,
+                          size_t ws_bytes, ssbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,12 @@ SIGNATURES = {
     "ssbev_wino_dgemm_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino_dgemm": (C.c_int, [_P, _P, _P, C.POINTER(WinoDims), C.c_int, _P]),
     "ssbev_wino_bgemm": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "ssbev_wino43_df_supported": (C.c_int, [C.POINTER(WinoDims), C.c_int]),
+    "ssbev_wino43_df_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "ssbev_wino43_df_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ssbev_wino43_df_gemm": (C.c_int, [_P, _P, _P, C.POINTER(WinoDims), C.c_int, _P]),
+    "ssbev_wino43_df_wgrad_workspace": (C.c_size_t, [C.POINTER(WinoDims), C.c_int]),
+    "ssbev_wino43_df_wgrad": (C.c_int, [_P, _P, _P, C.POINTER(WinoDims), C.c_int, _P, C.c_size_t, _P]),
     "ssbev_wino2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

@@ -463,7 +463,12 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
             and st == (1, 1, 1) and pd == (0, 0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
         return linear_cl(x, weight, bias)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x, weight, st, pd, dl):
-        y = _WinoConv.apply(x, weight)
+        B, Cin, D, H, W = x.shape
+        if tuple(weight.shape[2:]) == (3, 3, 3) and H % 4 == 0 and W % 4 == 0 and \
+                _wino_df_applicable(B, D, H, W, Cin, weight.shape[0]):
+            y = _WinoConvDF.apply(x, weight)
+        else:
+            y = _WinoConv.apply(x, weight)
         return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
     return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0))
 
@@ -633,6 +638,82 @@ WINO_F43_2D = os.environ.get("SSBEV_WINO_F43_2D", "0") != "0"
 # to 1.1 % (tools/grad_l2_probe.py), so the default keeps F(2,3) along d.
 WINO_F444 = os.environ.get("SSBEV_WINO_F444", "0") != "0"
 WINO_F444_MIN_CIN = int(os.environ.get("SSBEV_WINO_F444_MIN_CIN", "0"))     # with F444 on: only layers at least this wide
+
+
+# Default realisation of the wide 3-D layers (r2): F(4,3)^2 over (h, w) in memory + F(2,3) along d in registers inside the
+# hand-written MFMA contraction csrc/winograd_fused.hip (forward, data and weight gradient): no library GEMM, transformed
+# tensors 2.25x instead of 4.5x.  SSBEV_WINO_DF=0 restores the F(2x4x4) transforms + 144 batched rocBLAS GEMMs.
+WINO_DF = os.environ.get("SSBEV_WINO_DF", "1") != "0"
+
+
+def _wino_df_applicable(B, D, H, W, Cin, Cout):
+    if not (WINO_DF and WINO_F43 and PRECISION == "fp32" and not (WINO_DEPTH_FUSED or WINO_OWN_GEMM or WINO_F444)):
+        return False
+    lib = capi.load()
+    return bool(lib.ssbev_wino43_df_supported(C.byref(capi.WinoDims(B, D, H, W, Cin)), Cout)) and \
+        bool(lib.ssbev_wino43_df_supported(C.byref(capi.WinoDims(B, D, H, W, Cout)), Cin)) and Cout % 4 == 0
+
+
+def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl):
+    """(h,w) input transform -> depth-fused MFMA contraction -> (h,w) output transform of a channels-last volume with K
+    input / N output channels.  mode 0: forward (w [N,K,3,3,3]); mode 1: data gradient (w [K,N,3,3,3], mirrored taps).
+    Returns (y_cl, P) -- P [36, B*D*H/4*W/4, K] is what the weight gradient needs."""
+    lib = capi.load()
+    Cout, Cin = (N, K) if mode == 0 else (K, N)
+    R = B * D * (H // 4) * (W // 4)
+    with _span("wino_transform", 0.0, 4.0 * xcl.numel() * 3.25, tag + " in"):
+        P = _wino_call("ssbev_wino43_2d_input_transform", xcl, capi.WinoDims(B, D, H, W, K), (36, R, K))
+    Wp = torch.empty(lib.ssbev_wino43_df_packed_elems(Cout, Cin), dtype=torch.float32, device=xcl.device)
+    capi.check(lib.ssbev_wino43_df_pack(capi.ptr(w), capi.ptr(Wp), Cout, Cin, mode, capi.stream()), "ssbev_wino43_df_pack")
+    Mo = torch.empty(36, R, N, dtype=torch.float32, device=xcl.device)
+    dims = capi.WinoDims(B, D, H, W, K)
+    nby = 4.0 * (B * D * H * W * (K + N) + 27 * K * N)
+    with _span("conv_wino_fused", fl, nby, tag, fl / 6.0):
+        capi.check(lib.ssbev_wino43_df_gemm(capi.ptr(P), capi.ptr(Wp), capi.ptr(Mo), C.byref(dims), N, capi.stream()),
+                   "ssbev_wino43_df_gemm")
+    with _span("wino_transform", 0.0, 4.0 * B * D * H * W * N * 3.25, tag + " out"):
+        y = _wino_call("ssbev_wino43_2d_output_transform", Mo, capi.WinoDims(B, D, H, W, N), (B, D, H, W, N))
+    return y, P
+
+
+class _WinoConvDF(torch.autograd.Function):
+    """3x3x3 / stride 1 / pad 1 convolution on the depth-fused Winograd kernels (see WINO_DF)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        xcl = to_cl(_f32(x, "wino_conv"))
+        B, D, H, W, Cin = xcl.shape
+        Cout = weight.shape[0]
+        fl = 2.0 * B * D * H * W * Cin * Cout * 27
+        w = weight.detach().contiguous()
+        y, P = _wino_df_gemm(xcl, w, B, D, H, W, Cin, Cout, 0, f"winoDF fwd {Cin}->{Cout} {D}x{H}x{W}", fl)
+        ctx.save_for_backward(P if weight.requires_grad else None, weight)
+        ctx.geom = (B, D, H, W, Cin, Cout, fl)
+        return from_cl(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        P, weight = ctx.saved_tensors
+        B, D, H, W, Cin, Cout, fl = ctx.geom
+        gcl = to_cl(gy)
+        lib = capi.load()
+        w = weight.detach().contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gxcl, _ = _wino_df_gemm(gcl, w, B, D, H, W, Cout, Cin, 1, f"winoDF dgrad {Cin}->{Cout} {D}x{H}x{W}", fl)
+            gx = from_cl(gxcl)
+        if ctx.needs_input_grad[1]:
+            R = B * D * (H // 4) * (W // 4)
+            with _span("wino_transform", 0.0, 4.0 * gcl.numel() * 3.25, "winoDF wgrad adjoint"):
+                Z = _wino_call("ssbev_wino43_2d_output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (36, R, Cout))
+            dims = capi.WinoDims(B, D, H, W, Cin)
+            ws = _ws(lib.ssbev_wino43_df_wgrad_workspace(C.byref(dims), Cout), gy.device)
+            gw = torch.empty_like(w)
+            nby = 4.0 * (B * D * H * W * (Cin + Cout) + 27 * Cin * Cout)
+            with _span("conv_wino_fused_wgrad", fl, nby, f"winoDF wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / 6.0):
+                capi.check(lib.ssbev_wino43_df_wgrad(capi.ptr(P), capi.ptr(Z), capi.ptr(gw), C.byref(dims), Cout, capi.ptr(ws),
+                                                     ws.numel(), capi.stream()), "ssbev_wino43_df_wgrad")
+        return gx, gw
 
 
 class _WinoConv(torch.autograd.Function):

@@ -668,6 +668,47 @@ def test_winograd_f43_tiles(case, monkeypatch):
         assert rel_max < tol_max and rel_l2 < tol_l2, (name, rel_max, rel_l2)
 
 
+@pytest.mark.parametrize("case", [(2, 128, 96, 6, 4, 4), (1, 96, 96, 4, 8, 12), (1, 384, 192, 2, 4, 8), (1, 64, 64, 6, 8, 8),
+                                  (1, 128, 128, 16, 8, 8), (2, 512, 256, 4, 4, 8), (1, 192, 384, 2, 36, 40), (1, 128, 160, 8, 32, 36),
+                                  (1, 256, 64, 4, 20, 16)])
+def test_winograd_depth_fused_f43(case, monkeypatch):
+    """The default realisation of the wide 3-D layers: (h, w)-only F(4,3) transforms + the depth-fused MFMA contraction of
+    csrc/winograd_fused.hip (F(2,3) along d in registers) for forward, data gradient and weight gradient, against ATen.
+    Cases: 2 / 3 / 4 waves per workgroup (N = 64 / 96, 192 / 128...), partial row groups (Thw = 1 .. 90), one to eight depth
+    tiles, K = 192 (second 128-channel block half empty in the weight gradient), several column / K blocks, batch 2.
+    Same transform constants as F(2x4x4): gate 2e-4 of the tensor max, L2 1e-4."""
+    B, Cin, Cout, D, H, W = case
+    monkeypatch.setattr(F, "WINO_DF", True)
+    assert F._wino_df_applicable(B, D, H, W, Cin, Cout)
+    x = S.hash_normal(f"wdf/x{case}", (B, Cin, D, H, W))
+    w = S.hash_uniform(f"wdf/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = TF.conv3d(xc, wc, None, 1, 1)
+    go = S.hash_normal(f"wdf/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    timer = F.KernelTimer(families=set())
+    F.KERNEL_TIMER = timer
+    try:
+        got = F.conv3d(xg, wg, None, 1, 1)
+        got.backward(go.to(DEV))
+    finally:
+        F.KERNEL_TIMER = None
+    assert timer.counts.get("conv_wino_fused", {}).get("launches") == 2 and "conv_wino_fused_wgrad" in timer.counts
+    for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad), ("gw", wg.grad, wc.grad)):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        rel_max = (a - b).abs().max().item() / b.abs().max().item()
+        rel_l2 = ((a - b).norm() / b.norm()).item()
+        assert rel_max < 2e-4 and rel_l2 < 1e-4, (name, rel_max, rel_l2)
+
+
+def test_winograd_depth_fused_falls_back_when_unsupported():
+    assert not F._wino_df_applicable(1, 4, 8, 8, 100, 128)       # K % 32 != 0
+    assert not F._wino_df_applicable(1, 4, 8, 8, 128, 100)       # ... on the data-gradient side
+    assert not F._wino_df_applicable(1, 3, 8, 8, 128, 128)       # odd depth
+    assert not F._wino_df_applicable(1, 4, 6, 8, 128, 128)       # H % 4 != 0
+
+
 BF16_DIRECT_CASES = [
     # kind, Cin, Cout, (D, H, W), kernel, stride, pad, dil, tile hint
     ("conv", 32, 32, (5, 6, 40), 3, 1, 1, 1, 9),        # tap-split LDS kernel, bf16 operands
