@@ -391,7 +391,7 @@ __device__ __forceinline__ void tile43(long t, const WinoGeom& g, int& b_or_bd, 
 }
 
 template <int DA, typename TF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : (DA == 2 ? 2 : 8))))
 wino43_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   constexpr int NA = DA ? DA + 2 : 1, NF = NA * 36;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -436,7 +436,7 @@ wino43_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g,
 }
 
 template <int DA, typename TF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : (DA == 2 ? 2 : 8))))
 wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
   constexpr int NA = DA ? DA + 2 : 1, NF = NA * 36;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -479,7 +479,7 @@ wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
 }
 
 template <int DA, typename TF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, DA == 4 ? 1 : (DA == 2 ? 2 : 8))))
 wino43_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   constexpr int NA = DA ? DA + 2 : 1, NG = DA ? DA : 1, NF = NA * 36;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -29,64 +29,87 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 typedef float wf32x16 __attribute__((ext_vector_type(16)));
 __device__ const float kDfZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
-constexpr int DF_BM = 64;       // rows (hw tiles) per workgroup
 constexpr int DF_BK = 32;       // channels per stage: one 128-byte line per row
-constexpr int DF_STAGE_FLOATS = 4 * DF_BM * DF_BK;   // 4 planes
 
 struct DfGeom {
   int B, D, Thw, K, N, NPad;
   int ND;         // depth tiles = D / 2
-  int nrowgrp;    // ceil(Thw / 64)
+  int nrowgrp;    // ceil(Thw / (32 * MT))
   int ncolgrp;    // column groups of NW * 32
-  int NU, NU8;    // row tasks per frequency (B * ND * nrowgrp) and its per-XCD share
+  int NU;         // row tasks per frequency (B * ND * nrowgrp)
   int nxi;        // (h, w) frequencies (36)
 };
 
-template <int DUMMY>
-__global__ void __launch_bounds__(256, 2)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Weight fragments are loaded by inline asm so that the compiler does not track them: with a global_load_lds in flight
+// hipcc drains vmcnt to 0 at the first use of ANY ordinary load result, which serialises the LDS-DMA prefetch of the next
+// A slab with the weight stream.  The waits below are counted by hand (vmcnt retires in order) and tied to the fragment
+// registers ("+v") so that no MFMA can be scheduled above its wait.
+__device__ __forceinline__ void df_load_b(v4f& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void df_wait_b(v4f (&b)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+// MT = 32-row tiles per wave (workgroup tile = 32 MT rows x NW*32 columns); NW = waves per workgroup
+template <int MT, int NW>
+__global__ void __launch_bounds__(64 * NW, 2)
 wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float* __restrict__ Mo, DfGeom g) {
-  extern __shared__ __align__(16) float lds[];            // [2 stages][4 planes][64 rows][32 k]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+  constexpr int BM = 32 * MT;                       // rows per workgroup
+  constexpr int PLANE = BM * DF_BK;                 // floats per plane per stage
+  constexpr int STAGE = 4 * PLANE;
+  constexpr int NI = 4 * BM / 8;                    // global_load_lds instructions per stage (1 KiB each)
+  constexpr int IPP = BM / 8;                       // ... per plane
+  constexpr int GL = NI / NW;                       // per wave (waves j < NI % NW issue one more: counts below are conservative)
+  extern __shared__ __align__(16) float lds[];      // [2 stages][4 planes][BM rows][32 k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
   const int li = lane & 31, lk = lane >> 5;
-  // ---- task decode (XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs)
-  const int id = blockIdx.x, xcd = id & 7, s = id >> 3;
-  const int per_xi = g.NU8 * g.ncolgrp;
-  const int xhw = s / per_xi, r = s - xhw * per_xi;
-  const int cg = r % g.ncolgrp, u = xcd * g.NU8 + r / g.ncolgrp;
-  if (u >= g.NU) return;
+  // ---- task decode.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs; the logical task list
+  // (xi_hw slowest, row task u, column group fastest) is cut into 8 contiguous ranges, one per XCD: an XCD works through
+  // whole frequencies (their weight slab and P planes meet in ITS L2), adjacent depth tiles / column groups run back to back.
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int cg = logical % g.ncolgrp, u = (logical / g.ncolgrp) % g.NU, xhw = logical / (g.ncolgrp * g.NU);
   const int i = u % g.ND, tg = (u / g.ND) % g.nrowgrp, b = u / (g.ND * g.nrowgrp);
-  const int t0 = tg * DF_BM;
+  const int t0 = tg * BM;
   const int n0 = (cg * NW + wave) * 32;
   const bool col_active = n0 < g.NPad;
   const long R = (long)g.B * g.D * g.Thw;
   const float* Px = P + (long)xhw * R * g.K;
   const int nst = g.K / DF_BK;
 
-  // ---- A staging: a stage = 4 planes x 64 rows x 8 slots of 16 bytes = 32 wave instructions of 1 KiB
+  // ---- A staging: a stage = 4 planes x BM rows x 8 slots of 16 bytes, 64 slots (1 KiB) per wave instruction
   auto issue = [&](int st, int buf) {
-    for (int j = wave; j < 32; j += NW) {
-      const int a = j >> 3, item = (j & 7) * 64 + lane;
+#pragma unroll
+    for (int e = 0; e < (NI + NW - 1) / NW; ++e) {
+      const int j = wave + NW * e;
+      if (NI % NW != 0 && j >= NI) break;
+      const int a = j / IPP, jj = j % IPP, item = jj * 64 + lane;
       const int row = item >> 3, slot = item & 7;
       const int d = 2 * i - 1 + a;
       const int t = t0 + row;
       const float* src = (d >= 0 && d < g.D && t < g.Thw)
                              ? Px + (((long)b * g.D + d) * g.Thw + t) * g.K + st * DF_BK + ((slot ^ (row & 7)) << 2)
                              : kDfZeros;
-      __builtin_amdgcn_global_load_lds(src, lds + buf * DF_STAGE_FLOATS + a * (DF_BM * DF_BK) + (j & 7) * 256, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, lds + buf * STAGE + a * PLANE + jj * 256, 16, 0, 0);
     }
   };
 
-  wf32x16 acc[4][2];
+  wf32x16 acc[4][MT];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[f][mt][rr] = 0.0f;
 
@@ -94,64 +117,74 @@ wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float*
   const int Q = g.K >> 3;
   const size_t fstride = (size_t)Q * 2 * g.NPad * 4;
   const float* wl = Wp + (size_t)xhw * 4 * fstride + ((size_t)lk * g.NPad + (col_active ? n0 : 0) + li) * 4;
-  auto load_b = [&](int q, float4 (&bv)[4]) {
+  const size_t qstride = (size_t)2 * g.NPad * 4;
+  auto load_b = [&](int q, v4f (&bv)[4]) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
-      bv[f] = *reinterpret_cast<const float4*>(wl + (size_t)f * fstride + (size_t)q * 2 * g.NPad * 4);
+    for (int f = 0; f < 4; ++f) df_load_b(bv[f], wl + (size_t)f * fstride + (size_t)q * qstride);
   };
 
-  float4 bcur[4], bnext[4];
-  load_b(0, bcur);
-  issue(0, 0);
-  for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nst) issue(st + 1, buf ^ 1);
-    // this stage's A slab has landed once at most the next stage's copies (issued after it) are outstanding
-    if (st + 1 < nst) {
-      if (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (NW == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // waves 0,1: 11 copies, wave 2: 10
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const float* ab = lds + buf * DF_STAGE_FLOATS;
+  // ---- pipeline.  Per k-step (8 channels): issue the weight fragments of the NEXT step, wait for this step's (issued one
+  // step earlier), 8 MT ds_read_b128 + depth transform + 16 MT MFMAs.  The LDS-DMA copies of stage st+1 are issued in
+  // k-step 1 of stage st (after that step's weight loads) into the buffer last read in stage st-1 -- every wave has passed
+  // this stage's barrier, so nobody reads it any more -- and are forced complete by the in-order wait of k-step 3, two
+  // k-steps (~4000 MFMA cycles) later.  One raw s_barrier per stage (__syncthreads() would drain vmcnt at every barrier).
+  //   in-flight queue (oldest first) at the wait of     k-step 0: B(q) B(q+1)             -> vmcnt(4)
+  //                                                     k-step 1: B(q) B(q+1) A(st+1)     -> vmcnt(4 + GL)
+  //                                                     k-step 2: B(q) A(st+1) B(q+1)     -> vmcnt(GL + 4)
+  //                                                     k-step 3: B(q) B(q+1)             -> vmcnt(4)  (retires A(st+1) too)
+  // The stage body is straight-line code and every fragment has landed (vmcnt(0)) before the loop's back edge: the
+  // compiler may copy or spill fragment registers at control-flow joins, and a copy of a register whose load is still in
+  // flight would read stale data (checked on the ISA: no v_mov of a fragment register between its load and its wait).
+  v4f bb[2][4];
+  auto stage = [&](int st, int buf, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    __builtin_amdgcn_s_barrier();                           // stage st's slab is in LDS for every wave
+    const float* ab = lds + buf * STAGE;
 #pragma unroll
     for (int qq = 0; qq < DF_BK / 8; ++qq) {
       const int q = st * (DF_BK / 8) + qq;
-      if (q + 1 < Q) load_b(q + 1, bnext);
-      float4 v[4][2];
+      v4f (&bc)[4] = bb[qq & 1];
+      v4f (&bn)[4] = bb[(qq + 1) & 1];
+      load_b(min(q + 1, Q - 1), bn);                        // (the very last step re-reads its own fragments: unused)
+      if (MORE && qq == 1) issue(st + 1, buf ^ 1);
+      if (MORE && (qq == 1 || qq == 2)) df_wait_b<4 + GL>(bc);
+      else df_wait_b<4>(bc);
+      v4f v[4][MT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 32 + li;
         const int off = row * DF_BK + (((2 * qq + lk) ^ (row & 7)) << 2);
-        const float4 p0 = *reinterpret_cast<const float4*>(ab + 0 * (DF_BM * DF_BK) + off);
-        const float4 p1 = *reinterpret_cast<const float4*>(ab + 1 * (DF_BM * DF_BK) + off);
-        const float4 p2 = *reinterpret_cast<const float4*>(ab + 2 * (DF_BM * DF_BK) + off);
-        const float4 p3 = *reinterpret_cast<const float4*>(ab + 3 * (DF_BM * DF_BK) + off);
-        v[0][mt] = make_float4(p0.x - p2.x, p0.y - p2.y, p0.z - p2.z, p0.w - p2.w);
-        v[1][mt] = make_float4(p1.x + p2.x, p1.y + p2.y, p1.z + p2.z, p1.w + p2.w);
-        v[2][mt] = make_float4(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, p2.w - p1.w);
-        v[3][mt] = make_float4(p1.x - p3.x, p1.y - p3.y, p1.z - p3.z, p1.w - p3.w);
+        const v4f p0 = *reinterpret_cast<const v4f*>(ab + 0 * PLANE + off);
+        const v4f p1 = *reinterpret_cast<const v4f*>(ab + 1 * PLANE + off);
+        const v4f p2 = *reinterpret_cast<const v4f*>(ab + 2 * PLANE + off);
+        const v4f p3 = *reinterpret_cast<const v4f*>(ab + 3 * PLANE + off);
+        v[0][mt] = p0 - p2;
+        v[1][mt] = p1 + p2;
+        v[2][mt] = p2 - p1;
+        v[3][mt] = p1 - p3;
       }
 #define SSBEV_DF_COMP(COMP)                                                                              \
       _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                      \
-      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
-        acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f][mt].COMP, bcur[f].COMP, acc[f][mt], 0, 0, 0);
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
+        acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f][mt].COMP, bc[f].COMP, acc[f][mt], 0, 0, 0);
       SSBEV_DF_COMP(x) SSBEV_DF_COMP(y) SSBEV_DF_COMP(z) SSBEV_DF_COMP(w)
 #undef SSBEV_DF_COMP
-#pragma unroll
-      for (int f = 0; f < 4; ++f) bcur[f] = bnext[f];
     }
-    __syncthreads();          // every wave is done with `buf` before the stage after next is copied into it
-  }
+    df_wait_b<0>(bb[0]);                                    // next stage's first fragments (and this wave's LDS-DMA) landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of `buf` are complete before it moves on
+  };
+  load_b(0, bb[0]);
+  issue(0, 0);
+  df_wait_b<0>(bb[0]);
+  for (int st = 0; st + 1 < nst; ++st) stage(st, st & 1, std::true_type{});
+  stage(nst - 1, (nst - 1) & 1, std::false_type{});
   // ---- epilogue: depth output transform; accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li
   if (!col_active) return;
   const int co = n0 + li;
   if (co >= g.N) return;
   float* Mx = Mo + (long)xhw * R * g.N;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     float* o0 = Mx + (((long)b * g.D + 2 * i) * g.Thw + t0 + mt * 32) * g.N + co;
     float* o1 = o0 + (long)g.Thw * g.N;
 #pragma unroll
@@ -187,19 +220,24 @@ __device__ __forceinline__ void g23(const float* g, int s, float* o, int so) {  
   o[3 * so] = g2;
 }
 
+// Workgroup = 64 columns x 4 consecutive k (one float4 of the packed layout per column): every thread transforms its
+// (k, n) filter, the 144 results go through LDS 36 frequencies at a time and leave as coalesced 16-byte stores (1 KiB per
+// wave instruction).  A direct store from the transforming thread would write 4-byte elements at a 16-byte stride.
 __global__ void __launch_bounds__(256)
 wino_df_pack_kernel(const float* __restrict__ w, float* __restrict__ Wp, int Cout, int Cin, int mode) {
+  __shared__ float4 stage[36][64];
   const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
   const int KPad = (K + 7) & ~7, NPad = (N + 31) & ~31;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= KPad * NPad) return;
-  const int n = idx % NPad, k = idx / NPad;
+  const int t = threadIdx.x >> 6, nl = threadIdx.x & 63;            // k = 4 * kq + t, n = 64 * nb + nl
+  const int nblocks = (NPad + 63) / 64;
+  const int nb = blockIdx.x % nblocks, kq = blockIdx.x / nblocks;
+  const int n = nb * 64 + nl, k = kq * 4 + t;
   float u[144];                                   // [fd][e][f]
   if (k < K && n < N) {
     float gk[27];                                 // [kd][kh][kw]
     const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;
 #pragma unroll
-    for (int t = 0; t < 27; ++t) gk[t] = w[((size_t)co * Cin + ci) * 27 + (mode == 0 ? t : 26 - t)];
+    for (int x = 0; x < 27; ++x) gk[x] = w[((size_t)co * Cin + ci) * 27 + (mode == 0 ? x : 26 - x)];
     float a1[54];                                 // [kd][kh][6] after w
 #pragma unroll
     for (int p = 0; p < 9; ++p) g43(gk + p * 3, 1, a1 + p * 6, 1);
@@ -214,12 +252,19 @@ wino_df_pack_kernel(const float* __restrict__ w, float* __restrict__ Wp, int Cou
 #pragma unroll
     for (int x = 0; x < 144; ++x) u[x] = 0.0f;
   }
-  const int Q = KPad >> 3, q = k >> 3, kh = (k >> 2) & 1, t = k & 3;
+  const int Q = KPad >> 3, q = kq >> 1, kh = kq & 1;
 #pragma unroll
-  for (int fd = 0; fd < 4; ++fd)
+  for (int fd = 0; fd < 4; ++fd) {
+    __syncthreads();
 #pragma unroll
-    for (int xhw = 0; xhw < 36; ++xhw)
-      Wp[(((((size_t)xhw * 4 + fd) * Q + q) * 2 + kh) * NPad + n) * 4 + t] = u[fd * 36 + xhw];
+    for (int xhw = 0; xhw < 36; ++xhw) reinterpret_cast<float*>(&stage[xhw][nl])[t] = u[fd * 36 + xhw];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 36 * 64; e += 256) {
+      const int xhw = e >> 6, c = e & 63;
+      if (nb * 64 + c < NPad)
+        *reinterpret_cast<float4*>(Wp + (((((size_t)xhw * 4 + fd) * Q + q) * 2 + kh) * NPad + nb * 64 + c) * 4) = stage[xhw][c];
+    }
+  }
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------------------------------
@@ -246,7 +291,7 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
   // LDS: [2 bufs][ P: 4 planes x 16 rows x 128 k | Z: 2 planes x 16 rows x 64 n ]
   extern __shared__ __align__(16) float lds[];
   constexpr int PF = 4 * DFW_BR * 128, ZF = 2 * DFW_BR * 64, SF = PF + ZF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
   const int li = lane & 31, lk = lane >> 5;
   // XCD-aware order: consecutive LOGICAL ids (column blocks / K blocks of one row chunk: they share the P and Z slabs) run
   // on one XCD and meet in its L2; hardware deals consecutive workgroup ids round-robin over the 8 XCDs
@@ -263,10 +308,13 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
   const int total_stages = g.B * g.ND * g.nrowstage;
   const int s_begin = chunk * g.stages_per_chunk, s_end = min(total_stages, s_begin + g.stages_per_chunk);
 
-  // one stage = P: 4 x 16 rows x 512 B = 32 KiB?  no: 4 planes x 16 rows x 128 ch x 4 B = 32 KiB;  Z: 2 x 16 x 64 x 4 = 8 KiB
+  // one stage = P: 4 planes x 16 rows x 128 ch x 4 B = 32 KiB; Z: 2 x 16 x 64 x 4 = 8 KiB.  Out-of-range rows / planes /
+  // channels read a 16-byte zero constant.  32-bit element offsets (one frequency slab holds < 2^31 elements, checked by the
+  // host): cheap enough that the compiler selects between the two sources instead of branching around the address math.
   auto issue = [&](int sidx, int buf) {
-    const int rs = sidx % g.nrowstage, bi = sidx / g.nrowstage;
-    const int i = bi % g.ND, b = bi / g.ND;
+    // depth tile fastest: consecutive stages share two of their four P planes (same rows) -> L2 hits
+    const int i = sidx % g.ND, br = sidx / g.ND;
+    const int rs = br % g.nrowstage, b = br / g.nrowstage;
     const int t0 = rs * DFW_BR;
     // P: 4 planes x 16 rows x 32 slots(16 B) = 2048 items = 32 wave instructions, 8 per wave
 #pragma unroll
@@ -275,7 +323,9 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
       const int row = item >> 5, slot = item & 31;
       const int d = 2 * i - 1 + a, t = t0 + row;
       const int kk = k0 + slot * 4;
-      const float* src = (d >= 0 && d < g.D && t < g.Thw && kk < g.K) ? Px + (((long)b * g.D + d) * g.Thw + t) * g.K + kk : kDfZeros;
+      const bool ok = d >= 0 && d < g.D && t < g.Thw && kk < g.K;
+      const int off = ((b * g.D + d) * g.Thw + t) * g.K + kk;
+      const float* src = ok ? Px + off : kDfZeros;
       __builtin_amdgcn_global_load_lds(src, lds + buf * SF + a * (DFW_BR * 128) + (j & 7) * 256, 16, 0, 0);
     }
     // Z: 2 planes x 16 rows x 16 slots = 512 items = 8 wave instructions, 2 per wave
@@ -284,7 +334,9 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
       const int j = wave + 4 * e, a = j >> 2, item = (j & 3) * 64 + lane;
       const int row = item >> 4, slot = item & 15;
       const int t = t0 + row, nn = n0 + slot * 4;
-      const float* src = (t < g.Thw && nn < g.N) ? Zx + (((long)b * g.D + 2 * i + a) * g.Thw + t) * g.N + nn : kDfZeros;
+      const bool ok = t < g.Thw && nn < g.N;
+      const int off = ((b * g.D + 2 * i + a) * g.Thw + t) * g.N + nn;
+      const float* src = ok ? Zx + off : kDfZeros;
       __builtin_amdgcn_global_load_lds(src, lds + buf * SF + PF + a * (DFW_BR * 64) + (j & 3) * 256, 16, 0, 0);
     }
   };
@@ -301,34 +353,51 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
   if (s_begin < s_end) issue(s_begin, 0);
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     const int buf = (sidx - s_begin) & 1;
-    if (sidx + 1 < s_end) {
-      issue(sidx + 1, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage sidx has landed (nothing else is in flight here)
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; and every wave is done with the other buffer
     const float* pb = lds + buf * SF;
     const float* zb = pb + PF;
-    if (kt_active)
+    // the other buffer was last read in the previous stage and every wave has passed the barrier: refill it now, the copies
+    // have this whole stage's 64 MFMAs per wave to land
+    if (sidx + 1 < s_end) issue(sidx + 1, buf ^ 1);
+    // (the kt_active test stays OUTSIDE the row-pair loop: one basic block, so that the LDS reads of the next row pairs are
+    //  scheduled under the MFMAs of the current one instead of an lgkmcnt(0) in front of every group of 8)
+    if (kt_active) {
+      // operands of row pair rp+1 are read from LDS before the 8 MFMAs of row pair rp are issued (explicit software
+      // pipeline: hipcc otherwise puts an lgkmcnt(0) in front of every group of MFMAs)
+      float pc[4], gc[2][2], pn[4], gn[2][2];
+      auto fetch = [&](int rp, float (&p)[4], float (&gz)[2][2]) {
+        const int row = 2 * rp + lk;
+        const int ko = row * 128 + wave * 32 + li;
 #pragma unroll
-    for (int rp = 0; rp < DFW_BR / 2; ++rp) {            // one MFMA k-step = 2 rows
-      const int row = 2 * rp + lk;
-      const int ko = row * 128 + wave * 32 + li;
-      const float p0 = pb[0 * (DFW_BR * 128) + ko], p1 = pb[1 * (DFW_BR * 128) + ko];
-      const float p2 = pb[2 * (DFW_BR * 128) + ko], p3 = pb[3 * (DFW_BR * 128) + ko];
-      const float v0 = p0 - p2, v1 = p1 + p2, v2 = p2 - p1, v3 = p1 - p3;
+        for (int a = 0; a < 4; ++a) p[a] = pb[a * (DFW_BR * 128) + ko];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int zo = row * 64 + nt * 32 + li;
-        const float g0 = zb[zo], g1 = zb[DFW_BR * 64 + zo];
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, g0, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, g0 + g1, acc[1][nt], 0, 0, 0);
-        acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, g0 - g1, acc[2][nt], 0, 0, 0);
-        acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, -g1, acc[3][nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) {
+          gz[nt][0] = zb[row * 64 + nt * 32 + li];
+          gz[nt][1] = zb[DFW_BR * 64 + row * 64 + nt * 32 + li];
+        }
+      };
+      fetch(0, pc, gc);
+#pragma unroll
+      for (int rp = 0; rp < DFW_BR / 2; ++rp) {            // one MFMA k-step = 2 rows
+        if (rp + 1 < DFW_BR / 2) fetch(rp + 1, pn, gn);
+        __builtin_amdgcn_sched_barrier(0);                   // keep the reads ABOVE this row pair's MFMAs
+        const float v0 = pc[0] - pc[2], v1 = pc[1] + pc[2], v2 = pc[2] - pc[1], v3 = pc[1] - pc[3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float g0 = gc[nt][0], g1 = gc[nt][1];
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, g0, acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, g0 + g1, acc[1][nt], 0, 0, 0);
+          acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, g0 - g1, acc[2][nt], 0, 0, 0);
+          acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, -g1, acc[3][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pc[a] = pn[a];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { gc[nt][0] = gn[nt][0]; gc[nt][1] = gn[nt][1]; }
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   // partial tile: part[chunk][fd][xhw][k][n]
   const int kt = k0 + wave * 32;
@@ -362,20 +431,28 @@ __device__ __forceinline__ void g23t(const float* u, int s, float* o, int so) { 
   o[2 * so] = 0.5f * (u1 + u2) + u3;
 }
 
+// part[0][x][idx] = sum over chunks (ascending: deterministic) of part[c][x][idx]
 __global__ void __launch_bounds__(256)
-wino_dfw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int Cout, int Cin, int nchunk) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // (ci, co), co fastest: coalesced partial reads
+wino_dfw_sum_kernel(float* __restrict__ part, size_t n4, int nchunk) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(part)[i];
+  for (int c = 1; c < nchunk; ++c) {
+    const float4 o = reinterpret_cast<const float4*>(part)[(size_t)c * n4 + i];
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+  }
+  reinterpret_cast<float4*>(part)[i] = a;
+}
+
+__global__ void __launch_bounds__(256)
+wino_dfw_reduce_kernel(const float* __restrict__ gU, float* __restrict__ gw, int Cout, int Cin) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // (ci, co), co fastest: coalesced reads of every frequency
   if (idx >= Cin * Cout) return;
   const int co = idx % Cout, ci = idx / Cout;
   float u[144];
   const size_t slab = (size_t)Cin * Cout;
 #pragma unroll
-  for (int x = 0; x < 144; ++x) u[x] = 0.0f;
-  for (int c = 0; c < nchunk; ++c) {                 // chunk order: deterministic
-    const float* pc = part + (size_t)c * 144 * slab + idx;
-#pragma unroll
-    for (int x = 0; x < 144; ++x) u[x] += pc[(size_t)x * slab];
-  }
+  for (int x = 0; x < 144; ++x) u[x] = gU[(size_t)x * slab + idx];
   float a1[72];                                     // [fd][6][3] after w
 #pragma unroll
   for (int p = 0; p < 24; ++p) g43t(u + p * 6, 1, a1 + p * 3, 1);
@@ -415,8 +492,9 @@ size_t ssbev_wino43_df_packed_elems(int Cout, int Cin) {
 int ssbev_wino43_df_pack(const float* w, float* Wp, int Cout, int Cin, int mode, ssbev_stream_t stream) {
   if (!w || !Wp || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
   const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
-  const size_t total = (size_t)((K + 7) & ~7) * ((N + 31) & ~31);
-  hipLaunchKernelGGL(wino_df_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, Wp, Cout, Cin, mode);
+  const int KPad = (K + 7) & ~7, NPad = (N + 31) & ~31;
+  hipLaunchKernelGGL(wino_df_pack_kernel, dim3((unsigned)((KPad / 4) * ((NPad + 63) / 64))), dim3(256), 0, as_stream(stream), w,
+                     Wp, Cout, Cin, mode);
   return ssbev_launch_status();
 }
 
@@ -427,22 +505,40 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
   DfGeom g;
   g.B = d->B; g.D = d->D; g.Thw = (d->H / 4) * (d->W / 4); g.K = d->C; g.N = N; g.NPad = (N + 31) & ~31;
   g.ND = d->D / 2;
-  g.nrowgrp = (g.Thw + DF_BM - 1) / DF_BM;
   const int ntile = g.NPad / 32;
   // waves per workgroup: the largest of 4, 3, 2 that wastes no column tile (N = 192 -> 3, 128 / 256 / 512 -> 4)
-  static const int forced_nw = env_int("SSBEV_DF_NW", 0);
+  static const int forced_nw = env_int("SSBEV_DF_NW", 0), forced_mt = env_int("SSBEV_DF_MT", 0);
   int nw = ntile % 4 == 0 ? 4 : (ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 4));
   if (forced_nw >= 2 && forced_nw <= 4) nw = forced_nw;
   g.ncolgrp = (ntile + nw - 1) / nw;
+  // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than twice covered
+  int mt = 2;
+  if ((long)36 * g.B * g.ND * ((g.Thw + 63) / 64) * g.ncolgrp < 1024) mt = 1;
+  if (forced_mt == 1 || forced_mt == 2) mt = forced_mt;
+  g.nrowgrp = (g.Thw + 32 * mt - 1) / (32 * mt);
   g.NU = g.B * g.ND * g.nrowgrp;
-  g.NU8 = (g.NU + 7) / 8;
   g.nxi = 36;
-  const size_t lds = (size_t)2 * DF_STAGE_FLOATS * sizeof(float);        // 64 KiB
-  auto kern = wino_df_kernel<0>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return SSBEV_ELAUNCH;
-  const long nwg = (long)8 * g.nxi * g.NU8 * g.ncolgrp;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * nw), lds, as_stream(stream), P, Wp, Mo, g);
+  const size_t lds = (size_t)2 * 4 * 32 * mt * DF_BK * sizeof(float);        // 64 KiB (MT = 2) / 32 KiB
+  const long nwg = (long)g.nxi * g.NU * g.ncolgrp;
+  hipStream_t st = as_stream(stream);
+#define SSBEV_DF_LAUNCH(MT_, NW_)                                                                                          \
+  do {                                                                                                                     \
+    auto kern = wino_df_kernel<MT_, NW_>;                                                                                  \
+    if (lds > 64 * 1024 - 1 &&                                                                                             \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+            hipSuccess)                                                                                                    \
+      return SSBEV_ELAUNCH;                                                                                                \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW_), lds, st, P, Wp, Mo, g);                                  \
+  } while (0)
+  switch (mt * 10 + nw) {
+    case 24: SSBEV_DF_LAUNCH(2, 4); break;
+    case 23: SSBEV_DF_LAUNCH(2, 3); break;
+    case 22: SSBEV_DF_LAUNCH(2, 2); break;
+    case 14: SSBEV_DF_LAUNCH(1, 4); break;
+    case 13: SSBEV_DF_LAUNCH(1, 3); break;
+    default: SSBEV_DF_LAUNCH(1, 2); break;
+  }
+#undef SSBEV_DF_LAUNCH
   return ssbev_launch_status();
 }
 
@@ -453,7 +549,7 @@ static int dfw_chunks(const ssbev_wino_dims* d, int N) {
   const int total_stages = d->B * (d->D / 2) * ((Thw + DFW_BR - 1) / DFW_BR);
   const int nkb = (d->C + 127) / 128, nnb = (N + 63) / 64;
   // enough workgroups for ~3 rounds of 512 slots (2 per CU), but at least 8 stages per chunk
-  static const int target = env_int("SSBEV_DFW_WGS", 1536);
+  static const int target = env_int("SSBEV_DFW_WGS", 768);
   int nchunk = std::max(1, target / (36 * nkb * nnb));
   nchunk = std::min(nchunk, std::max(1, total_stages / 8));
   return nchunk;
@@ -468,6 +564,7 @@ int ssbev_wino43_df_wgrad(const float* P, const float* Z, float* gw, const ssbev
                           ssbev_stream_t stream) {
   if (!df_dims_ok(d, N) || !P || !Z || !gw || !ws) return SSBEV_EINVAL;
   if (N % 4 != 0) return SSBEV_EINVAL;
+  if ((long)d->B * d->D * (d->H / 4) * (d->W / 4) * std::max(d->C, N) >= (1L << 31)) return SSBEV_EINVAL;   // 32-bit slab offsets
   if (ws_bytes < ssbev_wino43_df_wgrad_workspace(d, N)) return SSBEV_EWORKSPACE;
   DfwGeom g;
   g.B = d->B; g.D = d->D; g.Thw = (d->H / 4) * (d->W / 4); g.K = d->C; g.N = N;
@@ -484,8 +581,11 @@ int ssbev_wino43_df_wgrad(const float* P, const float* Z, float* gw, const ssbev
   hipStream_t st = as_stream(stream);
   const long nwg = (long)g.nxi * g.nchunk * g.nkb * g.nnb;
   hipLaunchKernelGGL(wino_dfw_kernel, dim3((unsigned)nwg), dim3(256), lds, st, P, Z, static_cast<float*>(ws), g);
+  const size_t n4 = (size_t)144 * g.K * N / 4;
+  if (g.nchunk > 1)
+    hipLaunchKernelGGL(wino_dfw_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, static_cast<float*>(ws), n4, g.nchunk);
   hipLaunchKernelGGL(wino_dfw_reduce_kernel, dim3(cdiv((size_t)g.K * N, 256)), dim3(256), 0, st, static_cast<const float*>(ws), gw,
-                     N, g.K, g.nchunk);
+                     N, g.K);
   return ssbev_launch_status();
 }
 

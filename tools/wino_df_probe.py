@@ -45,3 +45,16 @@ for cin, cout, D, H, W in LAYERS:
         row.append(f"{'DF ' if df else 'lib'} fwd {tf:6.3f} ms ({gf / tf:5.0f} TF/s eff)  dgrad {td:6.3f}  wgrad {tw:6.3f}")
         del y, yd, yw
     print("   |   ".join(row), flush=True)
+    if os.environ.get("PROBE_STAGES"):
+        F.WINO_DF = True
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        t = F.KernelTimer()
+        F.KERNEL_TIMER = t
+        for _ in range(5):
+            y = F.conv3d(xg, wg, None, 1, 1)
+            y.backward(torch.ones_like(y))
+        F.KERNEL_TIMER = None
+        for (fam, tag), d in sorted(t.by_tag().items(), key=lambda kv: kv[0][1]):
+            ms = d["ms"] / d["launches"]
+            tf = d["executed"] / d["launches"] / ms / 1e9 if d["executed"] else 0.0
+            print(f"      {fam:22s} {tag:45s} {ms:7.3f} ms" + (f"  {tf:6.1f} TF/s executed" if tf else f"  {d['bytes'] / d['launches'] / ms / 1e9:6.2f} TB/s"))
