@@ -273,26 +273,35 @@ wino_df_pack_kernel(const float* __restrict__ w, float* __restrict__ Wp, int Cou
 //   planes 2i, 2i+1 of Zhw = wino43_2d_output_adjoint(gy)  ([36][B*D*Thw][N]).
 // The reduction runs over rows, the MFMA k dimension: A fragment lane (li, lk) = v[row 2s + lk][k0 + li], B fragment =
 // z[row 2s + lk][n0 + li] -- both operands are read row-wise, 32 consecutive channels per half wave, straight from the
-// row-major tensors through LDS (no transposition anywhere).  Workgroup = 4 waves sharing one 32-row slab of P (4 planes x
-// 32 rows x KT*32 channels... see below) and Z; wave w owns k-tile kt = w of a 128-channel K block and all NT n-tiles of an
-// NB-column block: accumulators 4 fd x NT tiles.  Row slabs of 16 rows are double buffered by global_load_lds.  Partial
-// sums over row chunks go to a workspace [nchunks][4][36][K][N] reduced in chunk order by wino_dfw_reduce_kernel (+ G^T).
-constexpr int DFW_BR = 16;        // rows per stage
+// row-major tensors through LDS (no transposition anywhere).  Workgroup = 4 waves in a KW x (4 / KW) grid; a wave owns one
+// 32-channel k-tile and NT 32-column n-tiles (accumulators 4 fd x NT tiles):
+//   <KW = 4, NT = 3>: 128 k x  96 n   (N = 192, 384: the occupancy-head conv; P leaves L2 once per 96 columns)
+//   <KW = 4, NT = 2>: 128 k x  64 n
+//   <KW = 2, NT = 1>:  64 k x  64 n   (the 64-channel hourglass layers: all four waves busy)
+// Row slabs of 16 rows (4 P planes + 2 Z planes) are double buffered by global_load_lds; the slab of stage s+1 is requested
+// right after stage s's barrier.  Partial sums over row chunks go to a workspace [nchunks][4][36][K][N] reduced in chunk
+// order (deterministic) by wino_dfw_sum_kernel, then wino_dfw_reduce_kernel applies G^T along the three axes.
 struct DfwGeom {
   int B, D, Thw, K, N;
-  int ND, nrowstage;              // depth tiles, stages of DFW_BR rows per plane (ceil(Thw / 16))
-  int nkb, nnb;                   // 128-channel K blocks, 64-column N blocks
+  int ND, nrowstage;              // depth tiles, stages of BR rows per plane (ceil(Thw / BR))
+  int nkb, nnb;                   // K blocks of KW*32 channels, N blocks of (4/KW)*NT*32 columns
   int nchunk, stages_per_chunk;   // split of the (b, i, row stage) reduction over workgroups
   int nxi;
 };
 
+template <int KW, int NT, int DFW_BR>      // DFW_BR = rows per stage (16; 8 for NT = 3 so that two workgroups fit the 160 KiB of LDS)
 __global__ void __launch_bounds__(256, 2)
 wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float* __restrict__ part, DfwGeom g) {
-  // LDS: [2 bufs][ P: 4 planes x 16 rows x 128 k | Z: 2 planes x 16 rows x 64 n ]
-  extern __shared__ __align__(16) float lds[];
-  constexpr int PF = 4 * DFW_BR * 128, ZF = 2 * DFW_BR * 64, SF = PF + ZF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
+  constexpr int NWv = 4 / KW;                       // waves along n
+  constexpr int PC = KW * 32, ZC = NWv * NT * 32;   // channels / columns per workgroup
+  constexpr int PF = 4 * DFW_BR * PC, ZF = 2 * DFW_BR * ZC, SF = PF + ZF;
+  constexpr int PI = PF / 256, ZI = ZF / 256;       // global_load_lds instructions per stage (1 KiB each)
+  constexpr int PIP = PI / 4, ZIP = ZI / 2;         // ... per plane
+  constexpr int PSL = PC / 4, ZSL = ZC / 4;         // 16-byte slots per row
+  extern __shared__ __align__(16) float lds[];      // [2 bufs][ P: 4 planes x 16 rows x PC | Z: 2 planes x 16 rows x ZC ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int li = lane & 31, lk = lane >> 5;
+  const int kw = wave % KW, nw = wave / KW;
   // XCD-aware order: consecutive LOGICAL ids (column blocks / K blocks of one row chunk: they share the P and Z slabs) run
   // on one XCD and meet in its L2; hardware deals consecutive workgroup ids round-robin over the 8 XCDs
   const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
@@ -304,52 +313,54 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
   const long R = (long)g.B * g.D * g.Thw;
   const float* Px = P + (long)xhw * R * g.K;
   const float* Zx = Z + (long)xhw * R * g.N;
-  const int k0 = kb * 128, n0 = nb * 64;
+  const int k0 = kb * PC, n0 = nb * ZC;
   const int total_stages = g.B * g.ND * g.nrowstage;
   const int s_begin = chunk * g.stages_per_chunk, s_end = min(total_stages, s_begin + g.stages_per_chunk);
 
-  // one stage = P: 4 planes x 16 rows x 128 ch x 4 B = 32 KiB; Z: 2 x 16 x 64 x 4 = 8 KiB.  Out-of-range rows / planes /
-  // channels read a 16-byte zero constant.  32-bit element offsets (one frequency slab holds < 2^31 elements, checked by the
-  // host): cheap enough that the compiler selects between the two sources instead of branching around the address math.
+  // Out-of-range rows / planes / channels read a 16-byte zero constant.  32-bit element offsets (one frequency slab holds
+  // < 2^31 elements, checked by the host): cheap enough that the compiler selects between the two sources instead of
+  // branching around the address math (the copies must stay straight-line code).
   auto issue = [&](int sidx, int buf) {
     // depth tile fastest: consecutive stages share two of their four P planes (same rows) -> L2 hits
     const int i = sidx % g.ND, br = sidx / g.ND;
     const int rs = br % g.nrowstage, b = br / g.nrowstage;
     const int t0 = rs * DFW_BR;
-    // P: 4 planes x 16 rows x 32 slots(16 B) = 2048 items = 32 wave instructions, 8 per wave
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = wave + 4 * e, a = j >> 3, item = (j & 7) * 64 + lane;
-      const int row = item >> 5, slot = item & 31;
+    for (int e = 0; e < (PI + 3) / 4; ++e) {
+      const int j = wave + 4 * e;
+      if (PI % 4 != 0 && j >= PI) break;
+      const int a = j / PIP, jj = j % PIP, item = jj * 64 + lane;
+      const int row = item / PSL, slot = item % PSL;
       const int d = 2 * i - 1 + a, t = t0 + row;
       const int kk = k0 + slot * 4;
       const bool ok = d >= 0 && d < g.D && t < g.Thw && kk < g.K;
       const int off = ((b * g.D + d) * g.Thw + t) * g.K + kk;
       const float* src = ok ? Px + off : kDfZeros;
-      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + a * (DFW_BR * 128) + (j & 7) * 256, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + a * (DFW_BR * PC) + jj * 256, 16, 0, 0);
     }
-    // Z: 2 planes x 16 rows x 16 slots = 512 items = 8 wave instructions, 2 per wave
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int j = wave + 4 * e, a = j >> 2, item = (j & 3) * 64 + lane;
-      const int row = item >> 4, slot = item & 15;
+    for (int e = 0; e < (ZI + 3) / 4; ++e) {
+      const int j = wave + 4 * e;
+      if (ZI % 4 != 0 && j >= ZI) break;
+      const int a = j / ZIP, jj = j % ZIP, item = jj * 64 + lane;
+      const int row = item / ZSL, slot = item % ZSL;
       const int t = t0 + row, nn = n0 + slot * 4;
       const bool ok = t < g.Thw && nn < g.N;
       const int off = ((b * g.D + 2 * i + a) * g.Thw + t) * g.N + nn;
       const float* src = ok ? Zx + off : kDfZeros;
-      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + PF + a * (DFW_BR * 64) + (j & 3) * 256, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + PF + a * (DFW_BR * ZC) + jj * 256, 16, 0, 0);
     }
   };
 
-  wf32x16 acc[4][2];
+  wf32x16 acc[4][NT];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[f][nt][rr] = 0.0f;
 
-  const bool kt_active = k0 + wave * 32 < g.K;         // K = 192: the second 128-channel block has two live k-tiles
+  const bool tile_active = k0 + kw * 32 < g.K && n0 + nw * NT * 32 < g.N;   // K = 192: the second 128-block has two live k-tiles
   if (s_begin < s_end) issue(s_begin, 0);
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     const int buf = (sidx - s_begin) & 1;
@@ -358,23 +369,21 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
     const float* pb = lds + buf * SF;
     const float* zb = pb + PF;
     // the other buffer was last read in the previous stage and every wave has passed the barrier: refill it now, the copies
-    // have this whole stage's 64 MFMAs per wave to land
+    // have this whole stage's MFMAs to land
     if (sidx + 1 < s_end) issue(sidx + 1, buf ^ 1);
-    // (the kt_active test stays OUTSIDE the row-pair loop: one basic block, so that the LDS reads of the next row pairs are
-    //  scheduled under the MFMAs of the current one instead of an lgkmcnt(0) in front of every group of 8)
-    if (kt_active) {
-      // operands of row pair rp+1 are read from LDS before the 8 MFMAs of row pair rp are issued (explicit software
+    // (the tile_active test stays OUTSIDE the row-pair loop: one basic block)
+    if (tile_active) {
+      // operands of row pair rp+1 are read from LDS before the MFMAs of row pair rp are issued (explicit software
       // pipeline: hipcc otherwise puts an lgkmcnt(0) in front of every group of MFMAs)
-      float pc[4], gc[2][2], pn[4], gn[2][2];
-      auto fetch = [&](int rp, float (&p)[4], float (&gz)[2][2]) {
+      float pc[4], gc[NT][2], pn[4], gn[NT][2];
+      auto fetch = [&](int rp, float (&pv)[4], float (&gz)[NT][2]) {
         const int row = 2 * rp + lk;
-        const int ko = row * 128 + wave * 32 + li;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) p[a] = pb[a * (DFW_BR * 128) + ko];
+        for (int a = 0; a < 4; ++a) pv[a] = pb[a * (DFW_BR * PC) + row * PC + kw * 32 + li];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          gz[nt][0] = zb[row * 64 + nt * 32 + li];
-          gz[nt][1] = zb[DFW_BR * 64 + row * 64 + nt * 32 + li];
+        for (int nt = 0; nt < NT; ++nt) {
+          gz[nt][0] = zb[row * ZC + (nw * NT + nt) * 32 + li];
+          gz[nt][1] = zb[DFW_BR * ZC + row * ZC + (nw * NT + nt) * 32 + li];
         }
       };
       fetch(0, pc, gc);
@@ -384,7 +393,7 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
         __builtin_amdgcn_sched_barrier(0);                   // keep the reads ABOVE this row pair's MFMAs
         const float v0 = pc[0] - pc[2], v1 = pc[1] + pc[2], v2 = pc[2] - pc[1], v3 = pc[1] - pc[3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           const float g0 = gc[nt][0], g1 = gc[nt][1];
           acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, g0, acc[0][nt], 0, 0, 0);
           acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, g0 + g1, acc[1][nt], 0, 0, 0);
@@ -394,19 +403,19 @@ wino_dfw_kernel(const float* __restrict__ P, const float* __restrict__ Z, float*
 #pragma unroll
         for (int a = 0; a < 4; ++a) pc[a] = pn[a];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) { gc[nt][0] = gn[nt][0]; gc[nt][1] = gn[nt][1]; }
+        for (int nt = 0; nt < NT; ++nt) { gc[nt][0] = gn[nt][0]; gc[nt][1] = gn[nt][1]; }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   // partial tile: part[chunk][fd][xhw][k][n]
-  const int kt = k0 + wave * 32;
+  const int kt = k0 + kw * 32;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     float* dst = part + ((((size_t)chunk * 4 + f) * g.nxi + xhw) * g.K) * g.N;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + nt * 32 + li;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (nw * NT + nt) * 32 + li;
       if (n >= g.N) continue;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
@@ -544,20 +553,30 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
 
 // Weight gradient.  P [36][B*D*Thw][K] (saved by the forward), Z [36][B*D*Thw][N] = ssbev_wino43_2d_output_adjoint(gy),
 // gw [N = Cout][K = Cin][27].  Workspace: ssbev_wino43_df_wgrad_workspace bytes.
-static int dfw_chunks(const ssbev_wino_dims* d, int N) {
+struct DfwPlan { int kw, nt, br, pc, zc, nkb, nnb, nchunk, total_stages; };
+
+static DfwPlan dfw_plan(const ssbev_wino_dims* d, int N) {
+  DfwPlan p;
+  const int K = d->C;
+  if (K <= 64) { p.kw = 2; p.nt = 1; p.br = 16; }
+  else if (N % 96 == 0) { p.kw = 4; p.nt = 3; p.br = 8; }
+  else { p.kw = 4; p.nt = 2; p.br = 16; }
+  p.pc = p.kw * 32;
+  p.zc = (4 / p.kw) * p.nt * 32;
+  p.nkb = (K + p.pc - 1) / p.pc;
+  p.nnb = (N + p.zc - 1) / p.zc;
   const int Thw = (d->H / 4) * (d->W / 4);
-  const int total_stages = d->B * (d->D / 2) * ((Thw + DFW_BR - 1) / DFW_BR);
-  const int nkb = (d->C + 127) / 128, nnb = (N + 63) / 64;
-  // enough workgroups for ~3 rounds of 512 slots (2 per CU), but at least 8 stages per chunk
-  static const int target = env_int("SSBEV_DFW_WGS", 768);
-  int nchunk = std::max(1, target / (36 * nkb * nnb));
-  nchunk = std::min(nchunk, std::max(1, total_stages / 8));
-  return nchunk;
+  p.total_stages = d->B * (d->D / 2) * ((Thw + p.br - 1) / p.br);
+  // enough workgroups for ~2 rounds of the 512 slots (2 per CU), but at least 8 stages per chunk
+  static const int target = env_int("SSBEV_DFW_WGS", 1024);
+  int nchunk = std::max(1, target / (36 * p.nkb * p.nnb));
+  p.nchunk = std::min(nchunk, std::max(1, p.total_stages / 8));
+  return p;
 }
 
 size_t ssbev_wino43_df_wgrad_workspace(const ssbev_wino_dims* d, int N) {
   if (!df_dims_ok(d, N)) return 0;
-  return (size_t)dfw_chunks(d, N) * 144 * d->C * N * sizeof(float);
+  return (size_t)dfw_plan(d, N).nchunk * 144 * d->C * N * sizeof(float);
 }
 
 int ssbev_wino43_df_wgrad(const float* P, const float* Z, float* gw, const ssbev_wino_dims* d, int N, void* ws, size_t ws_bytes,
@@ -566,21 +585,29 @@ int ssbev_wino43_df_wgrad(const float* P, const float* Z, float* gw, const ssbev
   if (N % 4 != 0) return SSBEV_EINVAL;
   if ((long)d->B * d->D * (d->H / 4) * (d->W / 4) * std::max(d->C, N) >= (1L << 31)) return SSBEV_EINVAL;   // 32-bit slab offsets
   if (ws_bytes < ssbev_wino43_df_wgrad_workspace(d, N)) return SSBEV_EWORKSPACE;
+  const DfwPlan pl = dfw_plan(d, N);
   DfwGeom g;
   g.B = d->B; g.D = d->D; g.Thw = (d->H / 4) * (d->W / 4); g.K = d->C; g.N = N;
-  g.ND = d->D / 2; g.nrowstage = (g.Thw + DFW_BR - 1) / DFW_BR;
-  g.nkb = (g.K + 127) / 128; g.nnb = (N + 63) / 64;
-  g.nchunk = dfw_chunks(d, N);
-  const int total_stages = g.B * g.ND * g.nrowstage;
-  g.stages_per_chunk = (total_stages + g.nchunk - 1) / g.nchunk;
+  g.ND = d->D / 2; g.nrowstage = (g.Thw + pl.br - 1) / pl.br;
+  g.nkb = pl.nkb; g.nnb = pl.nnb;
+  g.nchunk = pl.nchunk;
+  g.stages_per_chunk = (pl.total_stages + g.nchunk - 1) / g.nchunk;
   g.nxi = 36;
-  const size_t lds = (size_t)2 * (4 * DFW_BR * 128 + 2 * DFW_BR * 64) * sizeof(float);     // 80 KiB
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_dfw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return SSBEV_ELAUNCH;
+  const size_t lds = (size_t)2 * (4 * pl.br * pl.pc + 2 * pl.br * pl.zc) * sizeof(float);     // 80 / 44 / 48 KiB
   hipStream_t st = as_stream(stream);
   const long nwg = (long)g.nxi * g.nchunk * g.nkb * g.nnb;
-  hipLaunchKernelGGL(wino_dfw_kernel, dim3((unsigned)nwg), dim3(256), lds, st, P, Z, static_cast<float*>(ws), g);
+#define SSBEV_DFW_LAUNCH(KW_, NT_, BR_)                                                                                       \
+  do {                                                                                                                     \
+    auto kern = wino_dfw_kernel<KW_, NT_, BR_>;                                                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+        hipSuccess)                                                                                                        \
+      return SSBEV_ELAUNCH;                                                                                                \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, P, Z, static_cast<float*>(ws), g);                   \
+  } while (0)
+  if (pl.kw == 2) SSBEV_DFW_LAUNCH(2, 1, 16);
+  else if (pl.nt == 3) SSBEV_DFW_LAUNCH(4, 3, 8);
+  else SSBEV_DFW_LAUNCH(4, 2, 16);
+#undef SSBEV_DFW_LAUNCH
   const size_t n4 = (size_t)144 * g.K * N / 4;
   if (g.nchunk > 1)
     hipLaunchKernelGGL(wino_dfw_sum_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, static_cast<float*>(ws), n4, g.nchunk);

@@ -644,10 +644,16 @@ WINO_F444_MIN_CIN = int(os.environ.get("SSBEV_WINO_F444_MIN_CIN", "0"))     # wi
 # hand-written MFMA contraction csrc/winograd_fused.hip (forward, data and weight gradient): no library GEMM, transformed
 # tensors 2.25x instead of 4.5x.  SSBEV_WINO_DF=0 restores the F(2x4x4) transforms + 144 batched rocBLAS GEMMs.
 WINO_DF = os.environ.get("SSBEV_WINO_DF", "1") != "0"
+WINO_DF_MIN_ROWS = int(os.environ.get("SSBEV_WINO_DF_MIN_ROWS", "1024"))
 
 
 def _wino_df_applicable(B, D, H, W, Cin, Cout):
     if not (WINO_DF and WINO_F43 and PRECISION == "fp32" and not (WINO_DEPTH_FUSED or WINO_OWN_GEMM or WINO_F444)):
+        return False
+    # Layers with few rows per frequency (512 channels on the 32 x 32 x 4 grid: 256 rows against 4 x 512 x 512 weights per
+    # frequency) are weight-streaming problems: 151 MB of transformed weights for 10 GF of MFMA work.  The row-blocked fused
+    # kernel re-reads that slab per 32-row block; they stay on the 144-GEMM pipeline (SSBEV_WINO_DF_MIN_ROWS=0: all fused).
+    if B * D * (H // 4) * (W // 4) < WINO_DF_MIN_ROWS:
         return False
     lib = capi.load()
     return bool(lib.ssbev_wino43_df_supported(C.byref(capi.WinoDims(B, D, H, W, Cin)), Cout)) and \

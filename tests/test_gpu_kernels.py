@@ -679,6 +679,7 @@ def test_winograd_depth_fused_f43(case, monkeypatch):
     Same transform constants as F(2x4x4): gate 2e-4 of the tensor max, L2 1e-4."""
     B, Cin, Cout, D, H, W = case
     monkeypatch.setattr(F, "WINO_DF", True)
+    monkeypatch.setattr(F, "WINO_DF_MIN_ROWS", 0)           # (a dispatch heuristic, not a limit of the kernels)
     assert F._wino_df_applicable(B, D, H, W, Cin, Cout)
     x = S.hash_normal(f"wdf/x{case}", (B, Cin, D, H, W))
     w = S.hash_uniform(f"wdf/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
@@ -702,11 +703,15 @@ def test_winograd_depth_fused_f43(case, monkeypatch):
         assert rel_max < 2e-4 and rel_l2 < 1e-4, (name, rel_max, rel_l2)
 
 
-def test_winograd_depth_fused_falls_back_when_unsupported():
+def test_winograd_depth_fused_falls_back_when_unsupported(monkeypatch):
+    monkeypatch.setattr(F, "WINO_DF_MIN_ROWS", 0)
     assert not F._wino_df_applicable(1, 4, 8, 8, 100, 128)       # K % 32 != 0
     assert not F._wino_df_applicable(1, 4, 8, 8, 128, 100)       # ... on the data-gradient side
     assert not F._wino_df_applicable(1, 3, 8, 8, 128, 128)       # odd depth
     assert not F._wino_df_applicable(1, 4, 6, 8, 128, 128)       # H % 4 != 0
+    monkeypatch.setattr(F, "WINO_DF_MIN_ROWS", 1024)
+    assert not F._wino_df_applicable(1, 4, 32, 32, 512, 512)     # 256 rows per frequency: weight-streaming layer
+    assert F._wino_df_applicable(1, 16, 128, 128, 128, 128)
 
 
 BF16_DIRECT_CASES = [

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from stereoscene_amd import functional as F  # noqa: E402
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-LAYERS = [(128, 128, 16, 128, 128), (384, 192, 16, 128, 128), (256, 256, 8, 64, 64), (512, 512, 4, 32, 32), (128, 256, 8, 64, 64)]
+LAYERS = [(128, 128, 16, 128, 128), (384, 192, 16, 128, 128), (256, 256, 8, 64, 64), (64, 64, 96, 24, 80), (128, 128, 48, 12, 40)]
 
 
 def timed(fn):
