@@ -6,6 +6,7 @@ import sys
 
 FAMILIES = [
     ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_thin_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_thin_kernel"),
+    ("depth-fused Winograd contraction, own MFMA kernels (wino_df_kernel fwd/dgrad, wino_dfw_kernel wgrad, + pack / sum / reduce)", r"wino_df"),
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
     ("rocBLAS / hipBLASLt GEMMs (Cijk_*: Winograd frequency GEMMs, BRI products, image-branch pointwise convs)", r"Cijk_"),
     ("weight gradient, direct (wgrad_lds/wgrad_thin/wgrad_1x1/wgrad_cf/wgrad_kernel + reduce)", r"wgrad"),
