@@ -184,8 +184,15 @@ def runner_kwargs_from_config(cfg):
 
 
 def optimizer_from_config(model, cfg, reducer=None):
-    """``optimizer = dict(type='AdamW', lr, weight_decay)`` + ``optimizer_config.grad_clip.max_norm`` -> train.FlatAdamW."""
-    from .train import FlatAdamW
+    """``optimizer = dict(type='AdamW', lr, weight_decay)`` + ``optimizer_config.grad_clip.max_norm`` -> train.FlatAdamW.
+    A ``fp16 = dict(loss_scale=...)`` entry (mmdet_train.py:131-134 wraps the optimizer step in ``Fp16OptimizerHook``) selects
+    the mixed-precision policy: bf16 conv arithmetic (functional.set_precision) + the hook's loss scaler; fp32 master state."""
+    from .train import FlatAdamW, LossScaler
+    from . import functional as F
+    scaler = None
+    if cfg.get("fp16") is not None:
+        scaler = LossScaler.from_config(cfg.get("fp16"))
+        F.set_precision("bf16")
     opt = dict(cfg["optimizer"])
     if opt.pop("type") != "AdamW":
         raise NotImplementedError("the hot-path configs train with AdamW")
@@ -193,4 +200,4 @@ def optimizer_from_config(model, cfg, reducer=None):
     if clip and clip.get("norm_type", 2) != 2:
         raise NotImplementedError("only the 2-norm clip is fused")
     return FlatAdamW(model, lr=opt["lr"], weight_decay=opt.get("weight_decay", 0.01), betas=tuple(opt.get("betas", (0.9, 0.999))),
-                     eps=opt.get("eps", 1e-8), max_grad_norm=float(clip.get("max_norm", 0.0)), reducer=reducer)
+                     eps=opt.get("eps", 1e-8), max_grad_norm=float(clip.get("max_norm", 0.0)), reducer=reducer, loss_scaler=scaler)

@@ -12,12 +12,61 @@ from . import capi
 from .dp import FlatGradAllReduce
 
 
+class LossScaler:
+    """mmcv ``LossScaler`` as ``Fp16OptimizerHook`` drives it (the reference: occupancy/apis/mmdet_train.py:131-134,
+    ``fp16 = dict(loss_scale=512.)`` or ``'dynamic'``): the loss is multiplied by ``scale`` before backward; an inf / nan
+    gradient norm skips the update and halves a dynamic scale; ``scale_window`` clean steps double it.  Static mode keeps the
+    scale (overflow steps are still skipped, as in mmcv)."""
+
+    def __init__(self, init_scale=2.0 ** 32, mode="dynamic", scale_factor=2.0, scale_window=1000):
+        if mode not in ("dynamic", "static"):
+            raise ValueError("mode must be 'dynamic' or 'static'")
+        self.cur_scale, self.mode = float(init_scale), mode
+        self.scale_factor, self.scale_window = float(scale_factor), int(scale_window)
+        self.cur_iter, self.last_overflow_iter = 0, -1
+
+    @classmethod
+    def from_config(cls, fp16_cfg):
+        """``fp16_cfg`` = the reference's ``fp16`` dict: ``loss_scale`` = number (static) | 'dynamic' | dict(LossScaler kwargs)."""
+        ls = (fp16_cfg or {}).get("loss_scale", 512.0)
+        if ls == "dynamic":
+            return cls(mode="dynamic")
+        if isinstance(ls, dict):
+            return cls(**ls)
+        return cls(init_scale=float(ls), mode="static")
+
+    @property
+    def loss_scale(self):
+        return self.cur_scale
+
+    def update_scale(self, overflow):
+        if self.mode == "dynamic":
+            if overflow:
+                self.cur_scale = max(self.cur_scale / self.scale_factor, 1.0)
+                self.last_overflow_iter = self.cur_iter
+            elif (self.cur_iter - self.last_overflow_iter) % self.scale_window == 0:
+                self.cur_scale *= self.scale_factor
+        self.cur_iter += 1
+
+    def state_dict(self):
+        return dict(cur_scale=self.cur_scale, cur_iter=self.cur_iter, mode=self.mode, scale_factor=self.scale_factor,
+                    scale_window=self.scale_window, last_overflow_iter=self.last_overflow_iter)
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            setattr(self, k, v)
+
+
 class FlatAdamW:
     """AdamW over one flat fp32 buffer holding every trainable parameter (``param.data`` become views),
     with clip-by-global-norm folded into the update kernel.  One norm pass + one update pass per step."""
 
     def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
-                 reducer=None):
+                 reducer=None, loss_scaler=None):
+        # Mixed-precision policy (BASELINE configs[3]; the reference's Fp16OptimizerHook): parameters, moments and the flat
+        # gradient buffer are fp32 -- they ARE the master weights, the bf16 mode only narrows what the conv kernels compute
+        # on -- so the hook reduces to its loss scaler: scaled loss, unscale before the clip, skip + rescale on overflow.
+        self.loss_scaler = loss_scaler
         self.reducer = reducer or FlatGradAllReduce(module)
         params = self.reducer.params                       # same order as the flat gradient buffer
         n = self.reducer.flat.numel()
@@ -47,12 +96,20 @@ class FlatAdamW:
         self.reducer.finish()
         g = self.reducer.flat
         n = g.numel()
-        self.step_count += 1
         norm_ptr = None
-        if self.max_grad_norm and self.max_grad_norm > 0:
+        scaler = self.loss_scaler
+        if scaler is not None:
+            g.mul_(1.0 / scaler.loss_scale)                     # unscale (one pass over the flat buffer; bf16 mode only)
+        if (self.max_grad_norm and self.max_grad_norm > 0) or scaler is not None:
             capi.check(lib.ssbev_grad_norm(capi.ptr(g), n, capi.ptr(self.norm), capi.ptr(self._ws), self._ws.numel(),
                                            capi.stream()), "ssbev_grad_norm")
-            norm_ptr = capi.ptr(self.norm)
+            norm_ptr = capi.ptr(self.norm) if (self.max_grad_norm and self.max_grad_norm > 0) else None
+        if scaler is not None:
+            overflow = not bool(torch.isfinite(self.norm).item())      # the hook's has_overflow(): one host round trip
+            scaler.update_scale(overflow)
+            if overflow:
+                return self.norm                                        # skipped step: parameters and moments untouched
+        self.step_count += 1
         cfg = capi.AdamWCfg(self.lr, self.betas[0], self.betas[1], self.eps, self.wd, float(self.max_grad_norm or 0.0),
                             self.step_count)
         # parameters without a gradient this step (ablation modes) are skipped like torch.optim.AdamW skips grad None:
@@ -64,12 +121,17 @@ class FlatAdamW:
         return self.norm
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        sd = {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        if self.loss_scaler is not None:
+            sd["loss_scaler"] = self.loss_scaler.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        if self.loss_scaler is not None and "loss_scaler" in sd:
+            self.loss_scaler.load_state_dict(sd["loss_scaler"])
 
 
 def step_lr(base_lr, epoch, milestones=(20, 25), gamma=0.1):
@@ -82,6 +144,8 @@ def train_step(model, optimizer, img_inputs, gt_occ):
     exchange), clip + AdamW.  Returns the loss dict (device scalars)."""
     optimizer.zero_grad()
     losses = model.forward_train(img_inputs=img_inputs, gt_occ=gt_occ)
-    sum(v for k, v in losses.items() if k.startswith("loss")).backward()
+    total = sum(v for k, v in losses.items() if k.startswith("loss"))
+    scaler = getattr(optimizer, "loss_scaler", None)
+    (total * scaler.loss_scale if scaler is not None else total).backward()
     optimizer.step()
     return losses

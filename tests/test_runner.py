@@ -84,3 +84,27 @@ def test_runner_kwargs_from_the_reference_config():
     assert kw == dict(base_lr=1e-4, lr_step=(20, 25), lr_gamma=0.1, max_epochs=30, ckpt_interval=1, max_keep_ckpts=2,
                       eval_interval=2, save_best="semkitti_combined_IoU", rule="greater")
     assert cfg.optimizer["type"] == "AdamW" and cfg.optimizer_config["grad_clip"]["max_norm"] == 5
+
+
+def test_loss_scaler_policy_matches_mmcv_semantics():
+    """The reference's Fp16OptimizerHook drives mmcv's LossScaler (mmdet_train.py:131-134): static scale from
+    ``fp16 = dict(loss_scale=512.)``, dynamic = halve on overflow / double after ``scale_window`` clean steps."""
+    from stereoscene_amd.train import LossScaler
+    s = LossScaler.from_config(dict(loss_scale=512.0))
+    assert s.mode == "static" and s.loss_scale == 512.0
+    s.update_scale(True)
+    s.update_scale(False)
+    assert s.loss_scale == 512.0                               # static: never changes
+    d = LossScaler(init_scale=1024.0, mode="dynamic", scale_window=3)
+    d.update_scale(True)                                       # iter 0 overflows -> 512
+    assert d.loss_scale == 512.0 and d.last_overflow_iter == 0
+    for _ in range(2):
+        d.update_scale(False)                                  # iters 1, 2: (i - 0) % 3 != 0
+    assert d.loss_scale == 512.0
+    d.update_scale(False)                                      # iter 3: window complete -> doubled
+    assert d.loss_scale == 1024.0
+    assert LossScaler.from_config(dict(loss_scale="dynamic")).mode == "dynamic"
+    sd = d.state_dict()
+    e = LossScaler()
+    e.load_state_dict(sd)
+    assert e.loss_scale == d.loss_scale and e.cur_iter == d.cur_iter
