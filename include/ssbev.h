@@ -395,6 +395,34 @@ int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_win
  * streamed through LDS once, U in the ssbev_wino_dgemm_pack layout. */
 int ssbev_wino_bgemm(const float* A, const float* Wp, float* Cm, int64_t T, int K, int N, ssbev_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Plain fp32 GEMMs on the matrix cores (csrc/gemm.hip): the layers that are matrix products in the channels-last layout
+ * -- kernel == stride transposed convolutions of SECONDFPN3D (second_fpn_3d.py:50-69), wide pointwise convolutions
+ * (ASPP 3200 -> 640), the DCN group contractions (BD:490-498), the six products of a BRI block (attention.py:72-81), the
+ * batched frequency products of the 2-D Winograd layers.  Replaces the rocBLAS calls behind torch.mm / torch.bmm.
+ *   nn: C[b][m][n] = sum_k A[b][m][k] B[b][k][n]      nt: ... W[b][n][k]      tn: C[b][k][n] = sum_r A[b][r][k] B[b][r][n]
+ * Leading dimensions / batch strides in floats; K, N, lda, ldb multiples of 4.  d2s_*: depth-to-space index map of a k == s
+ * transposed convolution (d2s_kd = 0: off): row m = coarse voxel (bb, d, h, w), wide index tap * Co + co <-> fine voxel
+ * (d kd + a, h kh + b, w kw + c), channel co.  nn scatters C, nt gathers A, tn gathers B through it.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int M, N, K, batch;
+  int64_t lda, ldb, ldc, sa, sb, sc;
+  int relu;
+  int d2s_D, d2s_H, d2s_W, d2s_kd, d2s_kh, d2s_kw, d2s_Co;
+  const int64_t* d2s_rowoff;      /* device table of M row offsets (ssbev_gemm_d2s_rowoff), required when d2s_kd > 0 */
+} ssbev_gemm_dims;
+int ssbev_gemm_d2s_rowoff(int64_t* rowoff, int M, int D, int H, int W, int kd, int kh, int kw, int Co, ssbev_stream_t stream);
+size_t ssbev_gemm_nn_workspace(const ssbev_gemm_dims* d);      /* split-K partials (0 when the output tiles fill the chip) */
+size_t ssbev_gemm_nt_workspace(const ssbev_gemm_dims* d);
+int ssbev_gemm_nn(const float* A, const float* B, const float* bias, float* C, const ssbev_gemm_dims* d, void* workspace,
+                  size_t ws_bytes, ssbev_stream_t stream);
+int ssbev_gemm_nt(const float* A, const float* W, const float* bias, float* C, const ssbev_gemm_dims* d, void* workspace,
+                  size_t ws_bytes, ssbev_stream_t stream);
+size_t ssbev_gemm_tn_workspace(const ssbev_gemm_dims* d);
+int ssbev_gemm_tn(const float* A, const float* B, float* C, const ssbev_gemm_dims* d, void* workspace, size_t ws_bytes,
+                  ssbev_stream_t stream);
+
 /* Depth-fused Winograd contraction (csrc/winograd_fused.hip): F(4,3) x F(4,3) over (h, w) in memory (P / Mo / Z are
  * [36][B*D*(H/4)*(W/4)][C], the 2-D transforms above with D as a batch axis), F(2,3) along d in registers around the MFMAs.
  * The default realisation of the wide stride-1 3x3x3 layers (resnet3d.py:18-32, second_fpn_3d.py:53-69, occhead.py:100-107):

@@ -66,6 +66,14 @@ class AttnDims(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("Dh", C.c_int)]
 
 
+class GemmDims(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64), ("sc", C.c_int64),
+                ("relu", C.c_int),
+                ("d2s_D", C.c_int), ("d2s_H", C.c_int), ("d2s_W", C.c_int), ("d2s_kd", C.c_int), ("d2s_kh", C.c_int),
+                ("d2s_kw", C.c_int), ("d2s_Co", C.c_int), ("d2s_rowoff", C.c_void_p)]
+
+
 class AdamWCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_int)]
@@ -128,6 +136,13 @@ SIGNATURES = {
     "ssbev_wino_dgemm_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino_dgemm": (C.c_int, [_P, _P, _P, C.POINTER(WinoDims), C.c_int, _P]),
     "ssbev_wino_bgemm": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "ssbev_gemm_d2s_rowoff": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ssbev_gemm_nn_workspace": (C.c_size_t, [C.POINTER(GemmDims)]),
+    "ssbev_gemm_nt_workspace": (C.c_size_t, [C.POINTER(GemmDims)]),
+    "ssbev_gemm_nn": (C.c_int, [_P, _P, _P, _P, C.POINTER(GemmDims), _P, C.c_size_t, _P]),
+    "ssbev_gemm_nt": (C.c_int, [_P, _P, _P, _P, C.POINTER(GemmDims), _P, C.c_size_t, _P]),
+    "ssbev_gemm_tn_workspace": (C.c_size_t, [C.POINTER(GemmDims)]),
+    "ssbev_gemm_tn": (C.c_int, [_P, _P, _P, C.POINTER(GemmDims), _P, C.c_size_t, _P]),
     "ssbev_wino43_df_supported": (C.c_int, [C.POINTER(WinoDims), C.c_int]),
     "ssbev_wino43_df_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "ssbev_wino43_df_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -1,0 +1,514 @@
+// Plain fp32 GEMMs of the hot path on the matrix cores, gfx950 -- the layers that ARE matrix products in the channels-last
+// layout: kernel == stride transposed convolutions of SECONDFPN3D (second_fpn_3d.py:50-69), wide pointwise convolutions
+// (ASPP's 3200 -> 640, BD:312-414), the group contractions of DepthNet's DCN (BD:490-498), the six products of a BRI block
+// (attention.py:72-81) and the batched frequency products of the 2-D / weight-streaming Winograd layers.  Round 1 sent
+// these to rocBLAS; this file is their own realisation (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   NN:  C[b][m][n] = sum_k A[b][m][k] * B[b][k][n] (+ bias[n])         A, B, C row-major, arbitrary leading dimensions
+//   NT:  C[b][m][n] = sum_k A[b][m][k] * W[b][n][k] (+ bias[n])         (the nn.Linear / pointwise-conv layout: no transposes)
+//   TN:  C[b][k][n] = sum_r A[b][r][k] * B[b][r][n]                      (reduction over ROWS: weight gradients)
+// A pointwise layer is NT forward, NN data gradient, TN weight gradient.  The kernel == stride transposed convolution is the
+// same trio around a depth-to-space index map (ssbev_gemm_dims.d2s): NN scatters its result rows to y[(d kd + a, h kh + b,
+// w kw + c)][co] for column (tap, co) -- the permute copy of the library realisation never happens --, NT gathers its A rows
+// and TN its B rows from there.
+//
+// Every operand is read ROW-WISE (32 consecutive floats per half wave), so nothing is packed or transposed:
+//   NT  B fragment = like A: W[n0 + li][8q + 4lk .. +3], one ds_read_b128 out of a swizzled [BN rows][32 k] slab;
+//   NN  A fragment: lane (li, lk) holds A[m0 + li][8q + 4lk .. +3]  -- one ds_read_b128 out of a [rows][32 k] LDS slab whose
+//       16-byte slots are XOR-swizzled by (row & 7) on the global side of the copy (conflict-free);
+//       B fragment: B[8q + 4lk + t][n0 + li], t = 0..3 -- four ds_read_b32 out of a linear [32 k][BN] slab;
+//   TN  A fragment: A[2s + lk][k0 + li], B fragment: B[2s + lk][n0 + li] -- one ds_read_b32 each.
+// Slabs travel global -> LDS by global_load_lds_dwordx4 (no staging registers), double buffered: the copies of stage s+1 are
+// issued right after stage s's barrier and have the whole stage's MFMAs to land; one raw s_barrier per stage; the only
+// vmem traffic of a wave is its own LDS-DMA, so `s_waitcnt vmcnt(0)` at the top of a stage is exact.
+// Workgroup = 4 waves in a 2 x 2 grid, wave tile 64 x (32 WN): tiles 128 x 128 (WN = 2) or 128 x 64 (WN = 1).
+// Workgroup ids are cut into 8 contiguous logical ranges (one per XCD); column blocks of a row block are adjacent.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+typedef float gv4f __attribute__((ext_vector_type(4)));
+__device__ const float kGemmZeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct GemmGeom {
+  int M, N, K, batch;
+  long lda, ldb, ldc;          // leading dimensions (floats)
+  long sa, sb, sc;             // batch strides (floats; 0 = shared operand)
+  int mblocks, nblocks;
+  int nchunk, rows_per_chunk;  // TN: split of the row reduction (partials [chunk][batch][K][N], then gemm_sum_kernel)
+  int relu;
+  // depth-to-space map of a kernel == stride transposed convolution (kd = 0: off): row m = (bb, d, h, w) of the coarse grid
+  // [D, H, W], "wide" index j = tap * Co + co with tap = (a * kh + b) * kw + c  <->  fine[bb][d kd + a][h kh + b][w kw + c][co].
+  // rowoff[m] = float offset of fine[bb][d kd][h kh][w kw][0] (built once per shape by gemm_d2s_rowoff_kernel: no integer
+  // divisions in the GEMM loops); a tap adds ((a FH + b) FW + c) * Co.
+  int d2s_D, d2s_H, d2s_W, d2s_kd, d2s_kh, d2s_kw, d2s_Co;
+  const long* rowoff;
+};
+
+__device__ __forceinline__ long d2s_tapoff(const GemmGeom& g, int tap) {
+  const int c = tap % g.d2s_kw, ab = tap / g.d2s_kw;
+  const int b = ab % g.d2s_kh, a = ab / g.d2s_kh;
+  return (((long)a * (g.d2s_H * g.d2s_kh) + b) * (g.d2s_W * g.d2s_kw) + c) * g.d2s_Co;
+}
+
+__global__ void gemm_d2s_rowoff_kernel(long* __restrict__ rowoff, int M, int D, int H, int W, int kd, int kh, int kw, int Co) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int w = m % W; int t = m / W;
+  const int h = t % H; t /= H;
+  const int d = t % D; const int bb = t / D;
+  rowoff[m] = ((((long)bb * (D * kd) + (long)d * kd) * (H * kh) + (long)h * kh) * (W * kw) + (long)w * kw) * Co;
+}
+
+__device__ __forceinline__ int xcd_logical(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- NN / NT
+// BT = false: B is [K][N] (NN);  BT = true: B is [N][K] (NT).  D2S: 0 = plain, 1 = NN scatters its C rows, 2 = NT gathers its A rows.
+template <int WN, bool BT, int D2S>
+__global__ void __launch_bounds__(256, 2)
+gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias, float* __restrict__ Cm,
+               GemmGeom g) {
+  constexpr int BM = 128, BN = 64 * WN, BK = 32;
+  constexpr int AF = BM * BK, BF = BK * BN, SF = AF + BF;         // floats per stage
+  constexpr int AI = AF / 256, BI = BF / 256;                     // 1 KiB LDS-DMA instructions per stage
+  constexpr int AE = AI / 4, BE = BI / 4;                         // ... per wave
+  extern __shared__ __align__(16) float lds[];                    // [2][A slab | B slab]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = xcd_logical(blockIdx.x, gridDim.x);
+  const int nb = id % g.nblocks; id /= g.nblocks;
+  const int mb = id % g.mblocks; id /= g.mblocks;
+  const int chunk = id % g.nchunk;                 // split-K: k stages [st_begin, st_end) of this chunk
+  const int b = id / g.nchunk;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const float* Ab = A + (long)b * g.sa;
+  const float* Bb = B + (long)b * g.sb;
+  const int nst_all = (g.K + BK - 1) / BK;
+  const int st_begin = chunk * g.rows_per_chunk, st_end = min(nst_all, st_begin + g.rows_per_chunk);
+
+  // Per-lane copy sources are formed ONCE: the rows / columns a lane copies are the same in every stage, a stage only adds
+  // k0 (A, NT-B) or k0 * ldb (NN-B).  Out-of-range rows and columns read a 16-byte zero constant for the whole loop; the K
+  // tail (K % 32 != 0) is one compare per copy.  Straight-line selects: no branch inside the stage loop.
+  const float* ap[AE]; int ak[AE];
+#pragma unroll
+  for (int e = 0; e < AE; ++e) {                  // A: 128 rows x 8 slots of 16 B, slots XOR-swizzled by (row & 7)
+    const int item = (wave + 4 * e) * 64 + lane, row = item >> 3, slot = item & 7;
+    const int m = m0 + row;
+    ak[e] = (slot ^ (row & 7)) << 2;
+    ap[e] = m < g.M ? (D2S == 2 ? Ab + g.rowoff[m] : Ab + (long)m * g.lda) + ak[e] : nullptr;
+  }
+  const float* bp[BE]; int bk[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    const int item = (wave + 4 * e) * 64 + lane;
+    if (BT) {                                     // W: BN rows x 8 slots, same swizzle
+      const int row = item >> 3, slot = item & 7, n = n0 + row;
+      bk[e] = (slot ^ (row & 7)) << 2;
+      bp[e] = n < g.N ? Bb + (long)n * g.ldb + bk[e] : nullptr;
+    } else {                                      // B: 32 k-rows x BN/4 slots of 16 B, linear
+      const int kr = item / (BN / 4), slot = item % (BN / 4), n = n0 + slot * 4;
+      bk[e] = kr;
+      bp[e] = n < g.N ? Bb + (long)kr * g.ldb + n : nullptr;
+    }
+  }
+
+  auto issue = [&](int st, int buf) {
+    const int k0 = st * BK;
+    long aoff = k0;
+    if (D2S == 2) aoff = d2s_tapoff(g, k0 / g.d2s_Co) + (k0 % g.d2s_Co);    // a 32-wide stage lies inside one tap
+    const long boff = BT ? (long)k0 : (long)k0 * g.ldb;
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      const float* src = (ap[e] != nullptr && k0 + ak[e] < g.K) ? ap[e] + aoff : kGemmZeros;
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + (wave + 4 * e) * 256, 16, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      const float* src = (bp[e] != nullptr && k0 + bk[e] < g.K) ? bp[e] + boff : kGemmZeros;
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + AF + (wave + 4 * e) * 256, 16, 0, 0);
+    }
+  };
+
+  gf32x16 acc[2][WN];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  if (st_begin < st_end) issue(st_begin, 0);
+  for (int st = st_begin; st < st_end; ++st) {
+    const int buf = (st - st_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < st_end) issue(st + 1, buf ^ 1);
+    const float* as = lds + buf * SF;
+    const float* bs = as + AF;
+    // fragments of k-step q+1 are read from LDS before the MFMAs of k-step q are issued (explicit software pipeline)
+    gv4f ac[2], bc[WN], an[2], bn[WN];
+    auto fetch = [&](int q, gv4f (&a)[2], gv4f (&bf)[WN]) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = (wm * 2 + mt) * 32 + li;
+        a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ (row & 7)) << 2));
+      }
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        if (BT) {
+          const int row = (wn * WN + nt) * 32 + li;
+          bf[nt] = *reinterpret_cast<const gv4f*>(bs + row * BK + (((2 * q + lk) ^ (row & 7)) << 2));
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[nt][t] = bs[(8 * q + 4 * lk + t) * BN + (wn * WN + nt) * 32 + li];
+        }
+      }
+    };
+    fetch(0, ac, bc);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      if (q + 1 < BK / 8) fetch(q + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt][t], bc[nt][t], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) ac[mt] = an[mt];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // epilogue: accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li
+  float* Cb = Cm + ((long)chunk * g.batch + b) * g.sc;       // split-K partials: [chunk][batch][M][ldc] (bias / ReLU in the sum pass)
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int n = n0 + (wn * WN + nt) * 32 + li;
+    if (n >= g.N) continue;
+    const int co = D2S == 1 ? n % g.d2s_Co : n;
+    const float bv = bias ? bias[co] : 0.0f;
+    const long coloff = D2S == 1 ? d2s_tapoff(g, n / g.d2s_Co) + co : n;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m < g.M) {
+          float v = acc[mt][nt][r] + bv;
+          if (g.relu) v = fmaxf(v, 0.0f);
+          Cb[(D2S == 1 ? g.rowoff[m] : (long)m * g.ldc) + coloff] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- TN
+// C[b][k][n] = sum_r A[b][r][k] B[b][r][n]; workgroup tile 128 k x (64 WN) n, 32 rows per stage.
+template <int WN>
+__global__ void __launch_bounds__(256, 2)
+gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, GemmGeom g) {
+  constexpr int BKK = 128, BN = 64 * WN, BR = 32;
+  constexpr int AF = BR * BKK, BF = BR * BN, SF = AF + BF;
+  constexpr int AI = AF / 256, BI = BF / 256;
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int wk = wave >> 1, wn = wave & 1;
+  int id = xcd_logical(blockIdx.x, gridDim.x);
+  const int nb = id % g.nblocks; id /= g.nblocks;
+  const int kb = id % g.mblocks; id /= g.mblocks;
+  const int chunk = id % g.nchunk;
+  const int b = id / g.nchunk;
+  const int k0 = kb * BKK, n0 = nb * BN;
+  const float* Ab = A + (long)b * g.sa;
+  const float* Bb = B + (long)b * g.sb;
+  const int r_begin = chunk * g.rows_per_chunk, r_end = min(g.M, r_begin + g.rows_per_chunk);     // g.M = rows
+  const int nst = (r_end - r_begin + BR - 1) / BR;
+
+  const bool gather_b = g.d2s_kd > 0;
+  // gathered B (k == s deconv weight gradient): the column block lies inside one tap (Co % BN == 0, host-checked); the row
+  // offsets of a stage come from the rowoff table, fetched one stage ahead
+  const long ncoloff = gather_b ? d2s_tapoff(g, n0 / g.d2s_Co) + (n0 % g.d2s_Co) - n0 : 0;
+  long brow[BI / 4];
+  auto load_rowoff = [&](int st) {
+#pragma unroll
+    for (int e = 0; e < BI / 4; ++e) {
+      const int r = r_begin + st * BR + ((wave + 4 * e) * 64 + lane) / (BN / 4);
+      brow[e] = r < r_end ? (gather_b ? g.rowoff[r] : (long)r * g.ldb) : -1;
+    }
+  };
+  auto issue = [&](int st, int buf) {           // uses brow[] = row offsets of stage st
+    const int r0 = r_begin + st * BR;
+#pragma unroll
+    for (int e = 0; e < AI / 4; ++e) {            // A: 32 rows x 32 slots
+      const int j = wave + 4 * e, item = j * 64 + lane;
+      const int row = item >> 5, slot = item & 31;
+      const int r = r0 + row, k = k0 + slot * 4;
+      const float* src = (r < r_end && k < g.K) ? Ab + (long)r * g.lda + k : kGemmZeros;
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + j * 256, 16, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < BI / 4; ++e) {            // B: 32 rows x BN/4 slots
+      const int j = wave + 4 * e, item = j * 64 + lane;
+      const int slot = item % (BN / 4);
+      const int n = n0 + slot * 4;
+      const float* src = (brow[e] >= 0 && n < g.N) ? Bb + brow[e] + ncoloff + n : kGemmZeros;
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + AF + j * 256, 16, 0, 0);
+    }
+  };
+
+  gf32x16 acc[2][WN];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][nt][r] = 0.0f;
+
+  if (nst > 0) { load_rowoff(0); issue(0, 0); load_rowoff(1); }
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage st's slabs AND the row offsets of stage st+1
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_rowoff(st + 2); }
+    const float* as = lds + buf * SF;
+    const float* bs = as + AF;
+    float ac[2], bc[WN], an[2], bn[WN];
+    auto fetch = [&](int rp, float (&av)[2], float (&bv)[WN]) {
+      const int row = 2 * rp + lk;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) av[kt] = as[row * BKK + (wk * 2 + kt) * 32 + li];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bv[nt] = bs[row * BN + (wn * WN + nt) * 32 + li];
+    };
+    fetch(0, ac, bc);
+#pragma unroll
+    for (int rp = 0; rp < BR / 2; ++rp) {
+      if (rp + 1 < BR / 2) fetch(rp + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kt], bc[nt], acc[kt][nt], 0, 0, 0);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) ac[kt] = an[kt];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float* Cb = Cm + ((long)chunk * g.batch + b) * g.sc;
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int n = n0 + (wn * WN + nt) * 32 + li;
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + (wk * 2 + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (k < g.K) Cb[(long)k * g.ldc + n] = acc[kt][nt][r];
+      }
+  }
+}
+
+// out[i] = sum over chunks (ascending: deterministic) of part[c][i] (+ bias[i % N], ReLU)
+__global__ void __launch_bounds__(256)
+gemm_sum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nchunk, const float* __restrict__ bias,
+                int N, int relu) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = part[i];
+  for (int c = 1; c < nchunk; ++c) a += part[(size_t)c * n + i];
+  if (bias) a += bias[i % N];
+  if (relu) a = fmaxf(a, 0.0f);
+  out[i] = a;
+}
+
+bool gemm_ok(const ssbev_gemm_dims* d) {
+  if (!(d && d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->K % 4 == 0 && d->N % 4 == 0 && d->lda % 4 == 0 &&
+        d->ldb % 4 == 0 && d->ldc >= 0))
+    return false;
+  if (d->d2s_kd > 0)      // column / k blocks must not straddle a tap: Co a multiple of 64 (and of 128 when 128-wide tiles are used)
+    return d->d2s_kh > 0 && d->d2s_kw > 0 && d->d2s_D > 0 && d->d2s_H > 0 && d->d2s_W > 0 && d->d2s_Co > 0 && d->d2s_Co % 64 == 0 &&
+           d->M % (d->d2s_D * d->d2s_H * d->d2s_W) == 0 && d->d2s_rowoff != nullptr;
+  return true;
+}
+
+void fill_geom(GemmGeom& g, const ssbev_gemm_dims* d) {
+  g.M = d->M; g.N = d->N; g.K = d->K; g.batch = d->batch;
+  g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.sa = d->sa; g.sb = d->sb; g.sc = d->sc;
+  g.nchunk = 1; g.rows_per_chunk = 0; g.relu = d->relu;
+  g.d2s_D = d->d2s_D; g.d2s_H = d->d2s_H; g.d2s_W = d->d2s_W; g.d2s_kd = d->d2s_kd; g.d2s_kh = d->d2s_kh; g.d2s_kw = d->d2s_kw;
+  g.d2s_Co = d->d2s_Co;
+  g.rowoff = reinterpret_cast<const long*>(d->d2s_rowoff);
+}
+
+// 128-wide column tiles unless 64-wide ones pad less (N = 192 -> 3 x 64, N = 160 -> 3 x 64, N = 640 -> 5 x 128)
+int pick_wn(int N, int tap_width = 0) {
+  const int pad2 = (N + 127) / 128 * 128 - N, pad1 = (N + 63) / 64 * 64 - N;
+  if (tap_width && tap_width % 128 != 0) return 1;          // d2s: a column block stays inside one tap
+  return pad2 <= pad1 ? 2 : 1;
+}
+
+int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
+  // TN: M = reduction rows.  Enough workgroups for ~2 rounds of the 512 slots, at least 256 rows per chunk.
+  int nchunk = std::max(1, 1024 / std::max(1, tiles * d->batch));
+  nchunk = std::min(nchunk, std::max(1, d->M / 256));
+  return nchunk;
+}
+
+// split-K: when the output tiles alone leave the 512 workgroup slots under-filled and K is deep (BRI's 192 x 7680 products,
+// the k4 deconv's data gradient), the k stages are cut into chunks whose partial tiles are summed in chunk order
+int nn_chunks(const ssbev_gemm_dims* d, int tiles) {
+  if (d->d2s_kd > 0 && d->N != d->K) { /* scatter epilogue writes final values: no split */ }
+  const int nst = (d->K + 31) / 32;
+  int nchunk = std::max(1, 512 / std::max(1, tiles * d->batch));
+  nchunk = std::min(nchunk, std::max(1, nst / 16));          // at least 16 stages (512 k) per chunk
+  return std::min(nchunk, 16);
+}
+
+template <bool BT>
+size_t nn_workspace(const ssbev_gemm_dims* d) {
+  const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
+  const int tiles = ((d->M + 127) / 128) * ((d->N + 64 * wn - 1) / (64 * wn));
+  const int nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, tiles);
+  return nchunk > 1 ? (size_t)nchunk * d->batch * d->M * d->N * sizeof(float) : 0;
+}
+
+template <bool BT>
+int launch_nn(const float* A, const float* B, const float* bias, float* Cm, const ssbev_gemm_dims* d, void* ws, size_t ws_bytes,
+              hipStream_t st) {
+  GemmGeom g;
+  fill_geom(g, d);
+  const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
+  const int BN = 64 * wn;
+  g.mblocks = (d->M + 127) / 128;
+  g.nblocks = (d->N + BN - 1) / BN;
+  g.nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, g.mblocks * g.nblocks);
+  const int nst = (d->K + 31) / 32;
+  g.rows_per_chunk = (nst + g.nchunk - 1) / g.nchunk;         // k stages per chunk
+  float* dst = Cm;
+  const float* kbias = bias;
+  if (g.nchunk > 1) {
+    if (!ws || ws_bytes < nn_workspace<BT>(d)) return SSBEV_EWORKSPACE;
+    dst = static_cast<float*>(ws);
+    g.ldc = d->N; g.sc = (long)d->M * d->N; g.relu = 0;
+    kbias = nullptr;
+  }
+  const long nwg = (long)g.batch * g.nchunk * g.mblocks * g.nblocks;
+  const size_t lds = (size_t)2 * (128 * 32 + 32 * BN) * sizeof(float);       // 64 / 48 KiB
+  constexpr int DM = BT ? 2 : 1;          // what d2s means for this form
+#define SSBEV_GEMM_LAUNCH(WN_, D2S_)                                                                                       \
+  do {                                                                                                                     \
+    auto kern = gemm_nn_kernel<WN_, BT, D2S_>;                                                                             \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+        hipSuccess)                                                                                                        \
+      return SSBEV_ELAUNCH;                                                                                                \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, kbias, dst, g);                                \
+  } while (0)
+  if (d->d2s_kd > 0) { if (wn == 2) SSBEV_GEMM_LAUNCH(2, DM); else SSBEV_GEMM_LAUNCH(1, DM); }
+  else { if (wn == 2) SSBEV_GEMM_LAUNCH(2, 0); else SSBEV_GEMM_LAUNCH(1, 0); }
+#undef SSBEV_GEMM_LAUNCH
+  if (g.nchunk > 1) {
+    if (d->ldc != d->N || (d->batch > 1 && d->sc != (long)d->M * d->N)) return SSBEV_EINVAL;     // split-K needs a dense C
+    const size_t n = (size_t)g.batch * d->M * d->N;
+    hipLaunchKernelGGL(gemm_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, Cm, n, g.nchunk, bias, d->N, d->relu);
+  }
+  return ssbev_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// rowoff[m] for the d2s modes: M = B * D * H * W coarse voxels (int64 float offsets into the fine tensor)
+int ssbev_gemm_d2s_rowoff(int64_t* rowoff, int M, int D, int H, int W, int kd, int kh, int kw, int Co, ssbev_stream_t stream) {
+  if (!rowoff || M <= 0 || D <= 0 || H <= 0 || W <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || Co <= 0 || M % (D * H * W) != 0)
+    return SSBEV_EINVAL;
+  hipLaunchKernelGGL(gemm_d2s_rowoff_kernel, dim3(cdiv(M, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<long*>(rowoff),
+                     M, D, H, W, kd, kh, kw, Co);
+  return ssbev_launch_status();
+}
+
+// C[b] = A[b] x B[b] (+ bias, ReLU).  M rows, K inner, N columns; lda / ldb / ldc leading dimensions and sa / sb / sc batch
+// strides in floats (sb = 0: one B for every batch).  K, N, lda, ldb multiples of 4 (16-byte LDS-DMA granules).
+// d2s set: the result row m, column (tap, co) is stored at the depth-to-space position of the fine grid (ldc / sc unused,
+// C = the fine tensor of batch element b = 0; bias indexed by co).
+size_t ssbev_gemm_nn_workspace(const ssbev_gemm_dims* d) { return gemm_ok(d) ? nn_workspace<false>(d) : 0; }
+size_t ssbev_gemm_nt_workspace(const ssbev_gemm_dims* d) { return gemm_ok(d) ? nn_workspace<true>(d) : 0; }
+
+int ssbev_gemm_nn(const float* A, const float* B, const float* bias, float* Cm, const ssbev_gemm_dims* d, void* ws, size_t ws_bytes,
+                  ssbev_stream_t stream) {
+  if (!gemm_ok(d) || !A || !B || !Cm || d->lda < d->K || d->ldb < d->N) return SSBEV_EINVAL;
+  if (d->d2s_kd > 0 ? (d->batch != 1 || d->N != d->d2s_kd * d->d2s_kh * d->d2s_kw * d->d2s_Co) : d->ldc < d->N) return SSBEV_EINVAL;
+  return launch_nn<false>(A, B, bias, Cm, d, ws, ws_bytes, as_stream(stream));
+}
+
+// C[b][m][n] = sum_k A[b][m][k] W[b][n][k] (+ bias, ReLU): W is [N][K] with leading dimension ldb >= K.
+// d2s set: row m of A is GATHERED from the fine grid (K = taps * Co wide; lda / sa unused, batch = 1).
+int ssbev_gemm_nt(const float* A, const float* W, const float* bias, float* Cm, const ssbev_gemm_dims* d, void* ws, size_t ws_bytes,
+                  ssbev_stream_t stream) {
+  if (!gemm_ok(d) || !A || !W || !Cm || d->ldb < d->K || d->ldc < d->N) return SSBEV_EINVAL;
+  if (d->d2s_kd > 0 ? (d->batch != 1 || d->K != d->d2s_kd * d->d2s_kh * d->d2s_kw * d->d2s_Co) : d->lda < d->K) return SSBEV_EINVAL;
+  return launch_nn<true>(A, W, bias, Cm, d, ws, ws_bytes, as_stream(stream));
+}
+
+// C[b][k][n] = sum_r A[b][r][k] B[b][r][n]: d->M = rows (the reduction), d->K x d->N the dense result (ldc = N).
+// d2s set: row r of B is gathered from the fine grid (N = taps * Co wide).  Workspace: partial results of the row chunks
+// (ssbev_gemm_tn_workspace bytes; 0 when one chunk suffices), summed in chunk order (deterministic).
+size_t ssbev_gemm_tn_workspace(const ssbev_gemm_dims* d) {
+  if (!gemm_ok(d)) return 0;
+  const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
+  const int tiles = ((d->K + 127) / 128) * ((d->N + 64 * wn - 1) / (64 * wn));
+  const int nchunk = tn_chunks(d, tiles);
+  return nchunk > 1 ? (size_t)nchunk * d->batch * d->K * d->N * sizeof(float) : 0;
+}
+
+int ssbev_gemm_tn(const float* A, const float* B, float* Cm, const ssbev_gemm_dims* d, void* ws, size_t ws_bytes,
+                  ssbev_stream_t stream) {
+  if (!gemm_ok(d) || !A || !B || !Cm || d->lda < d->K) return SSBEV_EINVAL;
+  if (d->d2s_kd > 0 ? (d->batch != 1 || d->N != d->d2s_kd * d->d2s_kh * d->d2s_kw * d->d2s_Co) : d->ldb < d->N) return SSBEV_EINVAL;
+  GemmGeom g;
+  fill_geom(g, d);
+  g.ldc = d->N; g.sc = (long)d->K * d->N; g.relu = 0;
+  const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
+  const int BN = 64 * wn;
+  g.mblocks = (d->K + 127) / 128;
+  g.nblocks = (d->N + BN - 1) / BN;
+  g.nchunk = tn_chunks(d, g.mblocks * g.nblocks);
+  g.rows_per_chunk = ((d->M + g.nchunk - 1) / g.nchunk + 31) / 32 * 32;
+  if (g.nchunk > 1 && (!ws || ws_bytes < ssbev_gemm_tn_workspace(d))) return SSBEV_EWORKSPACE;
+  float* dst = g.nchunk > 1 ? static_cast<float*>(ws) : Cm;
+  const long nwg = (long)g.batch * g.nchunk * g.mblocks * g.nblocks;
+  const size_t lds = (size_t)2 * (32 * 128 + 32 * BN) * sizeof(float);       // 64 / 48 KiB
+  hipStream_t st = as_stream(stream);
+  if (wn == 2) {
+    auto kern = gemm_tn_kernel<2>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, dst, g);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, st, A, B, dst, g);
+  }
+  if (g.nchunk > 1) {
+    const size_t n = (size_t)g.batch * d->K * d->N;
+    hipLaunchKernelGGL(gemm_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, Cm, n, g.nchunk, (const float*)nullptr, 1, 0);
+  }
+  return ssbev_launch_status();
+}
+
+}  // extern "C"

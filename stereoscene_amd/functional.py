@@ -473,6 +473,206 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0))
 
 
+# -------------------------------------------------------------------------------------------------
+# plain fp32 GEMMs on the matrix cores (csrc/gemm.hip): no library GEMM on the hot path
+# -------------------------------------------------------------------------------------------------
+# SSBEV_OWN_GEMM=0 sends these products back to rocBLAS (torch.mm / torch.bmm), for A/B runs.
+OWN_GEMM = os.environ.get("SSBEV_OWN_GEMM", "1") != "0"
+# Per call site: comma list out of deconv, linear, wino, bri; "all" = every site.  Default = where the own kernels win or tie
+# in the step (profiles/r2l_own_gemm_sites.txt, ms/step against 91.3 with none): deconv -0.75 (the depth-to-space permute
+# copies disappear), bri +0.2 (no operand transposes; the north-star block on own kernels).  The wide pointwise layers
+# (+1.5) and the batched frequency products of the 2-D / weight-streaming Winograd layers (+1.0) are plain library GEMMs
+# where rocBLAS's tuned kernels run at 90 % of the fp32 matrix peak against ~75 % here: they stay on rocBLAS by default.
+OWN_GEMM_SITES = set(os.environ.get("SSBEV_OWN_GEMM_SITES", "deconv,bri").split(","))
+
+
+def own_gemm_site(name):
+    return OWN_GEMM and ("all" in OWN_GEMM_SITES or name in OWN_GEMM_SITES)
+
+
+def _rows(t):
+    """[.., R, C] tensor with a contiguous last axis and uniform row / batch strides -> (tensor, ld, batch_stride)."""
+    if t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.stride(-2) % 4 != 0 or t.stride(-2) < t.shape[-1]:
+        t = t.contiguous()
+    return t, t.stride(-2), (t.stride(0) if t.dim() == 3 else 0)
+
+
+def _rawptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _gemm_supported(*ts):
+    return OWN_GEMM and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def _gdims(M, N, K, batch, lda, ldb, ldc, sa, sb, sc, relu=0, d2s=None):
+    g = capi.GemmDims(int(M), int(N), int(K), int(batch), int(lda), int(ldb), int(ldc), int(sa), int(sb), int(sc), int(relu),
+                      0, 0, 0, 0, 0, 0, 0, None)
+    if d2s is not None:
+        (g.d2s_D, g.d2s_H, g.d2s_W, g.d2s_kd, g.d2s_kh, g.d2s_kw, g.d2s_Co), table = d2s
+        g.d2s_rowoff = table.data_ptr()
+    return g
+
+
+def gemm_nn(a, b, bias=None, relu=False, tag=None):
+    """C = A @ B (+ bias, ReLU): a [M,K] or [Bt,M,K]; b [K,N] or [Bt,K,N] (a 2-D b is shared by the batch)."""
+    if not _gemm_supported(a, b) or a.shape[-1] % 4 or b.shape[-1] % 4:
+        y = torch.matmul(a, b)
+        y = y if bias is None else y + bias
+        return torch.relu(y) if relu else y
+    a, lda, sa = _rows(a)
+    b, ldb, sb = _rows(b)
+    batch = a.shape[0] if a.dim() == 3 else 1
+    M, K, N = a.shape[-2], a.shape[-1], b.shape[-1]
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    g = _gdims(M, N, K, batch, lda, ldb, N, sa, sb if b.dim() == 3 else 0, M * N, relu)
+    fl = 2.0 * batch * M * N * K
+    lib = capi.load()
+    ws = _ws(lib.ssbev_gemm_nn_workspace(C.byref(g)), a.device)
+    with _span("gemm_own", fl, 4.0 * (a.numel() + b.numel() + out.numel()), tag or f"nn {batch}x{M}x{K}x{N}"):
+        capi.check(lib.ssbev_gemm_nn(_rawptr(a), _rawptr(b), _rawptr(bias.contiguous() if bias is not None else None),
+                                     capi.ptr(out), C.byref(g), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_gemm_nn")
+    return out
+
+
+def gemm_nt(a, w, bias=None, relu=False, tag=None):
+    """C = A @ W^T (+ bias, ReLU): a [M,K] / [Bt,M,K], w [N,K] / [Bt,N,K] -- the nn.Linear layout, nothing transposed."""
+    if not _gemm_supported(a, w) or a.shape[-1] % 4 or w.shape[-2] % 4:
+        y = torch.matmul(a, w.transpose(-1, -2))
+        y = y if bias is None else y + bias
+        return torch.relu(y) if relu else y
+    a, lda, sa = _rows(a)
+    w, ldb, sb = _rows(w)
+    batch = a.shape[0] if a.dim() == 3 else 1
+    M, K, N = a.shape[-2], a.shape[-1], w.shape[-2]
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    g = _gdims(M, N, K, batch, lda, ldb, N, sa, sb if w.dim() == 3 else 0, M * N, relu)
+    fl = 2.0 * batch * M * N * K
+    lib = capi.load()
+    ws = _ws(lib.ssbev_gemm_nt_workspace(C.byref(g)), a.device)
+    with _span("gemm_own", fl, 4.0 * (a.numel() + w.numel() + out.numel()), tag or f"nt {batch}x{M}x{K}x{N}"):
+        capi.check(lib.ssbev_gemm_nt(_rawptr(a), _rawptr(w), _rawptr(bias.contiguous() if bias is not None else None),
+                                     capi.ptr(out), C.byref(g), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, tag=None):
+    """C = A^T @ B over the ROW axis: a [R,K] / [Bt,R,K], b [R,N] / [Bt,R,N] -> [K,N] / [Bt,K,N] (weight gradients)."""
+    if not _gemm_supported(a, b) or a.shape[-1] % 4 or b.shape[-1] % 4:
+        return torch.matmul(a.transpose(-1, -2), b)
+    a, lda, sa = _rows(a)
+    b, ldb, sb = _rows(b)
+    batch = a.shape[0] if a.dim() == 3 else 1
+    R, K, N = a.shape[-2], a.shape[-1], b.shape[-1]
+    out = torch.empty(*a.shape[:-2], K, N, dtype=torch.float32, device=a.device)
+    g = _gdims(R, N, K, batch, lda, ldb, N, sa, sb, K * N)
+    lib = capi.load()
+    ws = _ws(lib.ssbev_gemm_tn_workspace(C.byref(g)), a.device)
+    fl = 2.0 * batch * R * N * K
+    with _span("gemm_own", fl, 4.0 * (a.numel() + b.numel() + out.numel()), tag or f"tn {batch}x{R}x{K}x{N}"):
+        capi.check(lib.ssbev_gemm_tn(_rawptr(a), _rawptr(b), capi.ptr(out), C.byref(g), capi.ptr(ws), ws.numel(), capi.stream()),
+                   "ssbev_gemm_tn")
+    return out
+
+
+class _LinearCL(torch.autograd.Function):
+    """Pointwise (1x1 / stride 1) convolution of a channels-last map = y[rows, Cout] = x[rows, Cin] @ W[Cout, Cin]^T + b:
+    NT forward, NN data gradient, TN weight gradient on the gemm.hip kernels, no transposes anywhere."""
+
+    @staticmethod
+    def forward(ctx, x2, w2, bias):
+        ctx.save_for_backward(x2, w2)
+        ctx.has_bias = bias is not None
+        return gemm_nt(x2, w2, bias, tag=f"linear fwd {w2.shape[1]}->{w2.shape[0]} rows={x2.shape[0]}")
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nn(gy, w2, tag=f"linear dgrad {w2.shape[1]}->{w2.shape[0]} rows={x2.shape[0]}")
+        if ctx.needs_input_grad[1]:
+            gw = gemm_tn(gy, x2, tag=f"linear wgrad {w2.shape[1]}->{w2.shape[0]} rows={x2.shape[0]}")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+_D2S_TABLES = {}
+
+
+def _d2s_table(B, D, H, W, k, Co, device):
+    key = (B, D, H, W, k, Co, str(device))
+    t = _D2S_TABLES.get(key)
+    if t is None:
+        t = torch.empty(B * D * H * W, dtype=torch.int64, device=device)
+        capi.check(capi.load().ssbev_gemm_d2s_rowoff(capi.ptr(t), B * D * H * W, D, H, W, k[0], k[1], k[2], Co, capi.stream()),
+                   "ssbev_gemm_d2s_rowoff")
+        _D2S_TABLES[key] = t
+    return t
+
+
+class _DeconvKS(torch.autograd.Function):
+    """kernel == stride ConvTranspose3d (SECONDFPN3D levels, second_fpn_3d.py:50-69) as the GEMM it is, with the
+    depth-to-space index map inside the kernels: forward = NN with a scattering epilogue (the [B,D,H,W,kd,kh,kw,Co] ->
+    [B,D kd,H kh,W kw,Co] permute copy of the library realisation never happens), data gradient = NT with gathered rows,
+    weight gradient = TN with gathered rows."""
+
+    @staticmethod
+    def forward(ctx, xcl, weight, bias, k):
+        B, D, H, W, Ci = xcl.shape
+        Co = weight.shape[1]
+        kd, kh, kw = k
+        taps = kd * kh * kw
+        wk = weight.detach().permute(0, 2, 3, 4, 1).reshape(Ci, taps * Co).contiguous()       # [Ci][tap][co]: a few MB
+        table = _d2s_table(B, D, H, W, k, Co, xcl.device)
+        y = torch.empty(B, D * kd, H * kh, W * kw, Co, dtype=torch.float32, device=xcl.device)
+        x2 = xcl.reshape(-1, Ci)
+        R = x2.shape[0]
+        g = _gdims(R, taps * Co, Ci, 1, Ci, taps * Co, 0, 0, 0, 0, 0, ((D, H, W, kd, kh, kw, Co), table))
+        fl = 2.0 * R * Ci * taps * Co
+        with _span("gemm_own", fl, 4.0 * (x2.numel() + wk.numel() + y.numel()), f"deconv k=s fwd {Ci}->{Co} k{kd}{kh}{kw}"):
+            capi.check(capi.load().ssbev_gemm_nn(capi.ptr(x2), capi.ptr(wk), capi.ptr(bias.detach().contiguous() if bias is not None else None),
+                                                 capi.ptr(y), C.byref(g), None, 0, capi.stream()), "ssbev_gemm_nn")
+        ctx.save_for_backward(x2, wk)
+        ctx.meta = (B, D, H, W, Ci, Co, k, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wk = ctx.saved_tensors
+        B, D, H, W, Ci, Co, k, has_bias = ctx.meta
+        kd, kh, kw = k
+        taps = kd * kh * kw
+        gy = gy.contiguous()
+        table = _d2s_table(B, D, H, W, k, Co, gy.device)
+        d2s = ((D, H, W, kd, kh, kw, Co), table)
+        R = x2.shape[0]
+        lib = capi.load()
+        gx = gw = gb = None
+        fl = 2.0 * R * Ci * taps * Co
+        if ctx.needs_input_grad[0]:      # gx[r][ci] = sum_(tap,co) gy_fine[r; tap, co] wk[ci][(tap,co)]  (NT, gathered A)
+            gx2 = torch.empty(R, Ci, dtype=torch.float32, device=gy.device)
+            g = _gdims(R, Ci, taps * Co, 1, 0, taps * Co, Ci, 0, 0, 0, 0, d2s)
+            ws = _ws(lib.ssbev_gemm_nt_workspace(C.byref(g)), gy.device)
+            with _span("gemm_own", fl, 4.0 * (gy.numel() + wk.numel() + gx2.numel()), f"deconv k=s dgrad {Ci}->{Co} k{kd}{kh}{kw}"):
+                capi.check(lib.ssbev_gemm_nt(capi.ptr(gy), capi.ptr(wk), None, capi.ptr(gx2), C.byref(g), capi.ptr(ws), ws.numel(),
+                                             capi.stream()), "ssbev_gemm_nt")
+            gx = gx2.view(B, D, H, W, Ci)
+        if ctx.needs_input_grad[1]:      # gwk[ci][(tap,co)] = sum_r x[r][ci] gy_fine[r; tap, co]               (TN, gathered B)
+            gwk = torch.empty(Ci, taps * Co, dtype=torch.float32, device=gy.device)
+            g = _gdims(R, taps * Co, Ci, 1, Ci, 0, taps * Co, 0, 0, Ci * taps * Co, 0, d2s)
+            ws = _ws(lib.ssbev_gemm_tn_workspace(C.byref(g)), gy.device)
+            with _span("gemm_own", fl, 4.0 * (gy.numel() + x2.numel() + gwk.numel()), f"deconv k=s wgrad {Ci}->{Co} k{kd}{kh}{kw}"):
+                capi.check(lib.ssbev_gemm_tn(capi.ptr(x2), capi.ptr(gy), capi.ptr(gwk), C.byref(g), capi.ptr(ws), ws.numel(),
+                                             capi.stream()), "ssbev_gemm_tn")
+            gw = gwk.view(Ci, kd, kh, kw, Co).permute(0, 4, 1, 2, 3).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.reshape(-1, Co).sum(0)
+        return gx, gw, gb, None
+
+
 # Layers that are plain GEMMs in the channels-last layout go to rocBLAS (forward, data and weight gradient through
 # autograd's mm): wide pointwise convolutions ([pixels, Cin] x [Cin, Cout]) and the kernel == stride transposed
 # convolutions of the FPN ([voxels, Cin] x [Cin, k^3 * Cout] followed by a depth-to-space copy).  The hand-written
@@ -486,6 +686,8 @@ def _deconv_k_eq_s_gemm(x, weight, bias, k):
     B, D, H, W, Ci = xcl.shape
     Co = weight.shape[1]
     kd, kh, kw = k
+    if own_gemm_site("deconv") and Co % 64 == 0 and Ci % 4 == 0:
+        return from_cl(_DeconvKS.apply(xcl, weight, bias, (int(kd), int(kh), int(kw))))
     w2 = weight.permute(0, 2, 3, 4, 1).reshape(Ci, kd * kh * kw * Co)
     fl = 2.0 * B * D * H * W * Ci * kd * kh * kw * Co
     nby = 4.0 * (xcl.numel() + w2.numel() + B * D * H * W * kd * kh * kw * Co)
@@ -772,7 +974,7 @@ class _WinoConv(torch.autograd.Function):
                 y = _wino_call(pre + "output_transform_bf16", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
             else:
                 V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-                M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM and not f43) else torch.bmm(V, U)
+                M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM and not f43) else (gemm_nn(V, U, tag=tag + " gemm") if own_gemm_site("wino") else torch.bmm(V, U))
                 y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(xcl if fused else V, weight)
         ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red)
@@ -800,7 +1002,7 @@ class _WinoConv(torch.autograd.Function):
             with _span("conv_winograd", fl, nby, f"wino{vtag} dgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
                 Vg = _wino_call(pre + "input_transform" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
                 Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf and not f43) \
-                    else torch.bmm(Vg, Ut.to(fdt))
+                    else (torch.bmm(Vg, Ut.to(fdt)) if (bf or not own_gemm_site("wino")) else gemm_nn(Vg, Ut, tag="wino dgrad gemm"))
                 del Vg
                 gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
             gx = from_cl(gxcl)
@@ -809,7 +1011,7 @@ class _WinoConv(torch.autograd.Function):
                 if fused:
                     V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
-                gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else torch.bmm(V.transpose(1, 2), Z)
+                gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else (gemm_tn(V, Z, tag="wino wgrad gemm") if own_gemm_site("wino") else torch.bmm(V.transpose(1, 2), Z))
             gw = torch.empty_like(w)
             wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
             capi.check(wg(capi.ptr(gU), capi.ptr(gw), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
@@ -1182,6 +1384,9 @@ def linear_cl(x, weight, bias=None):
     shp = xcl.shape
     w2 = weight.reshape(weight.shape[0], -1)
     x2 = xcl.reshape(-1, shp[-1])
+    if own_gemm_site("linear") and x2.shape[1] % 4 == 0 and w2.shape[0] % 4 == 0 and x2.shape[0] >= 64:
+        y = _LinearCL.apply(x2, w2, bias)
+        return from_cl(y.view(*shp[:-1], w2.shape[0]))
     fl = 2.0 * x2.shape[0] * x2.shape[1] * w2.shape[0]
     nby = 4.0 * (x2.numel() + w2.numel() + x2.shape[0] * w2.shape[0])
     mult = 3.0 if (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) else 1.0

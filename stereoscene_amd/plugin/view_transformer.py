@@ -272,29 +272,45 @@ class attention(nn.Module):
 class _BriCore(torch.autograd.Function):
     """out[b,:,i] = sum_j softmax_j(Q[:,i].K[:,j]) * conf[j] * V[:,j]   (ATT:72-81) for [B,D,T] operands.
 
-    Every product is arranged as a plain row-major (NN) GEMM with the 192-wide head dimension as an
-    outer size and small explicit operand transposes: the strided/transposed forms autograd would
-    otherwise hand to the BLAS ran ~15x slower on this shape (measured: 19 ms vs 0.3 ms per product).
+    The six products run on the path's own MFMA GEMM kernels (csrc/gemm.hip) in the form each operand already has in
+    memory -- [D, T] with the token axis contiguous -- so nothing is transposed or copied:
+      energy = Q^T K      TN (reduction over the D rows)        out  = Vc att^T   NT
+      gatt   = go^T Vc    TN                                    gVc  = go att     NN
+      gQ     = K gE^T     NT                                    gK   = Q gE       NN
     """
 
     @staticmethod
     def forward(ctx, Q, K, V, conf):
-        att = torch.softmax(torch.bmm(Q.transpose(1, 2).contiguous(), K), dim=-1)      # [B,T(i),T(j)]
+        own = F.own_gemm_site("bri")
         Vc = V * conf.unsqueeze(1)                                                      # key-side re-weight
-        out = torch.bmm(att, Vc.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()   # [B,D,T(i)]
+        if own:
+            att = torch.softmax(F.gemm_tn(Q, K, tag="bri energy"), dim=-1)              # [B,T(i),T(j)]
+            out = F.gemm_nt(Vc, att, tag="bri out")                                     # [B,D,T(i)]
+        else:       # library realisation: plain NN products around explicit operand transposes
+            att = torch.softmax(torch.bmm(Q.transpose(1, 2).contiguous(), K), dim=-1)
+            out = torch.bmm(att, Vc.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
         ctx.save_for_backward(Q, K, V, conf, att)
+        ctx.own = own
         return out
 
     @staticmethod
     def backward(ctx, gout):
         Q, K, V, conf, att = ctx.saved_tensors
         Vc = V * conf.unsqueeze(1)
-        goT = gout.transpose(1, 2).contiguous()                                         # [B,T(i),D]
-        gatt = torch.bmm(goT, Vc)                                                       # [B,T(i),T(j)]
-        gVc = torch.bmm(gout.contiguous(), att)                                         # [B,D,T(j)]
+        gout = gout.contiguous()
+        if ctx.own:
+            gatt = F.gemm_tn(gout, Vc, tag="bri gatt")                                  # [B,T(i),T(j)]
+            gVc = F.gemm_nn(gout, att, tag="bri gVc")                                   # [B,D,T(j)]
+        else:
+            gatt = torch.bmm(gout.transpose(1, 2).contiguous(), Vc)
+            gVc = torch.bmm(gout, att)
         gE = att * (gatt - (gatt * att).sum(-1, keepdim=True))                          # softmax backward
-        gQ = torch.bmm(gE, K.transpose(1, 2).contiguous()).transpose(1, 2)              # [B,D,T(i)]
-        gK = torch.bmm(Q, gE)                                                           # [B,D,T(j)]
+        if ctx.own:
+            gQ = F.gemm_nt(K, gE, tag="bri gQ")                                         # [B,D,T(i)]
+            gK = F.gemm_nn(Q, gE, tag="bri gK")                                         # [B,D,T(j)]
+        else:
+            gQ = torch.bmm(gE, K.transpose(1, 2).contiguous()).transpose(1, 2)
+            gK = torch.bmm(Q, gE)
         return gQ, gK, gVc * conf.unsqueeze(1), (gVc * V).sum(1)
 
 

@@ -820,3 +820,76 @@ def test_dilated_conv_polyphase_winograd(case):
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------ own GEMM family (csrc/gemm.hip)
+@pytest.mark.parametrize("case", [(1, 300, 128, 96), (1, 7680, 3200, 640), (3, 200, 64, 160), (1, 130, 36, 20), (2, 1920, 640, 640),
+                                  (1, 64, 192, 7680)])
+def test_gemm_nn_nt_tn_vs_torch(case):
+    """ssbev_gemm_nn / nt / tn (fp32 MFMA, LDS-DMA staged) against torch.matmul in float64: ragged M / N / K (row, column and
+    k tails), batches, a shared B, 64- and 128-wide column tiles, bias + ReLU epilogue, the row-chunked TN reduction."""
+    Bt, M, K, N = case
+    a = S.hash_normal(f"gm/a{case}", (Bt, M, K)).to(DEV)
+    b = S.hash_normal(f"gm/b{case}", (Bt, K, N)).to(DEV)
+    bias = S.hash_normal(f"gm/c{case}", (N,)).to(DEV)
+    scale = K ** 0.5
+    ref = torch.matmul(a.double(), b.double())
+    got = F.gemm_nn(a, b)
+    assert (got.double() - ref).abs().max().item() < 2e-5 * scale
+    got = F.gemm_nn(a[0], b[0], bias, relu=True)
+    assert (got.double() - torch.relu(ref[0] + bias.double())).abs().max().item() < 2e-5 * scale
+    got = F.gemm_nn(a, b[0])                                       # one B for every batch element
+    assert (got.double() - torch.matmul(a.double(), b[0].double())).abs().max().item() < 2e-5 * scale
+    w = b.transpose(1, 2).contiguous()                             # [Bt, N, K]
+    got = F.gemm_nt(a, w, bias)
+    assert (got.double() - (ref + bias.double())).abs().max().item() < 2e-5 * scale
+    a2 = S.hash_normal(f"gm/a2{case}", (Bt, M, N)).to(DEV)        # TN: reduction over the M rows
+    got = F.gemm_tn(a, a2)
+    ref = torch.matmul(a.double().transpose(1, 2), a2.double())
+    assert (got.double() - ref).abs().max().item() < 2e-5 * M ** 0.5
+    # strided rows (a column slice of a wider buffer): leading dimension > K
+    wide = S.hash_normal(f"gm/w{case}", (M, K + 8)).to(DEV)
+    got = F.gemm_nn(wide[:, 4:4 + K], b[0])
+    assert (got.double() - wide[:, 4:4 + K].double() @ b[0].double()).abs().max().item() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("case", [(1, 128, 128, 3, 4, 5, 1), (2, 256, 128, 2, 3, 4, 2), (1, 512, 128, 2, 2, 3, 4), (1, 128, 64, 1, 5, 2, 2)])
+def test_deconv_k_eq_s_own_gemm_vs_aten(case, monkeypatch):
+    """kernel == stride ConvTranspose3d of SECONDFPN3D (second_fpn_3d.py:50-69) on the own GEMM kernels with the
+    depth-to-space map inside (scatter epilogue / gathered operands): forward, data, weight and bias gradient vs ATen."""
+    B, Ci, Co, D, H, W, k = case
+    monkeypatch.setattr(F, "OWN_GEMM", True)
+    x = S.hash_normal(f"dks/x{case}", (B, Ci, D, H, W))
+    w = S.hash_uniform(f"dks/w{case}", (Ci, Co, k, k, k), -1, 1) * (1.0 / Ci) ** 0.5
+    bias = S.hash_uniform(f"dks/b{case}", (Co,), -0.5, 0.5)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, bias))
+    want = TF.conv_transpose3d(xc, wc, bc, stride=k)
+    go = S.hash_normal(f"dks/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, bias))
+    timer = F.KernelTimer(families=set())
+    F.KERNEL_TIMER = timer
+    try:
+        got = F.conv_transpose3d(xg, wg, bg, stride=k)
+        got.backward(go.to(DEV))
+    finally:
+        F.KERNEL_TIMER = None
+    assert timer.counts.get("gemm_own", {}).get("launches") == 3
+    for name, a, b_ in (("y", got, want), ("gx", xg.grad, xc.grad), ("gw", wg.grad, wc.grad), ("gb", bg.grad, bc.grad)):
+        assert maxdiff(a, b_) < 3e-5 * max(1.0, b_.abs().max().item()), name
+
+
+def test_linear_cl_own_gemm_vs_aten(monkeypatch):
+    monkeypatch.setattr(F, "OWN_GEMM", True)
+    x = S.hash_normal("lcl/x", (2, 3200, 12, 20))
+    w = S.hash_uniform("lcl/w", (640, 3200, 1, 1), -1, 1) * (1.0 / 3200) ** 0.5
+    b = S.hash_uniform("lcl/b", (640,), -0.5, 0.5)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = TF.conv2d(xc, wc, bc)
+    go = S.hash_normal("lcl/go", tuple(want.shape))
+    want.backward(go)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    got = F.conv2d(xg, wg, bg)
+    got.backward(go.to(DEV))
+    for a, b_ in ((got, want), (xg.grad, xc.grad), (wg.grad, wc.grad), (bg.grad, bc.grad)):
+        assert maxdiff(a, b_) < 3e-5 * max(1.0, b_.abs().max().item())
