@@ -42,7 +42,7 @@ CPU_BASELINE_THREADS = 32
 # the step by summed duration).  value = (kernel name, bound)
 SINGLE_KERNEL_FAMILIES = {
     "conv_tap_h": ("conv_taph_kernel", "mfma"),
-    "conv_wino_fused": ("wino_fused_kernel", "mfma"),
+    "conv_wino_fused": ("wino_df_kernel", "mfma"),
 }
 
 

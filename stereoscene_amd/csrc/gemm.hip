@@ -325,6 +325,114 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- TN, skinny
+// K, N <= 64 with a very long row reduction (weight gradients of the 1x1x1 convolutions on the cost volume: 1.47 M rows of
+// 32 channels): an HBM-streaming problem -- 256 bytes of operands per MFMA.  No LDS, no sharing: every WAVE walks its own
+// contiguous run of rows, a half wave reads one 128-byte row segment per load (8 row pairs in flight), and leaves a partial
+// [K][N] tile; gemm_sum_kernel adds the partials in wave order (deterministic).
+// QUAD = false (K, N <= 64): the four waves of a workgroup walk DIFFERENT row runs and fold their tiles through LDS.
+// QUAD = true  (K, N <= 128): the four waves walk the SAME rows, wave (qk, qn) owns the 64 x 64 quadrant (qk, qn) of the result
+//              (each operand row is read by two waves: the second read hits L1).
+template <int KT, int NT, bool QUAD>
+__global__ void __launch_bounds__(256)
+gemm_tn_skinny_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, GemmGeom g, int rows_per_run) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int run = QUAD ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;               // row run of this wave
+  const int ko = QUAD ? (wave >> 1) * 64 : 0, no = QUAD ? (wave & 1) * 64 : 0;        // quadrant origin
+  const int b = blockIdx.y;
+  const float* Ab = A + (long)b * g.sa + ko;
+  const float* Bb = B + (long)b * g.sb + no;
+  const long r_begin = (long)run * rows_per_run, r_end = min((long)g.M, r_begin + rows_per_run);
+  gf32x16 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][nt][r] = 0.0f;
+  const bool kok[2] = {ko + li < g.K, ko + 32 + li < g.K}, nok[2] = {no + li < g.N, no + 32 + li < g.N};
+  constexpr int U = 8;
+  for (long r0 = r_begin; r0 < r_end; r0 += 2 * U) {
+    float a[U][KT], bb[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = r0 + 2 * u + lk;
+      const bool rok = r < r_end;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) a[u][kt] = (rok && kok[kt]) ? Ab[r * g.lda + kt * 32 + li] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bb[u][nt] = (rok && nok[nt]) ? Bb[r * g.ldb + nt * 32 + li] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][kt], bb[u][nt], acc[kt][nt], 0, 0, 0);
+  }
+  float* dst = part + ((size_t)blockIdx.x * g.batch + b) * g.K * g.N;               // one partial per workgroup
+  if (QUAD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = no + nt * 32 + li;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = ko + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (k < g.K && n < g.N) dst[(size_t)k * g.N + n] = acc[kt][nt][r];
+        }
+    }
+    return;
+  }
+  // the four waves of the workgroup fold their tiles through LDS in wave order
+  __shared__ float fold[QUAD ? 1 : 4][KT * NT * 1024];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fold[wave][((kt * NT + nt) * 16 + r) * 64 + lane] = acc[kt][nt][r];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 32 + li;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int o = ((kt * NT + nt) * 16 + r) * 64 + lane;
+        const float v = ((fold[0][o] + fold[1][o]) + fold[2][o]) + fold[3][o];
+        if (k < g.K && n < g.N) dst[(size_t)k * g.N + n] = v;
+      }
+  }
+}
+
+// Many partials, few elements (the skinny TN): a workgroup = 64 consecutive elements x 16 contiguous chunk groups; every
+// group adds its chunks in ascending order, the 16 group sums are folded in group order (fixed order: deterministic).
+__global__ void __launch_bounds__(1024)
+gemm_sum_wide_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nchunk) {
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + e;
+  const int per = (nchunk + 15) / 16, c0 = grp * per, c1 = min(nchunk, c0 + per);
+  float a = 0.0f;
+  if (i < n)
+    for (int c = c0; c < c1; ++c) a += part[(size_t)c * n + i];
+  red[grp][e] = a;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float v = red[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v += red[q][e];
+    out[i] = v;
+  }
+}
+
 // out[i] = sum over chunks (ascending: deterministic) of part[c][i] (+ bias[i % N], ReLU)
 __global__ void __launch_bounds__(256)
 gemm_sum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nchunk, const float* __restrict__ bias,
@@ -470,8 +578,18 @@ int ssbev_gemm_nt(const float* A, const float* W, const float* bias, float* Cm, 
 // C[b][k][n] = sum_r A[b][r][k] B[b][r][n]: d->M = rows (the reduction), d->K x d->N the dense result (ldc = N).
 // d2s set: row r of B is gathered from the fine grid (N = taps * Co wide).  Workspace: partial results of the row chunks
 // (ssbev_gemm_tn_workspace bytes; 0 when one chunk suffices), summed in chunk order (deterministic).
+static bool tn_skinny(const ssbev_gemm_dims* d) { return d->K <= 128 && d->N <= 128 && d->M >= 32768 && d->d2s_kd == 0; }
+static bool tn_quad(const ssbev_gemm_dims* d) { return d->K > 64 || d->N > 64; }
+static int tn_skinny_wgs(const ssbev_gemm_dims* d) {
+  // ~2 workgroups per CU (8 waves streaming per CU), at least 256 rows per run
+  const long runs = tn_quad(d) ? 512 : 2048;
+  const long w = std::min<long>(runs, std::max<long>(4, d->M / 256));
+  return tn_quad(d) ? (int)w : (int)((w + 3) / 4);
+}
+
 size_t ssbev_gemm_tn_workspace(const ssbev_gemm_dims* d) {
   if (!gemm_ok(d)) return 0;
+  if (tn_skinny(d)) return (size_t)tn_skinny_wgs(d) * d->batch * d->K * d->N * sizeof(float);
   const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
   const int tiles = ((d->K + 127) / 128) * ((d->N + 64 * wn - 1) / (64 * wn));
   const int nchunk = tn_chunks(d, tiles);
@@ -485,6 +603,28 @@ int ssbev_gemm_tn(const float* A, const float* B, float* Cm, const ssbev_gemm_di
   GemmGeom g;
   fill_geom(g, d);
   g.ldc = d->N; g.sc = (long)d->K * d->N; g.relu = 0;
+  if (tn_skinny(d)) {
+    if (!ws || ws_bytes < ssbev_gemm_tn_workspace(d)) return SSBEV_EWORKSPACE;
+    const int wgs = tn_skinny_wgs(d);
+    const bool quad = tn_quad(d);
+    const long runs = quad ? wgs : (long)wgs * 4;
+    const int rows_per_run = (int)(((long)d->M + runs - 1) / runs + 1) / 2 * 2;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(wgs, d->batch), block(256);
+    float* part = static_cast<float*>(ws);
+    if (quad) {
+      hipLaunchKernelGGL((gemm_tn_skinny_kernel<2, 2, true>), grid, block, 0, st, A, B, part, g, rows_per_run);
+    } else {
+      const int kt = (d->K + 31) / 32, nt = (d->N + 31) / 32;
+      if (kt == 1 && nt == 1) hipLaunchKernelGGL((gemm_tn_skinny_kernel<1, 1, false>), grid, block, 0, st, A, B, part, g, rows_per_run);
+      else if (kt == 1) hipLaunchKernelGGL((gemm_tn_skinny_kernel<1, 2, false>), grid, block, 0, st, A, B, part, g, rows_per_run);
+      else if (nt == 1) hipLaunchKernelGGL((gemm_tn_skinny_kernel<2, 1, false>), grid, block, 0, st, A, B, part, g, rows_per_run);
+      else hipLaunchKernelGGL((gemm_tn_skinny_kernel<2, 2, false>), grid, block, 0, st, A, B, part, g, rows_per_run);
+    }
+    const size_t n = (size_t)d->batch * d->K * d->N;
+    hipLaunchKernelGGL(gemm_sum_wide_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, part, Cm, n, wgs);
+    return ssbev_launch_status();
+  }
   const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
   const int BN = 64 * wn;
   g.mblocks = (d->K + 127) / 128;

@@ -437,7 +437,13 @@ class _ConvNd(torch.autograd.Function):
             if kpad:
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
-        if ctx.needs_input_grad[1]:
+        pointwise = (not transposed and tuple(weight.shape[2:]) == (1, 1, 1) and stride == (1, 1, 1) and padding == (0, 0, 0)
+                     and not kpad and not cpad and weight.shape[0] <= 128 and weight.shape[1] <= 128 and gcl.numel() // gcl.shape[-1] >= 32768)
+        if ctx.needs_input_grad[1] and pointwise and OWN_GEMM and PRECISION == "fp32":
+            # 1x1x1 layers on the cost volume: gw[co][ci] = sum_rows gy[row][co] x[row][ci], an HBM-streaming skinny TN product
+            with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
+                gw = gemm_tn(gcl.reshape(-1, gcl.shape[-1]), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
+        elif ctx.needs_input_grad[1]:
             gwp = torch.empty(tuple(w5.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
             with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):

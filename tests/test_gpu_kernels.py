@@ -824,7 +824,7 @@ def test_dilated_conv_polyphase_winograd(case):
 
 # ------------------------------------------------------------------------------------ own GEMM family (csrc/gemm.hip)
 @pytest.mark.parametrize("case", [(1, 300, 128, 96), (1, 7680, 3200, 640), (3, 200, 64, 160), (1, 130, 36, 20), (2, 1920, 640, 640),
-                                  (1, 64, 192, 7680)])
+                                  (1, 64, 192, 7680), (1, 40000, 32, 64), (2, 33000, 64, 36), (1, 34000, 128, 100), (1, 33000, 96, 128)])
 def test_gemm_nn_nt_tn_vs_torch(case):
     """ssbev_gemm_nn / nt / tn (fp32 MFMA, LDS-DMA staged) against torch.matmul in float64: ragged M / N / K (row, column and
     k tails), batches, a shared B, 64- and 128-wide column tiles, bias + ReLU epilogue, the row-chunked TN reduction."""

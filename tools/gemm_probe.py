@@ -18,7 +18,10 @@ CASES = [("nn", 16, 1920, 640, 640, "2-D wino fwd"), ("tn", 16, 1920, 640, 640, 
          ("nn", 1, 192, 7680, 7680, "bri gVc"), ("nt", 1, 7680, 3200, 640, "aspp 3200->640"), ("nn", 1, 7680, 640, 3200, "aspp dgrad"),
          ("tn", 1, 7680, 640, 3200, "aspp wgrad"), ("nn", 1, 4096, 512, 8192, "fpn k4 fwd"), ("nt", 1, 4096, 8192, 512, "fpn k4 dgrad"),
          ("tn", 1, 4096, 512, 8192, "fpn k4 wgrad"), ("nn", 1, 262144, 128, 128, "fpn k1 fwd"), ("tn", 1, 262144, 128, 128, "fpn k1 wgrad"),
-         ("nt", 1, 7680, 1440, 160, "dcn group")]
+         ("nt", 1, 7680, 1440, 160, "dcn group"),
+         ("nt", 1, 1474560, 32, 32, "1x1x1 32ch fwd"), ("nn", 1, 1474560, 32, 32, "1x1x1 32ch dgrad"), ("tn", 1, 1474560, 32, 32, "1x1x1 32ch wgrad"),
+         ("nt", 1, 184320, 64, 64, "1x1x1 64ch fwd"), ("nn", 1, 184320, 64, 64, "1x1x1 64ch dgrad"), ("tn", 1, 184320, 64, 64, "1x1x1 64ch wgrad"),
+         ("nt", 1, 262144, 128, 128, "input_proj fwd"), ("tn", 1, 262144, 128, 128, "input_proj wgrad"), ("nt", 1, 262144, 192, 20, "head 192->20")]
 for form, bt, M, K, N, what in CASES:
     if form == "tn":      # rows = M (reduction), result K x N
         a = torch.randn(bt, M, K, device="cuda"); b = torch.randn(bt, M, N, device="cuda")
