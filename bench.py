@@ -36,7 +36,7 @@ XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0
 VOXELS_PER_SAMPLE = 256 * 256 * 32
 
 # CPU baseline thread count: profiles/r2_cpu_thread_sweep.txt (oracle step time vs torch threads on the GPU box's host)
-CPU_BASELINE_THREADS = 32
+CPU_BASELINE_THREADS = 16
 
 # Families whose launches are ONE kernel each: candidates for the `roofline` object (the dominant single kernel of
 # the step by summed duration).  value = (kernel name, bound)

@@ -7,10 +7,13 @@ streaming kernels of this path (gwc_warp_fwd writes 188.7 MB, pool_gather 134.2 
 it is doubled."""
 import collections, csv, json, sys
 
-FAMILIES = [("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
+FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_dfw_kernel",)),
+            ("gemm_nn_kernel", ("gemm_nn_kernel",)), ("gemm_tn_kernel", ("gemm_tn_kernel", "gemm_tn_skinny_kernel")),
+            ("gwc_warp_bwd2", ("gwc_warp_bwd2_kernel",)), ("lift_splat_bwd2", ("lift_splat_bwd2_kernel",)),
+            ("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
             ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
-            ("gwc_warp_fwd", ("gwc_warp_fwd_kernel",)), ("pool_gather", ("pool_gather_kernel",)),
+            ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel")),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
             ("wino_input_kernel", ("wino_input_kernel", "wino43_input_kernel")),
             ("wino_output_kernel", ("wino_output_kernel", "wino43_output_kernel")), ("rocblas_gemm_Cijk", ("Cijk_",))]
