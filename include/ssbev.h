@@ -145,8 +145,24 @@ typedef struct {
 size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d);
 /* which kernel family ssbev_conv_fwd (mode 0) / ssbev_conv_bwd_data (mode 1) dispatches this problem to -- for FLOP
  * accounting in profilers (bench.py): 0 = generic gather kernels, 1 = conv_tap_kernel, 2 = conv_taph_kernel (Winograd
- * F(2,3) along h inside the kernel: executes 2/3 of the operator's multiply-adds), 3 = conv_thin_kernel; < 0 = error */
+ * F(2,3) along h inside the kernel: executes 2/3 of the operator's multiply-adds), 3 = conv_thin_kernel, 4 =
+ * conv_thinin_kernel (1 / 2 / 4 -> 32 channels: the K-role tensor is taken UNPADDED, Cin % 4 is not required),
+ * 5 = a 32 -> 1 / 2 / 4 channel problem for which the two-pass ssbev_conv_thin_* entry points below are available
+ * (ssbev_conv_fwd / _bwd_data themselves run such a problem on class 3 or 0); mode 2 asks about ssbev_conv_bwd_weight:
+ * 6 = wgrad_thinside_kernel (32 <-> 1 / 2 / 4 channels; x and gy are taken UNPADDED), 0 = the other weight-gradient
+ * kernels; < 0 = error */
 int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode);
+
+/* 32 -> 1 / 2 / 4 channel 3x3x3 stride-1 "same" layers (the 32 -> 1 classifiers of the cost-volume stack,
+ * ViewTransformerLSSVoxel.py:185-187, 239-241; mode 1: the data gradient of a 1 / 2 / 4 -> 32 layer) as one pass over the
+ * wide tensor on the matrix pipe + one pass over 9 N partial planes in a caller-owned workspace
+ * (ssbev_conv_thin_workspace bytes; 0 = not applicable).  Weights: torch layout -> ssbev_conv_thin_pack
+ * (ssbev_conv_thin_packed_elems floats).  Tensors channels-last as for ssbev_conv_fwd; mode 0 applies bias / ReLU. */
+size_t ssbev_conv_thin_workspace(const ssbev_conv_dims* d, int mode);
+size_t ssbev_conv_thin_packed_elems(const ssbev_conv_dims* d, int mode);
+int ssbev_conv_thin_pack(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode, ssbev_stream_t stream);
+int ssbev_conv_thin_run(const float* x, const float* w_packed, const float* bias, float* y, const ssbev_conv_dims* d,
+                        int mode, void* workspace, size_t ws_bytes, ssbev_stream_t stream);
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream);
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
@@ -262,6 +278,11 @@ int ssbev_bn_update_running(const float* mean, const float* rstd, float* running
 int ssbev_softmax_axis_fwd(const float* x, float* y, int64_t outer, int C, int64_t inner, ssbev_stream_t stream);
 int ssbev_softmax_axis_bwd(const float* y, const float* gy, float* gx, int64_t outer, int C, int64_t inner,
                            ssbev_stream_t stream);
+/* Softmax along the innermost axis of `rows` rows of C contiguous floats (C % 4 == 0, C <= 8192): the BRI attention
+ * matrix softmax(energy, -1) of attention.py:66-68 (T = 7680).  One read + one write of the matrix forward, two reads +
+ * one write backward (gx = y * (gy - sum_c y * gy)); y may alias x and gx may alias gy. */
+int ssbev_softmax_rows_fwd(const float* x, float* y, int64_t rows, int C, ssbev_stream_t stream);
+int ssbev_softmax_rows_bwd(const float* y, const float* gy, float* gx, int64_t rows, int C, ssbev_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Deformable convolution v1, sampling stages (mmcv DeformConv2dPack as built by DepthNet, bevdepth.py:490-498;

@@ -99,6 +99,10 @@ SIGNATURES = {
     "ssbev_conv_packed_weight_elems": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_kernel_class": (C.c_int, [C.POINTER(ConvDims), C.c_int]),
     "ssbev_conv_pack_weight": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),
+    "ssbev_conv_thin_workspace": (C.c_size_t, [C.POINTER(ConvDims), C.c_int]),
+    "ssbev_conv_thin_packed_elems": (C.c_size_t, [C.POINTER(ConvDims), C.c_int]),
+    "ssbev_conv_thin_pack": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),
+    "ssbev_conv_thin_run": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), C.c_int, _P, C.c_size_t, _P]),
     "ssbev_conv_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), _P]),
     "ssbev_conv_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),
     "ssbev_conv_bwd_weight_workspace": (C.c_size_t, [C.POINTER(ConvDims)]),
@@ -177,6 +181,8 @@ SIGNATURES = {
     "ssbev_wino2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_softmax_axis_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_softmax_axis_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
+    "ssbev_softmax_rows_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "ssbev_softmax_rows_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),
     "ssbev_occ_loss_num_sums": (C.c_int, []),
     "ssbev_occ_loss_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),

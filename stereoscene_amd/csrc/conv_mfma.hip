@@ -25,6 +25,7 @@
 // The wide (>= 64 channel) stride-1 3x3(x3) layers normally do not come here at all: functional.conv3d / conv2d route them
 // through the Winograd path (winograd.hip).
 #include "common.h"
+#include "conv_thin_mfma.h"
 
 #include <algorithm>
 #include <array>
@@ -2530,7 +2531,10 @@ void launch_wgrad(const float* P, const float* Qt, float* ws, const WgradGeom& g
 extern "C" {
 
 int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
-  if (!conv_dims_ok(d) || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (!conv_dims_ok(d) || mode < 0 || mode > 2) return SSBEV_EINVAL;
+  if (mode == 2) return ssbev_thin::wgrad_applicable(d) ? 6 : 0;      // weight gradient: 6 = wgrad_thinside_kernel (unpadded thin side)
+  if (ssbev_thin::thinin_applicable(d, mode)) return 4;
+  if (ssbev_thin::thinout_applicable(d, mode)) return 5;     // ssbev_conv_thin_* (caller-owned workspace); ssbev_conv_fwd falls back to class 3 / 0
   if (conv_thin_applicable(d, mode)) return 3;
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
@@ -2549,6 +2553,7 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (ssbev_thin::thinin_applicable(d, mode)) return ssbev_thin::thinin_pack(w_src, w_packed, d, mode, as_stream(stream));
   if (conv_thin_applicable(d, mode)) {       // <= 4 output channels: LDS-resident [tap][n][k] table (conv_thin_kernel)
     hipLaunchKernelGGL(pack_thin_kernel, dim3(cdiv(27 * kThinNP * 32, 256)), dim3(256), 0, as_stream(stream), w_src,
                        w_packed, d->Cout, d->Cin, mode);
@@ -2581,6 +2586,7 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                    const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
+  if (ssbev_thin::thinin_applicable(d, 0)) return ssbev_thin::thinin_launch(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
@@ -2599,6 +2605,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  if (ssbev_thin::thinin_applicable(d, 1)) return ssbev_thin::thinin_launch(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
@@ -2616,6 +2623,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
 
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
+  if (ssbev_thin::wgrad_applicable(d)) return ssbev_thin::wgrad_workspace(d);
   {
     const WgradThinPlan tp = plan_wgrad_thin(d);
     if (tp.ok) return align256b((size_t)tp.nchunks * 27 * d->Cin * d->Cout * sizeof(float));
@@ -2645,6 +2653,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
+  if (ssbev_thin::wgrad_applicable(d)) return ssbev_thin::wgrad_launch(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
   {
     const WgradThinPlan tp = plan_wgrad_thin(d);
     if (tp.ok) {                                 // 32 -> (<= 4) heads: VALU reduction over the LDS ring

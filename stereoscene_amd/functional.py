@@ -387,6 +387,16 @@ def _packed(weight5, d, mode):
     return wp
 
 
+def _thin_out_run(lib, src, weight5, bias, out, d, mode):
+    """32 -> 1 / 2 / 4 channel 3x3x3 layers on the two-pass MFMA kernels (ssbev_conv_thin_*, kernel class 5)."""
+    wp = torch.empty(lib.ssbev_conv_thin_packed_elems(C.byref(d), mode), dtype=torch.float32, device=src.device)
+    capi.check(lib.ssbev_conv_thin_pack(capi.ptr(weight5.contiguous()), capi.ptr(wp), C.byref(d), mode, capi.stream()),
+               "ssbev_conv_thin_pack")
+    ws = _ws(lib.ssbev_conv_thin_workspace(C.byref(d), mode), src.device)
+    capi.check(lib.ssbev_conv_thin_run(capi.ptr(src), capi.ptr(wp), capi.ptr(bias), capi.ptr(out), C.byref(d), mode,
+                                       capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_conv_thin_run")
+
+
 class _ConvNd(torch.autograd.Function):
     """x logical [B,Cin,D,H,W] (channels-last memory), weight in the torch layout (5-D)."""
 
@@ -396,19 +406,27 @@ class _ConvNd(torch.autograd.Function):
         xcl = to_cl(_f32(x, "conv"))
         kpad = (-xcl.shape[-1]) % 4
         w5 = weight
-        if kpad:   # the K-role channel count must be a multiple of 4 (float4 operand loads)
+        thin_in = False
+        if kpad and not transposed:   # 1..2 -> 32 channel 3x3x3 layers: conv_thinin_kernel gathers the thin side unpadded
+            d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
+            thin_in = lib.ssbev_conv_kernel_class(C.byref(d0), 0) == 4
+        if kpad and not thin_in:   # the K-role channel count must be a multiple of 4 (float4 operand loads)
             xcl = torch.nn.functional.pad(xcl, (0, kpad))
             w5 = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0) + ((0, 0, 0, kpad) if transposed else (0, kpad)))
         d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), stride, padding, dilation, transposed, output_padding)
-        wp = _packed(w5.detach(), d, 0)
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
         fam = _conv_family(lib, d, 0)
         with _span(fam, conv_flops(d), conv_bytes(d), _conv_tag(d, "fwd"), conv_flops(d) / _EXEC_DIV[fam]):
-            capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
-                                          capi.stream()), "ssbev_conv_fwd")
+            if lib.ssbev_conv_kernel_class(C.byref(d), 0) == 5:
+                _thin_out_run(lib, xcl, w5.detach(), b, y, d, 0)
+            else:
+                wp = _packed(w5.detach(), d, 0)
+                capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
+                                              capi.stream()), "ssbev_conv_fwd")
         ctx.save_for_backward(xcl, weight)
-        ctx.cfg = (stride, padding, dilation, transposed, output_padding, kpad, bias is not None)
+        ctx.cfg = (stride, padding, dilation, transposed, output_padding, 0 if thin_in else kpad, bias is not None)
+        ctx.thin_in = thin_in
         return from_cl(y)
 
     @staticmethod
@@ -416,7 +434,7 @@ class _ConvNd(torch.autograd.Function):
         lib = capi.load()
         xcl, weight = ctx.saved_tensors
         stride, padding, dilation, transposed, output_padding, kpad, has_bias = ctx.cfg
-        gcl = to_cl(gy)
+        gcl = gcl0 = to_cl(gy)
         w5 = weight.detach()
         if kpad:
             w5 = torch.nn.functional.pad(w5, (0, 0, 0, 0, 0, 0) + ((0, 0, 0, kpad) if transposed else (0, kpad)))
@@ -428,12 +446,20 @@ class _ConvNd(torch.autograd.Function):
         d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), stride, padding, dilation, transposed, output_padding)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wpt = _packed(w5, d, 1)
+            dd, gdl, wd = d, gcl, w5
+            if cpad and not transposed:   # 32 -> 1..2 layers: the data gradient gathers the unpadded thin gradient
+                d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
+                if lib.ssbev_conv_kernel_class(C.byref(d0), 1) == 4:
+                    dd, gdl, wd = d0, gcl0, weight.detach()
             gxcl = torch.empty_like(xcl)
-            fam = _conv_family(lib, d, 1)
-            with _span(fam, conv_flops(d), conv_bytes(d), _conv_tag(d, "dgrad"), conv_flops(d) / _EXEC_DIV[fam]):
-                capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d),
-                                                   capi.stream()), "ssbev_conv_bwd_data")
+            fam = _conv_family(lib, dd, 1)
+            with _span(fam, conv_flops(dd), conv_bytes(dd), _conv_tag(dd, "dgrad"), conv_flops(dd) / _EXEC_DIV[fam]):
+                if lib.ssbev_conv_kernel_class(C.byref(dd), 1) == 5:
+                    _thin_out_run(lib, gdl, wd, None, gxcl, dd, 1)
+                else:
+                    wpt = _packed(wd, dd, 1)
+                    capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gdl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(dd),
+                                                       capi.stream()), "ssbev_conv_bwd_data")
             if kpad:
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
@@ -444,14 +470,26 @@ class _ConvNd(torch.autograd.Function):
             with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
                 gw = gemm_tn(gcl.reshape(-1, gcl.shape[-1]), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
         elif ctx.needs_input_grad[1]:
-            gwp = torch.empty(tuple(w5.shape), dtype=torch.float32, device=gy.device)
-            ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
-                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d),
+            xw, gw_src, dw, wshape = xcl, gcl, d, tuple(w5.shape)
+            tpad = (-xcl.shape[-1]) % 4 if ctx.thin_in else 0
+            thin_w = False
+            if not transposed and not kpad and (cpad or tpad):     # thin-side layers: wgrad_thinside_kernel takes both tensors unpadded
+                d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
+                thin_w = lib.ssbev_conv_kernel_class(C.byref(d0), 2) == 6
+            if thin_w:
+                gw_src, dw, wshape = gcl0, d0, tuple(weight.shape)
+            elif tpad:    # forward ran on the unpadded thin input (conv_thinin_kernel); the other weight-gradient kernels want K % 4 == 0
+                xw = torch.nn.functional.pad(xcl, (0, tpad))
+                wshape = (wshape[0], wshape[1] + tpad) + wshape[2:]
+                dw = _conv_dims(tuple(xw.shape), wshape, stride, padding, dilation, transposed, output_padding)
+            gwp = torch.empty(wshape, dtype=torch.float32, device=gy.device)
+            ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(dw)), gy.device)
+            with _span("conv_wgrad", conv_flops(dw), conv_bytes(dw), _conv_tag(dw, "wgrad")):
+                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xw), capi.ptr(gw_src), capi.ptr(gwp), C.byref(dw),
                                                      capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_conv_bwd_weight")
             ci = slice(0, weight.shape[0]), slice(0, weight.shape[1])
-            gw = gwp[ci[0], ci[1]].contiguous() if (kpad or cpad) else gwp
+            gw = gwp[ci[0], ci[1]].contiguous() if ((kpad or cpad or tpad) and not thin_w) else gwp
         if has_bias and ctx.needs_input_grad[2]:
             gb = gcl[..., : gcl.shape[-1] - cpad].reshape(-1, gcl.shape[-1] - cpad).sum(0) if cpad else \
                 gcl.reshape(-1, gcl.shape[-1]).sum(0)
@@ -1217,6 +1255,27 @@ class _SoftmaxAxis(torch.autograd.Function):
             capi.check(lib.ssbev_softmax_axis_bwd(capi.ptr(y), capi.ptr(gy), capi.ptr(gx), outer, Cn, inner, capi.stream()),
                        "ssbev_softmax_axis_bwd")
         return gx, None
+
+
+def softmax_rows_(x):
+    """In-place softmax over the innermost axis of a contiguous fp32 tensor with rows of <= 8192 floats (the BRI
+    attention matrix, attention.py:66-68): ssbev_softmax_rows_fwd, one read + one write.  No autograd."""
+    n = x.shape[-1]
+    capi.check(capi.load().ssbev_softmax_rows_fwd(capi.ptr(x), capi.ptr(x), x.numel() // n, n, capi.stream()),
+               "ssbev_softmax_rows_fwd")
+    return x
+
+
+def softmax_rows_bwd_(y, gy):
+    """gy <- y * (gy - sum(y * gy, -1)) in place (softmax backward along the innermost axis)."""
+    n = y.shape[-1]
+    capi.check(capi.load().ssbev_softmax_rows_bwd(capi.ptr(y), capi.ptr(gy), capi.ptr(gy), y.numel() // n, n,
+                                                  capi.stream()), "ssbev_softmax_rows_bwd")
+    return gy
+
+
+def softmax_rows_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0 and x.shape[-1] <= 8192
 
 
 def softmax(x, dim):

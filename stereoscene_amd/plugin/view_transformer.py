@@ -284,7 +284,8 @@ class _BriCore(torch.autograd.Function):
         own = F.own_gemm_site("bri")
         Vc = V * conf.unsqueeze(1)                                                      # key-side re-weight
         if own:
-            att = torch.softmax(F.gemm_tn(Q, K, tag="bri energy"), dim=-1)              # [B,T(i),T(j)]
+            att = F.gemm_tn(Q, K, tag="bri energy")                                     # [B,T(i),T(j)]
+            att = F.softmax_rows_(att) if F.softmax_rows_ok(att) else torch.softmax(att, dim=-1)
             out = F.gemm_nt(Vc, att, tag="bri out")                                     # [B,D,T(i)]
         else:       # library realisation: plain NN products around explicit operand transposes
             att = torch.softmax(torch.bmm(Q.transpose(1, 2).contiguous(), K), dim=-1)
@@ -304,7 +305,10 @@ class _BriCore(torch.autograd.Function):
         else:
             gatt = torch.bmm(gout.transpose(1, 2).contiguous(), Vc)
             gVc = torch.bmm(gout, att)
-        gE = att * (gatt - (gatt * att).sum(-1, keepdim=True))                          # softmax backward
+        if ctx.own and F.softmax_rows_ok(att) and gatt.is_contiguous():
+            gE = F.softmax_rows_bwd_(att, gatt)                                         # softmax backward, in place
+        else:
+            gE = att * (gatt - (gatt * att).sum(-1, keepdim=True))
         if ctx.own:
             gQ = F.gemm_nt(K, gE, tag="bri gQ")                                         # [B,D,T(i)]
             gK = F.gemm_nn(Q, gE, tag="bri gK")                                         # [B,D,T(j)]

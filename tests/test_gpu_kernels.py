@@ -377,6 +377,46 @@ def test_bri_attention_fwd_bwd_vs_dense(B, Dh, T):
         assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,C", [(5, 120), (33, 4096), (7, 7680), (3, 8192), (64, 4)])
+def test_softmax_rows_inplace_fwd_bwd(rows, C):
+    """Innermost-axis row softmax (BRI attention matrix): in-place forward and in-place backward vs ATen."""
+    x = S.hash_normal("smr/x", (2, rows, C), 3.0)
+    g = S.hash_normal("smr/g", (2, rows, C))
+    xc = x.clone().requires_grad_(True)
+    want = torch.softmax(xc, -1)
+    want.backward(g)
+    xg = x.to(DEV).clone()
+    assert F.softmax_rows_ok(xg)
+    y = F.softmax_rows_(xg)
+    assert y.data_ptr() == xg.data_ptr() and maxdiff(y, want) < 1e-6
+    gg = g.to(DEV).clone()
+    gx = F.softmax_rows_bwd_(y, gg)
+    assert gx.data_ptr() == gg.data_ptr() and maxdiff(gx, xc.grad) < 1e-6 * max(1.0, xc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("own", ["deconv,bri", "deconv"])
+def test_bri_core_gemm_realisation_fwd_bwd_vs_dense(own, monkeypatch):
+    """The default BRI realisation (six products + row softmax, own kernels or library) against the dense formula."""
+    from stereoscene_amd.plugin.view_transformer import _BriCore
+    monkeypatch.setattr(F, "OWN_GEMM_SITES", frozenset(own.split(",")))
+    B, Dh, T = 1, 48, 480
+    q = torch.softmax(S.hash_normal("bric/q", (B, Dh, T), 2.0), 1) * 3.0 + 0.1
+    k = torch.softmax(S.hash_normal("bric/k", (B, Dh, T), 2.0), 1) * 5.0 - 0.2
+    v = S.hash_normal("bric/v", (B, Dh, T))
+    conf = S.hash_uniform("bric/c", (B, T), 0.1, 1.0)
+    cs = [t.clone().requires_grad_(True) for t in (q, k, v, conf)]
+    att = torch.softmax(torch.bmm(cs[0].transpose(1, 2) * 10.0, cs[1]), -1) * cs[3].unsqueeze(1)
+    want = torch.bmm(cs[2], att.transpose(1, 2))
+    gs = [t.to(DEV).requires_grad_(True) for t in (q, k, v, conf)]
+    got = _BriCore.apply(gs[0] * 10.0, gs[1], gs[2], gs[3])
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal("bric/go", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    for a, c in zip(gs, cs):
+        assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("path", ["gemm", "flash"])
 def test_bri_attention_golden_module(path, monkeypatch):
     """The attention module (scalar affine q/k/v + gamma) against the reference fixture, both realisations."""
@@ -522,6 +562,33 @@ def test_conv_tap_split_lds_kernel(case, hint):
     assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 1, 32, 3, 4, 33, True), (2, 2, 32, 2, 3, 70, False), (1, 4, 32, 4, 5, 160, True),
+                                  (1, 32, 1, 4, 5, 45, False), (1, 32, 2, 3, 3, 31, True), (1, 32, 4, 2, 6, 64, False),
+                                  (1, 1, 32, 1, 1, 5, True), (2, 32, 1, 1, 2, 96, True), (1, 2, 32, 5, 1, 40, False)])
+def test_conv_thin_side_layers_mfma_kernels(case):
+    """1..4 <-> 32 channel 3x3x3 layers (the 32 -> 1 classifiers and the 2 -> 32 entry of the cost-volume stack) on the
+    streaming MFMA kernels of conv_thin_mfma.hip, library's own dispatch (no tile hint): forward, data gradient and
+    weight gradient against ATen, incl. ragged rows, one-plane / one-row volumes and batch 2."""
+    B, Cin, Cout, D, H, W, has_bias = case
+    x = S.hash_normal(f"thin/x{case}", (B, Cin, D, H, W))
+    w = S.hash_uniform(f"thin/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5
+    b = S.hash_uniform(f"thin/b{case}", (Cout,), -0.5, 0.5) if has_bias else None
+    xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bc = b.clone().requires_grad_(True) if has_bias else None
+    want = TF.conv3d(xc, wc, bc, 1, 1)
+    go = S.hash_normal(f"thin/go{case}", tuple(want.shape))
+    want.backward(go)
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if has_bias else None
+    got = F.conv3d(xg, wg, bg, 1, 1)
+    got.backward(go.to(DEV))
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    if has_bias:
+        assert maxdiff(bg.grad, bc.grad) < 5e-5 * max(1.0, bc.grad.abs().max().item())
 
 
 def test_conv_tap_winograd_h_full_size_agrees_with_plain_tap_kernels():
