@@ -183,8 +183,10 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
  *   y = relu?( (x - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c] + residual? )
  *   stats_given = 1: mean/rstd are inputs (eval-mode BatchNorm), otherwise outputs.
  * BatchNorm3d in training mode = the same call with G = C on the tensor viewed as [1, B*S, C].
+ *   pre_act = 1: the normalised quantity is gelu(x) (exact erf form) -- the Conv3d -> GELU -> GroupNorm triples of CA3D
+ *   (attention.py:94-111) without the two elementwise passes of the activation; backward returns the gradient w.r.t. x.
  * ------------------------------------------------------------------------------------------ */
-typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; } ssbev_norm_dims;
+typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; int pre_act; } ssbev_norm_dims;
 size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d);
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                         float* y, float* mean, float* rstd, const ssbev_norm_dims* d, void* ws,

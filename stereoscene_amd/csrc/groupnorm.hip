@@ -24,7 +24,14 @@ struct GnGeom {
   long chunk_len;    // voxels per chunk
   float eps;
   int relu;
+  int pre;           // 1: u = gelu(x) (exact, erf) is what gets normalised; x is still the tensor in memory
 };
+
+// exact GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
 
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): (sum g, sum g * xhat) with g = gy * [y > 0] when relu is fused.
@@ -59,7 +66,11 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
     for (long s = s0 + r; s < s1; s += rows) {
       const size_t off = base + (size_t)s * g.C + c;
       const float4 xv = *reinterpret_cast<const float4*>(x + off);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (g.pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k] = gelu_f(xs[k]);
+      }
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a0[k] += xs[k]; a1[k] += xs[k] * xs[k]; }
@@ -225,6 +236,10 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
     }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (g.pre) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+    }
     float rr[4] = {0, 0, 0, 0};
     if (res) { const float4 t = reinterpret_cast<const float4*>(res)[i]; rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
 #pragma unroll
@@ -344,8 +359,10 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float xh = (xs[k] - mu[k]) * rs[k];
+      const float u = g.pre ? gelu_f(xs[k]) : xs[k];
+      const float xh = (u - mu[k]) * rs[k];
       o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k];
+      if (g.pre) o[k] *= gelu_grad_f(xs[k]);
     }
     reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (gres) reinterpret_cast<float4*>(gres)[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
@@ -363,12 +380,12 @@ unsigned apply_blocks(long total4, int q) {
 }
 
 bool gn_ok(const ssbev_norm_dims* d) {
-  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0;
+  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0 && (d->pre_act == 0 || d->pre_act == 1);
 }
 
 GnGeom make_geom(const ssbev_norm_dims* d) {
   GnGeom g;
-  g.B = d->B; g.C = d->C; g.G = d->G; g.S = d->S; g.eps = d->eps; g.relu = d->relu;
+  g.B = d->B; g.C = d->C; g.G = d->G; g.S = d->S; g.eps = d->eps; g.relu = d->relu; g.pre = d->pre_act;
   // ~768 blocks over the chip (3 per CU), each at least 64 voxels: enough to saturate HBM, few enough that
   // the single-workgroup-per-group finalize pass stays in the 10-us range
   long chunks = 768 / d->B;

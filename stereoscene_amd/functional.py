@@ -1140,7 +1140,7 @@ class _GroupNorm(torch.autograd.Function):
     """GroupNorm on a channels-last volume with optional fused residual add and ReLU."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd):
+    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd, pre_act=0):
         lib = capi.load()
         ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) statistics outputs
         xcl = to_cl(_f32(x, "group_norm"))
@@ -1149,7 +1149,7 @@ class _GroupNorm(torch.autograd.Function):
         S = xcl.numel() // (B * Cch)
         rcl = to_cl(residual) if residual is not None else None
         given = given_mean is not None
-        d = capi.NormDims(B, Cch, groups, S, float(eps), int(relu), int(given))
+        d = capi.NormDims(B, Cch, groups, S, float(eps), int(relu), int(given), int(pre_act))
         y = torch.empty_like(xcl)
         mean = given_mean.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = given_rstd.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
@@ -1169,7 +1169,7 @@ class _GroupNorm(torch.autograd.Function):
                                                    capi.stream()), "ssbev_groupnorm_fwd")
         ctx.save_for_backward(xcl, (mask if use_mask else y) if relu else None, w, mean, rstd)
         ctx.use_mask = use_mask
-        ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given)
+        ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given, int(pre_act))
         ctx.mark_non_differentiable(mean, rstd)
         return from_cl(y), mean, rstd
 
@@ -1177,11 +1177,11 @@ class _GroupNorm(torch.autograd.Function):
     def backward(ctx, gy, _gm, _gr):
         lib = capi.load()
         xcl, y, w, mean, rstd = ctx.saved_tensors
-        B, S, Cch, groups, eps, relu, has_res, given = ctx.meta
+        B, S, Cch, groups, eps, relu, has_res, given, pre_act = ctx.meta
         if given:
             raise capi.SsbevError("eval-mode (given statistics) normalisation has no HIP backward; use torch for it")
         gcl = to_cl(gy)
-        d = capi.NormDims(B, Cch, groups, S, eps, relu, 0)
+        d = capi.NormDims(B, Cch, groups, S, eps, relu, 0, pre_act)
         gx = torch.empty_like(xcl)
         gres = torch.empty_like(xcl) if has_res else None
         gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
@@ -1194,12 +1194,15 @@ class _GroupNorm(torch.autograd.Function):
             capi.check(fn(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
                           capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
                           C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_groupnorm_bwd")
-        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None
+        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None
 
 
-def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False):
-    """relu?(GroupNorm(x) + residual?) on a channels-last volume (any spatial rank)."""
-    return _GroupNorm.apply(x, weight, bias, residual, int(groups), eps, relu, False, None, None)[0]
+def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False, pre_act=None):
+    """relu?(GroupNorm(act?(x)) + residual?) on a channels-last volume (any spatial rank); ``pre_act="gelu"`` normalises
+    gelu(x) (exact form) without materialising it."""
+    if pre_act not in (None, "gelu"):
+        raise ValueError(f"group_norm: unknown pre_act {pre_act!r}")
+    return _GroupNorm.apply(x, weight, bias, residual, int(groups), eps, relu, False, None, None, 1 if pre_act else 0)[0]
 
 
 def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False):

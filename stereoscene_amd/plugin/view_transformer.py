@@ -328,12 +328,29 @@ class CA3D(nn.Module):
                                    nn.Conv3d(channel // 8, channel, 1), nn.GELU())
         self.conv = nn.Sequential(Conv3d(channel, channel, 3, 1, 1), nn.GELU(), GroupNorm(1, channel))
 
-    def forward(self, x):
-        data = self.conv1(x)
+    def forward(self, x, residual=None, alpha=None):
+        """ATT:113-120.  Three algebraic rearrangements keep the 189 MB activations out of elementwise passes: GELU is the
+        pre-activation of the GroupNorm kernel; the per-channel gate sigmoid(s) multiplies the INPUT channels of the last
+        conv, i.e. its weight columns (B == 1); ``alpha * CA3D(x) + x`` of the Residual wrapper (VT:236-268) is GroupNorm
+        with affine (alpha gamma, alpha beta) and a fused residual add."""
+        c1, gn1, c2, gn2 = self.conv1[0], self.conv1[2], self.conv[0], self.conv[2]
+        if not x.is_cuda:
+            data = self.conv1(x)
+        else:
+            data = F.group_norm(c1(x), gn1.num_groups, gn1.weight, gn1.bias, gn1.eps, pre_act="gelu")
         pool = data.mean(dim=(2, 3, 4))
         s = TF.gelu(TF.linear(pool, self.conv2[0].weight.flatten(1), self.conv2[0].bias))
         s = TF.gelu(TF.linear(s, self.conv2[2].weight.flatten(1), self.conv2[2].bias))
-        return self.conv(torch.sigmoid(s)[..., None, None, None] * data)
+        gate = torch.sigmoid(s)
+        if not x.is_cuda:
+            y = self.conv(gate[..., None, None, None] * data)
+            return y if residual is None else alpha * y + residual
+        if data.shape[0] == 1:
+            y = F.conv3d(data, c2.weight * gate.view(1, -1, 1, 1, 1), c2.bias, c2.stride, c2.padding, c2.dilation)
+        else:
+            y = c2(gate[..., None, None, None] * data)
+        gamma, beta = (gn2.weight, gn2.bias) if alpha is None else (alpha * gn2.weight, alpha * gn2.bias)
+        return F.group_norm(y, gn2.num_groups, gamma, beta, gn2.eps, residual=residual, pre_act="gelu")
 
 
 class Residual(nn.Module):
@@ -343,6 +360,8 @@ class Residual(nn.Module):
         self.alpha = nn.Parameter(torch.zeros(1))
 
     def forward(self, x):
+        if isinstance(self.fn, CA3D):
+            return self.fn(x, residual=x, alpha=self.alpha)
         return self.alpha * self.fn(x) + x
 
 

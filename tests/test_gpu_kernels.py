@@ -340,6 +340,29 @@ def test_batch_norm_train_and_eval():
     assert maxdiff(ev, torch.relu(TF.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5))) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(1, 32, 1, (6, 5, 8), True), (2, 16, 2, (3, 4, 5), False), (1, 64, 32, (4, 4, 4), True)])
+def test_group_norm_gelu_pre_activation(case):
+    """GroupNorm(gelu(x)) (+ residual) with the activation folded into the norm kernels (ssbev_norm_dims.pre_act = 1:
+    CA3D's Conv3d -> GELU -> GroupNorm triples, attention.py:94-111) against ATen, forward and all gradients."""
+    B, Cch, G, sp, has_res = case
+    x = S.hash_normal(f"gng/x{case}", (B, Cch) + sp, 1.5)
+    w = S.hash_uniform(f"gng/w{case}", (Cch,), 0.5, 1.5)
+    b = S.hash_uniform(f"gng/b{case}", (Cch,), -0.5, 0.5)
+    r = S.hash_normal(f"gng/r{case}", (B, Cch) + sp) if has_res else None
+    cs = [t.clone().requires_grad_(True) if t is not None else None for t in (x, w, b, r)]
+    want = TF.group_norm(TF.gelu(cs[0]), G, cs[1], cs[2], 1e-5)
+    want = want + cs[3] if has_res else want
+    go = S.hash_normal(f"gng/go{case}", tuple(want.shape))
+    want.backward(go)
+    gs = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (x, w, b, r)]
+    got = F.group_norm(gs[0], G, gs[1], gs[2], 1e-5, residual=gs[3], pre_act="gelu")
+    got.backward(go.to(DEV))
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    for a, c in zip(gs, cs):
+        if a is not None:
+            assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------ trilinear x2
 @pytest.mark.parametrize("B,C,sp", [(1, 20, (8, 8, 4)), (2, 4, (3, 5, 2)), (1, 20, (16, 12, 8))])
 def test_trilinear2x_fwd_bwd(B, C, sp):
