@@ -27,15 +27,30 @@ struct GnGeom {
   int pre;           // 1: u = gelu(x) (exact, erf) is what gets normalised; x is still the tensor in memory
 };
 
-// exact GELU (nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+// GELU in its exact (erf) form, nn.GELU's default, and its derivative from ONE exponential: with z = x / sqrt(2),
+// Phi(x) = 1 - q / 2 (z >= 0) or q / 2 (z < 0), q = erfc(|z|) = poly(t) exp(-z^2), t = 1 / (1 + p |z|) (Abramowitz &
+// Stegun 7.1.26, |error| <= 1.5e-7, no cancellation on the negative side); gelu = x Phi, gelu' = Phi + x phi with
+// phi = exp(-z^2) / sqrt(2 pi).  libm's erff costs ~40 VALU instructions per element -- enough to make the streaming
+// normalisation passes compute-bound (measured: +0.15 ms per 189 MB pass).
+__device__ __forceinline__ void gelu_both(float x, float& u, float& du) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float hq = 0.5f * poly * e;                       // erfc(|z|) / 2
+  const float cdf = x >= 0.0f ? 1.0f - hq : hq;
+  u = x * cdf;
+  du = cdf + x * 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float u, du;
+  gelu_both(x, u, du);
+  return u;
 }
 
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): (sum g, sum g * xhat) with g = gy * [y > 0] when relu is fused.
-template <int MODE>
+template <int MODE, bool PRE>
 __global__ void __launch_bounds__(NT)
 gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ y,
                   const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
@@ -67,7 +82,7 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
       const size_t off = base + (size_t)s * g.C + c;
       const float4 xv = *reinterpret_cast<const float4*>(x + off);
       float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      if (g.pre) {
+      if (PRE) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) xs[k] = gelu_f(xs[k]);
       }
@@ -207,6 +222,7 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
 }
 
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
+template <bool PRE>
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const float* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -236,7 +252,7 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
     }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
-    if (g.pre) {
+    if (PRE) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
     }
@@ -313,6 +329,7 @@ gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restric
 }
 
 // gx = (gamma * g - xhat * ds/n - db/n) * rstd ;  gres = g  (g = gy masked by the fused ReLU)
+template <bool PRE>
 __global__ void __launch_bounds__(NT)
 gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -359,10 +376,10 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float u = g.pre ? gelu_f(xs[k]) : xs[k];
+      float u = xs[k], du = 1.0f;
+      if (PRE) gelu_both(xs[k], u, du);
       const float xh = (u - mu[k]) * rs[k];
-      o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k];
-      if (g.pre) o[k] *= gelu_grad_f(xs[k]);
+      o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
     }
     reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (gres) reinterpret_cast<float4*>(gres)[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
@@ -443,8 +460,12 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
-    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, partial, g);
+    if (g.pre)
+      hipLaunchKernelGGL((gn_partial_kernel<0, true>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, partial, g);
+    else
+      hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
       hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, mean, rstd, g);
     else
@@ -452,8 +473,12 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
-  hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
-                     d->relu ? mask : nullptr, g, total4);
+  if (g.pre)
+    hipLaunchKernelGGL(gn_apply_fwd_kernel<true>, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                       d->relu ? mask : nullptr, g, total4);
+  else
+    hipLaunchKernelGGL(gn_apply_fwd_kernel<false>, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                       d->relu ? mask : nullptr, g, total4);
   return ssbev_launch_status();
 }
 
@@ -492,16 +517,24 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
   const size_t lds = lds_bytes(g);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
-  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mask, mean, rstd,
-                     partial, g);
+  if (g.pre)
+    hipLaunchKernelGGL((gn_partial_kernel<1, true>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mask, mean,
+                       rstd, partial, g);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<1, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, gy, y, mask, mean,
+                       rstd, partial, g);
   if (g.G == g.C)
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
-  hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
-                     gresidual, mask, g, total4);
+  if (g.pre)
+    hipLaunchKernelGGL(gn_apply_bwd_kernel<true>, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+                       gresidual, mask, g, total4);
+  else
+    hipLaunchKernelGGL(gn_apply_bwd_kernel<false>, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+                       gresidual, mask, g, total4);
   return ssbev_launch_status();
 }
 

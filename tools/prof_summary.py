@@ -5,14 +5,15 @@ import re
 import sys
 
 FAMILIES = [
-    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_thin_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_thin_kernel"),
+    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_thin*_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_thin"),
+    ("own MFMA GEMM family (gemm_nn / gemm_tn / skinny / sum: BRI products, k == s deconvs, pointwise weight gradients)", r"gemm_"),
     ("depth-fused Winograd contraction, own MFMA kernels (wino_df_kernel fwd/dgrad, wino_dfw_kernel wgrad, + pack / sum / reduce)", r"wino_df"),
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
     ("rocBLAS / hipBLASLt GEMMs (Cijk_*: Winograd frequency GEMMs, BRI products, image-branch pointwise convs)", r"Cijk_"),
     ("weight gradient, direct (wgrad_lds/wgrad_thin/wgrad_1x1/wgrad_cf/wgrad_kernel + reduce)", r"wgrad"),
     ("GroupNorm / BatchNorm (gn_*, bn_*)", r"gn_|bn_"),
     ("weight packing (pack_*)", r"pack_"),
-    ("cost volume, lift/splat, scatter prep, DCN, softmax, losses, trilinear, image-branch ops", r"gwc_|pool_|lift_|voxel_index|histogram|scan_|fill_kernel|canonicalise|dcn_|softmax_axis|occ_loss|trilinear|bri_|dw_|swish|chan_|adamw|sumsq"),
+    ("cost volume, lift/splat, scatter prep, DCN, softmax, losses, trilinear, image-branch ops", r"gwc_|pool_|lift_|voxel_index|histogram|scan_|fill_kernel|canonicalise|dcn_|softmax_axis|softmax_row|occ_loss|trilinear|bri_|dw_|swish|chan_|adamw|sumsq"),
 ]
 
 
