@@ -174,14 +174,17 @@ def grid_origin(bx, dx):
     return (bx.detach().float().cpu() - dx.detach().float().cpu() / 2.0)
 
 
-def voxel_index(geom, bx, dx, nx, return_idx=False):
-    """geom [B, ..., 3] fp32 (cuda) -> vox int32 [B*P] (linear voxel or -1) [, idx3 int32 [B*P,3]]."""
+def voxel_index(geom, bx, dx, nx, return_idx=False, grid_host=None):
+    """geom [B, ..., 3] fp32 (cuda) -> vox int32 [B*P] (linear voxel or -1) [, idx3 int32 [B*P,3]].
+    ``grid_host`` = (origin, dx, n) python lists, if the caller already holds host copies of the grid parameters."""
     lib = capi.load()
     B = geom.shape[0]
     g = _f32(geom, "voxel_index").reshape(B, -1, 3).contiguous()
     P = g.shape[1]
-    n = [int(v) for v in nx.tolist()]
-    d = _pool_dims(B, P, 1, n[0], n[1], n[2], grid_origin(bx, dx).tolist(), dx.detach().float().cpu().tolist())
+    if grid_host is None:
+        grid_host = (grid_origin(bx, dx).tolist(), dx.detach().float().cpu().tolist(), [int(v) for v in nx.tolist()])
+    origin, dxl, n = grid_host
+    d = _pool_dims(B, P, 1, n[0], n[1], n[2], origin, dxl)
     vox = torch.empty(B * P, dtype=torch.int32, device=geom.device)
     idx3 = torch.empty(B * P, 3, dtype=torch.int32, device=geom.device) if return_idx else None
     capi.check(lib.ssbev_voxel_index(capi.ptr(g), capi.ptr(vox), capi.ptr(idx3), C.byref(d), capi.stream()),
@@ -287,13 +290,13 @@ class _LiftSplat(torch.autograd.Function):
         return gd, from_cl(gf), None, None, None, None, None, None
 
 
-def lift_splat(depth_prob, img_feat, geom, bx, dx, nx):
+def lift_splat(depth_prob, img_feat, geom, bx, dx, nx, grid_host=None):
     """Fused Lift+Splat: depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W], geom [B,N,D,H,W,3]
     -> bev [B,C,X,Y,Z] (channels-last memory).  Equivalent of VT:517-523."""
     B, N = geom.shape[:2]
-    n = [int(v) for v in nx.tolist()]
+    n = grid_host[2] if grid_host is not None else [int(v) for v in nx.tolist()]
     with torch.no_grad():
-        vox = voxel_index(geom, bx, dx, nx)
+        vox = voxel_index(geom, bx, dx, nx, grid_host=grid_host)
         starts, order = pool_prepare(vox, B, n[0], n[1], n[2])
     return _LiftSplat.apply(depth_prob, img_feat, vox, starts, order, B, N, tuple(n))
 

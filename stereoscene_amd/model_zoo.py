@@ -1,5 +1,7 @@
 """Model construction helpers for the benchmark / smoke / tests: the reference's model dict
 (projects/configs/occupancy/semantickitti/stereoscene.py:57-126) re-derived for a given grid."""
+import torch
+
 from . import synthetic as S
 
 
@@ -51,6 +53,9 @@ def img_inputs_from_sample(smp, device="cuda"):
     the image-neck features instead of raw images."""
     def side(x, geo, gt_depths, calib):
         rots, trans, intr, post_rots, post_trans, bda = (t.to(device) for t in geo)
+        if torch.device(device).type == "cuda":      # what the data layer does (pipelines.collate): see attach_host_inverses
+            from .plugin.view_transformer import attach_host_inverses
+            attach_host_inverses(post_rots, intr, geo[3], geo[2])
         B = x.shape[0]
         s2s = intr.new_zeros(B, 1, 4, 4)
         return (x.to(device), rots, trans, intr, post_rots, post_trans, bda, gt_depths.to(device), s2s,

@@ -510,6 +510,12 @@ def collate(samples, device="cuda"):
                 cols.append(torch.stack([t.reshape(()).float() for t in items]).to(device))
             else:
                 cols.append(torch.stack([t.float() for t in items]).to(device))
+        if torch.device(device).type == "cuda":
+            # inverse(post_rots) / inverse(intrins) of get_geometry, taken here on the host copies: the forward pass then has
+            # no read-back of device matrices (a stream synchronisation per step)
+            from .plugin.view_transformer import attach_host_inverses
+            host = [torch.stack([torch.as_tensor(s["img_inputs"][k][j]).float() for s in samples]) for j in (4, 3)]
+            attach_host_inverses(cols[4], cols[3], host[0], host[1])
         views.append(tuple(cols))
     gt = torch.stack([torch.as_tensor(s["gt_occ"]).long() for s in samples]).to(device)
     return dict(img_inputs=tuple(views), gt_occ=gt)

@@ -388,6 +388,16 @@ class volume_interaction(nn.Module):
 
 
 # ------------------------------------------------------------------------------- the transformer
+def attach_host_inverses(post_rots, intrins, post_rots_host=None, intrins_host=None):
+    """Data-layer hook: attach inverse(post_rots) and inverse(intrins[..., :3, :3]), computed on the host in fp32 exactly as
+    ``get_geometry`` would (``*_host`` = CPU copies of the same matrices, e.g. the batch before it was moved to the GPU), to
+    the device tensors, so that the forward pass does not have to read the matrices back."""
+    for dev_t, host_t in ((post_rots, post_rots_host), (intrins, intrins_host)):
+        h = (host_t if host_t is not None else dev_t.cpu()).float()
+        dev_t._ssbev_inverse = torch.inverse(h[..., :3, :3]).to(dev_t.device, non_blocking=True)
+    return post_rots, intrins
+
+
 def gen_dx_bx(xbound, ybound, zbound):
     rows = (xbound, ybound, zbound)
     dx = torch.tensor([r[2] for r in rows], dtype=torch.float64).float()
@@ -458,22 +468,41 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         return m[..., 0] * x + m[..., 1] * y + m[..., 2] * z
 
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
-        """Frustum -> ego frame (BD:123-156).  3x3 inverses are taken on the host in fp32."""
+        """Frustum -> ego frame (BD:123-156).  3x3 inverses are taken on the host in fp32 (the oracle's arithmetic).  For
+        device-resident matrices that read-back is a stream synchronisation at the top of every step; the data layer
+        therefore attaches the host-computed inverses to the tensors it hands over (``attach_host_inverses``), and they
+        are used when present."""
         B, N, _ = trans.shape
-        inv = lambda m: torch.inverse(m.float().cpu()).to(m.device)   # noqa: E731 (tiny, latency-free on CPU)
+
+        def inv(m, hint):
+            if hint is not None and hint.device == m.device:
+                return hint
+            return torch.inverse(m.float().cpu()).to(m.device)
+
+        intr_hint = getattr(intrins, "_ssbev_inverse", None)
         pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
-        pts = self._apply3x3(inv(post_rots), pts)
+        pts = self._apply3x3(inv(post_rots, getattr(post_rots, "_ssbev_inverse", None)), pts)
         pts = torch.cat((pts[..., :2] * pts[..., 2:3], pts[..., 2:3]), -1)
         if intrins.shape[3] == 4:
             pts = pts - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3)
             intrins = intrins[:, :, :3, :3]
-        pts = self._apply3x3(rots.matmul(inv(intrins)), pts)
+        pts = self._apply3x3(rots.matmul(inv(intrins, intr_hint)), pts)
         pts = pts + trans.view(B, N, 1, 1, 1, 3)
         if bda.shape[-1] == 4:
             pts = self._apply3x3(bda[:, None, :3, :3], pts) + bda[:, :3, 3].view(B, 1, 1, 1, 1, 3)
         else:
             pts = self._apply3x3(bda[:, None], pts)
         return pts
+
+    def _grid_host(self):
+        """Host copies of the (constant) voxel-grid parameters: read back once, not once per step (each read-back of a
+        device-resident nn.Parameter is a stream synchronisation in the middle of the forward pass)."""
+        key = tuple((p.data_ptr(), p._version) for p in (self.bx, self.dx, self.nx))
+        if getattr(self, "_grid_host_key", None) != key:
+            self._grid_host_val = (F.grid_origin(self.bx, self.dx).tolist(), self.dx.detach().float().cpu().tolist(),
+                                   [int(v) for v in self.nx.tolist()])
+            self._grid_host_key = key
+        return self._grid_host_val
 
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
         """30-vector of camera parameters for the SE gates (BD:604-659)."""
@@ -529,7 +558,12 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         _, labels = self.get_downsampled_gt_depth(depth_labels)
         preds = depth_preds.float().permute(0, 2, 3, 1).reshape(-1, self.D)
         fg = labels.max(dim=1).values > 0.0
-        loss = TF.binary_cross_entropy(preds[fg], labels[fg], reduction="none").sum() / torch.clamp(fg.sum(), min=1.0)
+        # rows without a LiDAR return are masked out instead of being gathered away (VT:411-414 index with the boolean mask,
+        # which is a nonzero() + host synchronisation in the middle of the step); the background rows' labels are all zero,
+        # their predictions are replaced by zero, so their BCE terms vanish exactly
+        m = fg.unsqueeze(1)
+        bce = TF.binary_cross_entropy(torch.where(m, preds, torch.zeros_like(preds)), labels, reduction="none")
+        loss = bce.sum() / torch.clamp(fg.sum(), min=1.0)
         return self.loss_depth_weight * loss
 
     # forward ----------------------------------------------------------------------------------
@@ -551,5 +585,5 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             depth_prob = self.volume_interaction(stereo, depth_prob)
         elif self.ablation == "stereo_only":
             depth_prob = stereo
-        bev_feat = F.lift_splat(depth_prob, img_feat, geom, self.bx, self.dx, self.nx)
+        bev_feat = F.lift_splat(depth_prob, img_feat, geom, self.bx, self.dx, self.nx, grid_host=self._grid_host())
         return bev_feat, depth_prob
