@@ -10,6 +10,8 @@ import collections, csv, json, sys
 FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_dfw_kernel",)),
             ("gemm_nn_kernel", ("gemm_nn_kernel",)), ("gemm_tn_kernel", ("gemm_tn_kernel", "gemm_tn_skinny_kernel")),
             ("gwc_warp_bwd2", ("gwc_warp_bwd2_kernel",)), ("lift_splat_bwd2", ("lift_splat_bwd2_kernel",)),
+            ("conv_thinin_kernel", ("conv_thinin_kernel",)), ("conv_thinout_u_kernel", ("conv_thinout_u_kernel",)),
+            ("wgrad_thinside_kernel", ("wgrad_thinside_kernel",)), ("softmax_row", ("softmax_row_",)),
             ("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
             ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
