@@ -83,7 +83,21 @@ def test_geometry_buffers_and_mlp_input_on_cpu():
     geo = S.kitti_calibration(2, 320)
     assert torch.equal(vt.get_mlp_input(*geo[:6]), O.get_mlp_input(*geo[:6]))
     g = load_golden("vt_small")
-    assert np.abs(vt.get_geometry(*geo[:6]).numpy() - g["geom"]).max() < 1e-4
+    plain = vt.get_geometry(*geo[:6])
+    assert np.abs(plain.numpy() - g["geom"]).max() < 1e-4
+    # the data layer's host-computed inverse hints (no read-back of device matrices in the step) change nothing, bit for bit
+    from stereoscene_amd.plugin.view_transformer import attach_host_inverses
+    rots, trans, intr, post_rots, post_trans, bda = (t.clone() for t in geo[:6])
+    attach_host_inverses(post_rots, intr)
+    assert hasattr(post_rots, "_ssbev_inverse") and hasattr(intr, "_ssbev_inverse")
+    assert torch.equal(vt.get_geometry(rots, trans, intr, post_rots, post_trans, bda), plain)
+    # ... and the cached host copies of the grid parameters follow in-place updates of the parameters
+    o1 = vt._grid_host()
+    assert o1[2] == [int(v) for v in vt.nx.tolist()] and vt._grid_host() is o1
+    with torch.no_grad():
+        vt.dx.mul_(2.0)
+    o2 = vt._grid_host()
+    assert o2 is not o1 and o2[1] == vt.dx.tolist()
 
 
 def test_modules_refuse_cpu_tensors():
