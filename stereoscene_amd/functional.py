@@ -922,7 +922,7 @@ def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl):
     capi.check(lib.ssbev_wino43_df_pack(capi.ptr(w), capi.ptr(Wp), Cout, Cin, mode, capi.stream()), "ssbev_wino43_df_pack")
     Mo = torch.empty(36, R, N, dtype=torch.float32, device=xcl.device)
     dims = capi.WinoDims(B, D, H, W, K)
-    nby = 4.0 * (B * D * H * W * (K + N) + 27 * K * N)
+    nby = 4.0 * (P.numel() + Mo.numel() + Wp.numel())          # the kernel's own operands: P and Mo are 2.25x the activations
     with _span("conv_wino_fused", fl, nby, tag, fl / 6.0):
         capi.check(lib.ssbev_wino43_df_gemm(capi.ptr(P), capi.ptr(Wp), capi.ptr(Mo), C.byref(dims), N, capi.stream()),
                    "ssbev_wino43_df_gemm")
@@ -964,7 +964,7 @@ class _WinoConvDF(torch.autograd.Function):
             dims = capi.WinoDims(B, D, H, W, Cin)
             ws = _ws(lib.ssbev_wino43_df_wgrad_workspace(C.byref(dims), Cout), gy.device)
             gw = torch.empty_like(w)
-            nby = 4.0 * (B * D * H * W * (Cin + Cout) + 27 * Cin * Cout)
+            nby = 4.0 * (P.numel() + Z.numel() + 144 * Cin * Cout)
             with _span("conv_wino_fused_wgrad", fl, nby, f"winoDF wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / 6.0):
                 capi.check(lib.ssbev_wino43_df_wgrad(capi.ptr(P), capi.ptr(Z), capi.ptr(gw), C.byref(dims), Cout, capi.ptr(ws),
                                                      ws.numel(), capi.stream()), "ssbev_wino43_df_wgrad")
