@@ -76,7 +76,7 @@ softmax_axis_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g
 // workgroup only touches its own row and reads it completely before the first store.
 template <int NV>
 __global__ void __launch_bounds__(256)
-softmax_row_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C4) {
+softmax_row_fwd_kernel(const float* x, float* y, int C4) {              // y may alias x: no __restrict__
   __shared__ float red[4];
   const v4f* px = reinterpret_cast<const v4f*>(x) + (long)blockIdx.x * C4;
   v4f* py = reinterpret_cast<v4f*>(y) + (long)blockIdx.x * C4;
@@ -119,7 +119,7 @@ softmax_row_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C
 
 template <int NV>
 __global__ void __launch_bounds__(256)
-softmax_row_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, int C4) {
+softmax_row_bwd_kernel(const float* __restrict__ y, const float* gy, float* gx, int C4) {   // gx may alias gy
   __shared__ float red[4];
   const v4f* py = reinterpret_cast<const v4f*>(y) + (long)blockIdx.x * C4;
   const v4f* pg = reinterpret_cast<const v4f*>(gy) + (long)blockIdx.x * C4;
