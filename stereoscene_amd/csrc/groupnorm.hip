@@ -78,6 +78,18 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
     }
     // a float4 never straddles groups when cpg % 4 == 0; otherwise handled per component below
     const size_t base = (size_t)b * g.S * g.C;
+    // MODE 0 accumulates SHIFTED sums, sum (u - p) and sum (u - p)^2 with the pivot p = the channel's value at voxel 0 of
+    // the sample: the fp32 partials then hold no large common offset, and the finalize kernels rebuild sum u and sum u^2
+    // in double -- E[u^2] - mean^2 from plain fp32 partials cancels catastrophically when |mean| >> std
+    float pv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+      const float4 p4 = *reinterpret_cast<const float4*>(x + base + c);
+      pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+      if (PRE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = gelu_f(pv[k]);
+      }
+    }
     for (long s = s0 + r; s < s1; s += rows) {
       const size_t off = base + (size_t)s * g.C + c;
       const float4 xv = *reinterpret_cast<const float4*>(x + off);
@@ -88,7 +100,7 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
       }
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a0[k] += xs[k]; a1[k] += xs[k] * xs[k]; }
+        for (int k = 0; k < 4; ++k) { const float dv = xs[k] - pv[k]; a0[k] += dv; a1[k] += dv * dv; }
       } else {
         const float4 gv = *reinterpret_cast<const float4*>(gy + off);
         float gs[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -141,7 +153,8 @@ __device__ __forceinline__ void block_sum2(double& a, double& q, double* s0, dou
 // forward finalize: one thread block per (b, group): mean / rstd in double.  Only B*G workgroups exist (2 for GN(2) at
 // B = 1), so the kernel is pure latency: 1024 threads, 8-byte loads, four independent partial sums per thread.
 __global__ void __launch_bounds__(FT)
-gn_finalize_fwd_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd, GnGeom g) {
+gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+                       float* __restrict__ rstd, GnGeom g) {
   __shared__ double s0[FT], s1[FT];
   const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
   const int cpg = g.C / g.G, n_el = g.chunks * cpg;
@@ -153,7 +166,14 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, float* __restrict__ me
       if (i < n_el) {
         const int chunk = i / cpg, c = grp * cpg + i % cpg;
         const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
-        a[k] += p.x; q[k] += p.y;
+        // shifted partials (pivot = the channel's value at voxel 0, see gn_partial_kernel): sum u = sum d + n p,
+        // sum u^2 = sum d^2 + 2 p sum d + n p^2, with n = voxels of this chunk
+        float pf = x[(size_t)b * g.S * g.C + c];
+        if (g.pre) pf = gelu_f(pf);
+        const double pd = pf;
+        const double n = (double)(min(g.S, (long)(chunk + 1) * g.chunk_len) - (long)chunk * g.chunk_len);
+        a[k] += (double)p.x + n * pd;
+        q[k] += (double)p.y + 2.0 * pd * (double)p.x + n * pd * pd;
       }
     }
   }
@@ -179,7 +199,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 __global__ void __launch_bounds__(256)
-bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd, GnGeom g) {
+bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+                            float* __restrict__ rstd, GnGeom g) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= g.B * g.C) return;
   const int b = i / g.C, c = i % g.C;
@@ -190,9 +211,13 @@ bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, float* __restrict
   }
   a = wave_sum_d(a); q = wave_sum_d(q);
   if (lane == 0) {
-    const double n = (double)g.S, m = a / n;
-    double var = q / n - m * m;
+    // one channel per group: the statistics of the SHIFTED values d = u - p directly (mean = p + E[d], var = var(d))
+    float pf = x[(size_t)b * g.S * g.C + c];
+    if (g.pre) pf = gelu_f(pf);
+    const double n = (double)g.S, md = a / n;
+    double var = q / n - md * md;
     if (var < 0.0) var = 0.0;
+    const double m = (double)pf + md;
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)g.eps));
   }
@@ -467,9 +492,9 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
       hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr,
                          nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, mean, rstd, g);
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g);
     else
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, mean, rstd, g);
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);

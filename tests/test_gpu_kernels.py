@@ -363,6 +363,20 @@ def test_group_norm_gelu_pre_activation(case):
             assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("G", [2, 32])
+def test_group_norm_large_mean_offset(G):
+    """|mean| >> std: statistics from shifted fp32 partial sums (pivot per channel) rebuilt in double -- E[x^2] - mean^2 from
+    plain fp32 partials loses the variance here (rstd off by percents)."""
+    B, Cch, sp = 1, 32, (16, 12, 20)
+    x = S.hash_normal("gnoff/x", (B, Cch) + sp, 0.5) + 300.0 + 40.0 * torch.arange(Cch).view(1, Cch, 1, 1, 1)
+    w = S.hash_uniform("gnoff/w", (Cch,), 0.5, 1.5)
+    b = S.hash_uniform("gnoff/b", (Cch,), -0.5, 0.5)
+    want = TF.group_norm(x.double(), G, w.double(), b.double(), 1e-5).float()
+    got = F.group_norm(x.to(DEV), G, w.to(DEV), b.to(DEV), 1e-5)
+    tol = 2e-4 if G == 32 else 2e-3        # G = 2: the group spans 16 channel offsets, the fp32 input itself carries 3e-5 / 0.5
+    assert maxdiff(got, want) < tol * max(1.0, want.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------ trilinear x2
 @pytest.mark.parametrize("B,C,sp", [(1, 20, (8, 8, 4)), (2, 4, (3, 5, 2)), (1, 20, (16, 12, 8))])
 def test_trilinear2x_fwd_bwd(B, C, sp):
