@@ -523,6 +523,9 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
   // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than twice covered
   int mt = 2;
   if ((long)36 * g.B * g.ND * ((g.Thw + 63) / 64) * g.ncolgrp < 1024) mt = 1;
+  // three-wave workgroups: two 64 KiB workgroups per CU put 6 waves on 4 SIMDs (2, 2, 1, 1); four 32 KiB ones are balanced
+  // (384 -> 192 head conv: 1.98 -> 1.72 ms)
+  if (nw == 3) mt = 1;
   if (forced_mt == 1 || forced_mt == 2) mt = forced_mt;
   g.nrowgrp = (g.Thw + 32 * mt - 1) / (32 * mt);
   g.NU = g.B * g.ND * g.nrowgrp;
@@ -569,7 +572,20 @@ static DfwPlan dfw_plan(const ssbev_wino_dims* d, int N) {
   p.total_stages = d->B * (d->D / 2) * ((Thw + p.br - 1) / p.br);
   // enough workgroups for ~2 rounds of the 512 slots (2 per CU), but at least 8 stages per chunk
   static const int target = env_int("SSBEV_DFW_WGS", 1024);
-  int nchunk = std::max(1, target / (36 * p.nkb * p.nnb));
+  const int per = 36 * p.nkb * p.nnb;
+  int nchunk = std::max(1, target / per);
+  // whole rounds of the chip's 512 workgroup slots (2 per CU): among the chunk counts around the target take the one whose
+  // last round is fullest (384 -> 192: 216 workgroups per chunk, 4 chunks = 1.7 rounds -> 7 chunks = 2.95 rounds, 1.97 -> 1.75 ms)
+  {
+    double best = -1.0;
+    int best_n = nchunk;
+    for (int n = std::max(1, nchunk * 2 / 3); n <= nchunk * 2; ++n) {
+      const long tot = (long)per * n, rounds = (tot + 511) / 512;
+      const double eff = (double)tot / (double)(rounds * 512) - 0.002 * std::abs(n - nchunk);
+      if (eff > best) { best = eff; best_n = n; }
+    }
+    nchunk = best_n;
+  }
   p.nchunk = std::min(nchunk, std::max(1, p.total_stages / 8));
   return p;
 }
