@@ -434,6 +434,12 @@ typedef struct {
   int relu;
   int d2s_D, d2s_H, d2s_W, d2s_kd, d2s_kh, d2s_kw, d2s_Co;
   const int64_t* d2s_rowoff;      /* device table of M row offsets (ssbev_gemm_d2s_rowoff), required when d2s_kd > 0 */
+  /* ssbev_gemm_tn only, both or neither: C[b][k][n] = ep_mul[b][k][n] * ((A^T B)[b][k][n] - ep_rowsub[b][k]), ep_mul laid out
+   * like C.  With A = grad_out, B = V conf, ep_mul = att, ep_rowsub[i] = <grad_out[:, i], out[:, i]> this is the softmax
+   * backward gE = att (.) (gatt - rowsum(gatt (.) att)) of the BRI attention (attention.py:63-81) inside the product that
+   * forms gatt: neither gatt nor a separate softmax-backward pass over the T x T matrices exists. */
+  const float* ep_mul;
+  const float* ep_rowsub;
 } ssbev_gemm_dims;
 int ssbev_gemm_d2s_rowoff(int64_t* rowoff, int M, int D, int H, int W, int kd, int kh, int kw, int Co, ssbev_stream_t stream);
 size_t ssbev_gemm_nn_workspace(const ssbev_gemm_dims* d);      /* split-K partials (0 when the output tiles fill the chip) */

@@ -71,7 +71,8 @@ class GemmDims(C.Structure):
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64), ("sc", C.c_int64),
                 ("relu", C.c_int),
                 ("d2s_D", C.c_int), ("d2s_H", C.c_int), ("d2s_W", C.c_int), ("d2s_kd", C.c_int), ("d2s_kh", C.c_int),
-                ("d2s_kw", C.c_int), ("d2s_Co", C.c_int), ("d2s_rowoff", C.c_void_p)]
+                ("d2s_kw", C.c_int), ("d2s_Co", C.c_int), ("d2s_rowoff", C.c_void_p),
+                ("ep_mul", C.c_void_p), ("ep_rowsub", C.c_void_p)]
 
 
 class AdamWCfg(C.Structure):

@@ -47,6 +47,9 @@ struct GemmGeom {
   // divisions in the GEMM loops); a tap adds ((a FH + b) FW + c) * Co.
   int d2s_D, d2s_H, d2s_W, d2s_kd, d2s_kh, d2s_kw, d2s_Co;
   const long* rowoff;
+  // TN epilogue C = ep_mul (.) (A^T B - ep_rowsub[row]) (softmax backward of the BRI attention, see ssbev_gemm_dims)
+  const float* ep_mul;
+  const float* ep_rowsub;
 };
 
 __device__ __forceinline__ long d2s_tapoff(const GemmGeom& g, int tap) {
@@ -345,7 +348,11 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = k0 + (wk * 2 + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (k < g.K) Cb[(long)k * g.ldc + n] = acc[kt][nt][r];
+        if (k < g.K) {
+          float v = acc[kt][nt][r];
+          if (g.ep_mul) v = g.ep_mul[(long)b * g.sc + (long)k * g.ldc + n] * (v - g.ep_rowsub[(long)b * g.K + k]);
+          Cb[(long)k * g.ldc + n] = v;
+        }
       }
   }
 }
@@ -488,6 +495,7 @@ void fill_geom(GemmGeom& g, const ssbev_gemm_dims* d) {
   g.d2s_D = d->d2s_D; g.d2s_H = d->d2s_H; g.d2s_W = d->d2s_W; g.d2s_kd = d->d2s_kd; g.d2s_kh = d->d2s_kh; g.d2s_kw = d->d2s_kw;
   g.d2s_Co = d->d2s_Co;
   g.rowoff = reinterpret_cast<const long*>(d->d2s_rowoff);
+  g.ep_mul = nullptr; g.ep_rowsub = nullptr;
 }
 
 // 128-wide column tiles unless 64-wide ones pad less (N = 192 -> 3 x 64, N = 160 -> 3 x 64, N = 640 -> 5 x 128)
@@ -628,6 +636,9 @@ int ssbev_gemm_tn(const float* A, const float* B, float* Cm, const ssbev_gemm_di
   GemmGeom g;
   fill_geom(g, d);
   g.ldc = d->N; g.sc = (long)d->K * d->N; g.relu = 0;
+  g.ep_mul = d->ep_mul; g.ep_rowsub = d->ep_rowsub;
+  if ((d->ep_mul != nullptr) != (d->ep_rowsub != nullptr)) return SSBEV_EINVAL;
+  if (d->ep_mul && (tn_skinny(d) || d->d2s_kd > 0)) return SSBEV_EINVAL;
   if (tn_skinny(d)) {
     if (!ws || ws_bytes < ssbev_gemm_tn_workspace(d)) return SSBEV_EWORKSPACE;
     const int wgs = tn_skinny_wgs(d);
@@ -654,7 +665,7 @@ int ssbev_gemm_tn(const float* A, const float* B, float* Cm, const ssbev_gemm_di
   const int BN = 64 * wn;
   g.mblocks = (d->K + 127) / 128;
   g.nblocks = (d->N + BN - 1) / BN;
-  g.nchunk = tn_chunks(d, g.mblocks * g.nblocks);
+  g.nchunk = d->ep_mul ? 1 : tn_chunks(d, g.mblocks * g.nblocks);      // the fused epilogue needs the complete row reduction
   g.rows_per_chunk = ((d->M + g.nchunk - 1) / g.nchunk + 31) / 32 * 32;
   if (g.nchunk > 1 && (!ws || ws_bytes < ssbev_gemm_tn_workspace(d))) return SSBEV_EWORKSPACE;
   float* dst = g.nchunk > 1 ? static_cast<float*>(ws) : Cm;

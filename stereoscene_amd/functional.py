@@ -554,7 +554,7 @@ def _gemm_supported(*ts):
 
 def _gdims(M, N, K, batch, lda, ldb, ldc, sa, sb, sc, relu=0, d2s=None):
     g = capi.GemmDims(int(M), int(N), int(K), int(batch), int(lda), int(ldb), int(ldc), int(sa), int(sb), int(sc), int(relu),
-                      0, 0, 0, 0, 0, 0, 0, None)
+                      0, 0, 0, 0, 0, 0, 0, None, None, None)
     if d2s is not None:
         (g.d2s_D, g.d2s_H, g.d2s_W, g.d2s_kd, g.d2s_kh, g.d2s_kw, g.d2s_Co), table = d2s
         g.d2s_rowoff = table.data_ptr()
@@ -603,20 +603,28 @@ def gemm_nt(a, w, bias=None, relu=False, tag=None):
     return out
 
 
-def gemm_tn(a, b, tag=None):
-    """C = A^T @ B over the ROW axis: a [R,K] / [Bt,R,K], b [R,N] / [Bt,R,N] -> [K,N] / [Bt,K,N] (weight gradients)."""
+def gemm_tn(a, b, tag=None, ep_mul=None, ep_rowsub=None):
+    """C = A^T @ B over the ROW axis: a [R,K] / [Bt,R,K], b [R,N] / [Bt,R,N] -> [K,N] / [Bt,K,N] (weight gradients).
+    ``ep_mul`` [.., K, N] (contiguous) and ``ep_rowsub`` [.., K]: fused epilogue C = ep_mul * (A^T B - ep_rowsub[..., None])."""
     if not _gemm_supported(a, b) or a.shape[-1] % 4 or b.shape[-1] % 4:
-        return torch.matmul(a.transpose(-1, -2), b)
+        c = torch.matmul(a.transpose(-1, -2), b)
+        return c if ep_mul is None else ep_mul * (c - ep_rowsub.unsqueeze(-1))
     a, lda, sa = _rows(a)
     b, ldb, sb = _rows(b)
     batch = a.shape[0] if a.dim() == 3 else 1
     R, K, N = a.shape[-2], a.shape[-1], b.shape[-1]
     out = torch.empty(*a.shape[:-2], K, N, dtype=torch.float32, device=a.device)
     g = _gdims(R, N, K, batch, lda, ldb, N, sa, sb, K * N)
+    if ep_mul is not None:
+        ep_mul, ep_rowsub = ep_mul.contiguous(), ep_rowsub.contiguous().float()
+        if tuple(ep_mul.shape) != tuple(out.shape) or ep_rowsub.numel() != batch * K:
+            raise capi.SsbevError("gemm_tn: epilogue operand shapes")
+        g.ep_mul, g.ep_rowsub = ep_mul.data_ptr(), ep_rowsub.data_ptr()
     lib = capi.load()
     ws = _ws(lib.ssbev_gemm_tn_workspace(C.byref(g)), a.device)
     fl = 2.0 * batch * R * N * K
-    with _span("gemm_own", fl, 4.0 * (a.numel() + b.numel() + out.numel()), tag or f"tn {batch}x{R}x{K}x{N}"):
+    with _span("gemm_own", fl, 4.0 * (a.numel() + b.numel() + out.numel() * (2 if ep_mul is not None else 1)),
+               tag or f"tn {batch}x{R}x{K}x{N}"):
         capi.check(lib.ssbev_gemm_tn(_rawptr(a), _rawptr(b), capi.ptr(out), C.byref(g), capi.ptr(ws), ws.numel(), capi.stream()),
                    "ssbev_gemm_tn")
     return out

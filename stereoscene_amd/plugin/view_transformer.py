@@ -290,24 +290,25 @@ class _BriCore(torch.autograd.Function):
         else:       # library realisation: plain NN products around explicit operand transposes
             att = torch.softmax(torch.bmm(Q.transpose(1, 2).contiguous(), K), dim=-1)
             out = torch.bmm(att, Vc.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
-        ctx.save_for_backward(Q, K, V, conf, att)
+        ctx.save_for_backward(Q, K, V, conf, att, out)
         ctx.own = own
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        Q, K, V, conf, att = ctx.saved_tensors
+        Q, K, V, conf, att, out = ctx.saved_tensors
         Vc = V * conf.unsqueeze(1)
         gout = gout.contiguous()
         if ctx.own:
-            gatt = F.gemm_tn(gout, Vc, tag="bri gatt")                                  # [B,T(i),T(j)]
+            # softmax backward gE = att (.) (gatt - rowsum(gatt (.) att)) with gatt = go^T Vc.  The row sums need no pass over
+            # the T x T matrices: sum_j gatt[i,j] att[i,j] = <go[:, i], sum_j att[i,j] Vc[:, j]> = <go[:, i], out[:, i]>; the
+            # rest is the epilogue of the product that forms gatt, which therefore never exists in memory
+            delta = (gout * out).sum(1)                                                 # [B,T(i)]
+            gE = F.gemm_tn(gout, Vc, tag="bri gatt+softmax bwd", ep_mul=att, ep_rowsub=delta)
             gVc = F.gemm_nn(gout, att, tag="bri gVc")                                   # [B,D,T(j)]
         else:
             gatt = torch.bmm(gout.transpose(1, 2).contiguous(), Vc)
             gVc = torch.bmm(gout, att)
-        if ctx.own and F.softmax_rows_ok(att) and gatt.is_contiguous():
-            gE = F.softmax_rows_bwd_(att, gatt)                                         # softmax backward, in place
-        else:
             gE = att * (gatt - (gatt * att).sum(-1, keepdim=True))
         if ctx.own:
             gQ = F.gemm_nt(K, gE, tag="bri gQ")                                         # [B,D,T(i)]

@@ -951,6 +951,12 @@ def test_gemm_nn_nt_tn_vs_torch(case):
     got = F.gemm_tn(a, a2)
     ref = torch.matmul(a.double().transpose(1, 2), a2.double())
     assert (got.double() - ref).abs().max().item() < 2e-5 * M ** 0.5
+    if M <= 2048:          # fused epilogue C = ep_mul * (A^T B - rowsub) (BRI softmax backward): whole reduction in one chunk
+        em = S.hash_normal(f"gm/em{case}", (Bt, K, N)).to(DEV)
+        rs = S.hash_normal(f"gm/rs{case}", (Bt, K)).to(DEV)
+        got = F.gemm_tn(a, a2, ep_mul=em, ep_rowsub=rs)
+        want = em.double() * (ref - rs.double().unsqueeze(-1))
+        assert (got.double() - want).abs().max().item() < 2e-5 * M ** 0.5 * max(1.0, em.abs().max().item())
     # strided rows (a column slice of a wider buffer): leading dimension > K
     wide = S.hash_normal(f"gm/w{case}", (M, K + 8)).to(DEV)
     got = F.gemm_nn(wide[:, 4:4 + K], b[0])
