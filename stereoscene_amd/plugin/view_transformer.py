@@ -525,7 +525,9 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         return torch.cat([v, sensor2ego], dim=-1)
 
     def get_depth_dist(self, x):
-        return F.softmax(x, dim=1)
+        # x is the first D channels of DepthNet's channels-last output: a standard-contiguous copy (5.9 MB) puts the softmax on the
+        # strided-axis HIP kernel (17 us) instead of ATen's generic path on the sliced view (138 us forward, 112 us backward)
+        return F.softmax(x.contiguous(), dim=1)
 
     # splat ------------------------------------------------------------------------------------
     def voxel_pooling(self, geom_feats, x):
