@@ -1131,8 +1131,10 @@ def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
     cols = _DcnIm2col.apply(x, offset, int(groups), int(k), int(padding), int(dilation))
     Cog = Cout // groups
     outs = []
-    for g in range(groups):
-        colg = cols[g].view(B, H, W, k * k * Cg).permute(0, 3, 1, 2)            # channels-last [B, K*Cg, H, W]
+    # unbind, not cols[g]: the backward of four selects is four zero-filled [groups, ...] tensors plus three accumulation adds
+    # (0.4 ms per step on the 177 MB column tensor); the backward of unbind is one stack
+    for g, cg in enumerate(cols.unbind(0)):
+        colg = cg.view(B, H, W, k * k * Cg).permute(0, 3, 1, 2)                 # channels-last [B, K*Cg, H, W]
         wg = weight[g * Cog:(g + 1) * Cog].permute(0, 2, 3, 1).reshape(Cog, k * k * Cg, 1, 1)
         outs.append(conv2d(colg, wg, None, 1, 0, 1))
     return torch.cat(outs, dim=1) if groups > 1 else outs[0]
