@@ -30,7 +30,7 @@ class Log(TorchDispatchMode):
         n = max(numel(out), numel(args))
         name = str(func)
         if n >= MIN and not any(k in name for k in ("view", "empty", "as_strided", "detach", "alias", "reshape", "permute",
-                                                     "transpose", "slice", "select", "unsqueeze", "squeeze", "expand", "t.default")):
+                                                     "transpose", "slice.Tensor", "select.int", "unsqueeze", "squeeze", "expand", "aten.t.default")):
             site = "(autograd engine)"
             for fr in reversed(traceback.extract_stack()):
                 if "stereoscene_amd" in fr.filename and "tools" not in fr.filename:
