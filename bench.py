@@ -54,8 +54,8 @@ SINGLE_KERNEL_FAMILIES = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="kitti_d192", help="kitti_d192 (BASELINE metric) | kitti_d112 | small_d48")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
     ap.add_argument("--cpu-sample", default="auto", choices=["auto", "small", "full", "none"])
@@ -398,7 +398,7 @@ def main():
                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": f"dp{world}", "train_mode": True},
                "roofline": roof, "roofline_other_timed_kernels": roof_other, "step_roofline": step_roof,
-               "losses": {k: float(v) for k, v in losses.items()}}
+               "losses": {k: float(v.detach()) for k, v in losses.items()}}
         if fo_ms is not None:
             out["forward_only"] = {"ms_per_step": fo_ms, "value": world * args.batch * scale / (fo_ms * 1e-3), "unit": "voxels/s",
                                    "note": "same model / inputs under no_grad, timed after the fwd+bwd region; not the metric"}
