@@ -369,6 +369,229 @@ pool_gather3_kernel(const float* __restrict__ depth, const float* __restrict__ f
   }
 }
 
+// Fifth layout = the third one plus a WIDE path for long lists.  What bounds gather3 is not its thousands of short voxels but
+// the handful of near-camera ones: the longest list of the KITTI frustum has 342 points, a 16-lane group keeps 8 feature rows
+// in flight, so that one voxel is a serial chain of 43 load latencies (~43 us of the kernel's 66).  The additions themselves
+// must stay sequential (ascending point id: the oracle's order, bit for bit) but they are cheap; the loads are not ordered.
+// Lists longer than POOL_LONG points are therefore summed by the WHOLE wave: a lane owns C / 64 channels, one instruction
+// loads one feature row, and 32 rows are in flight -- a quarter of the registers per row, four times the depth.
+// (Measured, tools/gather_probe.py: 66 -> 61 us.  The near-camera voxels are NEIGHBOURS, so a wave usually owns four long lists
+// and walks them one after the other; with lists cut to <= 64 points the kernel takes 58 us, to <= 1 point 51 us, and the bare
+// 134 MB zero store 28 us.  A 79-register variant (4 rows per batch, 6 waves per SIMD) brings the short lists to 34-40 us but
+// then spends 72 us on the real CSR: the long lists want registers, the short ones want occupancy, one kernel has one budget.)
+constexpr int POOL_LONG = 32;
+
+template <bool FUSED, int NV4>
+__global__ void __launch_bounds__(256)
+pool_gather5_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                    float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
+  constexpr int C = 64 * NV4, U = 8, UW = 32;
+  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
+  const int v = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+  const bool vok = v < nv;
+  const int s = vok ? starts[v] : 0, e0 = vok ? starts[v + 1] : 0;
+  const bool is_long = e0 - s > POOL_LONG;
+  const int e = is_long ? s : e0;                          // long lists are skipped here and summed by the whole wave below
+  const int b = vok ? v / vox_per_batch : 0;
+  float4 acc[NV4];
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int p_next = (s + gl < e) ? order[s + gl] : 0;
+  for (int base = s; base < e; base += 16) {
+    const int cnt = min(16, e - base);
+    const int p = p_next;
+    p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
+    int row = p;
+    float wgt = 1.0f;
+    if (FUSED) {
+      const int q = p - b * P;
+      const int n = q / (D * HW);
+      row = (b * N + n) * HW + (q % HW);
+      wgt = gl < cnt ? depth[p] : 0.0f;
+    }
+    for (int j0 = 0; j0 < cnt; j0 += U) {
+      float4 f[U][NV4];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = gbase + min(j0 + u, cnt - 1);
+        const int r = __shfl(row, jj, 64);
+        ww[u] = __shfl(wgt, jj, 64);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u < cnt) {
+#pragma unroll
+          for (int k = 0; k < NV4; ++k) {
+            if (FUSED) {
+              acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
+              acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
+              acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
+              acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
+            } else {
+              acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
+              acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
+              acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
+              acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (vok && !is_long) {
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
+  }
+  // ---- long lists: one voxel at a time on all 64 lanes, lane = NV4 consecutive channels
+  unsigned long long todo = __ballot(is_long && gl == 0);
+  while (todo) {
+    const int src_lane = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int vs = __shfl(s, src_lane, 64), ve = __shfl(e0, src_lane, 64), vv = __shfl(v, src_lane, 64);
+    const int vb = __shfl(b, src_lane, 64);
+    float a[NV4];
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) a[k] = 0.0f;
+    for (int base = vs; base < ve; base += 64) {
+      const int cnt = min(64, ve - base);
+      const int p = lane < cnt ? order[base + lane] : 0;
+      int row = p;
+      float wgt = 1.0f;
+      if (FUSED) {
+        const int q = p - vb * P;
+        const int n = q / (D * HW);
+        row = (vb * N + n) * HW + (q % HW);
+        wgt = lane < cnt ? depth[p] : 0.0f;
+      }
+      for (int j0 = 0; j0 < cnt; j0 += UW) {
+        float f[UW][NV4], ww[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int jj = min(j0 + u, cnt - 1);
+          const int r = __shfl(row, jj, 64);
+          ww[u] = __shfl(wgt, jj, 64);
+          const float* src = feat + (size_t)r * C + lane * NV4;
+          if (NV4 == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            f[u][0] = t.x; f[u][1 % NV4] = t.y; f[u][2 % NV4] = t.z; f[u][3 % NV4] = t.w;
+          } else if (NV4 == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(src);
+            f[u][0] = t.x; f[u][1 % NV4] = t.y;
+          } else {
+            f[u][0] = src[0];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          if (j0 + u < cnt) {
+#pragma unroll
+            for (int k = 0; k < NV4; ++k) a[k] = __fadd_rn(a[k], FUSED ? __fmul_rn(ww[u], f[u][k]) : f[u][k]);
+          }
+        }
+      }
+    }
+    float* dst = out + (size_t)vv * C + lane * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = a[k];
+  }
+}
+
+// Fourth layout = the third one made PERSISTENT and software-pipelined.  gather3 gives a wave four voxels and lets it die: its
+// three dependent loads (segment bounds -> point ids -> depth / feature rows) are exposed once per wave, and with ~4.6 k waves
+// resident the 65 k waves of the KITTI grid take 14 rounds of ~4 us (66 us; the 134 MB output alone would take 24 us).  Here
+// a wave walks groups g, g + nwaves, ...: the bounds of group i+2 and the first block of point ids of group i+1 are loaded
+// while group i is summed, so one latency (the rows) is exposed per group instead of three.  Same sums in the same order.
+template <bool FUSED, int NV4>
+__global__ void __launch_bounds__(256)
+pool_gather4_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                    float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
+  constexpr int C = 64 * NV4, U = 8;
+  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48, sub = lane >> 4;
+  const int nwaves = (int)((size_t)gridDim.x * blockDim.x >> 6);
+  const int ngroups = (nv + 3) >> 2;
+  int grp = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  auto bounds = [&](int g, int& s_, int& e_) {
+    const int vv = g * 4 + sub;
+    const bool ok = g < ngroups && vv < nv;
+    s_ = ok ? starts[vv] : 0;
+    e_ = ok ? starts[vv + 1] : 0;
+  };
+  int s, e, s1, e1;
+  bounds(grp, s, e);
+  bounds(grp + nwaves, s1, e1);
+  int p_first = (s + gl < e) ? order[s + gl] : 0;
+  for (; grp < ngroups; grp += nwaves) {
+    int s2, e2;
+    bounds(grp + 2 * nwaves, s2, e2);                               // two groups ahead
+    const int p_first1 = (s1 + gl < e1) ? order[s1 + gl] : 0;       // first id block of the next group
+    const int v = grp * 4 + sub;
+    const bool vok = v < nv;
+    const int b = vok ? v / vox_per_batch : 0;
+    float4 acc[NV4];
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int p_next = p_first;
+    for (int base = s; base < e; base += 16) {            // trip count differs between the four groups of a wave
+      const int cnt = min(16, e - base);
+      const int p = p_next;
+      p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
+      int row = p;
+      float wgt = 1.0f;
+      if (FUSED) {
+        const int q = p - b * P;
+        const int n = q / (D * HW);
+        row = (b * N + n) * HW + (q % HW);
+        wgt = gl < cnt ? depth[p] : 0.0f;
+      }
+      for (int j0 = 0; j0 < cnt; j0 += U) {
+        float4 f[U][NV4];
+        float ww[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jj = gbase + min(j0 + u, cnt - 1);     // a lane of this group (all of them are active here)
+          const int r = __shfl(row, jj, 64);
+          ww[u] = __shfl(wgt, jj, 64);
+          const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
+#pragma unroll
+          for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (j0 + u < cnt) {
+#pragma unroll
+            for (int k = 0; k < NV4; ++k) {
+              if (FUSED) {
+                acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
+                acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
+                acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
+                acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
+              } else {
+                acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
+                acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
+                acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
+                acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (vok) {
+      float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
+#pragma unroll
+      for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
+    }
+    s = s1; e = e1; s1 = s2; e1 = e2; p_first = p_first1;
+  }
+}
+
 // grad_feats[n,:] = grad_out[vox[n],:]
 __global__ void bev_pool_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ vox,
                                     float* __restrict__ gfeat, long total, int C) {
@@ -529,8 +752,36 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
                   const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st) {
   const int nv = d->B * d->nx * d->ny * d->nz;
   const int vpb = d->nx * d->ny * d->nz;
-  static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 3;   // 1 = r1 kernel, 2 = one voxel per wave at a time, 3 = four side by side
-  if (variant == 3 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+  static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 5;   // 1 = r1 kernel, 2 = one voxel per wave at a time, 3 = four side by side, 4 = 3 persistent + pipelined (not faster), 5 = 3 + whole-wave path for long lists
+  if (variant == 5 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+    dim3 grid5(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block5(256);
+    if (d->C == 64)
+      hipLaunchKernelGGL((pool_gather5_kernel<FUSED, 1>), grid5, block5, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else if (d->C == 128)
+      hipLaunchKernelGGL((pool_gather5_kernel<FUSED, 2>), grid5, block5, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else
+      hipLaunchKernelGGL((pool_gather5_kernel<FUSED, 4>), grid5, block5, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    return ssbev_launch_status();
+  }
+  if (variant == 4 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+    static const int wgs_env = getenv("SSBEV_POOL_GATHER_WGS") ? atoi(getenv("SSBEV_POOL_GATHER_WGS")) : 2048;
+    const unsigned need = cdiv((size_t)cdiv(nv, 4) * 64, 256);
+    dim3 grid4(std::min<unsigned>(need, (unsigned)std::max(1, wgs_env))), block4(256);
+    if (d->C == 64)
+      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 1>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else if (d->C == 128)
+      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 2>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    else
+      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 4>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
+                         vpb, N, D, HW);
+    return ssbev_launch_status();
+  }
+  if ((variant >= 3) && (d->C == 64 || d->C == 128 || d->C == 256)) {
     dim3 grid3(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block3(256);
     if (d->C == 64)
       hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 1>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
