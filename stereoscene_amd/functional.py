@@ -437,23 +437,32 @@ class _ConvNd(torch.autograd.Function):
         lib = capi.load()
         xcl, weight = ctx.saved_tensors
         stride, padding, dilation, transposed, output_padding, kpad, has_bias = ctx.cfg
-        gcl = gcl0 = to_cl(gy)
+        args = (stride, padding, dilation, transposed, output_padding)
+        gcl0 = to_cl(gy)                                    # gradient as it arrives: Cout channels
+        Cout_g = gcl0.shape[-1]
+        cpad = (-Cout_g) % 4                                # the data gradient's K role is the forward Cout: multiple of 4 ...
+        tpad = (-xcl.shape[-1]) % 4 if ctx.thin_in else 0   # ... and the weight gradient wants Cin % 4 == 0 (forward ran unpadded)
+        want_gx, want_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # ... except on the thin-side kernels (conv_thin_mfma.hip), which take both tensors as they are
+        thin_d = thin_w = False
+        d0 = None
+        if not transposed and not kpad and (cpad or tpad):
+            d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), *args)
+            thin_d = bool(cpad) and lib.ssbev_conv_kernel_class(C.byref(d0), 1) == 4
+            thin_w = lib.ssbev_conv_kernel_class(C.byref(d0), 2) == 6
         w5 = weight.detach()
         if kpad:
             w5 = torch.nn.functional.pad(w5, (0, 0, 0, 0, 0, 0) + ((0, 0, 0, kpad) if transposed else (0, kpad)))
-        # the data-gradient's K role is the forward Cout: pad it to a multiple of 4 as well
-        cpad = (-gcl.shape[-1]) % 4
-        if cpad:
-            gcl = torch.nn.functional.pad(gcl, (0, cpad))
+        gcl = gcl0
+        if cpad and ((want_gx and not thin_d) or (want_gw and not thin_w)):
+            gcl = torch.nn.functional.pad(gcl0, (0, cpad))
             w5 = torch.nn.functional.pad(w5, (0, 0, 0, 0, 0, 0) + ((0, cpad) if transposed else (0, 0, 0, cpad)))
-        d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), stride, padding, dilation, transposed, output_padding)
+        elif cpad:
+            w5 = None                                       # nobody needs the padded operands
+        d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), *args) if w5 is not None else d0
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            dd, gdl, wd = d, gcl, w5
-            if cpad and not transposed:   # 32 -> 1..2 layers: the data gradient gathers the unpadded thin gradient
-                d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
-                if lib.ssbev_conv_kernel_class(C.byref(d0), 1) == 4:
-                    dd, gdl, wd = d0, gcl0, weight.detach()
+        if want_gx:
+            dd, gdl, wd = (d0, gcl0, weight.detach()) if thin_d else (d, gcl, w5)
             gxcl = torch.empty_like(xcl)
             fam = _conv_family(lib, dd, 1)
             with _span(fam, conv_flops(dd), conv_bytes(dd), _conv_tag(dd, "dgrad"), conv_flops(dd) / _EXEC_DIV[fam]):
@@ -467,35 +476,30 @@ class _ConvNd(torch.autograd.Function):
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
         pointwise = (not transposed and tuple(weight.shape[2:]) == (1, 1, 1) and stride == (1, 1, 1) and padding == (0, 0, 0)
-                     and not kpad and not cpad and weight.shape[0] <= 128 and weight.shape[1] <= 128 and gcl.numel() // gcl.shape[-1] >= 32768)
-        if ctx.needs_input_grad[1] and pointwise and OWN_GEMM and PRECISION == "fp32":
+                     and not kpad and not cpad and not tpad and weight.shape[0] <= 128 and weight.shape[1] <= 128
+                     and gcl0.numel() // Cout_g >= 32768)
+        if want_gw and pointwise and OWN_GEMM and PRECISION == "fp32":
             # 1x1x1 layers on the cost volume: gw[co][ci] = sum_rows gy[row][co] x[row][ci], an HBM-streaming skinny TN product
             with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
-                gw = gemm_tn(gcl.reshape(-1, gcl.shape[-1]), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
-        elif ctx.needs_input_grad[1]:
-            xw, gw_src, dw, wshape = xcl, gcl, d, tuple(w5.shape)
-            tpad = (-xcl.shape[-1]) % 4 if ctx.thin_in else 0
-            thin_w = False
-            if not transposed and not kpad and (cpad or tpad):     # thin-side layers: wgrad_thinside_kernel takes both tensors unpadded
-                d0 = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
-                thin_w = lib.ssbev_conv_kernel_class(C.byref(d0), 2) == 6
+                gw = gemm_tn(gcl0.reshape(-1, Cout_g), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
+        elif want_gw:
             if thin_w:
-                gw_src, dw, wshape = gcl0, d0, tuple(weight.shape)
-            elif tpad:    # forward ran on the unpadded thin input (conv_thinin_kernel); the other weight-gradient kernels want K % 4 == 0
-                xw = torch.nn.functional.pad(xcl, (0, tpad))
-                wshape = (wshape[0], wshape[1] + tpad) + wshape[2:]
-                dw = _conv_dims(tuple(xw.shape), wshape, stride, padding, dilation, transposed, output_padding)
+                xw, gw_src, dw, wshape = xcl, gcl0, d0, tuple(weight.shape)
+            else:
+                xw, gw_src, dw, wshape = xcl, gcl, d, tuple(w5.shape)
+                if tpad:      # forward ran on the unpadded thin input (conv_thinin_kernel)
+                    xw = torch.nn.functional.pad(xcl, (0, tpad))
+                    wshape = (wshape[0], wshape[1] + tpad) + wshape[2:]
+                    dw = _conv_dims(tuple(xw.shape), wshape, *args)
             gwp = torch.empty(wshape, dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(dw)), gy.device)
             with _span("conv_wgrad", conv_flops(dw), conv_bytes(dw), _conv_tag(dw, "wgrad")):
                 capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xw), capi.ptr(gw_src), capi.ptr(gwp), C.byref(dw),
                                                      capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_conv_bwd_weight")
-            ci = slice(0, weight.shape[0]), slice(0, weight.shape[1])
-            gw = gwp[ci[0], ci[1]].contiguous() if ((kpad or cpad or tpad) and not thin_w) else gwp
+            gw = gwp if tuple(wshape) == tuple(weight.shape) else gwp[: weight.shape[0], : weight.shape[1]].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gcl[..., : gcl.shape[-1] - cpad].reshape(-1, gcl.shape[-1] - cpad).sum(0) if cpad else \
-                gcl.reshape(-1, gcl.shape[-1]).sum(0)
+            gb = gcl0.reshape(-1, Cout_g).sum(0)
         return gx, gw, gb, None, None, None, None, None
 
 
