@@ -43,10 +43,11 @@ class FlatGradAllReduce:
         self.average = average
         backend = dist.get_backend(process_group) if self.active else "none"
         self.native_avg = backend == "nccl"                   # RCCL: AVG + reduce-scatter available
+        explicit = exchange is not None                       # an explicit argument is honoured on any backend (tests emulate it on gloo)
         exchange = exchange or os.environ.get("SSBEV_DP_EXCHANGE", "rs_ag")
         if exchange not in ("rs_ag", "all_reduce"):
             raise ValueError(f"exchange must be 'rs_ag' or 'all_reduce', got {exchange!r}")
-        self.exchange = exchange if self.native_avg else "all_reduce"
+        self.exchange = exchange if (self.native_avg or explicit) else "all_reduce"
         params = [p for p in module.parameters() if p.requires_grad]
         # gradients become ready roughly in reverse registration order (head -> ... -> stereo net)
         self.params = list(reversed(params))
@@ -149,7 +150,7 @@ class FlatGradAllReduce:
                 if self.active:
                     self._exchange(b, async_op=False)
                     late.append(b)
-        if self.active and self.average and self.world > 1 and not self.native_avg:
+        if self.active and self.average and self.world > 1 and not self.native_avg and self.exchange == "all_reduce":
             self.flat.div_(self.world)             # gloo (CPU tests): SUM + scale
         self._handles = []
         self._arrived = [0] * len(self.buckets)
