@@ -156,8 +156,15 @@ __global__ void __launch_bounds__(FT)
 gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
                        float* __restrict__ rstd, GnGeom g) {
   __shared__ double s0[FT], s1[FT];
+  __shared__ float piv[FT];                           // pivots of this group's channels (when cpg <= FT)
   const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
   const int cpg = g.C / g.G, n_el = g.chunks * cpg;
+  const bool lds_piv = cpg <= FT;
+  if (lds_piv && (int)threadIdx.x < cpg) {
+    float pf = x[(size_t)b * g.S * g.C + grp * cpg + threadIdx.x];
+    piv[threadIdx.x] = g.pre ? gelu_f(pf) : pf;
+  }
+  __syncthreads();
   double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
 #pragma unroll
@@ -168,8 +175,8 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restric
         const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
         // shifted partials (pivot = the channel's value at voxel 0, see gn_partial_kernel): sum u = sum d + n p,
         // sum u^2 = sum d^2 + 2 p sum d + n p^2, with n = voxels of this chunk
-        float pf = x[(size_t)b * g.S * g.C + c];
-        if (g.pre) pf = gelu_f(pf);
+        float pf = lds_piv ? piv[i % cpg] : x[(size_t)b * g.S * g.C + c];
+        if (!lds_piv && g.pre) pf = gelu_f(pf);
         const double pd = pf;
         const double n = (double)(min(g.S, (long)(chunk + 1) * g.chunk_len) - (long)chunk * g.chunk_len);
         a[k] += (double)p.x + n * pd;
