@@ -159,28 +159,36 @@ gwc_warp_fwd4_kernel(const float* __restrict__ left, const float* __restrict__ r
   const float inv_cpg = 1.0f / (float)CPG;
   const int G4 = G >> 2;
   const size_t plane = (size_t)H * W * G;
-  for (int item = threadIdx.x; item < nrows * W * G4; item += blockDim.x) {
-    const int rr = item / (W * G4), wi = item - rr * (W * G4);
-    const int w = wi / G4, g4 = (wi - w * G4) << 2;
+  // blockDim.x is a multiple of G4 (launcher): a thread keeps its four groups for all of its pixels, so the group-axis
+  // taps (IEEE divisions) are computed once per thread instead of once per item
+  const int g4 = (threadIdx.x % G4) << 2, ppp = blockDim.x / G4;      // pixels per pass of the workgroup
+  float wy[4][2];
+  int cy[4][2];
+  bool okg[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int y0;
+    float w0, w1;
+    group_tap(g4 + j, G, align_corners, &y0, &w0, &w1);
+    okg[j][0] = y0 >= 0 && y0 < G;
+    okg[j][1] = y0 + 1 >= 0 && y0 + 1 < G;
+    cy[j][0] = okg[j][0] ? y0 * CPG : 0;
+    cy[j][1] = okg[j][1] ? (y0 + 1) * CPG : 0;
+    wy[j][0] = okg[j][0] ? w0 : 0.0f;
+    wy[j][1] = okg[j][1] ? w1 : 0.0f;
+  }
+  for (int pix = threadIdx.x / G4; pix < nrows * W; pix += ppp) {
+    const int rr = pix / W, w = pix - rr * W;
     const int row = row0 + rr, b = row / H, h = row - b * H;
     const float* Lrow_g = left + (size_t)row * W * C;
     const float* Rrow = STAGE ? lds : right + (size_t)row * W * C;
-    float l[4][2][CPG], wy[4][2];
-    int cy[4][2];
+    float l[4][2][CPG];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int y0;
-      float w0, w1;
-      group_tap(g4 + j, G, align_corners, &y0, &w0, &w1);
-      const bool ok0 = y0 >= 0 && y0 < G, ok1 = y0 + 1 >= 0 && y0 + 1 < G;
-      cy[j][0] = ok0 ? y0 * CPG : 0;
-      cy[j][1] = ok1 ? (y0 + 1) * CPG : 0;
-      wy[j][0] = ok0 ? w0 : 0.0f;
-      wy[j][1] = ok1 ? w1 : 0.0f;
 #pragma unroll
       for (int c = 0; c < CPG; ++c) {
-        l[j][0][c] = ok0 ? Lrow_g[w * C + cy[j][0] + c] : 0.0f;
-        l[j][1][c] = ok1 ? Lrow_g[w * C + cy[j][1] + c] : 0.0f;
+        l[j][0][c] = okg[j][0] ? Lrow_g[w * C + cy[j][0] + c] : 0.0f;
+        l[j][1][c] = okg[j][1] ? Lrow_g[w * C + cy[j][1] + c] : 0.0f;
       }
     }
     float m[4][2];
@@ -558,7 +566,10 @@ int launch_fwd(const float* l, const float* r, const float* calib, float* vol, c
           hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
               hipSuccess)
         return SSBEV_ELAUNCH;
-      hipLaunchKernelGGL(kern, dim3(nrow_groups, ch.n), dim3(std::min(512, std::max(64, threads))), lds, st, l, r, calib,
+      int unit = 64, g4 = d->G / 4;                 // block size: a multiple of the wave and of G / 4 (see the kernel)
+      while (unit % g4 != 0) unit += 64;
+      const int nthreads = std::max(unit, std::min(512, std::max(64, threads)) / unit * unit);
+      hipLaunchKernelGGL(kern, dim3(nrow_groups, ch.n), dim3(nthreads), lds, st, l, r, calib,
                          vol, ch, d->B, d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners, std::max(rows, 1));
       return ssbev_launch_status();
     }
