@@ -152,11 +152,12 @@ def test_full_size_forward_logits_vs_oracle(name, ac):
     assert agree > 0.9999
 
 
-def test_full_size_step_fwd_bwd_vs_oracle_kitti_d112():
-    """One fwd+bwd step at the reference's own config (D=112, 256x256x32 grid), train mode (batch-stat BN, dropout off):
-    4 losses and every parameter gradient against the oracle's autograd."""
+@pytest.mark.parametrize("cfg_name", ["kitti_d112", "kitti_d192"])
+def test_full_size_step_fwd_bwd_vs_oracle(cfg_name):
+    """One fwd+bwd step at the reference's own config (D=112) and at the BASELINE metric's config (D=192), 256x256x32 grid,
+    train mode (batch-stat BN, dropout off): 4 losses and every parameter gradient against the oracle's autograd."""
     import torch
-    cfg = S.CFG_K112
+    cfg = S.CONFIGS[cfg_name]
     model = model_zoo.build_detector(cfg).train()
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
@@ -188,7 +189,7 @@ def test_full_size_step_fwd_bwd_vs_oracle_kitti_d112():
         l2 = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
         worst = max(worst, (l2, name))
         checked += 1
-    print(f"kitti_d112 step: {checked} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
+    print(f"{cfg_name} step: {checked} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
     # measured 9.2e-3 on dres0.2.1.weight (profiles/r2_grad_gates.txt): 1.5 M voxels x 27 taps x 32 channels behind 20
     # ReLU layers -- sign flips of near-zero pre-activations, not rounding; every other tensor is below 5e-3
     assert checked > 150 and worst[0] < 2e-2, worst
