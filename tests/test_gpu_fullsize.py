@@ -152,6 +152,39 @@ def test_full_size_forward_logits_vs_oracle(name, ac):
     assert agree > 0.9999
 
 
+def test_full_size_bf16_mode_vs_oracle():
+    """BASELINE configs[3] at the KITTI size: the opt-in bf16 mode (bf16 MFMA operands in the conv / Winograd kernels, fp32
+    storage, norms and losses) against the fp32 ORACLE -- an error budget, not parity ("report max-abs and
+    argmax agreement"): max-abs below 5 % of the logit scale, argmax agreement above 97 %."""
+    cfg = S.CFG_K192
+    model = model_zoo.build_detector(cfg).eval()
+    smp = S.synthetic_sample(cfg, B=1, tag="fsbf16")
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    F.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            logits, depth = _coarse_outputs(model, inputs)
+    finally:
+        F.set_precision("fp32")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))
+    try:
+        with torch.no_grad():
+            _, aux = O.forward_train(sd, _oracle_inputs(smp), smp["gt_depths"], smp["gt_occ"],
+                                     _ocfg(cfg, model.img_view_transformer.D, True), train=False)
+    finally:
+        torch.set_num_threads(nt)
+    scale = aux["logits"].abs().max().item()
+    e_logit = (logits.float().cpu() - aux["logits"]).abs().max().item()
+    agree = (logits.float().cpu().argmax(1) == aux["logits"].argmax(1)).float().mean().item()
+    e_depth = (depth.float().cpu() - aux["depth_prob"]).abs().max().item()
+    print(f"kitti_d192 bf16 mode vs fp32 oracle: logits max-abs {e_logit:.3f} (scale {scale:.2f}), argmax agreement {agree:.4f}, "
+          f"depth_prob max-abs {e_depth:.2e}")
+    assert e_logit > 1e-3, "bf16 mode did not engage"
+    assert e_logit < 5e-2 * scale and agree > 0.97
+
+
 @pytest.mark.parametrize("cfg_name", ["kitti_d112", "kitti_d192"])
 def test_full_size_step_fwd_bwd_vs_oracle(cfg_name):
     """One fwd+bwd step at the reference's own config (D=112) and at the BASELINE metric's config (D=192), 256x256x32 grid,
