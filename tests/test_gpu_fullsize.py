@@ -152,6 +152,32 @@ def test_full_size_forward_logits_vs_oracle(name, ac):
     assert agree > 0.9999
 
 
+def test_full_size_forward_batch2_vs_oracle():
+    """Two samples per GPU (the per-GPU shape of BASELINE configs[3]) at kitti_d112: per-sample calibration in the cost volume,
+    the batch index of the voxel CSR, batch strides of every kernel -- logits and depth distribution vs the oracle."""
+    cfg = S.CFG_K112
+    model = model_zoo.build_detector(cfg).eval()
+    smp = S.synthetic_sample(cfg, B=2, tag="fsb2")
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    with torch.no_grad():
+        logits, depth = _coarse_outputs(model, inputs)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))
+    try:
+        with torch.no_grad():
+            _, aux = O.forward_train(sd, _oracle_inputs(smp), smp["gt_depths"], smp["gt_occ"],
+                                     _ocfg(cfg, model.img_view_transformer.D, True), train=False)
+    finally:
+        torch.set_num_threads(nt)
+    assert logits.shape == aux["logits"].shape == (2, 20, 128, 128, 16)
+    e_depth = (depth.cpu() - aux["depth_prob"]).abs().max().item()
+    e_logit = (logits.cpu() - aux["logits"]).abs().max().item()
+    print(f"kitti_d112 B=2: depth_prob max-abs {e_depth:.2e}, logits max-abs {e_logit:.2e} (scale {aux['logits'].abs().max().item():.2f})")
+    assert e_depth < 1e-4 and e_logit < 1e-3
+    assert (logits[0] - logits[1]).abs().max().item() > 1e-2          # the two samples really differ
+
+
 def test_full_size_bf16_mode_vs_oracle():
     """BASELINE configs[3] at the KITTI size: the opt-in bf16 mode (bf16 MFMA operands in the conv / Winograd kernels, fp32
     storage, norms and losses) against the fp32 ORACLE -- an error budget, not parity ("report max-abs and
