@@ -125,7 +125,9 @@ class OccHead(nn.Module):
         fuse_relu_(self)
         self.class_names = L.KITTI_CLASS_NAMES
         assert out_channel == len(self.class_names)
-        self.class_weights = L.semkitti_class_weights()
+        # non-persistent buffer: follows the module to the device (a per-step .to(device) of a host tensor is a blocking copy =
+        # a stream synchronisation right before the losses) without adding a state-dict key the reference does not have
+        self.register_buffer("class_weights", L.semkitti_class_weights(), persistent=False)
         self.semkitti_loss_weight_cfg = semkitti_loss_weight_cfg or {}
         for k in ("voxel_ohem", "voxel_lovasz", "frustum_dist", "voxel_dice", "voxel_lga"):
             if self.semkitti_loss_weight_cfg.get(k, 0.0) > 0:
