@@ -501,15 +501,22 @@ class CustomSemanticKITTILssDataset:
 def collate(samples, device="cuda"):
     """Batch of pipeline outputs -> the detector's call signature: ``img_inputs = (left10, right10)`` with a leading
     batch axis on every entry (what mmcv's collate + scatter produce upstream), ``gt_occ`` [B, X, Y, Z] int64."""
+    on_gpu = torch.device(device).type == "cuda"
+
+    def put(t):
+        # pinned staging + non-blocking copy: a plain .to(device) of pageable memory blocks until the stream has drained,
+        # i.e. every tensor of the next batch would wait for the whole previous step
+        return t.pin_memory().to(device, non_blocking=True) if (on_gpu and not t.is_cuda) else t.to(device)
+
     views = []
     for k in range(2):
         cols = []
         for j in range(10):
             items = [torch.as_tensor(s["img_inputs"][k][j]) for s in samples]
             if j == 9:                                              # calib: one scalar per sample
-                cols.append(torch.stack([t.reshape(()).float() for t in items]).to(device))
+                cols.append(put(torch.stack([t.reshape(()).float() for t in items])))
             else:
-                cols.append(torch.stack([t.float() for t in items]).to(device))
+                cols.append(put(torch.stack([t.float() for t in items])))
         if torch.device(device).type == "cuda":
             # inverse(post_rots) / inverse(intrins) of get_geometry, taken here on the host copies: the forward pass then has
             # no read-back of device matrices (a stream synchronisation per step)
@@ -517,7 +524,7 @@ def collate(samples, device="cuda"):
             host = [torch.stack([torch.as_tensor(s["img_inputs"][k][j]).float() for s in samples]) for j in (4, 3)]
             attach_host_inverses(cols[4], cols[3], host[0], host[1])
         views.append(tuple(cols))
-    gt = torch.stack([torch.as_tensor(s["gt_occ"]).long() for s in samples]).to(device)
+    gt = put(torch.stack([torch.as_tensor(s["gt_occ"]).long() for s in samples]))
     return dict(img_inputs=tuple(views), gt_occ=gt)
 
 

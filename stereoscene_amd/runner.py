@@ -152,12 +152,13 @@ class EpochBasedRunner:
             sums, n = {}, 0
             for batch in loader:
                 losses = self.step_fn(batch)
-                for k, v in losses.items():
-                    sums[k] = sums.get(k, 0.0) + float(v)
+                for k, v in losses.items():        # running sums stay on the device: a float() here is a host sync per step
+                    v = v.detach() if torch.is_tensor(v) else v
+                    sums[k] = sums[k] + v if k in sums else v
                 n += 1
                 self.iter += 1
             self.epoch += 1
-            rec = dict(epoch=self.epoch, lr=lr, **{k: v / max(n, 1) for k, v in sums.items()})
+            rec = dict(epoch=self.epoch, lr=lr, **{k: float(v) / max(n, 1) for k, v in sums.items()})
             # evaluation first: the epoch checkpoint / latest.pth then carry this epoch's best_score / best_ckpt, so a
             # resume() never overwrites a better 'best_*' file with a worse one
             if self.eval_fn is not None and self.eval_interval and self.epoch % self.eval_interval == 0:
