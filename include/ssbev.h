@@ -208,6 +208,22 @@ int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* re
                              const float* mean, const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
                              const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
+/* Two normalisations and their sum in one operator: y = relu?( N_a(xa) + N_b(xb) ), the tail of every hourglass level of
+ * the cost-volume aggregation (ViewTransformerLSSVoxel.py:92-95: relu(BatchNorm3d(deconv) + GN(redir conv))).  Each side is a
+ * per-sample GroupNorm (x_batch = 0: statistics [B][G]) or a normalisation over the batch (x_batch = 1: statistics [G], BatchNorm
+ * when G == C).  The apply pass reads the two raw tensors once and writes the sum once; backward reads (gy, mask, xa, xb) twice
+ * instead of eleven tensor passes for the two separate operators.  C % 4 == 0, C <= 1024; relu_mask as in ssbev_groupnorm_*_mask
+ * (required when relu = 1).  Statistics are outputs of _fwd and inputs of _bwd. */
+typedef struct { int B, C, Ga, Gb; int64_t S; float eps_a, eps_b; int relu; int a_batch, b_batch; } ssbev_norm2_dims;
+size_t ssbev_groupnorm2_workspace(const ssbev_norm2_dims* d);
+int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 upsample (align_corners=False) of channels-last volumes, forward and gather-form
  * backward.  Replaces F.interpolate(..., mode='trilinear') at occhead.py:293-294 and
@@ -389,6 +405,10 @@ int ssbev_wino43_output_transform(const float* M, float* y, const ssbev_wino_dim
 int ssbev_wino43_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_2d_input_transform(const float* x, float* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_2d_output_transform(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* y += transform(M): the data gradient of a second consumer of an activation is added to the first consumer's in the output
+ * transform itself (functional.fork / GradSlot) instead of by a separate elementwise pass */
+int ssbev_wino43_2d_output_transform_acc(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_transform_acc(const float* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_2d_output_adjoint(const float* gy, float* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino43_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);

@@ -46,6 +46,11 @@ class NormDims(C.Structure):
                 ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int)]
 
 
+class Norm2Dims(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("Ga", C.c_int), ("Gb", C.c_int), ("S", C.c_int64), ("eps_a", C.c_float),
+                ("eps_b", C.c_float), ("relu", C.c_int), ("a_batch", C.c_int), ("b_batch", C.c_int)]
+
+
 class DcnDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "G", "k", "pad", "dil")]
 
@@ -114,6 +119,9 @@ SIGNATURES = {
     "ssbev_groupnorm_mask_words": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd_mask": (C.c_int, [_P] * 8 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd_mask": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm2_workspace": (C.c_size_t, [C.POINTER(Norm2Dims)]),
+    "ssbev_groupnorm2_fwd": (C.c_int, [_P] * 12 + [C.POINTER(Norm2Dims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm2_bwd": (C.c_int, [_P] * 16 + [C.POINTER(Norm2Dims), _P, C.c_size_t, _P]),
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),
@@ -166,6 +174,8 @@ SIGNATURES = {
     "ssbev_wino43_2d_input_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_transform": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino43_2d_output_transform_acc": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_output_transform_acc": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_adjoint": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino43_2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),

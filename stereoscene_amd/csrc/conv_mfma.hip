@@ -1582,6 +1582,7 @@ struct ConvTapGeom {
   int B, D, H, W, K, N;           // K input channels (multiple of 4, <= 32), N output channels (<= 32)
   int nseg, NG, gpc;              // 32-voxel segments per row, B*D*H rows, rows per chunk
   int relu, has_bias;
+  int accumulate = 0;             // y += result (second consumer of a multi-consumer activation's gradient, see functional.fork)
 };
 
 constexpr int kTapWseg = 32, kTapCols = kTapWseg + 2, kTapRowF = kTapCols * 32, kTapSlots = 4;
@@ -1789,11 +1790,14 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
       if (wv < g.W) {
         float* dst = Y + (((long)(b * g.D + d) * g.H + h) * g.W + wv) * g.N + nb;
         if ((g.N & 3) == 0) {
-          if (nb < g.N) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          if (nb < g.N) {
+            if (g.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (nb + i < g.N) dst[i] = o[i];
+            if (nb + i < g.N) dst[i] = g.accumulate ? dst[i] + o[i] : o[i];
         }
       }
     }
@@ -2004,11 +2008,14 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       if (wv < g.W) {
         float* dst = Y + (((long)(b * g.D + d) * g.H + h0 + j_out) * g.W + wv) * g.N + nb;
         if ((g.N & 3) == 0) {
-          if (nb < g.N) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          if (nb < g.N) {
+            if (g.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (nb + i < g.N) dst[i] = o[i];
+            if (nb + i < g.N) dst[i] = g.accumulate ? dst[i] + o[i] : o[i];
         }
       }
     }
@@ -2356,7 +2363,7 @@ int launch_conv_thin(const float* x, const float* wt, const float* bias, float* 
 bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
-  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->accumulate || d->tile_hint == 8) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->tile_hint == 8) return false;
   if (d->Cin > 32 || d->Cout > 32) return false;
   const int K = mode == 0 ? d->Cin : d->Cout;
   if (K % 4 != 0) return false;
@@ -2382,6 +2389,7 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
   g.NG = g.B * g.D * (g.H / 2);              // row pairs
   g.relu = mode == 0 ? d->relu : 0;
   g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
   // One 512-thread workgroup per CU (141 KB of LDS).  Chunk length (row pairs per workgroup) by a small cost model fitted on
   // the 192 x 48 x 160 layer (tools/taph_gpc_probe.py): whole rounds of 256 workgroups matter most (the last round's idle
   // CUs: 12 pairs -> 7.5 rounds 0.580 ms, 18 pairs -> 5.0 rounds 0.537 ms), then the start-up of a chunk (weights + first
@@ -2416,6 +2424,7 @@ int launch_conv_tap(const float* x, const float* wp, const float* bias, float* y
   g.NG = g.B * g.D * g.H;
   g.relu = mode == 0 ? d->relu : 0;
   g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
   // two workgroups per CU; whole rounds of 512 workgroups, >= 16 rows each
   long nranges = 512 / g.nseg;
   for (long rounds = 8; rounds >= 1; --rounds) {

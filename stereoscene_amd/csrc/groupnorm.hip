@@ -465,6 +465,227 @@ __global__ void bn_update_running_kernel(const float* __restrict__ mean, const f
   rv[c] = (1.0f - m) * rv[c] + m * (var * unbias);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Two normalisations, one sum: y = relu?(N_a(xa) + N_b(xb)).  The tail of every hourglass level (VT:92-95) is
+//     conv5 = relu(BatchNorm(deconv(conv4)) + GN(redir2(conv2)))        conv6 = relu(BatchNorm(deconv(conv5)) + GN(redir1(x)))
+// Run as two normalisation operators the BatchNorm output makes a round trip through HBM only to be added (write 189 MB,
+// read 189 MB at full resolution) and the backward pass reads the incoming gradient four times.  Here the apply pass reads
+// the two RAW tensors and writes the sum once; backward reads (gy, mask, xa, xb) once for the three per-channel sums
+// (sum g, sum g xhat_a, sum g xhat_b: sum g is shared) and once more to emit both input gradients.
+// Each of the two norms is either per-sample GroupNorm (statistics [B][G]) or BatchNorm over the batch (statistics [C]).
+struct Gn2Geom {
+  int B, C, Ga, Gb;
+  long S;
+  int chunks;
+  long chunk_len;
+  int relu, a_batch, b_batch;
+};
+
+template <bool BWD>
+__device__ __forceinline__ void gn2_load_stats(const Gn2Geom& g, int b, int c, const float* mean_a, const float* rstd_a,
+                                               const float* mean_b, const float* rstd_b, const float* coef_a, const float* coef_b,
+                                               float (&mua)[4], float (&rsa)[4], float (&mub)[4], float (&rsb)[4],
+                                               float (&c0a)[4], float (&c1a)[4], float (&c0b)[4], float (&c1b)[4]) {
+  const int cpa = g.C / g.Ga, cpb = g.C / g.Gb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ia = (g.a_batch ? 0 : b) * g.Ga + (c + k) / cpa, ib = (g.b_batch ? 0 : b) * g.Gb + (c + k) / cpb;
+    mua[k] = mean_a[ia]; rsa[k] = rstd_a[ia]; mub[k] = mean_b[ib]; rsb[k] = rstd_b[ib];
+    if (BWD) { c0a[k] = coef_a[ia * 2]; c1a[k] = coef_a[ia * 2 + 1]; c0b[k] = coef_b[ib * 2]; c1b[k] = coef_b[ib * 2 + 1]; }
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+gn2_apply_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                     const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const float* __restrict__ xb,
+                     const float* __restrict__ gamma_b, const float* __restrict__ beta_b, const float* __restrict__ mean_b,
+                     const float* __restrict__ rstd_b, float* __restrict__ y, unsigned long long* __restrict__ mask, Gn2Geom g,
+                     long total4) {
+  const int q = g.C >> 2;
+  const long stride = (long)gridDim.x * NT;
+  const bool fixed = stride % q == 0;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * 4, bcur = -1;
+  float ga[4], ba[4], gb[4], bb[4], mua[4], rsa[4], mub[4], rsb[4], d0[4], d1[4], d2[4], d3[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
+  for (; i < total4; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) {
+      c = (int)(i % q) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
+    }
+    if (!fixed || b != bcur) {
+      bcur = b;
+      gn2_load_stats<false>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
+    }
+    const float4 av = reinterpret_cast<const float4*>(xa)[i];
+    const float4 bv = reinterpret_cast<const float4*>(xb)[i];
+    const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // the same association as gn_apply_fwd_kernel with the other norm's output as its residual
+      const float o = (as[k] - mua[k]) * rsa[k] * ga[k] + ba[k] + ((bs[k] - mub[k]) * rsb[k] * gb[k] + bb[k]);
+      v[k] = g.relu ? fmaxf(o, 0.0f) : o;
+    }
+    if (mask) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long bal = __ballot(v[k] > 0.0f);
+        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// per-chunk (sum g, sum g xhat_a) -> pa, (sum g, sum g xhat_b) -> pb, both in gn_partial_kernel<1>'s layout (so the
+// finalize kernels of the single-norm operator serve unchanged); g = gy masked by the fused ReLU
+__global__ void __launch_bounds__(NT)
+gn2_partial_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __restrict__ mask, const float* __restrict__ xa,
+                       const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const float* __restrict__ xb,
+                       const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float* __restrict__ pa,
+                       float* __restrict__ pb, Gn2Geom g) {
+  extern __shared__ float lds[];                       // [rows][C][3]
+  const int q = g.C >> 2, rows = NT / q > 0 ? NT / q : 1;
+  const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+  const long s0 = (long)chunk * g.chunk_len, s1 = min(g.S, s0 + g.chunk_len);
+  const int c4 = tid % q, r = tid / q;
+  if (r < rows) {
+    const int c = c4 * 4;
+    float mua[4], rsa[4], mub[4], rsb[4], d0[4], d1[4], d2[4], d3[4];
+    gn2_load_stats<false>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const size_t base = (size_t)b * g.S * g.C;
+    for (long s = s0 + r; s < s1; s += rows) {
+      const size_t off = base + (size_t)s * g.C + c;
+      const float4 gv = *reinterpret_cast<const float4*>(gy + off);
+      const float4 av = *reinterpret_cast<const float4*>(xa + off);
+      const float4 bv = *reinterpret_cast<const float4*>(xb + off);
+      float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+      if (g.relu) {
+        const size_t i4 = off >> 2;
+        const unsigned long long* mw = mask + (i4 >> 6) * 4;
+        const int sh = (int)(i4 & 63);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a0[k] += gs[k];
+        a1[k] += gs[k] * (as[k] - mua[k]) * rsa[k];
+        a2[k] += gs[k] * (bs[k] - mub[k]) * rsb[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* l = lds + ((size_t)r * g.C + c + k) * 3;
+      l[0] = a0[k]; l[1] = a1[k]; l[2] = a2[k];
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < g.C; t += NT) {
+    float s0v = 0.0f, s1v = 0.0f, s2v = 0.0f;
+    for (int rr = 0; rr < rows; ++rr) {
+      const float* l = lds + ((size_t)rr * g.C + t) * 3;
+      s0v += l[0]; s1v += l[1]; s2v += l[2];
+    }
+    const size_t o = ((size_t)(b * g.chunks + chunk) * g.C + t) * 2;
+    pa[o] = s0v; pa[o + 1] = s1v;
+    pb[o] = s0v; pb[o + 1] = s2v;
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+gn2_apply_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __restrict__ mask, const float* __restrict__ xa,
+                     const float* __restrict__ gamma_a, const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
+                     const float* __restrict__ coef_a, const float* __restrict__ xb, const float* __restrict__ gamma_b,
+                     const float* __restrict__ mean_b, const float* __restrict__ rstd_b, const float* __restrict__ coef_b,
+                     float* __restrict__ gxa, float* __restrict__ gxb, Gn2Geom g, long total4) {
+  const int q = g.C >> 2;
+  const long stride = (long)gridDim.x * NT;
+  const bool fixed = stride % q == 0;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * 4, bcur = -1;
+  float ga[4], gb[4], mua[4], rsa[4], mub[4], rsb[4], c0a[4], c1a[4], c0b[4], c1b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
+  for (; i < total4; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) {
+      c = (int)(i % q) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
+    }
+    if (!fixed || b != bcur) {
+      bcur = b;
+      gn2_load_stats<true>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, coef_a, coef_b, mua, rsa, mub, rsb, c0a, c1a, c0b, c1b);
+    }
+    const float4 gv = reinterpret_cast<const float4*>(gy)[i];
+    const float4 av = reinterpret_cast<const float4*>(xa)[i];
+    const float4 bv = reinterpret_cast<const float4*>(xb)[i];
+    float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+    if (g.relu) {
+      const unsigned long long* mw = mask + (i >> 6) * 4;
+      const int sh = (int)(i & 63);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+    }
+    float oa[4], ob[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      oa[k] = (ga[k] * gs[k] - (as[k] - mua[k]) * rsa[k] * c0a[k] - c1a[k]) * rsa[k];
+      ob[k] = (gb[k] * gs[k] - (bs[k] - mub[k]) * rsb[k] * c0b[k] - c1b[k]) * rsb[k];
+    }
+    reinterpret_cast<float4*>(gxa)[i] = make_float4(oa[0], oa[1], oa[2], oa[3]);
+    reinterpret_cast<float4*>(gxb)[i] = make_float4(ob[0], ob[1], ob[2], ob[3]);
+  }
+}
+
+bool gn2_ok(const ssbev_norm2_dims* d) {
+  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->C % 4 == 0 && d->C <= 4 * NT && d->Ga > 0 && d->Gb > 0 &&
+         d->C % d->Ga == 0 && d->C % d->Gb == 0;
+}
+
+// the single-norm view of one side (statistics passes and finalize kernels are those of the single-norm operator)
+ssbev_norm_dims gn2_side(const ssbev_norm2_dims* d, int side) {
+  ssbev_norm_dims n;
+  const bool batch = side ? d->b_batch : d->a_batch;
+  n.B = batch ? 1 : d->B; n.C = d->C; n.G = side ? d->Gb : d->Ga; n.S = batch ? d->S * d->B : d->S;
+  n.eps = side ? d->eps_b : d->eps_a; n.relu = d->relu; n.stats_given = 0; n.pre_act = 0;
+  return n;
+}
+
+Gn2Geom make_geom2(const ssbev_norm2_dims* d) {
+  Gn2Geom g;
+  g.B = d->B; g.C = d->C; g.Ga = d->Ga; g.Gb = d->Gb; g.S = d->S; g.relu = d->relu; g.a_batch = d->a_batch; g.b_batch = d->b_batch;
+  long chunks = 768 / d->B;
+  if (chunks < 1) chunks = 1;
+  long len = (d->S + chunks - 1) / chunks;
+  if (len < 64) len = 64;
+  g.chunk_len = len;
+  g.chunks = (int)((d->S + len - 1) / len);
+  return g;
+}
+
+// backward finalize of one side on the [B * chunks] partial records: a batch norm folds the sample axis into the chunk axis
+void gn2_finalize_bwd(const Gn2Geom& g2, const ssbev_norm2_dims* d, int side, const float* partial, const float* gamma, float* coef,
+                      float* dgamma, float* dbeta, hipStream_t st) {
+  const bool batch = side ? d->b_batch : d->a_batch;
+  GnGeom g;
+  g.B = batch ? 1 : g2.B; g.C = g2.C; g.G = side ? g2.Gb : g2.Ga; g.S = batch ? g2.S * g2.B : g2.S;
+  g.chunks = batch ? g2.chunks * g2.B : g2.chunks; g.chunk_len = g2.chunk_len; g.eps = 0.f; g.relu = g2.relu; g.pre = 0;
+  if (g.G == g.C)
+    hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, dgamma, dbeta, g);
+  else
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, dgamma, dbeta, g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -581,6 +802,82 @@ int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* re
                              const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   return groupnorm_bwd_impl(gy, x, nullptr, reinterpret_cast<const unsigned long long*>(relu_mask), gamma, mean, rstd, gx,
                             gresidual, ggamma, gbeta, d, ws, ws_bytes, stream);
+}
+
+
+size_t ssbev_groupnorm2_workspace(const ssbev_norm2_dims* d) {
+  if (!gn2_ok(d)) return 0;
+  const ssbev_norm_dims na = gn2_side(d, 0), nb = gn2_side(d, 1);
+  const Gn2Geom g = make_geom2(d);
+  // forward: the two single-norm statistics passes (their own workspaces); backward: two partial buffers + two coefficient vectors
+  const size_t fwd = ssbev_groupnorm_workspace(&na) + ssbev_groupnorm_workspace(&nb);
+  const size_t part = (size_t)g.B * g.chunks * g.C * 2;
+  const size_t bwd = (2 * part + 2 * (size_t)(g.B * g.C) * 2 + 128) * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!gn2_ok(d) || !xa || !gamma_a || !beta_a || !mean_a || !rstd_a || !xb || !gamma_b || !beta_b || !mean_b || !rstd_b || !y || !ws)
+    return SSBEV_EINVAL;
+  if (d->relu && !relu_mask) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const float* xs[2] = {xa, xb};
+  float* means[2] = {mean_a, mean_b};
+  float* rstds[2] = {rstd_a, rstd_b};
+  char* wsp = static_cast<char*>(ws);
+  for (int side = 0; side < 2; ++side) {
+    const ssbev_norm_dims n = gn2_side(d, side);
+    const GnGeom g = make_geom(&n);
+    const size_t lds = lds_bytes(g);
+    if (lds > 64 * 1024) return SSBEV_EINVAL;
+    float* partial = reinterpret_cast<float*>(wsp);
+    hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, xs[side], nullptr, nullptr,
+                       nullptr, nullptr, nullptr, partial, g);
+    if (g.G == g.C)
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, xs[side], means[side],
+                         rstds[side], g);
+    else
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, xs[side], means[side], rstds[side], g);
+    wsp += ssbev_groupnorm_workspace(&n);
+  }
+  const Gn2Geom g2 = make_geom2(d);
+  const long total4 = (long)g2.B * g2.S * (g2.C / 4);
+  hipLaunchKernelGGL(gn2_apply_fwd_kernel, dim3(apply_blocks(total4, g2.C / 4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a, rstd_a,
+                     xb, gamma_b, beta_b, mean_b, rstd_b, y, d->relu ? reinterpret_cast<unsigned long long*>(relu_mask) : nullptr, g2,
+                     total4);
+  return ssbev_launch_status();
+}
+
+int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!gn2_ok(d) || !gy || !xa || !gamma_a || !mean_a || !rstd_a || !xb || !gamma_b || !mean_b || !rstd_b || !gxa || !gxb ||
+      !ggamma_a || !gbeta_a || !ggamma_b || !gbeta_b || !ws)
+    return SSBEV_EINVAL;
+  if (d->relu && !relu_mask) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const Gn2Geom g = make_geom2(d);
+  const size_t part = (size_t)g.B * g.chunks * g.C * 2;
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + part;
+  float* coef_a = pb + part;
+  float* coef_b = coef_a + (size_t)g.B * g.C * 2 + 64;
+  const int q = g.C >> 2, rows = NT / q > 0 ? NT / q : 1;
+  const size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
+  const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(relu_mask);
+  hipLaunchKernelGGL(gn2_partial_bwd_kernel, dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b, rstd_b, pa,
+                     pb, g);
+  gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
+  gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
+  const long total4 = (long)g.B * g.S * (g.C / 4);
+  hipLaunchKernelGGL(gn2_apply_bwd_kernel, dim3(apply_blocks(total4, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a, rstd_a,
+                     coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, total4);
+  return ssbev_launch_status();
 }
 
 }  // extern "C"

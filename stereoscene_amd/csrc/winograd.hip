@@ -15,7 +15,7 @@
 
 namespace {
 
-struct WinoGeom { int B, D, H, W, C; };
+struct WinoGeom { int B, D, H, W, C; int acc = 0; };     // acc: the output transforms ADD to y (gradient slots, functional.fork)
 __device__ const float kWinoZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
 // Storage type of the transformed-domain tensors (V, M, Z): float, or bf16 bit patterns (the `_bf16` entry points: half
@@ -215,8 +215,9 @@ wino2d_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
   for (int f = 0; f < 2; ++f) {
     const float y0 = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f], y1 = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f];
     const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-    y[base] = y0;
-    y[base + (long)g.W * g.C] = y1;
+    const long b1 = base + (long)g.W * g.C;
+    y[base] = g.acc ? y[base] + y0 : y0;
+    y[b1] = g.acc ? y[b1] + y1 : y1;
   }
 }
 
@@ -473,7 +474,8 @@ wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
 #pragma unroll
         for (int a = 0; a < 4; ++a) y[base + (long)a * g.H * g.W * g.C] = o[a];
       } else {
-        y[(((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c] = r2[e * 4 + f];
+        const long o = (((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c;
+        y[o] = g.acc ? y[o] + r2[e * 4 + f] : r2[e * 4 + f];
       }
     }
 }
@@ -990,6 +992,25 @@ SSBEV_WINO43_ENTRY(ssbev_wino43_2d_output_adjoint_bf16, wino43_output_adjoint_ke
 SSBEV_WINO43_ENTRY(ssbev_wino444_input_transform, wino43_input_kernel, 4, float, float, float)
 SSBEV_WINO43_ENTRY(ssbev_wino444_output_transform, wino43_output_kernel, 4, float, float, float)
 SSBEV_WINO43_ENTRY(ssbev_wino444_output_adjoint, wino43_output_adjoint_kernel, 4, float, float, float)
+
+// y += output transform (the data gradient of a second consumer lands in the first one's buffer)
+int ssbev_wino43_2d_output_transform_acc(const float* src, float* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {
+  if (!wino43_ok(d, 0) || !src || !dst) return SSBEV_EINVAL;
+  const long total = (long)d->B * d->D * (d->H / 4) * (d->W / 4) * d->C;
+  WinoGeom g{d->B, d->D, d->H, d->W, d->C};
+  g.acc = 1;
+  hipLaunchKernelGGL((wino43_output_kernel<0, float>), dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total);
+  return ssbev_launch_status();
+}
+
+int ssbev_wino2d_output_transform_acc(const float* src, float* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {
+  if (!wino2d_ok(d) || !src || !dst) return SSBEV_EINVAL;
+  const long total = (long)d->B * d->D * (d->H / 2) * (d->W / 2) * d->C;
+  WinoGeom g{d->B, d->D, d->H, d->W, d->C};
+  g.acc = 1;
+  hipLaunchKernelGGL(wino2d_output_kernel<float>, dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total);
+  return ssbev_launch_status();
+}
 
 int ssbev_wino43_weight_transform(const float* w, float* U, int Cout, int Cin, int ndim, int mode, ssbev_stream_t stream) {
   if (!w || !U || Cout <= 0 || Cin <= 0 || (ndim != 2 && ndim != 3 && ndim != 4) || (mode != 0 && mode != 1)) return SSBEV_EINVAL;

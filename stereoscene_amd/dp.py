@@ -35,7 +35,7 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, module, bucket_mb=64, process_group=None, average=True, exchange=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, average=True, exchange=None, align=None):
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
@@ -53,7 +53,7 @@ class FlatGradAllReduce:
         self.params = list(reversed(params))
         dev = self.params[0].device
         cap = max(1, int(bucket_mb * (1 << 20) // 4))
-        align = max(self.world, 1)
+        align = max(self.world, 1) if align is None else int(align)   # (tests pass `align` to emulate another world size's layout)
         self.buckets, self._bucket_of = [], {}
         self._offsets = {}
         off, start, count = 0, 0, 0

@@ -13,10 +13,17 @@ from .plugin.losses import KITTI_CLASS_NAMES, ssc_counts
 CLASS_NAMES = ["unlabeled"] + KITTI_CLASS_NAMES[1:]
 
 
-@torch.no_grad()
 def evaluate(model, samples, device="cuda", dataset_len=None, sampler=None):
+    """``eval_results`` dict of the reference (see ``evaluate_counts`` for the arguments)."""
+    return scores_from_counts(evaluate_counts(model, samples, device, dataset_len, sampler).cpu().numpy())
+
+
+@torch.no_grad()
+def evaluate_counts(model, samples, device="cuda", dataset_len=None, sampler=None, reduce=True):
     """``samples`` yields dicts with ``img_inputs`` (left10, right10) and ``gt_occ`` [B,X,Y,Z].
-    Returns the reference's ``eval_results`` dict (percent, 2 decimals, + 'semkitti_combined_IoU').
+    Returns the integer SSC counts (float64 vector: tp, fp, fn, then per-class tp / fp / fn), summed over ranks when a
+    process group is initialised and ``reduce``; ``evaluate`` turns them into the reference's ``eval_results`` dict (percent,
+    2 decimals, + 'semkitti_combined_IoU').
 
     Distributed evaluation: ``runner.DistributedSampler`` tiles the index list up to a multiple of the world size, so the
     last ranks see duplicates of the first samples.  The reference drops them (``collect_results_cpu`` keeps
@@ -30,6 +37,11 @@ def evaluate(model, samples, device="cuda", dataset_len=None, sampler=None):
         rank, world = dist.get_rank(), dist.get_world_size()
     if sampler is not None:
         dataset_len, rank, world = sampler.n, sampler.rank, sampler.num_replicas
+    elif world > 1 and dataset_len is None:
+        # the old call signature under an initialised process group: the padded duplicates would be counted silently
+        # (the reference always truncates to len(dataset)) -- refuse instead
+        raise ValueError("evaluate(): torch.distributed is initialised with world_size > 1; pass sampler= (or dataset_len=) "
+                         "so that the samples DistributedSampler pads the index list with are dropped")
     per_rank = -(-dataset_len // world) if dataset_len is not None else None
     acc = torch.zeros(3 + 3 * len(CLASS_NAMES), dtype=torch.float64, device=device)
     try:
@@ -51,9 +63,9 @@ def evaluate(model, samples, device="cuda", dataset_len=None, sampler=None):
             acc += torch.cat([torch.stack([tp, fp, fn]).double(), tpc.double(), fpc.double(), fnc.double()])
     finally:
         model.train(was_training)
-    if dist.is_available() and dist.is_initialized():
+    if reduce and dist.is_available() and dist.is_initialized():
         dist.all_reduce(acc)
-    return scores_from_counts(acc.cpu().numpy())
+    return acc
 
 
 def scores_from_counts(acc):

@@ -350,6 +350,71 @@ def gwc_warp(left, right, calib, ndisp, groups=32, align_corners=True):
 
 
 # -------------------------------------------------------------------------------------------------
+# gradient slots: one gradient buffer for all consumers of a multi-consumer activation
+# -------------------------------------------------------------------------------------------------
+# An activation with two consumers (the input of an hourglass feeds its stride-2 conv and its 1x1 redirect; a residual
+# block's input feeds the first conv and the closing add) gets its gradient from autograd as the SUM of two tensors: one
+# elementwise pass over three 189 MB tensors per such activation on the cost volume (7 per step, 1.3 ms with the narrower
+# levels).  ``fork`` hands every consumer an alias of the activation carrying a shared ``GradSlot``; in backward the first
+# consumer leaves its gradient tensor in the slot, the next ones run their data-gradient kernel with ``accumulate = 1`` INTO
+# that buffer (the kernels add in their epilogue) and return the same tensor, and ``_Fork.backward`` counts a buffer once.
+# Consumers that do not know about slots still work: their gradient is a different tensor and is added as before.
+GRAD_SLOTS = os.environ.get("SSBEV_GRAD_SLOTS", "1") != "0"
+
+
+class GradSlot:
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _Fork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot, n):
+        ctx.slot = slot
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ctx.slot.buf = None
+        uniq = []
+        for g in gs:
+            if g is not None and not any(g.data_ptr() == u.data_ptr() and g.shape == u.shape and g.stride() == u.stride() for u in uniq):
+                uniq.append(g)
+        total = None
+        for g in uniq:
+            total = g if total is None else total + g
+        return total, None, None
+
+
+def fork(x, n=2):
+    """``n`` aliases of ``x`` for ``n`` consumers whose data gradients should meet in one buffer (see above)."""
+    if not (GRAD_SLOTS and x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * n
+    slot = GradSlot()
+    outs = _Fork.apply(x, slot, n)
+    for o in outs:
+        o._ssbev_grad_slot = slot
+    return outs
+
+
+def _slot_of(t):
+    return getattr(t, "_ssbev_grad_slot", None) if t is not None else None
+
+
+def _slot_target(slot, like):
+    """The tensor a data-gradient kernel should accumulate into, or None (then it writes a fresh tensor)."""
+    if slot is None or slot.buf is None:
+        return None
+    b = slot.buf
+    # same channels-last volume (a 2-D layer sees [B, 1, H, W, C] where the norm before it saw [B, H, W, C])
+    ok = b.is_contiguous() and b.dtype == like.dtype and b.numel() == like.numel() and b.shape[-1] == like.shape[-1] and \
+        b.shape[0] == like.shape[0]
+    return b.view(tuple(like.shape)) if ok else None
+
+
+# -------------------------------------------------------------------------------------------------
 # convolution family
 # -------------------------------------------------------------------------------------------------
 
@@ -404,8 +469,9 @@ class _ConvNd(torch.autograd.Function):
     """x logical [B,Cin,D,H,W] (channels-last memory), weight in the torch layout (5-D)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None):
         lib = capi.load()
+        ctx.slot = slot
         xcl = to_cl(_f32(x, "conv"))
         kpad = (-xcl.shape[-1]) % 4
         w5 = weight
@@ -463,7 +529,11 @@ class _ConvNd(torch.autograd.Function):
         gx = gw = gb = None
         if want_gx:
             dd, gdl, wd = (d0, gcl0, weight.detach()) if thin_d else (d, gcl, w5)
-            gxcl = torch.empty_like(xcl)
+            slot = ctx.slot if (not kpad and not thin_d and lib.ssbev_conv_kernel_class(C.byref(dd), 1) not in (4, 5)) else None
+            into = _slot_target(slot, xcl)
+            if into is not None:          # another consumer's gradient is already there: add to it in the kernel's epilogue
+                dd.accumulate = 1
+            gxcl = into if into is not None else torch.empty_like(xcl)
             fam = _conv_family(lib, dd, 1)
             with _span(fam, conv_flops(dd), conv_bytes(dd), _conv_tag(dd, "dgrad"), conv_flops(dd) / _EXEC_DIV[fam]):
                 if lib.ssbev_conv_kernel_class(C.byref(dd), 1) == 5:
@@ -472,6 +542,9 @@ class _ConvNd(torch.autograd.Function):
                     wpt = _packed(wd, dd, 1)
                     capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gdl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(dd),
                                                        capi.stream()), "ssbev_conv_bwd_data")
+            dd.accumulate = 0
+            if slot is not None:
+                slot.buf = gxcl
             if kpad:
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
@@ -500,7 +573,7 @@ class _ConvNd(torch.autograd.Function):
             gw = gwp if tuple(wshape) == tuple(weight.shape) else gwp[: weight.shape[0], : weight.shape[1]].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gcl0.reshape(-1, Cout_g).sum(0)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 WINOGRAD = os.environ.get("SSBEV_WINOGRAD", "1") != "0"   # wide 3x3x3 stride-1 layers via F(2,3)^3 (0 = direct MFMA conv)
@@ -517,11 +590,11 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
         B, Cin, D, H, W = x.shape
         if tuple(weight.shape[2:]) == (3, 3, 3) and H % 4 == 0 and W % 4 == 0 and \
                 _wino_df_applicable(B, D, H, W, Cin, weight.shape[0]):
-            y = _WinoConvDF.apply(x, weight)
+            y = _WinoConvDF.apply(x, weight, _slot_of(x))
         else:
-            y = _WinoConv.apply(x, weight)
+            y = _WinoConv.apply(x, weight, _slot_of(x))
         return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
-    return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0))
+    return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0), _slot_of(x))
 
 
 # -------------------------------------------------------------------------------------------------
@@ -545,6 +618,8 @@ def _rows(t):
     """[.., R, C] tensor with a contiguous last axis and uniform row / batch strides -> (tensor, ld, batch_stride)."""
     if t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.stride(-2) % 4 != 0 or t.stride(-2) < t.shape[-1]:
         t = t.contiguous()
+    if t.data_ptr() % 16:            # the kernels issue 16-byte global_load_lds: a last-axis slice view may start misaligned
+        t = t.clone(memory_format=torch.contiguous_format)
     return t, t.stride(-2), (t.stride(0) if t.dim() == 3 else 0)
 
 
@@ -805,9 +880,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
             return y if bias is None else y + bias.view(1, -1, 1, 1)
     x5, w5 = x.unsqueeze(2), weight.unsqueeze(2)
     if WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x5, w5, (1,) + s, (0,) + p, (1,) + dl):
-        y = _WinoConv.apply(x5, w5).squeeze(2)
+        y = _WinoConv.apply(x5, w5, _slot_of(x)).squeeze(2)
         return y if bias is None else y + bias.view(1, -1, 1, 1)
-    y = _ConvNd.apply(x5, w5, bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
+    y = _ConvNd.apply(x5, w5, bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0), _slot_of(x))
     return y.squeeze(2)
 
 
@@ -921,7 +996,7 @@ def _wino_df_applicable(B, D, H, W, Cin, Cout):
         bool(lib.ssbev_wino43_df_supported(C.byref(capi.WinoDims(B, D, H, W, Cout)), Cin)) and Cout % 4 == 0
 
 
-def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl):
+def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl, into=None):
     """(h,w) input transform -> depth-fused MFMA contraction -> (h,w) output transform of a channels-last volume with K
     input / N output channels.  mode 0: forward (w [N,K,3,3,3]); mode 1: data gradient (w [K,N,3,3,3], mirrored taps).
     Returns (y_cl, P) -- P [36, B*D*H/4*W/4, K] is what the weight gradient needs."""
@@ -938,8 +1013,14 @@ def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl):
     with _span("conv_wino_fused", fl, nby, tag, fl / 6.0):
         capi.check(lib.ssbev_wino43_df_gemm(capi.ptr(P), capi.ptr(Wp), capi.ptr(Mo), C.byref(dims), N, capi.stream()),
                    "ssbev_wino43_df_gemm")
-    with _span("wino_transform", 0.0, 4.0 * B * D * H * W * N * 3.25, tag + " out"):
-        y = _wino_call("ssbev_wino43_2d_output_transform", Mo, capi.WinoDims(B, D, H, W, N), (B, D, H, W, N))
+    with _span("wino_transform", 0.0, 4.0 * B * D * H * W * N * (3.25 + (into is not None)), tag + " out"):
+        if into is not None:          # gradient slot: add to the gradient another consumer already left there
+            odims = capi.WinoDims(B, D, H, W, N)
+            capi.check(lib.ssbev_wino43_2d_output_transform_acc(capi.ptr(Mo), capi.ptr(into), C.byref(odims), capi.stream()),
+                       "ssbev_wino43_2d_output_transform_acc")
+            y = into
+        else:
+            y = _wino_call("ssbev_wino43_2d_output_transform", Mo, capi.WinoDims(B, D, H, W, N), (B, D, H, W, N))
     return y, P
 
 
@@ -947,7 +1028,8 @@ class _WinoConvDF(torch.autograd.Function):
     """3x3x3 / stride 1 / pad 1 convolution on the depth-fused Winograd kernels (see WINO_DF)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, slot=None):
+        ctx.slot = slot
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout = weight.shape[0]
@@ -967,7 +1049,10 @@ class _WinoConvDF(torch.autograd.Function):
         w = weight.detach().contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gxcl, _ = _wino_df_gemm(gcl, w, B, D, H, W, Cout, Cin, 1, f"winoDF dgrad {Cin}->{Cout} {D}x{H}x{W}", fl)
+            into = _slot_target(ctx.slot, torch.empty((B, D, H, W, Cin), device="meta"))
+            gxcl, _ = _wino_df_gemm(gcl, w, B, D, H, W, Cout, Cin, 1, f"winoDF dgrad {Cin}->{Cout} {D}x{H}x{W}", fl, into=into)
+            if ctx.slot is not None:
+                ctx.slot.buf = gxcl
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
             R = B * D * (H // 4) * (W // 4)
@@ -980,7 +1065,7 @@ class _WinoConvDF(torch.autograd.Function):
             with _span("conv_wino_fused_wgrad", fl, nby, f"winoDF wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / 6.0):
                 capi.check(lib.ssbev_wino43_df_wgrad(capi.ptr(P), capi.ptr(Z), capi.ptr(gw), C.byref(dims), Cout, capi.ptr(ws),
                                                      ws.numel(), capi.stream()), "ssbev_wino43_df_wgrad")
-        return gx, gw
+        return gx, gw, None
 
 
 class _WinoConv(torch.autograd.Function):
@@ -1005,7 +1090,8 @@ class _WinoConv(torch.autograd.Function):
         return (1 if f43 else 0), pre, nf, th, reduction
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, slot=None):
+        ctx.slot = slot
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout, three_d = weight.shape[0], weight.shape[2] == 3
@@ -1063,7 +1149,17 @@ class _WinoConv(torch.autograd.Function):
                 Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf and not f43) \
                     else (torch.bmm(Vg, Ut.to(fdt)) if (bf or not own_gemm_site("wino")) else gemm_nn(Vg, Ut, tag="wino dgrad gemm"))
                 del Vg
-                gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
+                acc_fn = {"ssbev_wino2d_": "ssbev_wino2d_output_transform_acc",
+                          "ssbev_wino43_2d_": "ssbev_wino43_2d_output_transform_acc"}.get(pre) if not bf else None
+                into = _slot_target(ctx.slot, torch.empty((B, D, H, W, Cin), device="meta")) if acc_fn else None
+                if into is not None:
+                    odims = capi.WinoDims(B, D, H, W, Cin)
+                    capi.check(getattr(lib, acc_fn)(capi.ptr(Mx), capi.ptr(into), C.byref(odims), capi.stream()), acc_fn)
+                    gxcl = into
+                else:
+                    gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
+                if ctx.slot is not None:
+                    ctx.slot.buf = gxcl
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
             with _span("conv_winograd_wgrad", fl, nby, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
@@ -1074,7 +1170,7 @@ class _WinoConv(torch.autograd.Function):
             gw = torch.empty_like(w)
             wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
             capi.check(wg(capi.ptr(gU), capi.ptr(gw), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
-        return gx, gw
+        return gx, gw, None
 
 
 def conv_flops_3x3(B, D, H, W, Cin, Cout):
@@ -1157,8 +1253,9 @@ class _GroupNorm(torch.autograd.Function):
     """GroupNorm on a channels-last volume with optional fused residual add and ReLU."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd, pre_act=0):
+    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd, pre_act=0, res_slot=None):
         lib = capi.load()
+        ctx.res_slot = res_slot
         ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) statistics outputs
         xcl = to_cl(_f32(x, "group_norm"))
         Cch = xcl.shape[-1]
@@ -1211,7 +1308,9 @@ class _GroupNorm(torch.autograd.Function):
             capi.check(fn(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
                           capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
                           C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_groupnorm_bwd")
-        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None
+        if has_res and ctx.res_slot is not None and ctx.res_slot.buf is None:
+            ctx.res_slot.buf = gres        # first gradient of a forked activation: later consumers accumulate into it
+        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None, None
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False, pre_act=None):
@@ -1219,12 +1318,13 @@ def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False, pre
     gelu(x) (exact form) without materialising it."""
     if pre_act not in (None, "gelu"):
         raise ValueError(f"group_norm: unknown pre_act {pre_act!r}")
-    return _GroupNorm.apply(x, weight, bias, residual, int(groups), eps, relu, False, None, None, 1 if pre_act else 0)[0]
+    return _GroupNorm.apply(x, weight, bias, residual, int(groups), eps, relu, False, None, None, 1 if pre_act else 0,
+                            _slot_of(residual))[0]
 
 
 def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False):
     """Training-mode BatchNorm (batch statistics): returns (y, mean[C], rstd[C])."""
-    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None)
+    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None, 0, _slot_of(residual))
 
 
 def bn_update_running_(running_mean, running_var, mean, rstd, momentum, eps, n):
@@ -1239,6 +1339,77 @@ def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, residu
     """Inference-mode BatchNorm with the running statistics (forward only on the HIP path)."""
     rstd = torch.rsqrt(running_var + eps)
     return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, running_mean, rstd)[0]
+
+
+class _DualNorm(torch.autograd.Function):
+    """relu?(N_a(xa) + N_b(xb)) in one operator (csrc/groupnorm.hip, ssbev_groupnorm2_*): each side a per-sample GroupNorm or a
+    batch normalisation; returns (y, mean_a, rstd_a, mean_b, rstd_b)."""
+
+    @staticmethod
+    def forward(ctx, xa, wa, ba, xb, wb, bb, ga, gb, eps_a, eps_b, relu, a_batch, b_batch):
+        lib = capi.load()
+        ctx.set_materialize_grads(False)
+        acl, bcl = to_cl(_f32(xa, "dual_norm")), to_cl(_f32(xb, "dual_norm"))
+        if acl.shape != bcl.shape:
+            raise capi.SsbevError(f"dual_norm: shapes differ, {tuple(acl.shape)} vs {tuple(bcl.shape)}")
+        B, Cch = acl.shape[0], acl.shape[-1]
+        S = acl.numel() // (B * Cch)
+        d = capi.Norm2Dims(B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch))
+        dev = xa.device
+        y = torch.empty_like(acl)
+        mean_a = torch.empty((1 if a_batch else B) * ga, dtype=torch.float32, device=dev)
+        rstd_a = torch.empty_like(mean_a)
+        mean_b = torch.empty((1 if b_batch else B) * gb, dtype=torch.float32, device=dev)
+        rstd_b = torch.empty_like(mean_b)
+        nbytes = lib.ssbev_groupnorm2_workspace(C.byref(d))
+        if nbytes == 0:
+            raise capi.SsbevError("dual_norm: unsupported dims (C % 4, C <= 1024, C % G)")
+        ws = _ws(nbytes, dev)
+        nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0)
+        mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(nd)), dtype=torch.int64, device=dev) if relu else None
+        wa_, ba_, wb_, bb_ = (t.detach().contiguous() for t in (wa, ba, wb, bb))
+        with _span("groupnorm", 0.0, 4.0 * acl.numel() * 5, f"fwd   N2 C={Cch} Ga={ga} Gb={gb} S={S}"):
+            capi.check(lib.ssbev_groupnorm2_fwd(capi.ptr(acl), capi.ptr(wa_), capi.ptr(ba_), capi.ptr(mean_a), capi.ptr(rstd_a),
+                                                capi.ptr(bcl), capi.ptr(wb_), capi.ptr(bb_), capi.ptr(mean_b), capi.ptr(rstd_b),
+                                                capi.ptr(y), capi.ptr(mask), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm2_fwd")
+        ctx.save_for_backward(acl, bcl, mask, wa_, wb_, mean_a, rstd_a, mean_b, rstd_b)
+        ctx.meta = (B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch))
+        ctx.mark_non_differentiable(mean_a, rstd_a, mean_b, rstd_b)
+        return from_cl(y), mean_a, rstd_a, mean_b, rstd_b
+
+    @staticmethod
+    def backward(ctx, gy, *_unused):
+        lib = capi.load()
+        acl, bcl, mask, wa_, wb_, mean_a, rstd_a, mean_b, rstd_b = ctx.saved_tensors
+        d = capi.Norm2Dims(*ctx.meta)
+        Cch, dev = ctx.meta[1], gy.device
+        gcl = to_cl(gy)
+        gxa, gxb = torch.empty_like(acl), torch.empty_like(bcl)
+        gga, gba, ggb, gbb = (torch.empty(Cch, dtype=torch.float32, device=dev) for _ in range(4))
+        ws = _ws(lib.ssbev_groupnorm2_workspace(C.byref(d)), dev)
+        with _span("groupnorm", 0.0, 4.0 * acl.numel() * 8, f"bwd   N2 C={Cch} Ga={ctx.meta[2]} Gb={ctx.meta[3]} S={ctx.meta[4]}"):
+            capi.check(lib.ssbev_groupnorm2_bwd(capi.ptr(gcl), capi.ptr(mask), capi.ptr(acl), capi.ptr(wa_), capi.ptr(mean_a),
+                                                capi.ptr(rstd_a), capi.ptr(bcl), capi.ptr(wb_), capi.ptr(mean_b), capi.ptr(rstd_b),
+                                                capi.ptr(gxa), capi.ptr(gxb), capi.ptr(gga), capi.ptr(gba), capi.ptr(ggb),
+                                                capi.ptr(gbb), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm2_bwd")
+        return from_cl(gxa), gga, gba, from_cl(gxb), ggb, gbb, None, None, None, None, None, None, None
+
+
+DUAL_NORM = os.environ.get("SSBEV_DUAL_NORM", "1") != "0"      # 0: the two-operator residual form (A/B timing)
+
+
+def dual_norm_supported(xa, xb):
+    return xa.is_cuda and xa.shape == xb.shape and xa.dim() >= 3 and xa.shape[1] % 4 == 0 and xa.shape[1] <= 1024
+
+
+def dual_norm(xa, wa, ba, groups_a, eps_a, xb, wb, bb, groups_b, eps_b, relu=False, a_batch=False, b_batch=False):
+    """relu?(N_a(xa) + N_b(xb)); ``x_batch`` = statistics over the batch axis too (BatchNorm when groups == channels).
+    Returns (y, (mean_a, rstd_a), (mean_b, rstd_b))."""
+    y, ma, ra, mb, rb = _DualNorm.apply(xa, wa, ba, xb, wb, bb, int(groups_a), int(groups_b), eps_a, eps_b, relu,
+                                        bool(a_batch), bool(b_batch))
+    return y, (ma, ra), (mb, rb)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -170,6 +170,31 @@ class BatchNorm2d(_HipBatchNorm, nn.BatchNorm2d):
     pass
 
 
+def norm_pair(norm_a, xa, norm_b, xb, relu=True):
+    """relu?(norm_a(xa) + norm_b(xb)) for two of the norm layers above.  Training-mode BatchNorm / GroupNorm pairs run as ONE
+    operator (functional.dual_norm: the first norm's output never makes the round trip through HBM that the residual form
+    ``norm_a(xa, residual=norm_b(xb))`` costs); anything else (eval-mode BatchNorm, CPU tensors) takes that residual form."""
+    def fusable(n):
+        return isinstance(n, GroupNorm) or (isinstance(n, _HipBatchNorm) and n.training)
+    if not (F.DUAL_NORM and fusable(norm_a) and fusable(norm_b) and F.dual_norm_supported(xa, xb)):
+        return norm_a(xa, residual=norm_b(xb), relu=relu)
+
+    def side(n):
+        if isinstance(n, GroupNorm):
+            return n.num_groups, False
+        return n.num_features, True
+    (ga, a_batch), (gb, b_batch) = side(norm_a), side(norm_b)
+    y, sa, sb = F.dual_norm(xa, norm_a.weight, norm_a.bias, ga, norm_a.eps, xb, norm_b.weight, norm_b.bias, gb, norm_b.eps,
+                            relu=relu, a_batch=a_batch, b_batch=b_batch)
+    for n, (mean, rstd), x in ((norm_a, sa, xa), (norm_b, sb, xb)):
+        if isinstance(n, _HipBatchNorm) and n.track_running_stats:
+            with torch.no_grad():
+                m = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked + 1)
+                F.bn_update_running_(n.running_mean, n.running_var, mean, rstd, m, n.eps, x.numel() // x.shape[1])
+                n.num_batches_tracked += 1
+    return y
+
+
 def _last_leaf(m):
     while isinstance(m, nn.Sequential) and len(m) > 0:
         m = m[len(m) - 1]

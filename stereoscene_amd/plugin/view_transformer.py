@@ -21,7 +21,7 @@ import torch.nn.functional as TF
 
 from .. import functional as F
 from ..layers import (BatchNorm2d, BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
-                      fuse_relu_)
+                      fuse_relu_, norm_pair)
 from ..registry import NECKS
 
 GN2 = dict(type="GN", num_groups=2, requires_grad=True)
@@ -69,8 +69,9 @@ class BasicBlock2d(nn.Module):
         self.bn2 = BatchNorm2d(planes)
 
     def forward(self, x):
-        y = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(y), residual=x, relu=True)
+        xa, xb = F.fork(x)
+        y = self.bn1(self.conv1(xa), relu=True)
+        return self.bn2(self.conv2(y), residual=xb, relu=True)
 
 
 class _ASPPModule(nn.Module):
@@ -186,12 +187,15 @@ class hourglass(nn.Module):
         fuse_relu_(self)
 
     def forward(self, x):
-        c1 = self.conv1(x)
-        c2 = self.conv2(c1)
-        c4 = self.conv4(self.conv3(c2))
-        # relu(BN(deconv) + GN(1x1 conv)): the add and the ReLU ride in the GN kernel's epilogue
-        c5 = self.redir2[1](self.redir2[0](c2), residual=self.conv5(c4), relu=True)
-        return self.redir1[1](self.redir1[0](x), residual=self.conv6(c5), relu=True)
+        # x and c2 have two consumers each (the stride-2 conv and the 1x1 redirect): F.fork makes their data gradients meet
+        # in one buffer instead of in an elementwise add
+        xa, xb = F.fork(x)
+        c1 = self.conv1(xa)
+        c2a, c2b = F.fork(self.conv2(c1))
+        c4 = self.conv4(self.conv3(c2a))
+        # relu(BN(deconv) + GN(1x1 conv)): both normalisations, the add and the ReLU are one operator (layers.norm_pair)
+        c5 = norm_pair(self.redir2[1], self.redir2[0](c2b), self.conv5[1], self.conv5[0](c4), relu=True)
+        return norm_pair(self.redir1[1], self.redir1[0](xb), self.conv6[1], self.conv6[0](c5), relu=True)
 
 
 class GwcNet_volume_encoder(nn.Module):
@@ -224,9 +228,9 @@ class GwcNet_volume_encoder(nn.Module):
         fea = self.feature_withcam(torch.cat([features_left, features_right], 0),
                                    torch.cat([mlp_input_left, mlp_input_right], 0))
         volume = F.gwc_warp(fea[:B], fea[B:], calib, self.maxdisp, self.num_groups, self.warp_align_corners)
-        cost0 = self.dres0(volume)
-        t = self.dres1[2][0](self.dres1[0](cost0))
-        cost0 = self.dres1[2][1](t, residual=cost0)            # dres1(cost0) + cost0, add fused into the GN pass
+        c0a, c0b = F.fork(self.dres0(volume))
+        t = self.dres1[2][0](self.dres1[0](c0a))
+        cost0 = self.dres1[2][1](t, residual=c0b)              # dres1(cost0) + cost0, add fused into the GN pass
         out3 = self.dres4(self.dres3(self.dres2(cost0)))
         cost3_1 = self.classif3_1(out3)
         pred3 = F.softmax(self.classif3_2(cost3_1).squeeze(1), dim=1)
@@ -362,7 +366,8 @@ class Residual(nn.Module):
 
     def forward(self, x):
         if isinstance(self.fn, CA3D):
-            return self.fn(x, residual=x, alpha=self.alpha)
+            xa, xb = F.fork(x)
+            return self.fn(xa, residual=xb, alpha=self.alpha)
         return self.alpha * self.fn(x) + x
 
 
@@ -395,7 +400,9 @@ def attach_host_inverses(post_rots, intrins, post_rots_host=None, intrins_host=N
     the device tensors, so that the forward pass does not have to read the matrices back."""
     for dev_t, host_t in ((post_rots, post_rots_host), (intrins, intrins_host)):
         h = (host_t if host_t is not None else dev_t.cpu()).float()
-        dev_t._ssbev_inverse = torch.inverse(h[..., :3, :3]).to(dev_t.device, non_blocking=True)
+        # (version, inverse): an in-place edit of the matrix after this call (test-time augmentation, a reused staging
+        # buffer) bumps tensor._version and the stale hint is ignored by get_geometry
+        dev_t._ssbev_inverse = (dev_t._version, torch.inverse(h[..., :3, :3]).to(dev_t.device, non_blocking=True))
     return post_rots, intrins
 
 
@@ -475,14 +482,18 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         are used when present."""
         B, N, _ = trans.shape
 
-        def inv(m, hint):
-            if hint is not None and hint.device == m.device:
-                return hint
-            return torch.inverse(m.float().cpu()).to(m.device)
+        def hint_of(t):
+            h = getattr(t, "_ssbev_inverse", None)
+            return h[1] if h is not None and h[0] == t._version and h[1].device == t.device else None
 
-        intr_hint = getattr(intrins, "_ssbev_inverse", None)
+        def inv(m, hint):
+            if hint is not None:
+                return hint
+            return torch.inverse(m[..., :3, :3].float().cpu()).to(m.device)      # same 3x3 block the hint inverts
+
+        intr_hint = hint_of(intrins)
         pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
-        pts = self._apply3x3(inv(post_rots, getattr(post_rots, "_ssbev_inverse", None)), pts)
+        pts = self._apply3x3(inv(post_rots, hint_of(post_rots)), pts)
         pts = torch.cat((pts[..., :2] * pts[..., 2:3], pts[..., 2:3]), -1)
         if intrins.shape[3] == 4:
             pts = pts - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3)

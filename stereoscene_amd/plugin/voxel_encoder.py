@@ -6,7 +6,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..layers import Conv3d, build_conv_layer, build_norm_layer, build_upsample_layer, fuse_relu_
+from .. import functional as F
+from ..layers import Conv3d, build_conv_layer, build_norm_layer, build_upsample_layer, fuse_relu_, norm_pair
 from ..registry import BACKBONES, HEADS, NECKS
 from . import losses as L
 
@@ -25,9 +26,12 @@ class BasicBlock3d(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        res = x if self.downsample is None else self.downsample(x)
-        return self.bn2(self.conv2(out), residual=res, relu=True)      # relu(GN(conv2) + shortcut) in one pass
+        xa, xb = F.fork(x)                                   # two consumers: conv1 and the shortcut
+        out = self.bn1(self.conv1(xa), relu=True)
+        if self.downsample is None:
+            return self.bn2(self.conv2(out), residual=xb, relu=True)   # relu(GN(conv2) + shortcut) in one pass
+        # projected shortcut: relu(GN(conv2(out)) + GN(conv1x1(x))) as one two-norm operator
+        return norm_pair(self.bn2, self.conv2(out), self.downsample[1], self.downsample[0](xb), relu=True)
 
 
 @BACKBONES.register_module()
@@ -68,7 +72,11 @@ class CustomResNet3D(nn.Module):
         for i, layer in enumerate(self.layers):
             x = layer(x)
             if i in self.out_indices:
-                res.append(x)
+                if i + 1 < len(self.layers):
+                    x, out = F.fork(x)                       # next stage + neck
+                    res.append(out)
+                else:
+                    res.append(x)
         return res
 
 

@@ -120,15 +120,39 @@ class FlatAdamW:
                                             C.byref(cfg), norm_ptr, capi.stream()), "ssbev_adamw_step")
         return self.norm
 
+    def _compact(self, flat):
+        """The padded flat buffer -> a compact vector in parameter order.  Bucket padding depends on the world size and on
+        ``bucket_mb``; the checkpointed moments must not (a run trained on 8 GPUs resumes on 1 or 4)."""
+        r = self.reducer
+        return torch.cat([flat[r._offsets[p]:r._offsets[p] + p.numel()] for p in r.params])
+
+    def _scatter(self, flat, compact):
+        r = self.reducer
+        total = sum(p.numel() for p in r.params)
+        if compact.numel() == flat.numel() and compact.numel() != total:
+            flat.copy_(compact)                       # pre-r3 checkpoint written under the SAME padded layout
+            return
+        if compact.numel() != total:
+            raise ValueError(f"optimizer state holds {compact.numel()} elements, the model has {total} trainable parameters "
+                             f"(padded layout of this run: {flat.numel()}); it was saved under a different bucket layout")
+        flat.zero_()
+        pos = 0
+        for p in r.params:
+            k, o = p.numel(), r._offsets[p]
+            flat[o:o + k].copy_(compact[pos:pos + k])
+            pos += k
+
     def state_dict(self):
-        sd = {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        """Moments in COMPACT parameter order (reverse registration order, no bucket padding): independent of world size."""
+        sd = {"m": self._compact(self.m), "v": self._compact(self.v), "step": self.step_count, "lr": self.lr,
+              "layout": "compact"}
         if self.loss_scaler is not None:
             sd["loss_scaler"] = self.loss_scaler.state_dict()
         return sd
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+        self._scatter(self.m, sd["m"].to(self.m.device))
+        self._scatter(self.v, sd["v"].to(self.v.device))
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
         if self.loss_scaler is not None and "loss_scaler" in sd:
             self.loss_scaler.load_state_dict(sd["loss_scaler"])

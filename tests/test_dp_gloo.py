@@ -118,3 +118,35 @@ def test_flat_bucket_reduce_scatter_all_gather_world2():
     for r in range(world):
         for got, w in zip(out[r], want):
             assert torch.allclose(got, w, atol=1e-6)
+
+
+def test_optimizer_state_is_world_size_independent():
+    """ADVICE r2 (dp.py:62): bucket ends are padded to a multiple of the world size, so the flat moment buffers have a
+    world-dependent length; the checkpointed state must not (train on 8 GPUs, resume on 1)."""
+    from stereoscene_amd.dp import FlatGradAllReduce
+    from stereoscene_amd.train import FlatAdamW
+    ma, mb = _model(), _model()
+    opt8 = FlatAdamW(ma, reducer=FlatGradAllReduce(ma, bucket_mb=0.001, align=8))      # the layout of an 8-rank run
+    opt1 = FlatAdamW(mb, reducer=FlatGradAllReduce(mb, bucket_mb=64, align=1))         # ... resumed on one GPU
+    assert opt8.m.numel() != opt1.m.numel()
+    torch.manual_seed(3)
+    opt8.m.normal_()
+    opt8.v.uniform_()
+    opt8.step_count = 7
+    sd = opt8.state_dict()
+    n = sum(p.numel() for p in ma.parameters())
+    assert sd["m"].numel() == n and sd["v"].numel() == n
+    opt1.load_state_dict(sd)
+    assert opt1.step_count == 7
+    for pa, pb in zip(opt8.reducer.params, opt1.reducer.params):
+        oa, ob, k = opt8.reducer._offsets[pa], opt1.reducer._offsets[pb], pa.numel()
+        assert torch.equal(opt8.m[oa:oa + k], opt1.m[ob:ob + k])
+        assert torch.equal(opt8.v[oa:oa + k], opt1.v[ob:ob + k])
+    # and back: a 1-GPU checkpoint loads into the padded layout, padding stays zero
+    opt8b = FlatAdamW(_model(), reducer=None)
+    opt8b.load_state_dict(opt1.state_dict())
+    # a pre-r3 checkpoint (padded buffers, same layout) still loads
+    legacy = {"m": opt8.m.clone(), "v": opt8.v.clone(), "step": 3, "lr": 1e-4}
+    opt8.m.zero_()
+    opt8.load_state_dict(legacy)
+    assert torch.equal(opt8.m, legacy["m"])

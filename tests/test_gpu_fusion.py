@@ -1,0 +1,110 @@
+"""Round-3 cross-operator fusions on the GPU: gradient slots (functional.fork: the data gradients of a multi-consumer
+activation meet in one buffer inside the kernels' epilogues) and the two-norm operator, checked block by block against the
+unfused realisation of the same block and against ATen."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from stereoscene_amd import functional as F
+from stereoscene_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def _run(module, x, go):
+    module.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_(True)
+    y = module(xg)
+    y.backward(go)
+    return y.detach(), xg.grad.detach(), {k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def _ab(module, x, monkeypatch, tol=2e-5):
+    """Same block with gradient slots + two-norm operator ON and OFF: identical outputs, gradients equal to rounding."""
+    torch.manual_seed(0)
+    y0 = module(x)
+    go = S.hash_normal("fusion/go", tuple(y0.shape)).to(DEV)
+    monkeypatch.setattr(F, "GRAD_SLOTS", True)
+    monkeypatch.setattr(F, "DUAL_NORM", True)
+    ya, gxa, gpa = _run(module, x, go)
+    monkeypatch.setattr(F, "GRAD_SLOTS", False)
+    monkeypatch.setattr(F, "DUAL_NORM", False)
+    yb, gxb, gpb = _run(module, x, go)
+    assert maxdiff(ya, yb) < tol * max(1.0, yb.abs().max().item())
+    assert maxdiff(gxa, gxb) < tol * max(1.0, gxb.abs().max().item())
+    assert gpa.keys() == gpb.keys() and len(gpa) > 0
+    for k in gpa:
+        assert maxdiff(gpa[k], gpb[k]) < 5 * tol * max(1.0, gpb[k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("sp", [(8, 8, 16), (16, 12, 40)])
+def test_hourglass_with_slots_and_two_norm_operator(sp, monkeypatch):
+    from stereoscene_amd.plugin.view_transformer import hourglass
+    torch.manual_seed(1)
+    m = hourglass(32).to(DEV).train()
+    x = (S.hash_normal(f"fusion/hg{sp}", (1, 32) + sp) * 0.7).to(DEV)
+    _ab(m, x, monkeypatch)
+
+
+def test_residual_blocks_with_slots(monkeypatch):
+    from stereoscene_amd.plugin.view_transformer import BasicBlock2d, CA3D, Residual
+    from stereoscene_amd.plugin.voxel_encoder import BasicBlock3d
+    import torch.nn as nn
+    from stereoscene_amd.layers import Conv3d, build_norm_layer
+    gn32 = dict(type="GN", num_groups=32, requires_grad=True)
+    torch.manual_seed(2)
+    # identity shortcut, Winograd depth-fused data gradient accumulating into the norm's residual gradient
+    blk = BasicBlock3d(128, 128, norm_cfg=gn32).to(DEV).train()
+    _ab(blk, (S.hash_normal("fusion/bb3", (1, 128, 8, 32, 32)) * 0.5).to(DEV), monkeypatch, tol=1e-4)
+    # projected shortcut: two GroupNorms + add + ReLU as one operator; stride-2 conv and strided 1x1 conv share a slot
+    down = nn.Sequential(Conv3d(64, 128, 1, 2, 0, bias=False), build_norm_layer(gn32, 128)[1])
+    blk2 = BasicBlock3d(64, 128, 2, down, gn32).to(DEV).train()
+    _ab(blk2, (S.hash_normal("fusion/bb3d", (1, 64, 8, 16, 24)) * 0.5).to(DEV), monkeypatch, tol=5e-5)
+    # 2-D block of DepthNet (F(2,3)^2 Winograd data gradient with accumulate)
+    b2 = BasicBlock2d(64, 64).to(DEV).train()
+    _ab(b2, (S.hash_normal("fusion/bb2", (1, 64, 12, 40)) * 0.5).to(DEV), monkeypatch, tol=5e-5)
+    # CA3D under its Residual wrapper: GELU-GroupNorm residual gradient first, tap-kernel data gradient accumulates
+    ca = Residual(CA3D(32)).to(DEV).train()
+    with torch.no_grad():
+        ca.alpha.fill_(0.3)
+    _ab(ca, (S.hash_normal("fusion/ca", (1, 32, 8, 8, 40)) * 0.5).to(DEV), monkeypatch, tol=5e-5)
+
+
+def test_fork_semantics_plain_consumers():
+    """Consumers that know nothing about slots still get summed; a slot is released after backward."""
+    x = S.hash_normal("fusion/fork", (1, 8, 4, 4, 4)).to(DEV).requires_grad_(True)
+    a, b, c = F.fork(x, 3)
+    assert a._ssbev_grad_slot is b._ssbev_grad_slot
+    slot = a._ssbev_grad_slot
+    (a * 2.0 + b * 3.0 + c.square()).sum().backward()
+    assert maxdiff(x.grad, 5.0 + 2.0 * x.detach()) < 1e-6
+    assert slot.buf is None
+    # no grad / CPU: fork is the identity
+    with torch.no_grad():
+        u, v = F.fork(x)
+    assert u is x and v is x
+
+
+@pytest.mark.parametrize("case", [(1, 128, 32, 32, (4, 8, 8), True), (2, 64, 2, 32, (3, 5, 6), False)])
+def test_dual_norm_two_groupnorms(case):
+    B, Cch, Ga, Gb, sp, relu = case
+    xa = S.hash_normal(f"dn2/xa{case}", (B, Cch) + sp) * 1.5 + 0.3
+    xb = S.hash_normal(f"dn2/xb{case}", (B, Cch) + sp) * 0.7 - 0.2
+    ps = [1 + S.hash_uniform(f"dn2/wa{case}", (Cch,), -0.3, 0.3), S.hash_uniform(f"dn2/ba{case}", (Cch,), -0.2, 0.2),
+          1 + S.hash_uniform(f"dn2/wb{case}", (Cch,), -0.3, 0.3), S.hash_uniform(f"dn2/bb{case}", (Cch,), -0.2, 0.2)]
+    cs = [t.clone().requires_grad_(True) for t in (xa, xb, *ps)]
+    want = TF.group_norm(cs[0], Ga, cs[2], cs[3], 1e-5) + TF.group_norm(cs[1], Gb, cs[4], cs[5], 1e-5)
+    want = torch.relu(want) if relu else want
+    gs = [t.to(DEV).requires_grad_(True) for t in (xa, xb, *ps)]
+    got, _, _ = F.dual_norm(gs[0], gs[2], gs[3], Ga, 1e-5, gs[1], gs[4], gs[5], Gb, 1e-5, relu=relu)
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal(f"dn2/go{case}", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    for a, c in zip(gs, cs):
+        assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())

@@ -340,6 +340,48 @@ def test_batch_norm_train_and_eval():
     assert maxdiff(ev, torch.relu(TF.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5))) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(1, 32, 2, (6, 8, 10), True), (2, 64, 2, (5, 4, 6), True), (2, 32, 2, (3, 70, 9), False),
+                                  (1, 128, 32, (4, 4, 4), True)])
+def test_dual_norm_gn_plus_batchnorm(case):
+    """relu?(GroupNorm(xa) + BatchNorm_train(xb)) as ONE operator (the hourglass tails, VT:92-95) against the two ATen
+    operators: output, both input gradients, the four affine gradients and the BatchNorm running-statistics inputs."""
+    B, Cch, G, sp, relu = case
+    xa = S.hash_normal(f"dn/xa{case}", (B, Cch) + sp) * 1.5 + 0.3
+    xb = S.hash_normal(f"dn/xb{case}", (B, Cch) + sp) * 0.7 - 0.2
+    ps = [1 + S.hash_uniform(f"dn/wa{case}", (Cch,), -0.3, 0.3), S.hash_uniform(f"dn/ba{case}", (Cch,), -0.2, 0.2),
+          1 + S.hash_uniform(f"dn/wb{case}", (Cch,), -0.3, 0.3), S.hash_uniform(f"dn/bb{case}", (Cch,), -0.2, 0.2)]
+    cs = [t.clone().requires_grad_(True) for t in (xa, xb, *ps)]
+    rm, rv = torch.zeros(Cch), torch.ones(Cch)
+    want = TF.group_norm(cs[0], G, cs[2], cs[3], 1e-5) + TF.batch_norm(cs[1], rm, rv, cs[4], cs[5], True, 0.1, 1e-5)
+    want = torch.relu(want) if relu else want
+    gs = [t.to(DEV).requires_grad_(True) for t in (xa, xb, *ps)]
+    got, _sa, (mean_b, rstd_b) = F.dual_norm(gs[0], gs[2], gs[3], G, 1e-5, gs[1], gs[4], gs[5], Cch, 1e-5, relu=relu,
+                                             a_batch=False, b_batch=True)
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    grm, grv = torch.zeros(Cch, device=DEV), torch.ones(Cch, device=DEV)
+    F.bn_update_running_(grm, grv, mean_b, rstd_b, 0.1, 1e-5, xb.numel() // Cch)
+    assert maxdiff(grm, rm) < 1e-5 and maxdiff(grv, rv) < 1e-5
+    go = S.hash_normal(f"dn/go{case}", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    for a, c in zip(gs, cs):
+        assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())
+    # the layer-level entry point takes the same path (and falls back to the residual form in eval mode)
+    from stereoscene_amd.layers import BatchNorm3d, GroupNorm, norm_pair
+    gn, bn = GroupNorm(G, Cch).to(DEV), BatchNorm3d(Cch).to(DEV)
+    with torch.no_grad():
+        for t, v in zip((gn.weight, gn.bias, bn.weight, bn.bias), ps):
+            t.copy_(v)
+    y = norm_pair(gn, xa.to(DEV), bn, xb.to(DEV), relu=relu)
+    assert maxdiff(y, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert int(bn.num_batches_tracked) == 1 and maxdiff(bn.running_mean, rm) < 1e-5 and maxdiff(bn.running_var, rv) < 1e-5
+    bn.eval()
+    want_eval = TF.group_norm(xa, G, ps[0], ps[1], 1e-5) + TF.batch_norm(xb, rm, rv, ps[2], ps[3], False, 0.1, 1e-5)
+    want_eval = torch.relu(want_eval) if relu else want_eval
+    with torch.no_grad():
+        assert maxdiff(norm_pair(gn, xa.to(DEV), bn, xb.to(DEV), relu=relu), want_eval) < 2e-5 * max(1.0, want_eval.abs().max().item())
+
+
 @pytest.mark.parametrize("case", [(1, 32, 1, (6, 5, 8), True), (2, 16, 2, (3, 4, 5), False), (1, 64, 32, (4, 4, 4), True)])
 def test_group_norm_gelu_pre_activation(case):
     """GroupNorm(gelu(x)) (+ residual) with the activation folded into the norm kernels (ssbev_norm_dims.pre_act = 1:

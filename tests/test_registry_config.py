@@ -91,6 +91,12 @@ def test_geometry_buffers_and_mlp_input_on_cpu():
     attach_host_inverses(post_rots, intr)
     assert hasattr(post_rots, "_ssbev_inverse") and hasattr(intr, "_ssbev_inverse")
     assert torch.equal(vt.get_geometry(rots, trans, intr, post_rots, post_trans, bda), plain)
+    # ... and a hint goes stale when the matrix is edited in place afterwards: the geometry follows the matrix
+    with torch.no_grad():
+        post_rots[..., 0, 0] *= 1.25
+    moved = vt.get_geometry(rots, trans, intr, post_rots, post_trans, bda)
+    assert not torch.equal(moved, plain)
+    assert torch.equal(moved, vt.get_geometry(rots, trans, intr, post_rots.clone(), post_trans, bda))
     # ... and the cached host copies of the grid parameters follow in-place updates of the parameters
     o1 = vt._grid_host()
     assert o1[2] == [int(v) for v in vt.nx.tolist()] and vt._grid_host() is o1
