@@ -262,6 +262,18 @@ def main():
     save("hourglass", x=x, y_train=y_tr, y_eval=y_ev, **{"stat:" + k: v for k, v in rm.items()},
          **{"shape:" + k: np.array(v.shape) for k, v in hg.state_dict().items()})
 
+    # ---- (2b) hourglass GRADIENTS (train-mode BN) from the reference module's own autograd -----
+    # (separate file: the forward fixture above stays byte-identical)
+    hg2 = VT.hourglass(8)
+    S.fill_state_dict_(hg2, "hg.")
+    hg2.train()
+    xg = x.clone().requires_grad_(True)
+    yg = hg2(xg)
+    go = S.hash_normal("hg/go", tuple(yg.shape))
+    yg.backward(go)
+    save("hourglass_grad", x=x, go=go, y_train=yg, gx=xg.grad,
+         **{"g:" + k: p.grad for k, p in hg2.named_parameters()})
+
     # ---- (3) BRI attention + (4) volume_interaction ----------------------------------------
     print("attention / volume_interaction")
     Dv, Hv, Wv = 16, 8, 12
@@ -270,6 +282,15 @@ def main():
     att = ATT.attention(in_dim=1)
     S.fill_state_dict_(att, "att.")
     save("attention", q=q, kv=kv, out=att(q, kv), **{"w:" + k: v for k, v in sd_np(att).items()})
+    # ---- (3b) BRI attention GRADIENTS, separate file as above
+    att2 = ATT.attention(in_dim=1)
+    S.fill_state_dict_(att2, "att.")
+    qg, kvg = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    og = att2(qg, kvg)
+    goa = S.hash_normal("att/go", tuple(og.shape))
+    og.backward(goa)
+    save("attention_grad", q=q, kv=kv, go=goa, out=og, gq=qg.grad, gkv=kvg.grad,
+         **{"w:" + k: v for k, v in sd_np(att2).items()}, **{"g:" + k: p.grad for k, p in att2.named_parameters()})
     vi = VT.volume_interaction()
     S.fill_state_dict_(vi, "vi.")
     vi.eval()

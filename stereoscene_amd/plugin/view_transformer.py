@@ -25,6 +25,8 @@ from ..layers import (BatchNorm2d, BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d,
 from ..registry import NECKS
 
 GN2 = dict(type="GN", num_groups=2, requires_grad=True)
+# DepthNet on a second HIP stream next to the stereo branch (0: everything on the caller's stream)
+VT_STREAMS = os.environ.get("SSBEV_VT_STREAMS", "1") != "0"
 
 
 # ------------------------------------------------------------------------------- small blocks
@@ -506,6 +508,12 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             pts = self._apply3x3(bda[:, None], pts)
         return pts
 
+    def _side_stream(self, x):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != x.device:
+            st = self._side = torch.cuda.Stream(device=x.device)
+        return st
+
     def _grid_host(self):
         """Host copies of the (constant) voxel-grid parameters: read back once, not once per step (each read-back of a
         device-resident nn.Parameter is a stream synchronisation in the middle of the forward pass)."""
@@ -587,13 +595,29 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         calib = input[16]
         # geometry first: its tiny host-side 3x3 inverses must not stall the queued device work
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
+        B, N, C, H, W = x.shape
+        # The monocular branch (DepthNet: 2-D layers on the 48 x 160 map, kernels of a few hundred workgroups that cannot
+        # fill 256 CUs) and the stereo branch (3-D stack on the cost volume: chip-filling kernels with idle tails) are
+        # independent until the MIE block.  DepthNet runs on a second HIP stream; its backward follows on that stream by
+        # itself (autograd replays every node on its forward stream and orders the streams with events).
+        side = self._side_stream(x) if (VT_STREAMS and self.ablation != "bev_only" and x.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
+                depth_prob = self.get_depth_dist(y[:, :self.D])
         stereo = None
         if self.ablation != "bev_only":
             stereo = self.stereo_volume_net(x.squeeze(1), feature_right.squeeze(1), mlp_input, mlp_input_right,
                                             calib)["single_channel"]
-        B, N, C, H, W = x.shape
-        y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
-        depth_prob = self.get_depth_dist(y[:, :self.D])
+        if side is not None:
+            main.wait_stream(side)
+            for t in (y, depth_prob):            # allocated on the side stream, consumed on this one from here on
+                t.record_stream(main)
+        else:
+            y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
+            depth_prob = self.get_depth_dist(y[:, :self.D])
         img_feat = y[:, self.D:self.D + self.numC_Trans]
         if self.ablation == "full":
             depth_prob = self.volume_interaction(stereo, depth_prob)

@@ -211,44 +211,106 @@ def test_full_size_bf16_mode_vs_oracle():
     assert e_logit < 5e-2 * scale and agree > 0.97
 
 
-@pytest.mark.parametrize("cfg_name", ["kitti_d112", "kitti_d192"])
-def test_full_size_step_fwd_bwd_vs_oracle(cfg_name):
-    """One fwd+bwd step at the reference's own config (D=112) and at the BASELINE metric's config (D=192), 256x256x32 grid,
-    train mode (batch-stat BN, dropout off): 4 losses and every parameter gradient against the oracle's autograd."""
+_ORACLE_STEP = {}
+
+
+def _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=0):
+    """Oracle fwd+bwd of the step test (cached per case): (losses, aux, {name: grad}).  ``perturb`` = k multiplies both feature
+    maps by (1 + k * 2^-23): a one-ulp relative change of the INPUT, used to measure the oracle's own gradient sensitivity."""
+    key = (cfg_name, ac, perturb)
+    if key in _ORACLE_STEP:
+        return _ORACLE_STEP[key]
     import torch
     cfg = S.CONFIGS[cfg_name]
-    model = model_zoo.build_detector(cfg).train()
+    sd = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd0.items()}
+    oin = _oracle_inputs(smp)
+    if perturb:
+        f = 1.0 + perturb * 2.0 ** -23
+        oin[0], oin[8] = oin[0] * f, oin[8] * f
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))
+    try:
+        want, aux = O.forward_train(sd, oin, smp["gt_depths"], smp["gt_occ"], _ocfg(cfg, D, ac), train=True, stats_out={})
+        sum(want.values()).backward()
+    finally:
+        torch.set_num_threads(nt)
+    out = ({k: float(v.detach()) for k, v in want.items()}, {"logits": aux["logits"].detach()},
+           {k: v.grad for k, v in sd.items() if k in trainable and v.grad is not None})
+    _ORACLE_STEP[key] = out
+    return out
+
+
+def _l2_table(grads_a, grads_b):
+    rows = {}
+    for name, ref in grads_b.items():
+        if name in grads_a and ref.abs().max().item() >= 1e-8:
+            rows[name] = ((grads_a[name] - ref).norm() / ref.norm()).item()
+    return rows
+
+
+def _gpu_step(cfg_name, ac):
+    import torch
+    cfg = S.CONFIGS[cfg_name]
+    model = model_zoo.build_detector(cfg, warp_align_corners=ac).train()
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     smp = S.synthetic_sample(cfg, B=1, tag="fsstep")
     inputs = model_zoo.img_inputs_from_sample(smp)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    seen = {}
+    hook = model.pts_bbox_head.register_forward_hook(lambda mod, args, out: seen.update(logits=out["output_voxels"][0].detach()))
     losses = model.forward_train(img_inputs=inputs, gt_occ=smp["gt_occ"].to(DEV))
+    hook.remove()
     sum(v for k, v in losses.items() if k.startswith("loss")).backward()
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
-    sd = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd0.items()}
-    nt = torch.get_num_threads()
-    torch.set_num_threads(min(32, nt))
-    try:
-        want, _ = O.forward_train(sd, _oracle_inputs(smp), smp["gt_depths"], smp["gt_occ"],
-                                  _ocfg(cfg, model.img_view_transformer.D, True), train=True, stats_out={})
-        sum(want.values()).backward()
-    finally:
-        torch.set_num_threads(nt)
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if n in trainable and p.grad is not None}
+    return model, smp, sd0, trainable, {k: float(v.detach()) for k, v in losses.items()}, seen["logits"].cpu(), grads
+
+
+@pytest.mark.parametrize("cfg_name,ac", [("kitti_d112", True), ("kitti_d112", False), ("kitti_d192", True)])
+def test_full_size_step_fwd_bwd_vs_oracle(cfg_name, ac):
+    """One fwd+bwd step at the reference's own config (D=112, both `warp` modes) and at the BASELINE metric's config (D=192),
+    256x256x32 grid, train mode (batch-stat BN, dropout off): the TRAIN-mode coarse logits, the 4 losses and every parameter
+    gradient against the oracle's autograd."""
+    model, smp, sd0, trainable, losses, logits, grads = _gpu_step(cfg_name, ac)
+    want, aux, ograds = _oracle_step(cfg_name, ac, sd0, trainable, smp, model.img_view_transformer.D)
+    e_logit = (logits - aux["logits"]).abs().max().item()
+    print(f"{cfg_name} ac={ac} train-mode logits max-abs {e_logit:.2e} (scale {aux['logits'].abs().max().item():.2f})")
+    assert logits.shape == aux["logits"].shape and e_logit < 1e-3
     for k, v in want.items():
-        assert abs(float(losses[k].detach()) - float(v.detach())) < 1e-4 * max(1.0, abs(float(v.detach()))), (k, float(losses[k].detach()), float(v.detach()))
-    worst, checked = (0.0, None), 0
-    for name, p in model.named_parameters():
-        if name not in trainable or p.grad is None or sd[name].grad is None:
-            continue
-        ref = sd[name].grad
-        if ref.abs().max().item() < 1e-8:
-            continue
-        l2 = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
-        worst = max(worst, (l2, name))
-        checked += 1
-    print(f"{cfg_name} step: {checked} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
-    # measured 9.2e-3 on dres0.2.1.weight (profiles/r2_grad_gates.txt): 1.5 M voxels x 27 taps x 32 channels behind 20
-    # ReLU layers -- sign flips of near-zero pre-activations, not rounding; every other tensor is below 5e-3
-    assert checked > 150 and worst[0] < 2e-2, worst
+        assert abs(losses[k] - v) < 1e-4 * max(1.0, abs(v)), (k, losses[k], v)
+    rows = _l2_table(grads, ograds)
+    worst = max((v, k) for k, v in rows.items())
+    print(f"{cfg_name} ac={ac} step: {len(rows)} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
+    # measured 9.2e-3 on dres0.2.1.weight (profiles/r2_grad_gates.txt); test_gradient_gate_vs_oracle_noise_floor shows where
+    # that figure comes from (the oracle moves by as much under a one-ulp change of its input); every other tensor < 5e-3
+    assert len(rows) > 150 and worst[0] < 2e-2, worst
+
+
+def test_gradient_gate_vs_oracle_noise_floor():
+    """"ReLU sign flips is asserted, not shown".  The same L2 statistic between the ORACLE and the oracle fed
+    inputs that differ by one ulp (x * (1 + 2^-23)): if the reference's own arithmetic moves the dres0 / dres1 gradients by
+    the same ~1e-2 under a perturbation at rounding level, the GPU path's distance to the oracle on those tensors is the
+    noise floor of the problem and not a defect; everywhere the floor is low the GPU path has to be low as well."""
+    cfg_name, ac = "kitti_d112", True
+    model, smp, sd0, trainable, _losses, _logits, grads = _gpu_step(cfg_name, ac)
+    D = model.img_view_transformer.D
+    _, _, g0 = _oracle_step(cfg_name, ac, sd0, trainable, smp, D)
+    _, _, g1 = _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=1)
+    floor = _l2_table(g1, g0)               # oracle(x (1 + ulp)) vs oracle(x)
+    ours = _l2_table(grads, g0)             # GPU path vs oracle(x)
+    names = sorted(ours, key=lambda k: -ours[k])
+    lines = [f"{ours[k]:.3e}  floor {floor.get(k, float('nan')):.3e}  {k}" for k in names[:12]]
+    print("GPU-vs-oracle L2 | oracle-vs-perturbed-oracle L2 (worst 12):\n" + "\n".join(lines))
+    worst = names[0]
+    assert "dres" in worst or "stereo_volume_net" in worst, worst
+    # the tensors on which the GPU path is furthest from the oracle are the ones the oracle itself cannot pin down:
+    # its own one-ulp response there is at least a third of our distance ...
+    for k in names[:5]:
+        assert floor[k] > ours[k] / 3.0, (k, ours[k], floor[k])
+    # ... and wherever the oracle is stable (floor < 1e-4) the GPU path is within 2e-3
+    stable = [k for k in ours if floor.get(k, 1.0) < 1e-4]
+    assert len(stable) > 20
+    bad = [(k, ours[k]) for k in stable if ours[k] > 2e-3]
+    assert not bad, bad[:5]

@@ -24,22 +24,35 @@ def _run(module, x, go):
     return y.detach(), xg.grad.detach(), {k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
 
 
+def _rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
 def _ab(module, x, monkeypatch, tol=2e-5):
-    """Same block with gradient slots + two-norm operator ON and OFF: identical outputs, gradients equal to rounding."""
+    """The same block (a) with gradient slots on / off under the same norm realisation: the kernels are the same, only the
+    place of the addition moves -- equal to rounding everywhere; (b) with the two-norm operator on / off: another association
+    of the same sum, so a few ReLU decisions at |y| ~ 1e-7 may flip -- outputs equal to rounding, gradients in relative L2."""
     torch.manual_seed(0)
     y0 = module(x)
     go = S.hash_normal("fusion/go", tuple(y0.shape)).to(DEV)
-    monkeypatch.setattr(F, "GRAD_SLOTS", True)
-    monkeypatch.setattr(F, "DUAL_NORM", True)
-    ya, gxa, gpa = _run(module, x, go)
-    monkeypatch.setattr(F, "GRAD_SLOTS", False)
-    monkeypatch.setattr(F, "DUAL_NORM", False)
-    yb, gxb, gpb = _run(module, x, go)
+    runs = {}
+    for slots in (True, False):
+        for dual in (True, False):
+            monkeypatch.setattr(F, "GRAD_SLOTS", slots)
+            monkeypatch.setattr(F, "DUAL_NORM", dual)
+            runs[(slots, dual)] = _run(module, x, go)
+    for dual in (True, False):
+        (ya, gxa, gpa), (yb, gxb, gpb) = runs[(True, dual)], runs[(False, dual)]
+        assert torch.equal(ya, yb)
+        assert maxdiff(gxa, gxb) < tol * max(1.0, gxb.abs().max().item()), dual
+        assert gpa.keys() == gpb.keys() and len(gpa) > 0
+        for k in gpa:
+            assert maxdiff(gpa[k], gpb[k]) < 5 * tol * max(1.0, gpb[k].abs().max().item()), (dual, k)
+    (ya, gxa, gpa), (yb, gxb, gpb) = runs[(True, True)], runs[(True, False)]
     assert maxdiff(ya, yb) < tol * max(1.0, yb.abs().max().item())
-    assert maxdiff(gxa, gxb) < tol * max(1.0, gxb.abs().max().item())
-    assert gpa.keys() == gpb.keys() and len(gpa) > 0
+    assert _rel_l2(gxa, gxb) < 2e-3
     for k in gpa:
-        assert maxdiff(gpa[k], gpb[k]) < 5 * tol * max(1.0, gpb[k].abs().max().item()), k
+        assert _rel_l2(gpa[k], gpb[k]) < 2e-3, k
 
 
 @pytest.mark.parametrize("sp", [(8, 8, 16), (16, 12, 40)])
@@ -108,3 +121,55 @@ def test_dual_norm_two_groupnorms(case):
     got.backward(go.to(DEV))
     for a, c in zip(gs, cs):
         assert maxdiff(a.grad, c.grad) < 5e-5 * max(1.0, c.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------- reference-generated GRADIENT fixtures
+def test_hourglass_module_vs_reference_forward_and_gradients():
+    """hourglass(8) with the fill-by-key weights against what the imported reference module produced (oracle/make_golden.py
+    sections 2 / 2b): train- and eval-mode outputs, BatchNorm running statistics, input and all parameter gradients."""
+    from conftest import load_golden
+    from stereoscene_amd.plugin.view_transformer import hourglass
+    g, gg = load_golden("hourglass"), load_golden("hourglass_grad")
+    m = hourglass(8)
+    S.fill_state_dict_(m, "hg.")
+    m = m.to(DEV).train()
+    x = torch.from_numpy(gg["x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    assert maxdiff(y, torch.from_numpy(gg["y_train"])) < 2e-5
+    for k, v in g.items():
+        if k.startswith("stat:"):
+            assert maxdiff(m.state_dict()[k[5:]], torch.from_numpy(v)) < 1e-5, k
+    y.backward(torch.from_numpy(gg["go"]).to(DEV))
+    gx = torch.from_numpy(gg["gx"])
+    assert maxdiff(x.grad, gx) < 5e-5 * max(1.0, gx.abs().max().item())
+    n = 0
+    for name, p in m.named_parameters():
+        ref = torch.from_numpy(gg["g:" + name])
+        assert maxdiff(p.grad, ref) < 1e-4 * max(1.0, ref.abs().max().item()), name
+        n += 1
+    assert n >= 20
+    S.fill_state_dict_(m, "hg.")
+    m.eval()
+    with torch.no_grad():
+        assert maxdiff(m(torch.from_numpy(g["x"]).to(DEV)), torch.from_numpy(g["y_eval"])) < 2e-5
+
+
+@pytest.mark.parametrize("path", ["gemm", "flash"])
+def test_attention_module_gradients_vs_reference(path, monkeypatch):
+    from conftest import load_golden
+    from stereoscene_amd.plugin.view_transformer import attention
+    monkeypatch.setenv("SSBEV_BRI", path)
+    g = load_golden("attention_grad")
+    att = attention(1).to(DEV)
+    att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})
+    q = torch.from_numpy(g["q"]).to(DEV).requires_grad_(True)
+    kv = torch.from_numpy(g["kv"]).to(DEV).requires_grad_(True)
+    out = att(q, kv)
+    assert maxdiff(out, torch.from_numpy(g["out"])) < 2e-6
+    out.backward(torch.from_numpy(g["go"]).to(DEV))
+    for got, key in ((q.grad, "gq"), (kv.grad, "gkv")):
+        ref = torch.from_numpy(g[key])
+        assert maxdiff(got, ref) < 1e-5 * max(1.0, ref.abs().max().item()), key
+    for name, p in att.named_parameters():
+        ref = torch.from_numpy(g["g:" + name])
+        assert maxdiff(p.grad, ref) < 5e-5 * max(1.0, ref.abs().max().item()), name

@@ -63,6 +63,49 @@ def test_bri_attention():
     close(O.bri_attention(sd, "att", T(g["q"]), T(g["kv"])), g["out"], 1e-6)
 
 
+def _filled_sd(prefix, shapes):
+    sd = {}
+    for key, shp in shapes.items():
+        t = torch.zeros(tuple(int(v) for v in shp), dtype=torch.int64 if key.endswith("tracked") else torch.float32)
+        v = S.fill_value_for(prefix + key, t)
+        sd[prefix + key] = t if v is None else v.to(t.dtype)
+    return sd
+
+
+def test_hourglass_gradients_from_the_reference_autograd():
+    """the oracle's autograd through hourglass (train-mode BatchNorm) against the gradients the imported
+    reference module produced for the same input / output gradient (oracle/make_golden.py section 2b)."""
+    g, gs = load_golden("hourglass_grad"), load_golden("hourglass")
+    sd = _filled_sd("hg.", {k[6:]: v for k, v in gs.items() if k.startswith("shape:")})
+    names = [k[2:] for k in g if k.startswith("g:")]
+    for n in names:
+        sd["hg." + n] = sd["hg." + n].clone().requires_grad_(True)
+    x = T(g["x"]).clone().requires_grad_(True)
+    y = O.hourglass(sd, "hg", x, train=True, stats_out={})
+    close(y.detach(), g["y_train"], 2e-5)
+    y.backward(T(g["go"]))
+    close(x.grad, g["gx"], 2e-5 * max(1.0, float(np.abs(g["gx"]).max())))
+    assert len(names) >= 20
+    for n in names:
+        close(sd["hg." + n].grad, g["g:" + n], 5e-5 * max(1.0, float(np.abs(g["g:" + n]).max())))
+
+
+def test_bri_attention_gradients_from_the_reference_autograd():
+    """dq, dkv and the seven scalar parameters' gradients of the BRI block against the reference's."""
+    g = load_golden("attention_grad")
+    sd = {"att." + k[2:]: T(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("w:")}
+    q, kv = T(g["q"]).clone().requires_grad_(True), T(g["kv"]).clone().requires_grad_(True)
+    out = O.bri_attention(sd, "att", q, kv)
+    close(out.detach(), g["out"], 1e-6)
+    out.backward(T(g["go"]))
+    close(q.grad, g["gq"], 2e-6 * max(1.0, float(np.abs(g["gq"]).max())))
+    close(kv.grad, g["gkv"], 2e-6 * max(1.0, float(np.abs(g["gkv"]).max())))
+    names = [k[2:] for k in g if k.startswith("g:")]
+    assert len(names) == 7
+    for n in names:
+        close(sd["att." + n].grad, g["g:" + n], 1e-5 * max(1.0, float(np.abs(g["g:" + n]).max())))
+
+
 def test_volume_interaction():
     g = load_golden("volume_interaction")
     sd = {}
