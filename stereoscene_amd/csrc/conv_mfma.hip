@@ -356,30 +356,51 @@ conv_gather_kernel(const float* __restrict__ x, const float* __restrict__ wp, co
   if (LDSB && !active) return;
 
   // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lk, col = li ---------------------------
+  // voxel of accumulator row r of sub-tile mt (its coordinates live in lane `row`, any lk: fetched with shuffles)
+  auto row_vox = [&](int mt, int r, bool& rok) -> size_t {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int rb = __shfl(ob[mt], row, 64), rd = __shfl(od[mt], row, 64);
+    const int rh = __shfl(oh[mt], row, 64), rw = __shfl(ow[mt], row, 64);
+    rok = __shfl((int)mok[mt], row, 64) != 0;
+    if (g.form == 0) return (((size_t)rb * g.Do + rd) * g.Ho + rh) * g.Wo + rw;
+    return (((size_t)rb * g.Do + (rd * g.sd + par_d)) * g.Ho + (rh * g.sh + par_h)) * g.Wo + (rw * g.sw + par_w);
+  };
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (g.accumulate) {
+      // y += result (gradient slots): the old values of EIGHT rows are requested before any of them is needed -- two
+      // memory latencies per sub-tile; a load placed between the stores waits for each store in turn (+29 % on 32 -> 64)
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float oldv[8][NT];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          bool rok;
+          const size_t vox = row_vox(mt, r0 + r, rok);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = n0 + nt * 32 + li;
+            oldv[r][nt] = (rok && co < g.Cout) ? y[vox * g.Cout + co] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r0 + r] += oldv[r][nt];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      // voxel coordinates of `row` live in lane `row` (any lk): fetch them with a shuffle
-      const int rb = __shfl(ob[mt], row, 64), rd = __shfl(od[mt], row, 64);
-      const int rh = __shfl(oh[mt], row, 64), rw = __shfl(ow[mt], row, 64);
-      const bool rok = __shfl((int)mok[mt], row, 64) != 0;
-      size_t vox;
-      if (g.form == 0)
-        vox = (((size_t)rb * g.Do + rd) * g.Ho + rh) * g.Wo + rw;
-      else
-        vox = (((size_t)rb * g.Do + (rd * g.sd + par_d)) * g.Ho + (rh * g.sh + par_h)) * g.Wo + (rw * g.sw + par_w);
+      bool rok;
+      const size_t vox = row_vox(mt, r, rok);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 32 + li;
         if (rok && co < g.Cout) {
           float v = acc[mt][nt][r];
           if (bias) v += bias[co];
-          float* dst = y + vox * g.Cout + co;
-          if (g.accumulate) v += *dst;
           if (g.relu) v = fmaxf(v, 0.0f);
-          *dst = v;
+          y[vox * g.Cout + co] = v;
         }
       }
     }
@@ -1943,6 +1964,10 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
 
     const int offA = ((h0 + ra) % kTwSlots) * kTapRowF, offB = ((h0 + rb) % kTwSlots) * kTapRowF;
     float* red = red2 + (G & 1) * kTwRedF;
+    // y += result: the old values of this lane's output quad are requested here and have the whole tap walk to arrive
+    float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.accumulate && (g.N & 3) == 0 && w0 + li < g.W && nb < g.N)
+      told = *reinterpret_cast<const float4*>(Y + (((long)(b * g.D + d) * g.H + h0 + j_out) * g.W + w0 + li) * g.N + nb);
     f32x16 acc2[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -2008,10 +2033,8 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       if (wv < g.W) {
         float* dst = Y + (((long)(b * g.D + d) * g.H + h0 + j_out) * g.W + wv) * g.N + nb;
         if ((g.N & 3) == 0) {
-          if (nb < g.N) {
-            if (g.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
-            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-          }
+          if (nb < g.N)
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0] + told.x, o[1] + told.y, o[2] + told.z, o[3] + told.w);
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)

@@ -211,13 +211,21 @@ wino2d_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
     r[e * 2 + 0] = m[e * 4] + m[e * 4 + 1] + m[e * 4 + 2];
     r[e * 2 + 1] = m[e * 4 + 1] - m[e * 4 + 2] - m[e * 4 + 3];
   }
+  float oldv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.acc) {                                       // y += result: old values first, then the stores
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
+      oldv[2 * f] = y[base];
+      oldv[2 * f + 1] = y[base + (long)g.W * g.C];
+    }
+  }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const float y0 = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f], y1 = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f];
     const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-    const long b1 = base + (long)g.W * g.C;
-    y[base] = g.acc ? y[base] + y0 : y0;
-    y[b1] = g.acc ? y[b1] + y1 : y1;
+    y[base] = y0 + oldv[2 * f];
+    y[base + (long)g.W * g.C] = y1 + oldv[2 * f + 1];
   }
 }
 
@@ -458,6 +466,15 @@ wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
   for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int f = 0; f < 4; ++f) at6(r1 + a * 24 + f, 4, r2 + a * 16 + f, 4);
+  if (DA == 0 && g.acc) {                            // y += result: every old value is requested before the first store
+    float oldv[16];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) oldv[e * 4 + f] = y[(((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r2[k] += oldv[k];
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -474,8 +491,7 @@ wino43_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
 #pragma unroll
         for (int a = 0; a < 4; ++a) y[base + (long)a * g.H * g.W * g.C] = o[a];
       } else {
-        const long o = (((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c;
-        y[o] = g.acc ? y[o] + r2[e * 4 + f] : r2[e * 4 + f];
+        y[(((long)b * g.H + 4 * th + e) * g.W + 4 * tw + f) * g.C + c] = r2[e * 4 + f];
       }
     }
 }

@@ -35,7 +35,8 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, module, bucket_mb=64, process_group=None, average=True, exchange=None, align=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, average=True, exchange=None, align=None, comm_dtype=None,
+                 timeline=False):
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
@@ -48,6 +49,17 @@ class FlatGradAllReduce:
         if exchange not in ("rs_ag", "all_reduce"):
             raise ValueError(f"exchange must be 'rs_ag' or 'all_reduce', got {exchange!r}")
         self.exchange = exchange if (self.native_avg or explicit) else "all_reduce"
+        # Optional bf16 wire format (env SSBEV_DP_COMM_DTYPE=bf16): a bucket is rounded to bf16, exchanged (half the bytes over
+        # xGMI) and widened back into the fp32 flat buffer.  The SUM then happens in bf16 on the wire: relative error of the
+        # averaged gradient <= ~2^-8 per element (tests/test_dp_gloo.py measures it) -- opt-in, like the reference's fp16
+        # all-reduce under Fp16OptimizerHook; master gradients / moments stay fp32.
+        cd = comm_dtype or os.environ.get("SSBEV_DP_COMM_DTYPE", "fp32")
+        if cd not in ("fp32", "bf16"):
+            raise ValueError(f"comm_dtype must be 'fp32' or 'bf16', got {cd!r}")
+        self.comm_dtype = cd
+        self._wire = []                            # (bucket, bf16 buffer) pairs to widen back after the wait
+        # Optional per-bucket "ready" timeline (tools/bucket_timeline.py): one event when a bucket's last gradient has arrived
+        self.timeline = [] if timeline else None
         params = [p for p in module.parameters() if p.requires_grad]
         # gradients become ready roughly in reverse registration order (head -> ... -> stereo net)
         self.params = list(reversed(params))
@@ -106,7 +118,13 @@ class FlatGradAllReduce:
         """Launch the exchange of bucket b; returns the work handles (in issue order)."""
         s, e, _ = self.buckets[b]
         buf = self.flat[s:e]
-        self.bytes_exchanged += buf.numel() * 4
+        if self.comm_dtype == "bf16":
+            wire = buf.to(torch.bfloat16)
+            self.bytes_exchanged += wire.numel() * 2
+            self._wire.append((b, wire))
+            buf = wire
+        else:
+            self.bytes_exchanged += buf.numel() * 4
         if self.exchange == "rs_ag":
             n = (e - s) // self.world
             mine = buf[self.rank * n:(self.rank + 1) * n]
@@ -126,6 +144,10 @@ class FlatGradAllReduce:
         self._arrived[b] += 1
         if self._arrived[b] == self.buckets[b][2]:
             self._pack(b)
+            if self.timeline is not None and self.flat.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.timeline.append((b, ev))
             if self.active:
                 self._handles += self._exchange(b, async_op=True)
 
@@ -137,6 +159,9 @@ class FlatGradAllReduce:
         self._seen.clear()
         self.no_grad_ranges = []
         self.bytes_exchanged = 0
+        self._wire = []
+        if self.timeline is not None:
+            self.timeline = []
 
     def finish(self):
         """Wait for the in-flight buckets (call after backward()); returns bytes exchanged per rank."""
@@ -150,6 +175,10 @@ class FlatGradAllReduce:
                 if self.active:
                     self._exchange(b, async_op=False)
                     late.append(b)
+        for b, wire in self._wire:                 # bf16 wire format: widen the exchanged buckets back into the fp32 buffer
+            s, e, _ = self.buckets[b]
+            self.flat[s:e].copy_(wire)
+        self._wire = []
         if self.active and self.average and self.world > 1 and not self.native_avg and self.exchange == "all_reduce":
             self.flat.div_(self.world)             # gloo (CPU tests): SUM + scale
         self._handles = []

@@ -380,7 +380,8 @@ class _Fork(torch.autograd.Function):
         ctx.slot.buf = None
         uniq = []
         for g in gs:
-            if g is not None and not any(g.data_ptr() == u.data_ptr() and g.shape == u.shape and g.stride() == u.stride() for u in uniq):
+            # same buffer = same gradient (strides are not compared: those of size-1 axes are arbitrary)
+            if g is not None and not any(g.data_ptr() == u.data_ptr() and g.shape == u.shape for u in uniq):
                 uniq.append(g)
         total = None
         for g in uniq:

@@ -150,3 +150,34 @@ def test_optimizer_state_is_world_size_independent():
     opt8.m.zero_()
     opt8.load_state_dict(legacy)
     assert torch.equal(opt8.m, legacy["m"])
+
+
+def _bf16_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stereoscene_amd.dp import FlatGradAllReduce
+    res = {}
+    for cd in ("fp32", "bf16"):
+        m = _model()
+        red = FlatGradAllReduce(m, bucket_mb=0.001, comm_dtype=cd)
+        g = torch.Generator().manual_seed(100 + rank)
+        red.zero_grad()
+        m(torch.randn(5, 16, generator=g)).square().mean().backward()
+        nbytes = red.finish()
+        res[cd] = (red.flat.clone(), nbytes)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_format_halves_the_bytes_and_stays_within_bf16_rounding():
+    """SSBEV_DP_COMM_DTYPE=bf16: the exchanged mean gradient equals the fp32 exchange to bf16 rounding of
+    the operands and of the sum (<= 2^-7 relative to the largest gradient of a bucket), at half the bytes on the wire."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_bf16_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        (f32, b32), (bf, b16) = out[r]["fp32"], out[r]["bf16"]
+        assert b16 * 2 == b32
+        assert torch.equal(out[0]["bf16"][0], bf)                      # ranks agree bit for bit
+        err = (bf - f32).abs().max().item()
+        assert 0 < err <= 2.0 ** -7 * f32.abs().max().item(), err

@@ -11,7 +11,7 @@ FAMILIES = [
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
     ("rocBLAS / hipBLASLt GEMMs (Cijk_*: Winograd frequency GEMMs, BRI products, image-branch pointwise convs)", r"Cijk_"),
     ("weight gradient, direct (wgrad_lds/wgrad_thin/wgrad_1x1/wgrad_cf/wgrad_kernel + reduce)", r"wgrad"),
-    ("GroupNorm / BatchNorm (gn_*, bn_*)", r"gn_|bn_"),
+    ("GroupNorm / BatchNorm (gn_*, gn2_*, bn_*)", r"gn_|gn2_|bn_"),
     ("weight packing (pack_*)", r"pack_"),
     ("cost volume, lift/splat, scatter prep, DCN, softmax, losses, trilinear, image-branch ops", r"gwc_|pool_|lift_|voxel_index|histogram|scan_|fill_kernel|canonicalise|dcn_|softmax_axis|softmax_row|occ_loss|trilinear|bri_|dw_|swish|chan_|adamw|sumsq"),
 ]
