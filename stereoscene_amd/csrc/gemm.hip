@@ -74,11 +74,13 @@ __device__ __forceinline__ int xcd_logical(int bid, int nwg) {
 
 // ---------------------------------------------------------------------------------------------------------------- NN / NT
 // BT = false: B is [K][N] (NN);  BT = true: B is [N][K] (NT).  D2S: 0 = plain, 1 = NN scatters its C rows, 2 = NT gathers its A rows.
-template <int WN, bool BT, int D2S>
+// MW = 32-row tiles per wave along M: 2 (workgroup tile 128 rows) or 3 (192 rows: the BRI products have M = D = 192 rows, on
+// which 128-row tiles spend a quarter of their MFMAs on padding)
+template <int WN, bool BT, int D2S, int MW = 2>
 __global__ void __launch_bounds__(256, 2)
 gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias, float* __restrict__ Cm,
                GemmGeom g) {
-  constexpr int BM = 128, BN = 64 * WN, BK = 32;
+  constexpr int BM = 64 * MW, BN = 64 * WN, BK = 32;
   constexpr int AF = BM * BK, BF = BK * BN, SF = AF + BF;         // floats per stage
   constexpr int AI = AF / 256, BI = BF / 256;                     // 1 KiB LDS-DMA instructions per stage
   constexpr int AE = AI / 4, BE = BI / 4;                         // ... per wave
@@ -140,9 +142,9 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     }
   };
 
-  gf32x16 acc[2][WN];
+  gf32x16 acc[MW][WN];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
@@ -157,11 +159,11 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     const float* as = lds + buf * SF;
     const float* bs = as + AF;
     // fragments of k-step q+1 are read from LDS before the MFMAs of k-step q are issued (explicit software pipeline)
-    gv4f ac[2], bc[WN], an[2], bn[WN];
-    auto fetch = [&](int q, gv4f (&a)[2], gv4f (&bf)[WN]) {
+    gv4f ac[MW], bc[WN], an[MW], bn[WN];
+    auto fetch = [&](int q, gv4f (&a)[MW], gv4f (&bf)[WN]) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int row = (wm * 2 + mt) * 32 + li;
+      for (int mt = 0; mt < MW; ++mt) {
+        const int row = (wm * MW + mt) * 32 + li;
         a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ (row & 7)) << 2));
       }
 #pragma unroll
@@ -183,12 +185,12 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt][t], bc[nt][t], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) ac[mt] = an[mt];
+      for (int mt = 0; mt < MW; ++mt) ac[mt] = an[mt];
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
     }
@@ -208,17 +210,17 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     bv[nt] = bias ? bias[co] : 0.0f;
     coloff[nt] = D2S == 1 ? d2s_tapoff(g, n / g.d2s_Co) + co : n;
   }
-  long rowbase[2][16];
+  long rowbase[MW][16];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = min(m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, g.M - 1);
+      const int m = min(m0 + (wm * MW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, g.M - 1);
       rowbase[mt][r] = D2S == 1 ? g.rowoff[m] : (long)m * g.ldc;
     }
   if (D2S == 1) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rowbase[mt][r]));     // all offsets have landed: plain registers from here
   }
@@ -229,10 +231,10 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     const int n = n0 + (wn * WN + nt) * 32 + li;
     if (n >= g.N) continue;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = m0 + (wm * MW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (m < g.M) {
           float v = acc[mt][nt][r] + bv[nt];
           if (g.relu) v = fmaxf(v, 0.0f);
@@ -522,10 +524,20 @@ int nn_chunks(const ssbev_gemm_dims* d, int tiles) {
   return std::min(nchunk, 16);
 }
 
+// rows of the workgroup tile: 192 when that wastes fewer padded rows than 128 (M = 192: 0 % instead of 25 %)
+int pick_bm(const ssbev_gemm_dims* d, int wn) {
+  if (d->d2s_kd > 0 || wn != 2) return 128;
+  static const bool enabled = !(getenv("SSBEV_GEMM_BM192") && atoi(getenv("SSBEV_GEMM_BM192")) == 0);     // A/B hook
+  if (!enabled) return 128;
+  const long p128 = (long)((d->M + 127) / 128) * 128, p192 = (long)((d->M + 191) / 192) * 192;
+  return p192 * 8 <= p128 * 7 ? 192 : 128;              // at least 1/8 fewer MFMA rows
+}
+
 template <bool BT>
 size_t nn_workspace(const ssbev_gemm_dims* d) {
   const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
-  const int tiles = ((d->M + 127) / 128) * ((d->N + 64 * wn - 1) / (64 * wn));
+  const int bm = pick_bm(d, wn);
+  const int tiles = ((d->M + bm - 1) / bm) * ((d->N + 64 * wn - 1) / (64 * wn));
   const int nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, tiles);
   return nchunk > 1 ? (size_t)nchunk * d->batch * d->M * d->N * sizeof(float) : 0;
 }
@@ -537,7 +549,8 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
   fill_geom(g, d);
   const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
   const int BN = 64 * wn;
-  g.mblocks = (d->M + 127) / 128;
+  const int bm = pick_bm(d, wn);
+  g.mblocks = (d->M + bm - 1) / bm;
   g.nblocks = (d->N + BN - 1) / BN;
   g.nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, g.mblocks * g.nblocks);
   const int nst = (d->K + 31) / 32;
@@ -551,7 +564,7 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
     kbias = nullptr;
   }
   const long nwg = (long)g.batch * g.nchunk * g.mblocks * g.nblocks;
-  const size_t lds = (size_t)2 * (128 * 32 + 32 * BN) * sizeof(float);       // 64 / 48 KiB
+  const size_t lds = (size_t)2 * (bm * 32 + 32 * BN) * sizeof(float);        // 64 / 48 KiB (80 KiB for 192-row tiles)
   constexpr int DM = BT ? 2 : 1;          // what d2s means for this form
 #define SSBEV_GEMM_LAUNCH(WN_, D2S_)                                                                                       \
   do {                                                                                                                     \
@@ -562,6 +575,12 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, kbias, dst, g);                                \
   } while (0)
   if (d->d2s_kd > 0) { if (wn == 2) SSBEV_GEMM_LAUNCH(2, DM); else SSBEV_GEMM_LAUNCH(1, DM); }
+  else if (bm == 192) {
+    auto kern = gemm_nn_kernel<2, BT, 0, 3>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, kbias, dst, g);
+  }
   else { if (wn == 2) SSBEV_GEMM_LAUNCH(2, 0); else SSBEV_GEMM_LAUNCH(1, 0); }
 #undef SSBEV_GEMM_LAUNCH
   if (g.nchunk > 1) {

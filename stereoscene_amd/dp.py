@@ -99,6 +99,9 @@ class FlatGradAllReduce:
 
     def _pack(self, b):
         """Move the stolen gradient tensors of bucket b into the flat buffer (one multi-tensor copy)."""
+        if self.flat.is_cuda:
+            from . import streams
+            streams.join(self.flat.device)      # weight gradients computed on the side stream (streams.py) are read here
         dst, src = [], []
         for p in self._members[b]:
             view = self._views[p]

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import capi
+from . import capi, streams
 
 # -------------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream
@@ -290,14 +290,25 @@ class _LiftSplat(torch.autograd.Function):
         return gd, from_cl(gf), None, None, None, None, None, None
 
 
-def lift_splat(depth_prob, img_feat, geom, bx, dx, nx, grid_host=None):
-    """Fused Lift+Splat: depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W], geom [B,N,D,H,W,3]
-    -> bev [B,C,X,Y,Z] (channels-last memory).  Equivalent of VT:517-523."""
-    B, N = geom.shape[:2]
+def lift_splat_tables(geom, bx, dx, nx, grid_host=None):
+    """The frustum -> voxel tables of one geometry: (vox, starts, order).  They depend on the calibration only (SURVEY 8 row
+    a10: "static -> cacheable"): a caller that sees the same calibration again can keep them (``lift_splat(tables=...)``)."""
+    B = geom.shape[0]
     n = grid_host[2] if grid_host is not None else [int(v) for v in nx.tolist()]
     with torch.no_grad():
         vox = voxel_index(geom, bx, dx, nx, grid_host=grid_host)
         starts, order = pool_prepare(vox, B, n[0], n[1], n[2])
+    return vox, starts, order
+
+
+def lift_splat(depth_prob, img_feat, geom, bx, dx, nx, grid_host=None, tables=None):
+    """Fused Lift+Splat: depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W], geom [B,N,D,H,W,3]
+    -> bev [B,C,X,Y,Z] (channels-last memory).  Equivalent of VT:517-523.  ``tables`` = lift_splat_tables(geom, ...) of a
+    previous call with the same geometry (``geom`` may then be None)."""
+    n = grid_host[2] if grid_host is not None else [int(v) for v in nx.tolist()]
+    vox, starts, order = tables if tables is not None else lift_splat_tables(geom, bx, dx, nx, grid_host)
+    B = starts.numel() // (n[0] * n[1] * n[2])
+    N = depth_prob.shape[0] // B
     return _LiftSplat.apply(depth_prob, img_feat, vox, starts, order, B, N, tuple(n))
 
 
@@ -528,6 +539,40 @@ class _ConvNd(torch.autograd.Function):
             w5 = None                                       # nobody needs the padded operands
         d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), *args) if w5 is not None else d0
         gx = gw = gb = None
+
+        def weight_gradient():
+            pointwise = (not transposed and tuple(weight.shape[2:]) == (1, 1, 1) and stride == (1, 1, 1) and padding == (0, 0, 0)
+                         and not kpad and not cpad and not tpad and weight.shape[0] <= 128 and weight.shape[1] <= 128
+                         and gcl0.numel() // Cout_g >= 32768)
+            if pointwise and OWN_GEMM and PRECISION == "fp32":
+                # 1x1x1 layers on the cost volume: gw[co][ci] = sum_rows gy[row][co] x[row][ci], an HBM-streaming skinny TN product
+                with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
+                    gw = gemm_tn(gcl0.reshape(-1, Cout_g), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
+            else:
+                if thin_w:
+                    xw, gw_src, dw, wshape = xcl, gcl0, d0, tuple(weight.shape)
+                else:
+                    xw, gw_src, dw, wshape = xcl, gcl, d, tuple(w5.shape)
+                    if tpad:      # forward ran on the unpadded thin input (conv_thinin_kernel)
+                        xw = torch.nn.functional.pad(xcl, (0, tpad))
+                        wshape = (wshape[0], wshape[1] + tpad) + wshape[2:]
+                        dw = _conv_dims(tuple(xw.shape), wshape, *args)
+                gwp = torch.empty(wshape, dtype=torch.float32, device=gy.device)
+                ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(dw)), gy.device)
+                with _span("conv_wgrad", conv_flops(dw), conv_bytes(dw), _conv_tag(dw, "wgrad")):
+                    capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xw), capi.ptr(gw_src), capi.ptr(gwp), C.byref(dw),
+                                                         capi.ptr(ws), ws.numel(), capi.stream()),
+                               "ssbev_conv_bwd_weight")
+                gw = gwp if tuple(wshape) == tuple(weight.shape) else gwp[: weight.shape[0], : weight.shape[1]].contiguous()
+            return gw
+
+        # the weight gradient is a leaf of the backward chain: on the side stream it runs NEXT to the data gradient and the
+        # normalisation passes that follow it instead of in front of them (streams.py)
+        gw_side = want_gw and streams.wgrad_on_side(weight)
+        if gw_side:
+            with streams.on_side(gy.device, xcl, gcl0, gcl) as side:
+                gw = weight_gradient()
+                side.publish(gw)
         if want_gx:
             dd, gdl, wd = (d0, gcl0, weight.detach()) if thin_d else (d, gcl, w5)
             slot = ctx.slot if (not kpad and not thin_d and lib.ssbev_conv_kernel_class(C.byref(dd), 1) not in (4, 5)) else None
@@ -549,29 +594,8 @@ class _ConvNd(torch.autograd.Function):
             if kpad:
                 gxcl = gxcl[..., : xcl.shape[-1] - kpad]
             gx = from_cl(gxcl)
-        pointwise = (not transposed and tuple(weight.shape[2:]) == (1, 1, 1) and stride == (1, 1, 1) and padding == (0, 0, 0)
-                     and not kpad and not cpad and not tpad and weight.shape[0] <= 128 and weight.shape[1] <= 128
-                     and gcl0.numel() // Cout_g >= 32768)
-        if want_gw and pointwise and OWN_GEMM and PRECISION == "fp32":
-            # 1x1x1 layers on the cost volume: gw[co][ci] = sum_rows gy[row][co] x[row][ci], an HBM-streaming skinny TN product
-            with _span("conv_wgrad", conv_flops(d), conv_bytes(d), _conv_tag(d, "wgrad")):
-                gw = gemm_tn(gcl0.reshape(-1, Cout_g), xcl.reshape(-1, xcl.shape[-1])).view_as(weight)
-        elif want_gw:
-            if thin_w:
-                xw, gw_src, dw, wshape = xcl, gcl0, d0, tuple(weight.shape)
-            else:
-                xw, gw_src, dw, wshape = xcl, gcl, d, tuple(w5.shape)
-                if tpad:      # forward ran on the unpadded thin input (conv_thinin_kernel)
-                    xw = torch.nn.functional.pad(xcl, (0, tpad))
-                    wshape = (wshape[0], wshape[1] + tpad) + wshape[2:]
-                    dw = _conv_dims(tuple(xw.shape), wshape, *args)
-            gwp = torch.empty(wshape, dtype=torch.float32, device=gy.device)
-            ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(dw)), gy.device)
-            with _span("conv_wgrad", conv_flops(dw), conv_bytes(dw), _conv_tag(dw, "wgrad")):
-                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xw), capi.ptr(gw_src), capi.ptr(gwp), C.byref(dw),
-                                                     capi.ptr(ws), ws.numel(), capi.stream()),
-                           "ssbev_conv_bwd_weight")
-            gw = gwp if tuple(wshape) == tuple(weight.shape) else gwp[: weight.shape[0], : weight.shape[1]].contiguous()
+        if want_gw and not gw_side:
+            gw = weight_gradient()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gcl0.reshape(-1, Cout_g).sum(0)
         return gx, gw, gb, None, None, None, None, None, None
@@ -1049,23 +1073,33 @@ class _WinoConvDF(torch.autograd.Function):
         lib = capi.load()
         w = weight.detach().contiguous()
         gx = gw = None
+
+        def weight_gradient():
+            R = B * D * (H // 4) * (W // 4)
+            with _span("wino_transform", 0.0, 4.0 * gcl.numel() * 3.25, "winoDF wgrad adjoint"):
+                Z = _wino_call("ssbev_wino43_2d_output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (36, R, Cout))
+            dims = capi.WinoDims(B, D, H, W, Cin)
+            ws = _ws(lib.ssbev_wino43_df_wgrad_workspace(C.byref(dims), Cout), gy.device)
+            gwt = torch.empty_like(w)
+            nby = 4.0 * (P.numel() + Z.numel() + 144 * Cin * Cout)
+            with _span("conv_wino_fused_wgrad", fl, nby, f"winoDF wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / 6.0):
+                capi.check(lib.ssbev_wino43_df_wgrad(capi.ptr(P), capi.ptr(Z), capi.ptr(gwt), C.byref(dims), Cout, capi.ptr(ws),
+                                                     ws.numel(), capi.stream()), "ssbev_wino43_df_wgrad")
+            return gwt
+
+        gw_side = ctx.needs_input_grad[1] and streams.wgrad_on_side(weight)
+        if gw_side:                          # leaf of the backward chain: next to the data gradient, not in front of it
+            with streams.on_side(gy.device, gcl, P) as side:
+                gw = weight_gradient()
+                side.publish(gw)
         if ctx.needs_input_grad[0]:
             into = _slot_target(ctx.slot, torch.empty((B, D, H, W, Cin), device="meta"))
             gxcl, _ = _wino_df_gemm(gcl, w, B, D, H, W, Cout, Cin, 1, f"winoDF dgrad {Cin}->{Cout} {D}x{H}x{W}", fl, into=into)
             if ctx.slot is not None:
                 ctx.slot.buf = gxcl
             gx = from_cl(gxcl)
-        if ctx.needs_input_grad[1]:
-            R = B * D * (H // 4) * (W // 4)
-            with _span("wino_transform", 0.0, 4.0 * gcl.numel() * 3.25, "winoDF wgrad adjoint"):
-                Z = _wino_call("ssbev_wino43_2d_output_adjoint", gcl, capi.WinoDims(B, D, H, W, Cout), (36, R, Cout))
-            dims = capi.WinoDims(B, D, H, W, Cin)
-            ws = _ws(lib.ssbev_wino43_df_wgrad_workspace(C.byref(dims), Cout), gy.device)
-            gw = torch.empty_like(w)
-            nby = 4.0 * (P.numel() + Z.numel() + 144 * Cin * Cout)
-            with _span("conv_wino_fused_wgrad", fl, nby, f"winoDF wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / 6.0):
-                capi.check(lib.ssbev_wino43_df_wgrad(capi.ptr(P), capi.ptr(Z), capi.ptr(gw), C.byref(dims), Cout, capi.ptr(ws),
-                                                     ws.numel(), capi.stream()), "ssbev_wino43_df_wgrad")
+        if ctx.needs_input_grad[1] and not gw_side:
+            gw = weight_gradient()
         return gx, gw, None
 
 
@@ -1163,14 +1197,23 @@ class _WinoConv(torch.autograd.Function):
                     ctx.slot.buf = gxcl
             gx = from_cl(gxcl)
         if ctx.needs_input_grad[1]:
-            with _span("conv_winograd_wgrad", fl, nby, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
-                if fused:
-                    V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
-                Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
-                gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else (gemm_tn(V, Z, tag="wino wgrad gemm") if own_gemm_site("wino") else torch.bmm(V.transpose(1, 2), Z))
-            gw = torch.empty_like(w)
-            wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
-            capi.check(wg(capi.ptr(gU), capi.ptr(gw), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
+            def weight_gradient(V=V):
+                with _span("conv_winograd_wgrad", fl, nby, f"wino{vtag} wgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
+                    if fused:
+                        V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
+                    Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
+                    gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else (gemm_tn(V, Z, tag="wino wgrad gemm") if own_gemm_site("wino") else torch.bmm(V.transpose(1, 2), Z))
+                gwt = torch.empty_like(w)
+                wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
+                capi.check(wg(capi.ptr(gU), capi.ptr(gwt), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
+                return gwt
+
+            if streams.wgrad_on_side(weight):    # after the data gradient here (rocBLAS workspaces are per stream: no reordering)
+                with streams.on_side(gy.device, gcl, V) as side:
+                    gw = weight_gradient()
+                    side.publish(gw)
+            else:
+                gw = weight_gradient()
         return gx, gw, None
 
 

@@ -508,11 +508,27 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             pts = self._apply3x3(bda[:, None], pts)
         return pts
 
+    def _cached_tables(self, *calib):
+        """Frustum geometry -> voxel ids -> CSR of this calibration.  With ``geometry_cache = True`` (opt-in attribute; the
+        reference recomputes per forward, BD:123-156 + VT:432-476) the tables of the previous call are reused when the SAME
+        six calibration tensors come in again unmodified (identity + version counter; the cache holds references, so their
+        storage cannot be recycled under it) and the grid parameters are unchanged -- SemanticKITTI calibration is constant
+        per sequence.  Off by default: bench.py's headline always recomputes."""
+        grid = self._grid_host()
+        if getattr(self, "geometry_cache", False):
+            c = getattr(self, "_geo_cache", None)
+            if c is not None and c[2] is grid and len(c[0]) == len(calib) and \
+                    all(a is b and a._version == v for a, (b, v) in zip(calib, c[0])):
+                return c[1]
+        geom = self.get_geometry(*calib)
+        tables = F.lift_splat_tables(geom, self.bx, self.dx, self.nx, grid_host=grid)
+        if getattr(self, "geometry_cache", False):
+            self._geo_cache = ([(t, t._version) for t in calib], tables, grid)
+        return tables
+
     def _side_stream(self, x):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != x.device:
-            st = self._side = torch.cuda.Stream(device=x.device)
-        return st
+        from .. import streams
+        return streams.side_stream(x.device)[1]      # the one side stream of the device (shared with the weight gradients)
 
     def _grid_host(self):
         """Host copies of the (constant) voxel-grid parameters: read back once, not once per step (each read-back of a
@@ -594,7 +610,7 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         feature_right, mlp_input_right = input[8], input[15]
         calib = input[16]
         # geometry first: its tiny host-side 3x3 inverses must not stall the queued device work
-        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
+        tables = self._cached_tables(rots, trans, intrins, post_rots, post_trans, bda)
         B, N, C, H, W = x.shape
         # The monocular branch (DepthNet: 2-D layers on the 48 x 160 map, kernels of a few hundred workgroups that cannot
         # fill 256 CUs) and the stereo branch (3-D stack on the cost volume: chip-filling kernels with idle tails) are
@@ -623,5 +639,5 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             depth_prob = self.volume_interaction(stereo, depth_prob)
         elif self.ablation == "stereo_only":
             depth_prob = stereo
-        bev_feat = F.lift_splat(depth_prob, img_feat, geom, self.bx, self.dx, self.nx, grid_host=self._grid_host())
+        bev_feat = F.lift_splat(depth_prob, img_feat, None, self.bx, self.dx, self.nx, grid_host=self._grid_host(), tables=tables)
         return bev_feat, depth_prob

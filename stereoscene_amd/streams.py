@@ -1,0 +1,101 @@
+"""Second HIP stream for work that hangs off the critical chain of the backward pass.
+
+The data-gradient chain of backward is strictly sequential (layer L's needs layer L+1's), and between its matrix-core
+kernels sit the HBM-bound normalisation passes.  The WEIGHT gradients depend only on (saved input, incoming gradient): they
+are leaves of that chain.  Launched on a second stream they run next to the chain -- an MFMA-bound weight-gradient kernel
+shares the CUs with a streaming GroupNorm pass of the chain, and the idle tail of one kernel is filled by the head of the
+other -- instead of in front of it.  (HIP orders kernels of ONE stream with a barrier even when they are independent.)
+
+ONE side stream per device serves both users (the weight gradients and view_transformer's DepthNet branch): with two side
+streams next to the caller's -- three HIP streams waiting on one another's events -- the step dead-locked on the device in
+about half of the runs on ROCm 7.2 (never with two streams; bisected in profiles/r3_stream_hang_bisect.txt), although every
+wait refers to work enqueued earlier.  Work that is already ON the side stream (DepthNet's backward) runs in place.
+
+Contract (what keeps this safe with autograd and the caching allocator):
+  * ``with on_side(*reads)``: the side stream first waits for everything queued on the caller's stream (the tensors in
+    ``reads`` were produced there; they are also registered with the allocator as used on the side stream);
+  * tensors allocated inside the block and handed back to the caller's stream are passed through ``publish`` (registered as
+    used on the caller's stream);
+  * the caller's stream does NOT wait when the block ends.  It waits (``join``) when somebody is about to READ a result:
+    dp.FlatGradAllReduce._pack (gradient bucket complete) and an end-of-backward callback queued on the autograd engine, so
+    after ``backward()`` returns every gradient is ordered before later work on the caller's stream.
+  * a weight gradient is only computed on the side stream when autograd will merely STORE it (a leaf parameter whose
+    ``.grad is None``); an existing ``.grad`` would be read by AccumulateGrad on the caller's stream straight away, and so
+    would the gradient of a non-leaf weight by the node that produced it.
+"""
+import os
+
+import torch
+
+WGRAD_STREAM = os.environ.get("SSBEV_WGRAD_STREAM", "1") != "0"
+
+_SIDE = {}
+_DIRTY = set()          # device indices whose side stream holds work the caller's stream has not waited for
+_CB_QUEUED = set()
+
+
+def side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+    return idx, st
+
+
+def join(device=None):
+    """Make the current stream wait for the side stream(s) (no-op when they are idle)."""
+    for idx in list(_DIRTY):
+        if device is None or device.index in (None, idx):
+            torch.cuda.current_stream(idx).wait_stream(_SIDE[idx])
+            _DIRTY.discard(idx)
+
+
+def _end_of_backward():
+    _CB_QUEUED.clear()
+    join()
+
+
+class on_side:
+    def __init__(self, device, *reads):
+        self.device, self.reads = device, reads
+
+    def __enter__(self):
+        self.idx, self.side = side_stream(self.device)
+        self.main = torch.cuda.current_stream(self.idx)
+        self.inline = self.main == self.side       # already on the side stream (DepthNet's backward lives there): run in place
+        if self.inline:
+            return self
+        self.side.wait_stream(self.main)
+        for t in self.reads:
+            if t is not None:
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def publish(self, *tensors):
+        if self.inline:
+            return
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        if self.inline:
+            return False
+        self.ctx.__exit__(*exc)
+        _DIRTY.add(self.idx)
+        if self.idx not in _CB_QUEUED:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+                _CB_QUEUED.add(self.idx)
+            except RuntimeError:          # not inside an engine run (a backward() called by hand): order it right here
+                join()
+        return False
+
+
+def wgrad_on_side(weight):
+    """Should this weight gradient go to the side stream?  (Only when autograd will merely store it, see above.)"""
+    # a LEAF parameter: its gradient goes to AccumulateGrad, which keeps the tensor when .grad is None; the gradient of a
+    # computed weight (CA3D folds its channel gate into the weights) is read by the next backward node at once
+    return WGRAD_STREAM and weight.is_cuda and weight.is_leaf and weight.grad is None

@@ -178,13 +178,15 @@ def test_full_size_forward_batch2_vs_oracle():
     assert (logits[0] - logits[1]).abs().max().item() > 1e-2          # the two samples really differ
 
 
-def test_full_size_bf16_mode_vs_oracle():
+@pytest.mark.parametrize("cfg_name,B", [("kitti_d192", 1), ("kitti_d112", 2)])
+def test_full_size_bf16_mode_vs_oracle(cfg_name, B):
     """BASELINE configs[3] at the KITTI size: the opt-in bf16 mode (bf16 MFMA operands in the conv / Winograd kernels, fp32
     storage, norms and losses) against the fp32 ORACLE -- an error budget, not parity ("report max-abs and
-    argmax agreement"): max-abs below 5 % of the logit scale, argmax agreement above 97 %."""
-    cfg = S.CFG_K192
+    argmax agreement"): max-abs below 5 % of the logit scale, argmax agreement above 97 %.  B = 2 is the per-GPU shape
+    configs[3] names (two samples per GPU; VERDICT r2: "bf16 with B=2 has no test")."""
+    cfg = S.CONFIGS[cfg_name]
     model = model_zoo.build_detector(cfg).eval()
-    smp = S.synthetic_sample(cfg, B=1, tag="fsbf16")
+    smp = S.synthetic_sample(cfg, B=B, tag="fsbf16")
     inputs = model_zoo.img_inputs_from_sample(smp)
     F.set_precision("bf16")
     try:
@@ -205,7 +207,7 @@ def test_full_size_bf16_mode_vs_oracle():
     e_logit = (logits.float().cpu() - aux["logits"]).abs().max().item()
     agree = (logits.float().cpu().argmax(1) == aux["logits"].argmax(1)).float().mean().item()
     e_depth = (depth.float().cpu() - aux["depth_prob"]).abs().max().item()
-    print(f"kitti_d192 bf16 mode vs fp32 oracle: logits max-abs {e_logit:.3f} (scale {scale:.2f}), argmax agreement {agree:.4f}, "
+    print(f"{cfg_name} B={B} bf16 mode vs fp32 oracle: logits max-abs {e_logit:.3f} (scale {scale:.2f}), argmax agreement {agree:.4f}, "
           f"depth_prob max-abs {e_depth:.2e}")
     assert e_logit > 1e-3, "bf16 mode did not engage"
     assert e_logit < 5e-2 * scale and agree > 0.97
