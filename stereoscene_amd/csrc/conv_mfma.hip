@@ -1974,17 +1974,27 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[q][r] = 0.0f;
     float4 va[2], vb[2];
-    auto fetch = [&](int c, float4 (&v)[2]) {
+    // The raw ring rows of column c + 1 are REQUESTED right after the first MFMA of column c and COMBINED (V = xa +- xb,
+    // 8 VALU ops) only after all eight MFMAs of column c have been issued: the LDS latency is covered by seven MFMAs in the
+    // pipe.  (r2 did request + combine in one step after the first MFMA: the combination waited ~150 cycles for the LDS
+    // with one 64-cycle MFMA in flight, on a kernel that has only two waves per SIMD to hide it.)
+    float4 rxa[2], rxb[2];
+    auto request = [&](int c) {
       const int u = li + c % 3;
       const float* colp = ring + (c / 3) * kTwPlaneF + u * 32;
       const int sw = u & 7;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int o = ((2 * (2 * kg + q) + lk) ^ sw) << 2;
-        const float4 xa = *reinterpret_cast<const float4*>(colp + offA + o);
-        const float4 xb = *reinterpret_cast<const float4*>(colp + offB + o);
-        v[q] = make_float4(fmaf(sgn, xb.x, xa.x), fmaf(sgn, xb.y, xa.y), fmaf(sgn, xb.z, xa.z), fmaf(sgn, xb.w, xa.w));
+        rxa[q] = *reinterpret_cast<const float4*>(colp + offA + o);
+        rxb[q] = *reinterpret_cast<const float4*>(colp + offB + o);
       }
+    };
+    auto combine = [&](float4 (&v)[2]) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        v[q] = make_float4(fmaf(sgn, rxb[q].x, rxa[q].x), fmaf(sgn, rxb[q].y, rxa[q].y), fmaf(sgn, rxb[q].z, rxa[q].z),
+                           fmaf(sgn, rxb[q].w, rxa[q].w));
     };
     auto mm_head = [&](int c, const float4 (&v)[2]) { acc2[0] = mfma32(wr[c][0], v[0].x, acc2[0]); };
     auto mm_tail = [&](int c, const float4 (&v)[2]) {
@@ -1996,21 +2006,26 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       acc2[0] = mfma32(wr[c][3], v[0].w, acc2[0]);
       acc2[1] = mfma32(wr[c][7], v[1].w, acc2[1]);
     };
-    fetch(0, va);
+    request(0);
+    combine(va);
 #pragma unroll
     for (int c = 0; c < 9; c += 2) {
       mm_head(c, va);
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < 9) fetch(c + 1, vb);
+      if (c + 1 < 9) request(c + 1);
       __builtin_amdgcn_sched_barrier(0);
       mm_tail(c, va);
       __builtin_amdgcn_sched_barrier(0);
       if (c + 1 < 9) {
+        combine(vb);
+        __builtin_amdgcn_sched_barrier(0);
         mm_head(c + 1, vb);
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < 9) fetch(c + 2, va);
+        if (c + 2 < 9) request(c + 2);
         __builtin_amdgcn_sched_barrier(0);
         mm_tail(c + 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < 9) combine(va);
         __builtin_amdgcn_sched_barrier(0);
       }
     }

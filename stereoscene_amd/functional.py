@@ -508,6 +508,7 @@ class _ConvNd(torch.autograd.Function):
         ctx.save_for_backward(xcl, weight)
         ctx.cfg = (stride, padding, dilation, transposed, output_padding, 0 if thin_in else kpad, bias is not None)
         ctx.thin_in = thin_in
+        ctx.bias_leaf = bias is not None and bias.is_leaf and bias.grad is None
         return from_cl(y)
 
     @staticmethod
@@ -569,10 +570,14 @@ class _ConvNd(torch.autograd.Function):
         # the weight gradient is a leaf of the backward chain: on the side stream it runs NEXT to the data gradient and the
         # normalisation passes that follow it instead of in front of them (streams.py)
         gw_side = want_gw and streams.wgrad_on_side(weight)
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        gb_side = gw_side and want_gb and ctx.bias_leaf
         if gw_side:
             with streams.on_side(gy.device, xcl, gcl0, gcl) as side:
                 gw = weight_gradient()
-                side.publish(gw)
+                if gb_side:                                   # the bias gradient (a column sum of gy) is a leaf as well
+                    gb = gcl0.reshape(-1, Cout_g).sum(0)
+                side.publish(gw, gb)
         if want_gx:
             dd, gdl, wd = (d0, gcl0, weight.detach()) if thin_d else (d, gcl, w5)
             slot = ctx.slot if (not kpad and not thin_d and lib.ssbev_conv_kernel_class(C.byref(dd), 1) not in (4, 5)) else None
@@ -596,7 +601,7 @@ class _ConvNd(torch.autograd.Function):
             gx = from_cl(gxcl)
         if want_gw and not gw_side:
             gw = weight_gradient()
-        if has_bias and ctx.needs_input_grad[2]:
+        if want_gb and not gb_side:
             gb = gcl0.reshape(-1, Cout_g).sum(0)
         return gx, gw, gb, None, None, None, None, None, None
 
