@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--skip-forward-extra", action="store_true",
                     help="do not append the secondary forward-only measurement (profiling runs: keeps kernel totals per step clean)")
+    ap.add_argument("--skip-serial-replay", action="store_true",
+                    help="do not append the serial replay (side streams off) that measures the dominant kernel without co-scheduled "
+                         "kernels (profiling runs: keeps the per-kernel averages of the timed schedule clean)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the BASELINE metric (default); bf16 = BASELINE configs[3] (never the headline)")
     ap.add_argument("--ablation", default="full", choices=["full", "bev_only", "stereo_only"],
@@ -310,6 +313,33 @@ def main():
             dist.all_reduce(tf, op=dist.ReduceOp.MAX)
         fo_ms = float(tf) / args.steps * 1e3
 
+    # Serial replay: the same step with the side streams off (every kernel alone on the device), dominant kernels bracketed by
+    # HIP events.  In the timed region a conv_taph launch shares the CUs with weight-gradient / DepthNet kernels of the second
+    # stream, so its event-to-event time there measures the co-schedule, not the kernel; both are reported.
+    replay = None
+    from stereoscene_amd import streams as _streams
+    from stereoscene_amd.plugin import view_transformer as _vtm
+    concurrent = bool(_streams.WGRAD_STREAM or _vtm.VT_STREAMS)
+    if concurrent and not args.forward_only and not args.skip_serial_replay:
+        saved = (_streams.WGRAD_STREAM, _vtm.VT_STREAMS)
+        _streams.WGRAD_STREAM = _vtm.VT_STREAMS = False
+        try:
+            step()
+            rt = F.KernelTimer(families=fams)
+            F.KERNEL_TIMER = rt
+            fence()
+            t2 = time.perf_counter()
+            nrep = min(args.steps, 5)
+            for _ in range(nrep):
+                step()
+            fence()
+            rdt = (time.perf_counter() - t2) / nrep
+            F.KERNEL_TIMER = None
+            replay = (rt.summary(), nrep, rdt * 1e3)
+        finally:
+            _streams.WGRAD_STREAM, _vtm.VT_STREAMS = saved
+            F.KERNEL_TIMER = None
+
     exch = None
     if distributed and world > 1 and reducer is not None:
         exch = exchange_microbench(reducer, dist)
@@ -325,7 +355,7 @@ def main():
         # conv_taph_kernel is ONE symbol; wino_df_kernel<MT,NW> is a family of template instances whose largest member
         # (<2,4>: 6.7 ms/step in profiles/r2z_summary.txt) is below conv_taph_kernel's 7.7 ms/step, so the single dominant
         # kernel is conv_taph_kernel whenever it ran; the other timed kernel family is reported next to it.
-        def kernel_roofline(fam):
+        def kernel_roofline(fam, ks=ks, nsteps=args.steps, timing=None):
             k = ks[fam]
             kname, bound = SINGLE_KERNEL_FAMILIES[fam]
             n = k["launches"]
@@ -333,13 +363,15 @@ def main():
             exec_tf = k["executed"] / n / avg_s / 1e12
             oper_tf = k["flops"] / n / avg_s / 1e12
             traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+            if not os.path.exists(tfile):
+                tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
             if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
                 # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (committed
                 # summary of the same tree; PMC collection cannot run inside the timed process)
                 t = json.load(open(tfile))["kernels"].get(kname)
                 if t:
-                    traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r2_pmc_traffic.json"
+                    traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
             return {"bound": bound, "kernel": kname,
                     "achieved": exec_tf, "peak": peak, "unit": "TFLOP/s", "frac": exec_tf / peak,
                     "flop_convention": "achieved / frac count the multiply-adds the kernel EXECUTES (" + EXECUTED_NOTE[fam] +
@@ -348,13 +380,16 @@ def main():
                     "operator_tflops": oper_tf, "operator_frac": oper_tf / peak,
                     "peak_source": "fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md" if args.precision == "fp32"
                                    else "dense bf16 MFMA, MI355X_MICROARCH.md",
-                    "launches_per_step": n / args.steps, "avg_launch_us": avg_s * 1e6,
+                    "launches_per_step": n / nsteps, "avg_launch_us": avg_s * 1e6,
                     "executed_gflop_per_launch": k["executed"] / n / 1e9,
                     "algorithmic_gflop_per_launch": k["flops"] / n / 1e9,
                     "algorithmic_bytes_per_launch": k["bytes"] / n,
-                    "ms_per_step_in_kernel": k["ms"] / args.steps,
+                    "ms_per_step_in_kernel": k["ms"] / nsteps,
                     "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
-                    "timing": "HIP events on the launch stream around every launch inside the timed region"}
+                    "timing": timing or ("HIP events on the launch stream around every launch inside the timed region"
+                                         + ("; the step runs on TWO streams (weight gradients / DepthNet on the second), so a "
+                                            "launch's event-to-event time includes the CU share of co-scheduled kernels -- see "
+                                            "roofline_serial_replay for the kernel alone on the device" if concurrent else ""))}
 
         timed = [f for f in SINGLE_KERNEL_FAMILIES if f in ks and ks[f]["launches"]]
         roof, roof_other = None, {}
@@ -362,6 +397,14 @@ def main():
             dom = "conv_tap_h" if "conv_tap_h" in timed else max(timed, key=lambda f: ks[f]["ms"])
             roof = kernel_roofline(dom)
             roof_other = {SINGLE_KERNEL_FAMILIES[f][0]: kernel_roofline(f) for f in timed if f != dom}
+        roof_replay = None
+        if replay is not None and timed:
+            rks, nrep, rms = replay
+            note = ("HIP events around every launch in a serial replay of the same step after the timed region (side streams "
+                    f"off, {nrep} steps, {rms:.2f} ms/step): the kernel alone on the device")
+            roof_replay = {SINGLE_KERNEL_FAMILIES[f][0]: kernel_roofline(f, rks, nrep, note) for f in timed if f in rks and rks[f]["launches"]}
+            for v in roof_replay.values():
+                v["replay_ms_per_step"] = rms
         # ---- whole step against its own floor: sum over operator groups of max(flops / MFMA peak, bytes / HBM peak)
         floor_op = floor_ex = 0.0
         groups = {}
@@ -397,7 +440,9 @@ def main():
                                       + (" (precision: bf16 mixed, configs[3])" if args.precision != "fp32" else ""),
                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": f"dp{world}", "train_mode": True},
-               "roofline": roof, "roofline_other_timed_kernels": roof_other, "step_roofline": step_roof,
+               "roofline": roof, "roofline_other_timed_kernels": roof_other, "roofline_serial_replay": roof_replay,
+               "streams": {"side_stream_weight_gradients": bool(_streams.WGRAD_STREAM), "side_stream_depthnet": bool(_vtm.VT_STREAMS)},
+               "step_roofline": step_roof,
                "losses": {k: float(v.detach()) for k, v in losses.items()}}
         if fo_ms is not None:
             out["forward_only"] = {"ms_per_step": fo_ms, "value": world * args.batch * scale / (fo_ms * 1e-3), "unit": "voxels/s",

@@ -15,7 +15,8 @@
 // Every operand is read ROW-WISE (32 consecutive floats per half wave), so nothing is packed or transposed:
 //   NT  B fragment = like A: W[n0 + li][8q + 4lk .. +3], one ds_read_b128 out of a swizzled [BN rows][32 k] slab;
 //   NN  A fragment: lane (li, lk) holds A[m0 + li][8q + 4lk .. +3]  -- one ds_read_b128 out of a [rows][32 k] LDS slab whose
-//       16-byte slots are XOR-swizzled by (row & 7) on the global side of the copy (conflict-free);
+//       16-byte slots are XOR-swizzled by ((row >> 1) & 7) on the global side of the copy (conflict-free for the 16-lane groups
+//       of ds_read_b128; r2's key row & 7 was a 2-way conflict, see conv_mfma.hip);
 //       B fragment: B[8q + 4lk + t][n0 + li], t = 0..3 -- four ds_read_b32 out of a linear [32 k][BN] slab;
 //   TN  A fragment: A[2s + lk][k0 + li], B fragment: B[2s + lk][n0 + li] -- one ds_read_b32 each.
 // Slabs travel global -> LDS by global_load_lds_dwordx4 (no staging registers), double buffered: the copies of stage s+1 are
@@ -104,10 +105,10 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
   // tail (K % 32 != 0) is one compare per copy.  Straight-line selects: no branch inside the stage loop.
   const float* ap[AE]; int ak[AE];
 #pragma unroll
-  for (int e = 0; e < AE; ++e) {                  // A: 128 rows x 8 slots of 16 B, slots XOR-swizzled by (row & 7)
+  for (int e = 0; e < AE; ++e) {                  // A: BM rows x 8 slots of 16 B, slots XOR-swizzled by ((row >> 1) & 7)
     const int item = (wave + 4 * e) * 64 + lane, row = item >> 3, slot = item & 7;
     const int m = m0 + row;
-    ak[e] = (slot ^ (row & 7)) << 2;
+    ak[e] = (slot ^ ((row >> 1) & 7)) << 2;
     ap[e] = m < g.M ? (D2S == 2 ? Ab + g.rowoff[m] : Ab + (long)m * g.lda) + ak[e] : nullptr;
   }
   const float* bp[BE]; int bk[BE];
@@ -116,7 +117,7 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     const int item = (wave + 4 * e) * 64 + lane;
     if (BT) {                                     // W: BN rows x 8 slots, same swizzle
       const int row = item >> 3, slot = item & 7, n = n0 + row;
-      bk[e] = (slot ^ (row & 7)) << 2;
+      bk[e] = (slot ^ ((row >> 1) & 7)) << 2;
       bp[e] = n < g.N ? Bb + (long)n * g.ldb + bk[e] : nullptr;
     } else {                                      // B: 32 k-rows x BN/4 slots of 16 B, linear
       const int kr = item / (BN / 4), slot = item % (BN / 4), n = n0 + slot * 4;
@@ -164,13 +165,13 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
 #pragma unroll
       for (int mt = 0; mt < MW; ++mt) {
         const int row = (wm * MW + mt) * 32 + li;
-        a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ (row & 7)) << 2));
+        a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ ((row >> 1) & 7)) << 2));
       }
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) {
         if (BT) {
           const int row = (wn * WN + nt) * 32 + li;
-          bf[nt] = *reinterpret_cast<const gv4f*>(bs + row * BK + (((2 * q + lk) ^ (row & 7)) << 2));
+          bf[nt] = *reinterpret_cast<const gv4f*>(bs + row * BK + (((2 * q + lk) ^ ((row >> 1) & 7)) << 2));
         } else {
 #pragma unroll
           for (int t = 0; t < 4; ++t) bf[nt][t] = bs[(8 * q + 4 * lk + t) * BN + (wn * WN + nt) * 32 + li];

@@ -15,7 +15,7 @@
 //
 // Workgroup = NW waves (2..4), tile = 64 rows (hw-tiles of one (b, depth tile, xi_hw)) x NW*32 columns:
 //   * A: the 4 x 64 x 32-channel slab of a k-stage is copied global -> LDS by global_load_lds_dwordx4 (whole 128-byte rows,
-//     16-byte slots XOR-swizzled by (row & 7) on the GLOBAL side so that the per-lane ds_read_b128 of the MFMA A operand is
+//     16-byte slots XOR-swizzled by ((row >> 1) & 7) (r3; r2's key row & 7 left a 2-way bank conflict, see conv_mfma.hip) on the GLOBAL side so that the per-lane ds_read_b128 of the MFMA A operand is
 //     conflict-free); two stages in flight; every wave of the workgroup reads the same slab (A leaves LDS NW times per fetch);
 //   * B: packed weights Wp[xi_hw][f][q][kh][n][4] (L2 resident), one coalesced float4 per lane per (f, 8-channel step),
 //     prefetched one step ahead in registers;
@@ -99,7 +99,7 @@ wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float*
       const int d = 2 * i - 1 + a;
       const int t = t0 + row;
       const float* src = (d >= 0 && d < g.D && t < g.Thw)
-                             ? Px + (((long)b * g.D + d) * g.Thw + t) * g.K + st * DF_BK + ((slot ^ (row & 7)) << 2)
+                             ? Px + (((long)b * g.D + d) * g.Thw + t) * g.K + st * DF_BK + ((slot ^ ((row >> 1) & 7)) << 2)
                              : kDfZeros;
       __builtin_amdgcn_global_load_lds(src, lds + buf * STAGE + a * PLANE + jj * 256, 16, 0, 0);
     }
@@ -153,7 +153,7 @@ wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float*
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 32 + li;
-        const int off = row * DF_BK + (((2 * qq + lk) ^ (row & 7)) << 2);
+        const int off = row * DF_BK + (((2 * qq + lk) ^ ((row >> 1) & 7)) << 2);
         const v4f p0 = *reinterpret_cast<const v4f*>(ab + 0 * PLANE + off);
         const v4f p1 = *reinterpret_cast<const v4f*>(ab + 1 * PLANE + off);
         const v4f p2 = *reinterpret_cast<const v4f*>(ab + 2 * PLANE + off);
