@@ -637,7 +637,10 @@ OWN_GEMM = os.environ.get("SSBEV_OWN_GEMM", "1") != "0"
 # copies disappear), bri +0.2 (no operand transposes; the north-star block on own kernels).  The wide pointwise layers
 # (+1.5) and the batched frequency products of the 2-D / weight-streaming Winograd layers (+1.0) are plain library GEMMs
 # where rocBLAS's tuned kernels run at 90 % of the fp32 matrix peak against ~75 % here: they stay on rocBLAS by default.
-OWN_GEMM_SITES = set(os.environ.get("SSBEV_OWN_GEMM_SITES", "deconv,bri").split(","))
+# r3 (one side stream, DepthNet off the critical chain; profiles/r3m_own_gemm_sites.txt, ms/step): deconv,bri 78.85 |
+# + linear 78.92 (now free: default) | + wino 79.48 | all 79.85.  The batched frequency products of the 2-D / weight-streaming
+# Winograd layers stay on the library: 0.6 ms per step is what its tuned kernels are still worth there.
+OWN_GEMM_SITES = set(os.environ.get("SSBEV_OWN_GEMM_SITES", "deconv,bri,linear").split(","))
 
 
 def own_gemm_site(name):
