@@ -1,24 +1,37 @@
 #!/bin/bash
-# Regenerate the judged artifacts of a round from ONE tree on the GPU box: usage (inside gpurun) bash tools/final_artifacts.sh r2z
-# Writes gpurun_out/<tag>/*; copy what is to be judged into profiles/<tag>_*.
+# Regenerate the judged artifacts of a round from ONE tree on the GPU box: usage (inside gpurun) bash tools/final_artifacts.sh r3z
+# Writes gpurun_out/<tag>/*; copy what is to be judged into profiles/<tag>_*.  Every step runs under `timeout`.
 set -u
-tag=${1:-r2z}
+tag=${1:-r3z}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?" >> $out/smoke.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?" >> $out/smoke.txt
 timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err
 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-sample none --precision bf16 2>/dev/null | tail -1 > $out/bench_line_bf16.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra > $out/bench_under_rocprof.log 2>&1
+timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample none --precision bf16 --batch 2 --skip-forward-extra 2>/dev/null | tail -1 > $out/bench_line_bf16_b2.json
+# (a) the timed schedule (two streams): per-kernel averages agree with `roofline` of the bench line
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra --skip-serial-replay > $out/bench_under_rocprof.log 2>&1
 cp $(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 python tools/prof_summary.py $out/kernel_stats.csv 8 60 > $out/summary.txt 2>&1
+python tools/overlap_report.py $(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1) 8 > $out/overlap.txt 2>&1
+# (b) the serial schedule (side streams off): per-kernel averages agree with `roofline_serial_replay`
+SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$tag -o k -- python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra --skip-serial-replay > /dev/null 2>&1
+cp $(find /tmp/profs_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats_serial.csv
+python tools/prof_summary.py $out/kernel_stats_serial.csv 8 60 > $out/summary_serial.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${tag}_$c -o p -- python bench.py --steps 2 --warmup 1 --cpu-sample none --skip-forward-extra > /dev/null 2>&1
+  SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${tag}_$c -o p -- python bench.py --steps 2 --warmup 1 --cpu-sample none --skip-forward-extra --skip-serial-replay > /dev/null 2>&1
   cp $(find /tmp/pmc_${tag}_$c -name "*counter_collection.csv" | head -1) /tmp/pmc_${tag}_$c.csv
 done
 python tools/pmc_traffic.py /tmp/pmc_${tag}_FETCH_SIZE.csv /tmp/pmc_${tag}_WRITE_SIZE.csv $out/pmc_traffic.json > $out/pmc_traffic.txt 2>&1
+SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcm_$tag -o p -- python bench.py --steps 2 --warmup 1 --cpu-sample none --skip-forward-extra --skip-serial-replay > /dev/null 2>&1
+python tools/pmc_mfma.py $(find /tmp/pmcm_$tag -name "*counter_collection.csv" | head -1) > $out/pmc_mfma.txt 2>&1
 timeout 600 python tools/stream_probe.py > $out/stream_probe.txt 2>&1
-timeout 600 python tools/layer_table.py kitti_d192 3 2>&1 | grep -v amdgpu > $out/layer_table.txt
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $out/pytest_gpu.txt
-tail -3 $out/pytest_gpu.txt; head -12 $out/summary.txt; python -c "
-import json; d=json.loads(open('$out/bench_line.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['cpu_baseline'])"
+SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 600 python tools/layer_table.py kitti_d192 3 2>&1 | grep -v amdgpu > $out/layer_table.txt
+timeout 600 python tools/bucket_timeline.py 64 300 2>&1 | grep -v amdgpu > $out/bucket_timeline.txt
+for cfgline in "--config kitti_d112" "--batch 2" "--ablation stereo_only" "--ablation bev_only"; do
+  echo "$cfgline: $(timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra --skip-serial-replay $cfgline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), 'ms/step', round(d['value']/1e6,2), 'M voxels/s')")" >> $out/other_configs.txt
+done
+timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $out/pytest_gpu.txt
+tail -3 $out/pytest_gpu.txt; head -14 $out/summary.txt; cat $out/other_configs.txt; python -c "
+import json; d=json.loads(open('$out/bench_line.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'], {k: round(v['frac'], 3) for k, v in d['roofline_serial_replay'].items()}, d['cpu_baseline'])"

@@ -17,6 +17,7 @@ FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_
             ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
             ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel")),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
+            ("gn2_apply_fwd", ("gn2_apply_fwd_kernel",)), ("gn2_partial_bwd", ("gn2_partial_bwd_kernel",)), ("gn2_apply_bwd", ("gn2_apply_bwd_kernel",)),
             ("wino_input_kernel", ("wino_input_kernel", "wino43_input_kernel")),
             ("wino_output_kernel", ("wino_output_kernel", "wino43_output_kernel")), ("rocblas_gemm_Cijk", ("Cijk_",))]
 
