@@ -2002,7 +2002,10 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       acc2[1] = mfma32(wr[c][7], v[1].w, acc2[1]);
     };
     // (r3: requesting the raw rows after the first MFMA and combining them only after the eighth was measured at the same
-    // 0.557 ms per launch -- tools/taph_probe.py -- so the LDS latency of this step is not what holds the kernel at 63 %)
+    // 0.557 ms per launch -- tools/taph_probe.py -- so the LDS latency of this step is not what holds the kernel at 63 %;
+    // so was a phase-shifted schedule for the second wave of every SIMD (its non-MFMA window after the fourth MFMA of a
+    // column instead of after the first, so that the two waves that leave each barrier together do not idle the pipe
+    // together): 0.568 ms)
     fetch(0, va);
 #pragma unroll
     for (int c = 0; c < 9; c += 2) {
