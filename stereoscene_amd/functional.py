@@ -1002,6 +1002,30 @@ WINO_F43 = os.environ.get("SSBEV_WINO_F43", "1") != "0"
 # but its rounding error (reduction over 640 channels of values scaled by the 4 / 5 / 8 entries) more than doubles the
 # gradient noise of the DepthNet parameters in the full-step parity test (L2 1.1 % vs 0.45 %), for no accuracy budget left
 WINO_F43_2D = os.environ.get("SSBEV_WINO_F43_2D", "0") != "0"
+# ... or, opt-in, inside a `wino_f43_2d_scope()` (r3: DepthNet wraps its own 640 -> 640 layers; SSBEV_WINO_F43_2D_DEPTHNET=1).
+# Measured in r3 (profiles/r3p_f43_2d.txt): F(4,3)^2 on every 2-D layer = -1.5 ms per step, forward logits unchanged
+# (1.6e-4), but the stereo feature net's 640 -> 128 conv sits in front of the cost volume and its 1e-5 forward change flips
+# ReLU decisions in the 20-layer 3-D stack behind it: gradient distance of that stack to the oracle 0.87 % -> 1.85-2.1 %,
+# over the 2e-2 gate.  Limited to DepthNet the step is still 1.5 ms faster and every gate passes (worst gradient 1.3e-2),
+# but DepthNet's own gradients then sit at 0.9 % where the oracle moves by 0.2 % under a one-ulp input change
+# (tests/test_gpu_fullsize.py::test_gradient_gate_vs_oracle_noise_floor fails its 3x criterion): visible rounding, not
+# noise floor.  Parity first: off by default.
+WINO_F43_2D_DEPTHNET = os.environ.get("SSBEV_WINO_F43_2D_DEPTHNET", "0") != "0"
+_F43_2D_SCOPE = 0
+
+
+class wino_f43_2d_scope:
+    """2-D 3x3 layers built inside this scope use F(4,3)^2 tiles (the choice is recorded per call for its backward)."""
+
+    def __enter__(self):
+        global _F43_2D_SCOPE
+        _F43_2D_SCOPE += 1 if WINO_F43_2D_DEPTHNET else 0
+        return self
+
+    def __exit__(self, *exc):
+        global _F43_2D_SCOPE
+        _F43_2D_SCOPE -= 1 if WINO_F43_2D_DEPTHNET else 0
+        return False
 # F(4,3) along d as well (F(4x4x4): 216 GEMMs, 8x fewer multiply-adds, 3.375x transformed domain) when D % 4 == 0: opt-in.
 # Measured 106.3 vs 108.8 ms/step, but the third non-+-1 axis brings the gradient noise of the full-step parity test back
 # to 1.1 % (tools/grad_l2_probe.py), so the default keeps F(2,3) along d.
@@ -1120,7 +1144,7 @@ class _WinoConv(torch.autograd.Function):
     def _plan(three_d, D, H, W, bf, cin=1 << 30):
         # bf16 mode stays on F(2,3): its +-1 transforms add no error of their own, while the F(4,3) matrices amplify the
         # bf16 rounding of V / M by their 4 / 5 / 8 entries (measured: 11 % max error against 1 % for F(2,3))
-        f43 = WINO_F43 and (three_d or WINO_F43_2D) and not bf and H % 4 == 0 and W % 4 == 0 and \
+        f43 = WINO_F43 and (three_d or WINO_F43_2D or _F43_2D_SCOPE > 0) and not bf and H % 4 == 0 and W % 4 == 0 and \
             not (three_d and (WINO_DEPTH_FUSED or WINO_OWN_GEMM))
         if f43 and three_d and WINO_F444 and D % 4 == 0 and cin >= WINO_F444_MIN_CIN:
             return 4, "ssbev_wino444_", 216, 4, 8.0

@@ -142,9 +142,10 @@ class DepthNet(nn.Module):
 
     def forward(self, x, mlp_input):
         cam = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
-        x = self.reduce_conv(x)
-        context = self.context_conv(self.context_se(x, self.context_mlp(cam)[..., None, None]))
-        depth = self.depth_conv(self.depth_se(x, self.depth_mlp(cam)[..., None, None]))
+        with F.wino_f43_2d_scope():          # F(4,3)^2 tiles for this module's 640 -> 640 3x3 layers (functional.py)
+            x = self.reduce_conv(x)
+            context = self.context_conv(self.context_se(x, self.context_mlp(cam)[..., None, None]))
+            depth = self.depth_conv(self.depth_se(x, self.depth_mlp(cam)[..., None, None]))
         return torch.cat([depth, context], dim=1)
 
 
