@@ -357,7 +357,11 @@ def main():
         # kernel is conv_taph_kernel whenever it ran; the other timed kernel family is reported next to it.
         def kernel_roofline(fam, ks=ks, nsteps=args.steps, timing=None):
             k = ks[fam]
-            kname, bound = SINGLE_KERNEL_FAMILIES[fam]
+            base, _, inst = fam.partition(":")
+            kname, bound = SINGLE_KERNEL_FAMILIES[base]
+            tname = kname                                 # the PMC traffic file lists wino_df_kernel over all its instances
+            if inst:
+                kname = f"{kname}<{inst[0]}, {inst[1]}>"
             n = k["launches"]
             avg_s = k["ms"] * 1e-3 / n
             exec_tf = k["executed"] / n / avg_s / 1e12
@@ -369,12 +373,12 @@ def main():
             if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
                 # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (committed
                 # summary of the same tree; PMC collection cannot run inside the timed process)
-                t = json.load(open(tfile))["kernels"].get(kname)
+                t = json.load(open(tfile))["kernels"].get(tname)
                 if t:
                     traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
             return {"bound": bound, "kernel": kname,
                     "achieved": exec_tf, "peak": peak, "unit": "TFLOP/s", "frac": exec_tf / peak,
-                    "flop_convention": "achieved / frac count the multiply-adds the kernel EXECUTES (" + EXECUTED_NOTE[fam] +
+                    "flop_convention": "achieved / frac count the multiply-adds the kernel EXECUTES (" + EXECUTED_NOTE[base] +
                                        "), so frac <= 1 is matrix-pipe utilisation; operator_* count direct-convolution "
                                        "FLOPs (2*voxels*Cin*Cout*27, SURVEY 8(d))",
                     "operator_tflops": oper_tf, "operator_frac": oper_tf / peak,
@@ -391,24 +395,43 @@ def main():
                                             "launch's event-to-event time includes the CU share of co-scheduled kernels -- see "
                                             "roofline_serial_replay for the kernel alone on the device" if concurrent else ""))}
 
-        timed = [f for f in SINGLE_KERNEL_FAMILIES if f in ks and ks[f]["launches"]]
+        # every timed entry is ONE kernel symbol (conv_taph_kernel; wino_df_kernel<MT, NW> per template instance): the dominant
+        # kernel is the symbol with the largest summed duration in the timed region
+        timed = [f for f in ks if f.split(":")[0] in SINGLE_KERNEL_FAMILIES and ks[f]["launches"]]
         roof, roof_other = None, {}
         if timed:
-            dom = "conv_tap_h" if "conv_tap_h" in timed else max(timed, key=lambda f: ks[f]["ms"])
+            dom = max(timed, key=lambda f: ks[f]["ms"])
             roof = kernel_roofline(dom)
-            roof_other = {SINGLE_KERNEL_FAMILIES[f][0]: kernel_roofline(f) for f in timed if f != dom}
+            roof_other = {}
+            for f in sorted(timed, key=lambda f: -ks[f]["ms"]):
+                if f != dom:
+                    r = kernel_roofline(f)
+                    roof_other[r["kernel"]] = r
         roof_replay = None
         if replay is not None and timed:
             rks, nrep, rms = replay
             note = ("HIP events around every launch in a serial replay of the same step after the timed region (side streams "
                     f"off, {nrep} steps, {rms:.2f} ms/step): the kernel alone on the device")
-            roof_replay = {SINGLE_KERNEL_FAMILIES[f][0]: kernel_roofline(f, rks, nrep, note) for f in timed if f in rks and rks[f]["launches"]}
-            for v in roof_replay.values():
-                v["replay_ms_per_step"] = rms
+            roof_replay = {}
+            for f in sorted(timed, key=lambda f: -ks[f]["ms"]):
+                if f in rks and rks[f]["launches"]:
+                    r = kernel_roofline(f, rks, nrep, note)
+                    r["replay_ms_per_step"] = rms
+                    roof_replay[r["kernel"]] = r
         # ---- whole step against its own floor: sum over operator groups of max(flops / MFMA peak, bytes / HBM peak)
         floor_op = floor_ex = 0.0
         groups = {}
+        merged = {}
         for fam, c in timer.counts.items():
+            m = merged.setdefault(fam.split(":")[0], dict(launches=0, flops=0.0, bytes=0.0, executed=0.0))
+            for kk in m:
+                m[kk] += c[kk]
+        ks_fam = {}
+        for fam, v in ks.items():
+            m = ks_fam.setdefault(fam.split(":")[0], dict(launches=0, ms=0.0))
+            m["launches"] += v["launches"]
+            m["ms"] += v["ms"]
+        for fam, c in merged.items():
             t_b = c["bytes"] / (PEAK_HBM_TBS * 1e12)
             t_op = max(c["flops"] / (peak * 1e12), t_b)
             t_ex = max(c["executed"] / (peak * 1e12), t_b)
@@ -418,8 +441,8 @@ def main():
                            "executed_gflop_per_step": c["executed"] / 1e9 / args.steps,
                            "mbytes_per_step": c["bytes"] / 1e6 / args.steps,
                            "floor_ms_per_step": t_ex * 1e3 / args.steps}
-            if fam in ks and ks[fam]["launches"]:
-                groups[fam]["measured_ms_per_step"] = ks[fam]["ms"] / args.steps
+            if fam in ks_fam and ks_fam[fam]["launches"]:
+                groups[fam]["measured_ms_per_step"] = ks_fam[fam]["ms"] / args.steps
         step_roof = {"definition": "sum over instrumented operator groups of max(flops / MFMA peak, algorithmic bytes / 8 TB/s) "
                                    "divided by the measured step time; `frac` uses executed FLOPs (Winograd layers execute "
                                    "fewer multiply-adds than the operator defines) and is <= 1 by construction, "

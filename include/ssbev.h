@@ -479,6 +479,9 @@ int ssbev_gemm_tn(const float* A, const float* B, float* C, const ssbev_gemm_dim
  * weight gradient = ssbev_wino43_2d_output_adjoint(gy) + ssbev_wino43_df_wgrad(P saved by the forward).
  * d = (B, D, H, W, C = K).  Supported when H % 4 == W % 4 == 0, D even, K % 32 == 0. */
 int ssbev_wino43_df_supported(const ssbev_wino_dims* d, int N);
+/* template instance of the contraction kernel a problem runs on: MT * 10 + NW of wino_df_kernel<MT, NW> (0: unsupported dims) --
+ * lets a profiler attribute launches to kernel symbols (bench.py picks its roofline kernel by summed time per SYMBOL) */
+int ssbev_wino43_df_instance(const ssbev_wino_dims* d, int N);
 size_t ssbev_wino43_df_packed_elems(int Cout, int Cin);
 int ssbev_wino43_df_pack(const float* w, float* Wp, int Cout, int Cin, int mode, ssbev_stream_t stream);
 int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream);

@@ -157,6 +157,7 @@ SIGNATURES = {
     "ssbev_gemm_tn_workspace": (C.c_size_t, [C.POINTER(GemmDims)]),
     "ssbev_gemm_tn": (C.c_int, [_P, _P, _P, C.POINTER(GemmDims), _P, C.c_size_t, _P]),
     "ssbev_wino43_df_supported": (C.c_int, [C.POINTER(WinoDims), C.c_int]),
+    "ssbev_wino43_df_instance": (C.c_int, [C.POINTER(WinoDims), C.c_int]),
     "ssbev_wino43_df_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "ssbev_wino43_df_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ssbev_wino43_df_gemm": (C.c_int, [_P, _P, _P, C.POINTER(WinoDims), C.c_int, _P]),

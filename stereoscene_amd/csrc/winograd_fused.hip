@@ -507,6 +507,37 @@ int ssbev_wino43_df_pack(const float* w, float* Wp, int Cout, int Cin, int mode,
   return ssbev_launch_status();
 }
 
+// Template instance <MT, NW> of wino_df_kernel for a problem (also reported by ssbev_wino43_df_instance, so that a profiler can
+// attribute launches to kernel symbols)
+static void df_instance(const ssbev_wino_dims* d, int N, int& mt, int& nw) {
+  const int ntile = ((N + 31) & ~31) / 32, Thw = (d->H / 4) * (d->W / 4), ND = d->D / 2;
+  // waves per workgroup: the largest of 4, 3, 2 that wastes no column tile (N = 192 -> 3, 128 / 256 / 512 -> 4)
+  static const int forced_nw = env_int("SSBEV_DF_NW", 0), forced_mt = env_int("SSBEV_DF_MT", 0);
+  nw = ntile % 4 == 0 ? 4 : (ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 4));
+  if (forced_nw >= 2 && forced_nw <= 4) nw = forced_nw;
+  const int ncolgrp = (ntile + nw - 1) / nw;
+  // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than twice covered
+  mt = 2;
+  if ((long)36 * d->B * ND * ((Thw + 63) / 64) * ncolgrp < 1024) mt = 1;
+  // three-wave workgroups: two 64 KiB workgroups per CU put 6 waves on 4 SIMDs (2, 2, 1, 1); four 32 KiB ones are balanced
+  // (384 -> 192 head conv: 1.98 -> 1.72 ms)
+  if (nw == 3) mt = 1;
+  // two-wave workgroups (N = 64): at 64 KiB of LDS only two fit a CU = ONE wave per SIMD and nothing hides a wait; 32 KiB
+  // tiles put two waves on every SIMD (SSBEV_DF_NW2_MT=2 restores the r2 choice)
+  static const int nw2_mt = env_int("SSBEV_DF_NW2_MT", 1);
+  if (nw == 2) mt = nw2_mt == 2 ? 2 : 1;
+  if (forced_mt == 1 || forced_mt == 2) mt = forced_mt;
+  const int key = mt * 10 + nw;
+  if (key != 24 && key != 23 && key != 22 && key != 14 && key != 13 && key != 12) { mt = 1; nw = 2; }     // the launcher's default case
+}
+
+int ssbev_wino43_df_instance(const ssbev_wino_dims* d, int N) {
+  if (!df_dims_ok(d, N)) return 0;
+  int mt, nw;
+  df_instance(d, N, mt, nw);
+  return mt * 10 + nw;
+}
+
 // P [36][B*D*Thw][K] = ssbev_wino43_2d_input_transform(x), Wp = ssbev_wino43_df_pack(...), Mo [36][B*D*Thw][N];
 // d = (B, D, H, W, C = K).  Requires H % 4 == W % 4 == 0, even D, K % 32 == 0 (ssbev_wino43_df_supported).
 int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream) {
@@ -515,18 +546,9 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
   g.B = d->B; g.D = d->D; g.Thw = (d->H / 4) * (d->W / 4); g.K = d->C; g.N = N; g.NPad = (N + 31) & ~31;
   g.ND = d->D / 2;
   const int ntile = g.NPad / 32;
-  // waves per workgroup: the largest of 4, 3, 2 that wastes no column tile (N = 192 -> 3, 128 / 256 / 512 -> 4)
-  static const int forced_nw = env_int("SSBEV_DF_NW", 0), forced_mt = env_int("SSBEV_DF_MT", 0);
-  int nw = ntile % 4 == 0 ? 4 : (ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 4));
-  if (forced_nw >= 2 && forced_nw <= 4) nw = forced_nw;
+  int mt, nw;
+  df_instance(d, N, mt, nw);
   g.ncolgrp = (ntile + nw - 1) / nw;
-  // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than twice covered
-  int mt = 2;
-  if ((long)36 * g.B * g.ND * ((g.Thw + 63) / 64) * g.ncolgrp < 1024) mt = 1;
-  // three-wave workgroups: two 64 KiB workgroups per CU put 6 waves on 4 SIMDs (2, 2, 1, 1); four 32 KiB ones are balanced
-  // (384 -> 192 head conv: 1.98 -> 1.72 ms)
-  if (nw == 3) mt = 1;
-  if (forced_mt == 1 || forced_mt == 2) mt = forced_mt;
   g.nrowgrp = (g.Thw + 32 * mt - 1) / (32 * mt);
   g.NU = g.B * g.ND * g.nrowgrp;
   g.nxi = 36;

@@ -38,7 +38,7 @@ class KernelTimer:
         c["flops"] += flops
         c["bytes"] += nbytes
         c["executed"] += flops if executed is None else executed
-        if self.families is not None and family not in self.families:
+        if self.families is not None and family.split(":")[0] not in self.families:      # "family:instance" = one kernel symbol
             return _NOSPAN
         return _Span(self, family, flops, nbytes, tag, flops if executed is None else executed)
 
@@ -1067,7 +1067,9 @@ def _wino_df_gemm(xcl, w, B, D, H, W, K, N, mode, tag, fl, into=None):
     Mo = torch.empty(36, R, N, dtype=torch.float32, device=xcl.device)
     dims = capi.WinoDims(B, D, H, W, K)
     nby = 4.0 * (P.numel() + Mo.numel() + Wp.numel())          # the kernel's own operands: P and Mo are 2.25x the activations
-    with _span("conv_wino_fused", fl, nby, tag, fl / 6.0):
+    # span family "conv_wino_fused:<MT><NW>": one entry per template instance of wino_df_kernel (= per kernel symbol)
+    with _span(f"conv_wino_fused:{lib.ssbev_wino43_df_instance(C.byref(dims), N)}" if KERNEL_TIMER is not None else "conv_wino_fused",
+               fl, nby, tag, fl / 6.0):
         capi.check(lib.ssbev_wino43_df_gemm(capi.ptr(P), capi.ptr(Wp), capi.ptr(Mo), C.byref(dims), N, capi.stream()),
                    "ssbev_wino43_df_gemm")
     with _span("wino_transform", 0.0, 4.0 * B * D * H * W * N * (3.25 + (into is not None)), tag + " out"):
