@@ -1604,6 +1604,7 @@ struct ConvTapGeom {
   int nseg, NG, gpc;              // 32-voxel segments per row, B*D*H rows, rows per chunk
   int relu, has_bias;
   int accumulate = 0;             // y += result (second consumer of a multi-consumer activation's gradient, see functional.fork)
+  int Ds = 0, Hs = 0, Ws = 0;     // conv_tap2_kernel: source grid of the stride-2 gather (D / H / W are the destination grid)
 };
 
 constexpr int kTapWseg = 32, kTapCols = kTapWseg + 2, kTapRowF = kTapCols * 32, kTapSlots = 4;
@@ -2061,6 +2062,223 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_tap2_kernel (round 3): the stride-2 3x3x3 "down" gather with <= 32 input and 33..64 output channels on the LDS-ring /
+// register-weights design of conv_tap_kernel -- the first convolution of every hourglass (VT:73-76, 32 -> 64 on the
+// 192 x 48 x 160 cost volume) and the data gradient of its last transposed convolution (VT:86-88, 64 -> 32), 8 launches per
+// step that conv_gather_kernel runs at 66-69 TF/s (parked on its 27 x 128-byte operand lines: SQ_WAIT_ANY 37 %).
+//   * 8 waves = 4 tap groups x 2 output-channel halves; a wave keeps its 7 taps x (32 k x 32 n) weights in 112 VGPRs.
+//   * MFMA columns = 2 output rows x 16 output voxels (the 48 x 160 -> 24 x 80 level has 80 = 5 x 16 voxels per row: 32-voxel
+//     segments would leave a sixth of the columns empty), rows = output channels, k = input channels.
+//   * the ring holds the five source rows 2 h0 - 1 .. 2 h0 + 3 of three source planes (34 voxels each, filled by
+//     global_load_lds with the swizzle of conv_tap_kernel); the four NEW rows of the next row pair land while this pair
+//     computes (9 slots).  The B operand of a tap is one ds_read_b128 at voxel 2 v + kw of row 2 (h0 + r) + kh.
+//   * fold of the four tap groups through LDS per channel half, float4 stores; `accumulate` requests the old values first.
+constexpr int kT2Slots = 9, kT2PlaneF = kT2Slots * kTapRowF, kT2RingF = 3 * kT2PlaneF;
+constexpr int kT2RedF = 8 * 16 * 64;
+constexpr size_t kT2LdsBytes = (size_t)(kT2RingF + kT2RedF) * sizeof(float);
+constexpr int kT2PackedElems = 2 * 4 * 7 * 16 * 64;
+
+// w_packed[(((nh * 4 + tg) * 7 + tt) * 16 + q * 4 + c) * 64 + lane] = Weff[n = 32 nh + (lane & 31)][k = 8 q + 4 (lane >> 5) + c][tap = tg + 4 tt]
+// with Weff[n][k][tap] = w[(n * K + k) * 27 + tap]: conv forward (torch [Cout][Cin][27]) and transposed-conv data gradient
+// (torch [Cin][Cout][27], N = Cin, K = Cout; taps NOT mirrored: gx[i] = sum_k gy[2 i - 1 + k] w[k]) share the formula
+__global__ void __launch_bounds__(256)
+pack_tap2_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kT2PackedElems) return;
+  const int lane = i & 63, r = (i >> 6) & 15, wt = i >> 10;
+  const int tt = wt % 7, wv = wt / 7, tg = wv & 3, nh = wv >> 2;
+  const int tap = tg + 4 * tt, n = 32 * nh + (lane & 31), k = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  wp[i] = (tap < 27 && n < N && k < K) ? w[((size_t)n * K + k) * 27 + tap] : 0.0f;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                 float* __restrict__ Y, ConvTapGeom g) {      // g.NG / g.gpc count output row PAIRS
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [3 planes][9 slots][34 voxels][32 channels], 16-byte swizzled
+  float* red = tl + kT2RingF;                // [8 waves][16 rows][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int tg = wave & 3, nh = wave >> 2;
+  const int vx = li & 15, rw = li >> 4;      // output voxel within the segment, output row within the pair
+
+  float wr[7][16];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[tt][r] = wp[((wave * 7 + tt) * 16 + r) * 64 + lane];
+  const int ntap = tg < 3 ? 7 : 6;
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * 16;                   // first output voxel of the segment; its first source voxel is 2 w0 - 1
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  const int H2 = (g.H + 1) >> 1;
+
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 staging entries per (plane, row)
+  int xoff[2], xmeta[2];
+  const int plane_g = g.Hs * g.Ws * g.K;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int q = wave + n * 8;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ ((u >> 1) & 7)) << 2), wsrc = 2 * w0 - 1 + u;
+        off = (wsrc >= 0 && wsrc < g.Ws && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kT2PlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  // padded source row hp (= source row hp - 1) of source planes 2 d - 1 .. 2 d + 1 -> ring slot hp % 9
+  auto stage_row = [&](int b, int d, int hp) {
+    const float* base = X + ((long)(b * g.Ds + 2 * d - 1) * g.Hs + (hp - 1)) * (long)(g.Ws * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = 2 * d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.Hs && dp >= 0 && dp < g.Ds;
+      float* dst = ring + (meta >> 4) + (hp % kT2Slots) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+
+  int tp_plane[7], tp_kh[7], tp_kw[7];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    const int t = min(tg + 4 * tt, 26);
+    tp_plane[tt] = (t / 9) * kT2PlaneF; tp_kh[tt] = (t / 3) % 3; tp_kw[tt] = t % 3;
+  }
+  const int nb = 32 * nh + 8 * tg + 4 * lk;  // first of the 4 output channels this lane stores
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
+  }
+
+  bool fresh = true;
+  int h2 = g_begin % H2, d, b;
+  {
+    const int bd = g_begin / H2;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = 2 * h2;
+    if (fresh) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r) stage_row(b, d, 2 * h0 + r);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
+    if (same_plane) {
+#pragma unroll
+      for (int r = 5; r < 9; ++r) stage_row(b, d, 2 * h0 + r);
+    }
+    const int wv = w0 + vx, hrow = h0 + rw;
+    const bool ok = wv < g.W && hrow < g.H && nb < g.N;
+    float* dst = Y + (((long)(b * g.D + d) * g.H + hrow) * g.W + wv) * g.N + nb;
+    float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.accumulate && ok && (g.N & 3) == 0) told = *reinterpret_cast<const float4*>(dst);
+
+    // slot offsets of the padded rows 2 (h0 + rw) + kh, kh = 0..2 (per lane: rw differs between the half rows of a wave)
+    int srow[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) srow[kh] = ((2 * h0 + 2 * rw + kh) % kT2Slots) * kTapRowF;
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.0f;
+    float4 xa[4], xb4[4];
+    auto fetch = [&](int tt, float4 (&xv)[4]) {
+      const int u = 2 * vx + tp_kw[tt];
+      const float* rowp = ring + tp_plane[tt] + srow[tp_kh[tt]] + u * 32;
+      const int sw = (u >> 1) & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
+    };
+    auto mm_head = [&](int tt, const float4 (&xv)[4]) { acc2[0] = mfma32(wr[tt][0], xv[0].x, acc2[0]); };
+    auto mm_tail = [&](int tt, const float4 (&xv)[4]) {
+#pragma unroll
+      for (int q = 1; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 0], xv[q].x, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 1], xv[q].y, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 2], xv[q].z, acc2[q & 1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc2[q & 1] = mfma32(wr[tt][4 * q + 3], xv[q].w, acc2[q & 1]);
+    };
+    fetch(0, xa);
+#pragma unroll
+    for (int tt = 0; tt < 7; tt += 2) {
+      if (tt < ntap) {
+        mm_head(tt, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 1 < 7 && tt + 1 < ntap) fetch(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_tail(tt, xa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tt + 1 < 7 && tt + 1 < ntap) {
+        mm_head(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 2 < 7 && tt + 2 < ntap) fetch(tt + 2, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_tail(tt + 1, xb4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // fold the four tap groups of each channel half: every wave publishes its partial tile, then sums rows 4 tg .. 4 tg + 3
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * tg + i;
+        const float* rp = red + ((nh * 4) * 16 + r) * 64 + lane;
+        o[i] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64] + bv[i];
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      if (ok) {
+        if ((g.N & 3) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4(o[0] + told.x, o[1] + told.y, o[2] + told.z, o[3] + told.w);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < g.N) dst[i] = g.accumulate ? dst[i] + o[i] : o[i];
+        }
+      }
+    }
+    __syncthreads();                       // the partial buffer is reused by the next row pair
+    fresh = !same_plane;
+    if (++h2 == H2) {
+      h2 = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3x3 stride-1 "heads" with 32 input channels and <= 4 output channels (classif3_2 / redir2:
 // 32 -> 1).  On the MFMA kernel such a layer costs as much as a full 32 -> 32 one (31 of 32 tile columns are padding).
 // Here it is a VALU reduction over the LDS ring of conv_tap_kernel:
@@ -2392,6 +2610,58 @@ int launch_conv_thin(const float* x, const float* wt, const float* bias, float* 
   return ssbev_launch_status();
 }
 
+// Stride-2 "down" gather on conv_tap2_kernel: conv forward (mode 0, !transposed) or transposed-conv data gradient (mode 1,
+// transposed) with k3 s2 p1 (output_padding 1: source = 2 x destination), K <= 32 source channels, 33..64 destination channels.
+// tile_hint 8 keeps the generic gather kernel, 5 forces this one on small problems (tests).
+bool conv_tap2_applicable(const ssbev_conv_dims* d, int mode) {
+  if (!((mode == 0 && !d->transposed) || (mode == 1 && d->transposed))) return false;
+  if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->precision != 0 || d->tile_hint == 8 || (d->tile_hint != 0 && d->tile_hint != 5)) return false;
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  if (K > 32 || K < 16 || K % 4 != 0 || N <= 32 || N > 64 || N % 4 != 0) return false;
+  // source / destination grids of the gather and their stride-2 relation
+  const int Ds = mode == 0 ? d->Di : d->Do, Hs = mode == 0 ? d->Hi : d->Ho, Ws = mode == 0 ? d->Wi : d->Wo;
+  const int Dd = mode == 0 ? d->Do : d->Di, Hd = mode == 0 ? d->Ho : d->Hi, Wd = mode == 0 ? d->Wo : d->Wi;
+  if (Dd != (Ds - 1) / 2 + 1 || Hd != (Hs - 1) / 2 + 1 || Wd != (Ws - 1) / 2 + 1) return false;
+  if ((long)Hs * Ws * K >= (1L << 30)) return false;
+  // worth it when the row-pair walks fill the chip: >= 256 workgroups of >= 8 row pairs
+  return d->tile_hint == 5 || (long)d->B * Dd * ((Hd + 1) / 2) * ((Wd + 15) / 16) >= 256L * 8;
+}
+
+int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                     hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B;
+  g.Ds = mode == 0 ? d->Di : d->Do; g.Hs = mode == 0 ? d->Hi : d->Ho; g.Ws = mode == 0 ? d->Wi : d->Wo;
+  g.D = mode == 0 ? d->Do : d->Di; g.H = mode == 0 ? d->Ho : d->Hi; g.W = mode == 0 ? d->Wo : d->Wi;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + 15) / 16;
+  const int H2 = (g.H + 1) / 2;
+  g.NG = g.B * g.D * H2;                     // output row pairs
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
+  // one 512-thread workgroup per CU (150 KB of LDS): whole rounds of 256 workgroups, chunk start-up ~1 pair, plane crossing ~0.5
+  double best = 1e30;
+  g.gpc = 1;
+  for (int c = 1; c <= g.NG && c <= 96; ++c) {
+    const long blocks = (long)((g.NG + c - 1) / c) * g.nseg;
+    const long rounds = (blocks + 255) / 256;
+    const double crossings = H2 % c == 0 ? 0.0 : (c % H2 == 0 ? c / H2 - 1 : (double)c / H2);
+    const double cost = rounds * (c + 1.0 + 0.5 * crossings);
+    if (cost < best) { best = cost; g.gpc = c; }
+  }
+  if (const char* e = getenv("SSBEV_TAP2_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  const long nranges = (g.NG + g.gpc - 1) / g.gpc;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kT2LdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(conv_tap2_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(512), kT2LdsBytes, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
 // tile_hint 8 forces the generic gather kernels (A/B timing), 9 forces this kernel on small problems (tests)
 bool conv_tap_applicable(const ssbev_conv_dims* d, int mode) {
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
@@ -2578,6 +2848,7 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (ssbev_thin::thinin_applicable(d, mode)) return 4;
   if (ssbev_thin::thinout_applicable(d, mode)) return 5;     // ssbev_conv_thin_* (caller-owned workspace); ssbev_conv_fwd falls back to class 3 / 0
   if (conv_thin_applicable(d, mode)) return 3;
+  if (conv_tap2_applicable(d, mode)) return 7;                // stride-2 "down" gather on conv_tap2_kernel
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
   return 0;
@@ -2589,7 +2860,8 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
   const size_t generic = taps * (a > b ? a : b);
-  return generic > (size_t)kTwPackedElems ? generic : (size_t)kTwPackedElems;
+  const size_t special = (size_t)(kTwPackedElems > kT2PackedElems ? kTwPackedElems : kT2PackedElems);
+  return generic > special ? generic : special;
 }
 
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
@@ -2599,6 +2871,11 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   if (conv_thin_applicable(d, mode)) {       // <= 4 output channels: LDS-resident [tap][n][k] table (conv_thin_kernel)
     hipLaunchKernelGGL(pack_thin_kernel, dim3(cdiv(27 * kThinNP * 32, 256)), dim3(256), 0, as_stream(stream), w_src,
                        w_packed, d->Cout, d->Cin, mode);
+    return ssbev_launch_status();
+  }
+  if (conv_tap2_applicable(d, mode)) {       // stride-2 "down" gather: [N][K][27] in both roles, see pack_tap2_kernel
+    const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+    hipLaunchKernelGGL(pack_tap2_kernel, dim3(cdiv(kT2PackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, N, K);
     return ssbev_launch_status();
   }
   if (conv_taph_applicable(d, mode)) {       // Winograd-along-h variant of the tap kernel: U = G w per (kd, kw)
@@ -2631,6 +2908,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   if (ssbev_thin::thinin_applicable(d, 0)) return ssbev_thin::thinin_launch(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
+  if (conv_tap2_applicable(d, 0)) return launch_conv_tap2(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
@@ -2649,6 +2927,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
   if (ssbev_thin::thinin_applicable(d, 1)) return ssbev_thin::thinin_launch(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
+  if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin

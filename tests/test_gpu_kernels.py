@@ -221,6 +221,57 @@ def test_conv3d_family_fwd_bwd(case):
         assert maxdiff(bg.grad, bc.grad) < 5e-5 * max(1.0, bc.grad.abs().max().item())
 
 
+TAP2_CASES = [
+    # (B, K = source channels, N = destination channels, source D, H, W, transposed): stride-2 "down" gathers on
+    # conv_tap2_kernel (forced on small problems by tile hint 5): even / odd grids, ragged 16-voxel segments, odd row-pair
+    # counts, partial channel quads, the transposed convolution's data gradient
+    (1, 32, 64, 8, 12, 32, False), (2, 32, 64, 7, 9, 21, False), (1, 16, 48, 6, 8, 20, False), (1, 24, 64, 5, 10, 70, False),
+    (1, 32, 64, 4, 6, 10, True), (2, 32, 48, 3, 5, 9, True),
+]
+
+
+@pytest.mark.parametrize("case", TAP2_CASES)
+def test_conv_stride2_down_tap_kernel(case, monkeypatch):
+    """conv_tap2_kernel (round 3): k3 s2 p1 conv forward with <= 32 input / 33..64 output channels, and the data gradient of
+    the matching transposed conv (output_padding 1), against ATen; plus the accumulating epilogue through a gradient slot."""
+    B, K, N, D, H, W, tr = case
+    monkeypatch.setattr(F, "TILE_HINT", 5)
+    if not tr:
+        x = S.hash_normal(f"t2/x{case}", (B, K, D, H, W))
+        w = S.hash_uniform(f"t2/w{case}", (N, K, 3, 3, 3), -1, 1) * (3.0 / (K * 27)) ** 0.5
+        d = F._conv_dims((B, D, H, W, K), (N, K, 3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), False, (0, 0, 0))
+        assert F.capi.load().ssbev_conv_kernel_class(F.C.byref(d), 0) == 7
+        xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        want = TF.conv3d(xc, wc, None, 2, 1)
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        got = F.conv3d(xg, wg, None, 2, 1)
+    else:       # transposed conv N -> K (x has N channels on the coarse grid): its DATA gradient is the "down" gather
+        x = S.hash_normal(f"t2/x{case}", (B, N, D, H, W))
+        w = S.hash_uniform(f"t2/w{case}", (N, K, 3, 3, 3), -1, 1) * (3.0 / (N * 27 / 8)) ** 0.5
+        d = F._conv_dims((B, D, H, W, N), (N, K, 3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), True, (1, 1, 1))
+        assert F.capi.load().ssbev_conv_kernel_class(F.C.byref(d), 1) == 7
+        xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        want = TF.conv_transpose3d(xc, wc, None, 2, 1, 1)
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        got = F.conv_transpose3d(xg, wg, None, 2, 1, 1)
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    go = S.hash_normal(f"t2/go{case}", tuple(want.shape))
+    want.backward(go)
+    got.backward(go.to(DEV))
+    assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    if tr:      # two transposed convs share their input: the second data gradient accumulates into the first one's buffer
+        w2 = S.hash_uniform(f"t2/w2{case}", (N, K, 3, 3, 3), -1, 1) * 0.05
+        xa = x.to(DEV).requires_grad_(True)
+        a, b = F.fork(xa)
+        y = F.conv_transpose3d(a, wg.detach(), None, 2, 1, 1) + F.conv_transpose3d(b, w2.to(DEV), None, 2, 1, 1)
+        y.backward(go.to(DEV))
+        xr = x.clone().requires_grad_(True)
+        (TF.conv_transpose3d(xr, w, None, 2, 1, 1) + TF.conv_transpose3d(xr, w2, None, 2, 1, 1)).backward(go)
+        assert maxdiff(xa.grad, xr.grad) < 3e-5 * max(1.0, xr.grad.abs().max().item())
+
+
 WGRAD_LDS_CASES = [
     # (B, Cin, Cout, D, H, W, stride, transposed): 3x3x3 convs whose weight gradient runs on the LDS-staged kernel; the
     # shapes walk the planner's branches (32x32 k-split workgroups, 64x64 tiles, rows per step 1/2/4/8, w-segments,

@@ -47,3 +47,20 @@ for i, (s, e, n, q) in enumerate(ev):
 print("most-overlapped kernels (ms/step overlapped with another queue):")
 for n, v in ov.most_common(14):
     print(f"  {v / 1e6 / steps:7.2f}  {n}")
+
+# ---- occupancy table of the kernels with the largest summed duration: waves per SIMD the launch configuration allows
+# (LDS: 160 KiB per CU; VGPRs: 512 per SIMD lane incl. accumulation registers; 4 SIMDs per CU)
+agg = {}
+for r in rows:
+    n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:70]
+    a = agg.setdefault(n, [0, 0, r])
+    a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
+print("\nlaunch configuration of the 30 largest kernels (ms/step, LDS bytes, VGPRs incl. AGPRs, workgroup, workgroups; waves per SIMD allowed by LDS / by registers):")
+for n, (t, c, r) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+    lds = int(r["LDS_Block_Size"]); vg = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count", 0) or 0)
+    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    nwg = (int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])) // max(wg, 1)
+    waves = wg // 64
+    by_lds = (160 * 1024 // lds) * waves / 4.0 if lds else 99.0
+    by_reg = 512 // max(vg, 1)
+    print(f"  {t / 1e6 / steps:7.2f} ms  lds {lds:7d}  vgpr {vg:4d}  wg {wg:5d}  n {nwg:7d}   {min(by_lds, 8):4.1f} / {min(by_reg, 8):2d}   {n}")
