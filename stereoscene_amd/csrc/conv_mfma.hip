@@ -2279,6 +2279,200 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_tap2up_kernel (round 3): the stride-2 3x3x3 "up" gather -- transposed-conv forward 64 -> 32 (VT:86-88, the last layer of
+// every hourglass) and the data gradient of the stride-2 conv 32 -> 64 (VT:73-76) -- with 33..64 source channels on the coarse
+// grid and <= 32 destination channels on the fine grid (fine = 2 x coarse).  Along one axis a fine index 2 c + par receives
+//     par = 0:  w[k = 1] * x[c]                    par = 1:  w[k = 2] * x[c] + w[k = 0] * x[c + 1]
+// so the 8 fine voxels of a coarse cell are 8 parity CLASSES with 1, 2, 2, 2, 4, 4, 4, 8 taps (27 in all), each a GEMM over
+// the 64 source channels of the cell or of its +1 neighbours.  MFMA columns = 2 coarse rows x 16 coarse cells, rows = the 32
+// destination channels, k = source channels; the taps are dealt in pairs to fourteen waves by class (four waves share the 8-tap
+// class), every wave keeps its 2 taps x (64 k x 32 n) weights in 64 VGPRs; the ring
+// holds three coarse rows of two coarse planes (17 voxels x 64 channels, filled by global_load_lds, 16-byte quads XOR-swizzled
+// by the voxel index: the 16 lanes of a ds_read_b128 group read 16 different voxels); the class tiles meet in LDS and leave
+// as 16-byte stores (four per lane and class: 32 contiguous bytes per voxel and instruction).
+constexpr int kUpCols = 17, kUpRowF = kUpCols * 64, kUpSlots = 5, kUpPlaneF = kUpSlots * kUpRowF, kUpRingF = 2 * kUpPlaneF;
+constexpr int kUpTiles = 14, kUpRedF = kUpTiles * 16 * 64;
+constexpr size_t kUpLdsBytes = (size_t)(kUpRingF + kUpRedF) * sizeof(float);
+constexpr int kUpPackedElems = 16 * 2 * 32 * 64;
+static_assert(kUpRowF == kTapRowF, "17 voxels x 64 channels = 34 voxels x 32 channels");
+
+// SIXTEEN waves (1024 threads, four per SIMD at <= 128 VGPRs: a first version with eight waves x four taps needed 256 VGPRs
+// and spilled): wave w < 14 owns two taps of ONE parity class (kd * 9 + kh * 3 + kw, -1 = none) and one partial tile.
+// Per axis k = 1: parity 0; k = 2: parity 1, same cell; k = 0: parity 1, cell + 1.
+//   waves 0-3: class (1,1,1)   4, 5: (0,1,1)   6, 7: (1,0,1)   8, 9: (1,1,0)   10: (0,0,1)   11: (0,1,0)   12: (1,0,0)   13: (0,0,0)
+__device__ __constant__ int kUpTaps[16][2] = {{0, 2}, {6, 8}, {18, 20}, {24, 26}, {9, 11}, {15, 17}, {3, 5}, {21, 23},
+                                              {1, 7}, {19, 25}, {12, 14}, {10, 16}, {4, 22}, {13, -1}, {-1, -1}, {-1, -1}};
+// store phase: waves 2 c, 2 c + 1 write class kUpStoreClass[c] (pd * 4 + ph * 2 + pw) = the sum of its partial tiles
+__device__ __constant__ int kUpStoreClass[8] = {7, 3, 5, 6, 1, 2, 4, 0};
+__device__ __constant__ int kUpStoreTile[8] = {0, 4, 6, 8, 10, 11, 12, 13};
+__device__ __constant__ int kUpStoreNTiles[8] = {4, 2, 2, 2, 1, 1, 1, 1};
+
+// w_packed[((wave * 2 + tt) * 32 + q * 4 + c) * 64 + lane] = Weff[n = lane & 31][k = 8 q + 4 (lane >> 5) + c][tap kUpTaps[wave][tt]],
+// Weff[n][k][tap] = w[(k * N + n) * 27 + tap]: transposed-conv forward (torch [Cin = K][Cout = N][27]) and conv data gradient
+// (torch [Cout = K][Cin = N][27]) share the formula, taps NOT mirrored
+__global__ void __launch_bounds__(256)
+pack_tap2up_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kUpPackedElems) return;
+  const int lane = i & 63, r = (i >> 6) & 31, tt = (i >> 11) & 1, wave = i >> 12;
+  const int tap = kUpTaps[wave][tt], n = lane & 31, k = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  wp[i] = (tap >= 0 && n < N && k < K) ? w[((size_t)k * N + n) * 27 + tap] : 0.0f;
+}
+
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                   float* __restrict__ Y, ConvTapGeom g) {    // g.Ds/Hs/Ws: coarse source grid; g.D/H/W: fine grid = 2 x coarse
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [2 planes][5 slots][17 voxels][64 channels], 16-byte swizzled
+  float* red = tl + kUpRingF;                // [14 tiles][16 rows][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int vx = li & 15, rw = li >> 4;      // coarse cell within the segment, coarse row within the pair
+
+  // this wave's two taps: weights (A operands) in registers, per-tap cell shifts as scalars
+  float wr[2][32];
+  int t_pl[2], t_dh[2], t_dw[2];
+  int ntap = 0;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tap = kUpTaps[wave][tt];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wr[tt][r] = wp[((wave * 2 + tt) * 32 + r) * 64 + lane];
+    const int t = max(tap, 0), kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    t_pl[tt] = (kd == 0 ? 1 : 0) * kUpPlaneF; t_dh[tt] = kh == 0 ? 1 : 0; t_dw[tt] = kw == 0 ? 1 : 0;
+    ntap += tap >= 0 ? 1 : 0;
+  }
+  ntap = __builtin_amdgcn_readfirstlane(ntap);
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int c0 = seg * 16;                   // first coarse cell of the segment
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  const int H2 = (g.Hs + 1) >> 1;
+
+  constexpr int nxc = (kUpCols * 16 + 63) / 64;                 // 5 staging entries per (plane, row): waves 0..9 take one each
+  int xoff = -2, xmeta = -1;
+  const int plane_g = g.Hs * g.Ws * g.K;
+  if (wave < 2 * nxc) {
+    const int pl = wave / nxc, ch = wave % nxc;
+    const int j = ch * 64 + lane;
+    if (j < kUpCols * 16) {
+      const int u = j >> 4, c = (((j & 15) ^ (u & 15)) << 2), wsrc = c0 + u;
+      xoff = (wsrc < g.Ws && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+    }
+    xmeta = pl | ((pl * kUpPlaneF + ch * 256) << 4);
+  }
+  auto stage_row = [&](int b, int d, int hr) {      // coarse row hr of coarse planes d, d + 1 -> ring slot hr % 5
+    if (xmeta < 0) return;
+    const float* base = X + ((long)(b * g.Ds + d) * g.Hs + hr) * (long)(g.Ws * g.K);
+    const int pl = xmeta & 3;
+    const bool rowok = hr < g.Hs && d + pl < g.Ds;
+    float* dst = ring + (xmeta >> 4) + (hr % kUpSlots) * kUpRowF;
+    const float* src = (rowok && xoff >= 0) ? base + xoff : kWgZeros;
+    if (xoff != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+  };
+
+  const int sc = wave >> 1, jp = wave & 1;   // store phase: class slot and channel-group pair of this wave
+  const int scls = kUpStoreClass[sc], stile = kUpStoreTile[sc], sntile = kUpStoreNTiles[sc];
+  const int spd = scls >> 2, sph = (scls >> 1) & 1, spw = scls & 1;
+
+  bool fresh = true;
+  int h2 = g_begin % H2, d, b;
+  {
+    const int bd = g_begin / H2;
+    b = bd / g.Ds; d = bd % g.Ds;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = 2 * h2;
+    if (fresh) {
+      stage_row(b, d, h0); stage_row(b, d, h0 + 1); stage_row(b, d, h0 + 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
+    if (same_plane) { stage_row(b, d, h0 + 3); stage_row(b, d, h0 + 4); }
+
+    // ring offsets of the coarse rows h0 + rw (+ 1)
+    const int srow0 = ((h0 + rw) % kUpSlots) * kUpRowF, srow1 = ((h0 + rw + 1) % kUpSlots) * kUpRowF;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // group gi = (tap tt = gi >> 1, channel half = gi & 1): four 16-byte quads = 32 source channels, 16 MFMAs; the other
+    // three waves of the SIMD cover the LDS latency of a group, so the operand buffer is single
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int tt = gi >> 1, hq = gi & 1;
+      if (tt < ntap) {
+        const int u = vx + t_dw[tt];
+        const float* rowp = ring + t_pl[tt] + (t_dh[tt] ? srow1 : srow0) + u * 64;
+        const int sw = u & 15;
+        float4 xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * (4 * hq + q) + lk) ^ sw) << 2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 0], xv[q].x, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 1], xv[q].y, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 2], xv[q].z, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 3], xv[q].w, acc);
+        }
+      }
+    }
+    if (wave < kUpTiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      // waves 2 c, 2 c + 1 store class kUpStoreClass[c]: lane (cell li, lk) holds channels 8 j + 4 lk .. + 3; this wave j = 2 jp, 2 jp + 1
+      const int cw = c0 + vx, chr = h0 + rw;
+      const bool ok = cw < g.Ws && chr < g.Hs;
+      float* dst = Y + (((long)(b * g.D + 2 * d + spd) * g.H + 2 * chr + sph) * g.W + 2 * cw + spw) * g.N + 4 * lk;
+      float4 oldv[2];
+      if (g.accumulate && ok) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * jp + jj;
+          oldv[jj] = (8 * j + 4 * lk < g.N) ? *reinterpret_cast<const float4*>(dst + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jp + jj;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * j + i;
+          float v = red[(stile * 16 + r) * 64 + lane];
+          for (int t = 1; t < sntile; ++t) v += red[((stile + t) * 16 + r) * 64 + lane];
+          if (g.has_bias && 8 * j + 4 * lk + i < g.N) v += bias[8 * j + 4 * lk + i];      // (L2-resident; not kept in registers)
+          o[i] = g.relu ? fmaxf(v, 0.0f) : v;
+        }
+        if (ok && 8 * j + 4 * lk < g.N) {
+          if (g.accumulate) { o[0] += oldv[jj].x; o[1] += oldv[jj].y; o[2] += oldv[jj].z; o[3] += oldv[jj].w; }
+          *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+    __syncthreads();                       // the fold buffer is reused by the next row pair
+    fresh = !same_plane;
+    if (++h2 == H2) {
+      h2 = 0;
+      if (++d == g.Ds) { d = 0; ++b; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3x3 stride-1 "heads" with 32 input channels and <= 4 output channels (classif3_2 / redir2:
 // 32 -> 1).  On the MFMA kernel such a layer costs as much as a full 32 -> 32 one (31 of 32 tile columns are padding).
 // Here it is a VALU reduction over the LDS ring of conv_tap_kernel:
@@ -2614,6 +2808,8 @@ int launch_conv_thin(const float* x, const float* wt, const float* bias, float* 
 // transposed) with k3 s2 p1 (output_padding 1: source = 2 x destination), K <= 32 source channels, 33..64 destination channels.
 // tile_hint 8 keeps the generic gather kernel, 5 forces this one on small problems (tests).
 bool conv_tap2_applicable(const ssbev_conv_dims* d, int mode) {
+  static const bool enabled = !(getenv("SSBEV_TAP2") && atoi(getenv("SSBEV_TAP2")) == 0);          // A/B hook
+  if (!enabled && d->tile_hint != 5) return false;
   if (!((mode == 0 && !d->transposed) || (mode == 1 && d->transposed))) return false;
   if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
   if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
@@ -2659,6 +2855,57 @@ int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* 
                           (int)kT2LdsBytes) != hipSuccess)
     return SSBEV_ELAUNCH;
   hipLaunchKernelGGL(conv_tap2_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(512), kT2LdsBytes, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
+// Stride-2 "up" gather on conv_tap2up_kernel: transposed-conv forward (mode 0, transposed) or conv data gradient (mode 1,
+// !transposed) with k3 s2 p1, fine grid = 2 x coarse grid, 33..64 source channels, <= 32 destination channels (multiple of 8).
+bool conv_tap2up_applicable(const ssbev_conv_dims* d, int mode) {
+  static const bool enabled = !(getenv("SSBEV_TAP2UP") && atoi(getenv("SSBEV_TAP2UP")) == 0);      // A/B hook
+  if (!enabled && d->tile_hint != 5) return false;
+  if (!((mode == 0 && d->transposed) || (mode == 1 && !d->transposed))) return false;
+  if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->precision != 0 || d->tile_hint == 8 || (d->tile_hint != 0 && d->tile_hint != 5)) return false;
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  if (K <= 32 || K > 64 || K % 4 != 0 || N > 32 || N < 16 || N % 8 != 0) return false;
+  // coarse (source) and fine (destination) grids
+  const int Ds = mode == 0 ? d->Di : d->Do, Hs = mode == 0 ? d->Hi : d->Ho, Ws = mode == 0 ? d->Wi : d->Wo;
+  const int Dd = mode == 0 ? d->Do : d->Di, Hd = mode == 0 ? d->Ho : d->Hi, Wd = mode == 0 ? d->Wo : d->Wi;
+  if (Dd != 2 * Ds || Hd != 2 * Hs || Wd != 2 * Ws) return false;
+  if ((long)Hs * Ws * K >= (1L << 30)) return false;
+  return d->tile_hint == 5 || (long)d->B * Ds * ((Hs + 1) / 2) * ((Ws + 15) / 16) >= 256L * 8;
+}
+
+int launch_conv_tap2up(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                       hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B;
+  g.Ds = mode == 0 ? d->Di : d->Do; g.Hs = mode == 0 ? d->Hi : d->Ho; g.Ws = mode == 0 ? d->Wi : d->Wo;
+  g.D = 2 * g.Ds; g.H = 2 * g.Hs; g.W = 2 * g.Ws;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.Ws + 15) / 16;
+  const int H2 = (g.Hs + 1) / 2;
+  g.NG = g.B * g.Ds * H2;                    // coarse row pairs
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
+  double best = 1e30;
+  g.gpc = 1;
+  for (int c = 1; c <= g.NG && c <= 96; ++c) {
+    const long blocks = (long)((g.NG + c - 1) / c) * g.nseg;
+    const long rounds = (blocks + 255) / 256;
+    const double crossings = H2 % c == 0 ? 0.0 : (c % H2 == 0 ? c / H2 - 1 : (double)c / H2);
+    const double cost = rounds * (c + 1.0 + 0.5 * crossings);
+    if (cost < best) { best = cost; g.gpc = c; }
+  }
+  if (const char* e = getenv("SSBEV_TAP2UP_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  const long nranges = (g.NG + g.gpc - 1) / g.gpc;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kUpLdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(conv_tap2up_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(1024), kUpLdsBytes, st, x, wp, bias, y, g);
   return ssbev_launch_status();
 }
 
@@ -2849,6 +3096,7 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (ssbev_thin::thinout_applicable(d, mode)) return 5;     // ssbev_conv_thin_* (caller-owned workspace); ssbev_conv_fwd falls back to class 3 / 0
   if (conv_thin_applicable(d, mode)) return 3;
   if (conv_tap2_applicable(d, mode)) return 7;                // stride-2 "down" gather on conv_tap2_kernel
+  if (conv_tap2up_applicable(d, mode)) return 8;              // stride-2 "up" gather on conv_tap2up_kernel
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
   return 0;
@@ -2860,7 +3108,7 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
   const size_t generic = taps * (a > b ? a : b);
-  const size_t special = (size_t)(kTwPackedElems > kT2PackedElems ? kTwPackedElems : kT2PackedElems);
+  const size_t special = (size_t)std::max(kTwPackedElems, std::max(kT2PackedElems, kUpPackedElems));
   return generic > special ? generic : special;
 }
 
@@ -2876,6 +3124,11 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   if (conv_tap2_applicable(d, mode)) {       // stride-2 "down" gather: [N][K][27] in both roles, see pack_tap2_kernel
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     hipLaunchKernelGGL(pack_tap2_kernel, dim3(cdiv(kT2PackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, N, K);
+    return ssbev_launch_status();
+  }
+  if (conv_tap2up_applicable(d, mode)) {     // stride-2 "up" gather: [K][N][27] in both roles, see pack_tap2up_kernel
+    const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+    hipLaunchKernelGGL(pack_tap2up_kernel, dim3(cdiv(kUpPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, N, K);
     return ssbev_launch_status();
   }
   if (conv_taph_applicable(d, mode)) {       // Winograd-along-h variant of the tap kernel: U = G w per (kd, kw)
@@ -2909,6 +3162,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap2_applicable(d, 0)) return launch_conv_tap2(x, w_packed, bias, y, d, 0, as_stream(stream));
+  if (conv_tap2up_applicable(d, 0)) return launch_conv_tap2up(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
@@ -2928,6 +3182,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   if (ssbev_thin::thinin_applicable(d, 1)) return ssbev_thin::thinin_launch(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
+  if (conv_tap2up_applicable(d, 1)) return launch_conv_tap2up(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin

@@ -226,14 +226,16 @@ TAP2_CASES = [
     # conv_tap2_kernel (forced on small problems by tile hint 5): even / odd grids, ragged 16-voxel segments, odd row-pair
     # counts, partial channel quads, the transposed convolution's data gradient
     (1, 32, 64, 8, 12, 32, False), (2, 32, 64, 7, 9, 21, False), (1, 16, 48, 6, 8, 20, False), (1, 24, 64, 5, 10, 70, False),
-    (1, 32, 64, 4, 6, 10, True), (2, 32, 48, 3, 5, 9, True),
+    (2, 32, 64, 4, 6, 38, False), (1, 32, 64, 4, 6, 10, True), (2, 32, 48, 3, 5, 9, True), (1, 16, 40, 5, 7, 19, True),
 ]
 
 
 @pytest.mark.parametrize("case", TAP2_CASES)
 def test_conv_stride2_down_tap_kernel(case, monkeypatch):
-    """conv_tap2_kernel (round 3): k3 s2 p1 conv forward with <= 32 input / 33..64 output channels, and the data gradient of
-    the matching transposed conv (output_padding 1), against ATen; plus the accumulating epilogue through a gradient slot."""
+    """conv_tap2_kernel / conv_tap2up_kernel (round 3): the k3 s2 p1 conv with <= 32 input / 33..64 output channels and the
+    matching transposed conv (output_padding 1), forward and all gradients against ATen: conv forward and transposed-conv data
+    gradient run on the "down" kernel, transposed-conv forward and conv data gradient on the "up" kernel (even grids); plus
+    their accumulating epilogues through gradient slots."""
     B, K, N, D, H, W, tr = case
     monkeypatch.setattr(F, "TILE_HINT", 5)
     if not tr:
@@ -261,6 +263,19 @@ def test_conv_stride2_down_tap_kernel(case, monkeypatch):
     got.backward(go.to(DEV))
     assert maxdiff(xg.grad, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
     assert maxdiff(wg.grad, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    if not tr and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and N % 8 == 0:
+        # the conv's data gradient is the "up" gather (conv_tap2up_kernel, class 8); with a second consumer of x (the 1x1
+        # redirect of an hourglass) it ACCUMULATES into the other gradient through a gradient slot
+        assert F.capi.load().ssbev_conv_kernel_class(F.C.byref(d), 1) == 8
+        w1 = S.hash_uniform(f"t2/w1{case}", (K, K, 1, 1, 1), -1, 1) * 0.2
+        g1 = S.hash_normal(f"t2/g1{case}", (B, K, D, H, W))
+        xa = x.to(DEV).requires_grad_(True)
+        a, b = F.fork(xa)
+        ya, yb = F.conv3d(a, wg.detach(), None, 2, 1), F.conv3d(b, w1.to(DEV), None, 1, 0)
+        torch.autograd.backward([ya, yb], [go.to(DEV), g1.to(DEV)])
+        xr = x.clone().requires_grad_(True)
+        torch.autograd.backward([TF.conv3d(xr, w, None, 2, 1), TF.conv3d(xr, w1, None, 1, 0)], [go, g1])
+        assert maxdiff(xa.grad, xr.grad) < 3e-5 * max(1.0, xr.grad.abs().max().item())
     if tr:      # two transposed convs share their input: the second data gradient accumulates into the first one's buffer
         w2 = S.hash_uniform(f"t2/w2{case}", (N, K, 3, 3, 3), -1, 1) * 0.05
         xa = x.to(DEV).requires_grad_(True)

@@ -43,3 +43,27 @@ for (D, H, W) in ((192, 48, 160), (112, 48, 160)):
         ref = xc.grad.clone() if ref is None else ref
         print(f"deconv 64->32 dgrad @ {D}x{H}x{W}  hint {hint}: {t:.3f} ms  {fl / t / 1e9:6.1f} TF/s   maxdiff {(xc.grad - ref).abs().max().item():.2e} of {ref.abs().max().item():.2f}", flush=True)
     F.TILE_HINT = 0
+    # the "up" gather: transposed conv 64 -> 32 forward and the data gradient of the conv 32 -> 64
+    wt2 = torch.randn(64, 32, 3, 3, 3, device="cuda") * 0.03
+    xc2 = xc.detach()
+    ref = None
+    for hint in (8, 0, 8, 0):
+        F.TILE_HINT = hint
+        with torch.no_grad():
+            y = F.conv_transpose3d(xc2, wt2, None, 2, 1, 1)
+            t = timed(lambda: F.conv_transpose3d(xc2, wt2, None, 2, 1, 1))
+        ref = y if ref is None else ref
+        print(f"deconv 64->32 fwd @ {D}x{H}x{W}  hint {hint}: {t:.3f} ms  {fl / t / 1e9:6.1f} TF/s   maxdiff {(y - ref).abs().max().item():.2e} of {ref.abs().max().item():.2f}", flush=True)
+    xf = x.detach().requires_grad_(True)
+    gc = torch.randn(1, 64, D // 2, H // 2, W // 2, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    ref = None
+    for hint in (8, 0, 8, 0):
+        F.TILE_HINT = hint
+        yy = F.conv3d(xf, w, None, 2, 1)
+        def run2():
+            xf.grad = None
+            yy.backward(gc, retain_graph=True)
+        t = timed(run2)
+        ref = xf.grad.clone() if ref is None else ref
+        print(f"conv 32->64 dgrad @ {D}x{H}x{W}  hint {hint}: {t:.3f} ms  {fl / t / 1e9:6.1f} TF/s   maxdiff {(xf.grad - ref).abs().max().item():.2e} of {ref.abs().max().item():.2f}", flush=True)
+    F.TILE_HINT = 0
