@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?" >> $out/smoke.txt
 timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err
 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-sample none --precision bf16 2>/dev/null | tail -1 > $out/bench_line_bf16.json
-timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample none --precision bf16 --batch 2 --skip-forward-extra 2>/dev/null | tail -1 > $out/bench_line_bf16_b2.json
+timeout 300 python bench.py --steps 8 --warmup 5 --cpu-sample none --precision bf16 --batch 2 --skip-forward-extra 2>/dev/null | tail -1 > $out/bench_line_bf16_b2.json
 # (a) the timed schedule (two streams): per-kernel averages agree with `roofline` of the bench line
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra --skip-serial-replay > $out/bench_under_rocprof.log 2>&1
 cp $(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv

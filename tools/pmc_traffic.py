@@ -14,7 +14,8 @@ FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_
             ("wgrad_thinside_kernel", ("wgrad_thinside_kernel",)), ("softmax_row", ("softmax_row_",)),
             ("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
-            ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
+            ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)),
+            ("conv_tap2_kernel", ("conv_tap2_kernel",)), ("conv_tap2up_kernel", ("conv_tap2up_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
             ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel")),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
             ("gn2_apply_fwd", ("gn2_apply_fwd_kernel",)), ("gn2_partial_bwd", ("gn2_partial_bwd_kernel",)), ("gn2_apply_bwd", ("gn2_apply_bwd_kernel",)),

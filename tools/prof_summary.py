@@ -5,7 +5,7 @@ import re
 import sys
 
 FAMILIES = [
-    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_thin*_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_thin"),
+    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_tap2_kernel, conv_tap2up_kernel, conv_thin*_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_tap2_kernel|conv_tap2up_kernel|conv_thin"),
     ("own MFMA GEMM family (gemm_nn / gemm_tn / skinny / sum: BRI products, k == s deconvs, pointwise weight gradients)", r"gemm_"),
     ("depth-fused Winograd contraction, own MFMA kernels (wino_df_kernel fwd/dgrad, wino_dfw_kernel wgrad, + pack / sum / reduce)", r"wino_df"),
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
