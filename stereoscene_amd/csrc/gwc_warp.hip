@@ -229,6 +229,114 @@ gwc_warp_fwd4_kernel(const float* __restrict__ left, const float* __restrict__ r
   }
 }
 
+// ---- forward, one pixel per thread (round 3) ---------------------------------------------------------------------------
+// fwd4 walks its row in passes of blockDim / (G/4) pixels and loads the left-view operands of every pass from global
+// memory in front of that pass's stores: five load latencies per workgroup, each queued BEHIND the store stream the same
+// workgroups keep full (17 of its 47 us; the store pattern alone runs at 30 us, tools/micro/store_pattern.hip).  Here a
+// workgroup owns (row, tile of blockDim / (G/4) pixels, plane chunk) and a thread ONE (pixel, group quad): the left-view
+// operands are loaded once, before anything is stored, next to the staging of the right-view pixels the chunk can reach
+// ([w0 - dmax(chunk), w0 + PX): 10 KB for the far chunks instead of the 40 KB row), and the plane loop is stores and
+// multiply-adds only, with the next plane's tap read one iteration ahead.
+template <int CPG, bool NT>
+__global__ void __launch_bounds__(512)
+gwc_warp_fwd5_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                     const float* __restrict__ calib, float* __restrict__ vol, PlaneChunks chunks, int B, int C, int G,
+                     int D, int H, int W, float down, int align_corners, int ntiles) {
+  extern __shared__ __align__(16) float lds[];
+  const int stride = C + 4;
+  XTap* taps = reinterpret_cast<XTap*>(lds + W * stride);               // [chunk length <= D]
+  const int G4 = G >> 2, PX = blockDim.x / G4;
+  const int row = blockIdx.x / ntiles, tile = blockIdx.x - row * ntiles;
+  const int b = row / H, h = row - b * H;
+  const int w0 = tile * PX;
+  const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1];
+  const int g4 = (threadIdx.x % G4) << 2, w = w0 + threadIdx.x / G4;
+  const bool active = w < W;
+  const float inv_cpg = 1.0f / (float)CPG;
+
+  float wy[4][2];
+  int cy[4][2];
+  bool okg[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int y0;
+    float a0, a1;
+    group_tap(g4 + j, G, align_corners, &y0, &a0, &a1);
+    okg[j][0] = y0 >= 0 && y0 < G;
+    okg[j][1] = y0 + 1 >= 0 && y0 + 1 < G;
+    cy[j][0] = okg[j][0] ? y0 * CPG : 0;
+    cy[j][1] = okg[j][1] ? (y0 + 1) * CPG : 0;
+    wy[j][0] = okg[j][0] ? a0 : 0.0f;
+    wy[j][1] = okg[j][1] ? a1 : 0.0f;
+  }
+  // left-view operands: issued first, they land while the right-view pixels are staged
+  const float* Lpix = left + ((size_t)row * W + (active ? w : 0)) * C;
+  float l[4][2][CPG];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+      l[j][0][c] = Lpix[cy[j][0] + c];
+      l[j][1][c] = Lpix[cy[j][1] + c];
+    }
+  // right-view pixels this chunk can reach: x0(k) is monotone in k, so its extremes sit at the chunk's ends
+  const float cal = calib[b];
+  const XTap ta = depth_tap(cal, k_begin, D, down, align_corners), tb = depth_tap(cal, k_end - 1, D, down, align_corners);
+  const int d_hi = min(max(max(ta.x0, tb.x0) + 1, 0), W);
+  const int lo = max(0, w0 - d_hi), hi = min(W, w0 + PX);
+  {
+    const int vec_per_px = C >> 2;
+    const float4* src = reinterpret_cast<const float4*>(right + ((size_t)row * W + lo) * C);
+    for (int i = threadIdx.x; i < (hi - lo) * vec_per_px; i += blockDim.x) {
+      const int p = i / vec_per_px, v = i - p * vec_per_px;
+      *reinterpret_cast<float4*>(lds + p * stride + 4 * v) = src[i];
+    }
+  }
+  for (int i = threadIdx.x; i < k_end - k_begin; i += blockDim.x)
+    taps[i] = depth_tap(cal, k_begin + i, D, down, align_corners);
+  __syncthreads();
+  if (!active) return;
+
+  float m[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j][0] = m[j][1] = 0.0f;
+  int cur = INT32_MIN;
+  const size_t plane = (size_t)H * W * G;
+  float* dst = vol + ((((size_t)b * D + k_begin) * H + h) * W + w) * G + g4;
+  XTap t = taps[0];
+  for (int k = k_begin; k < k_end; ++k) {
+    const XTap tn = taps[min(k + 1, k_end - 1) - k_begin];   // next plane's tap: its LDS latency hides behind this plane
+    if (t.x0 != cur) {            // wave-uniform: a new run of planes that share their two disparity taps
+      cur = t.x0;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int d = cur + tx;
+        const bool valid = d >= 0 && d < D && w >= d;   // w >= d: the reference volume is zero left of the disparity
+        const float* r = lds + (valid ? (w - d - lo) : 0) * stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+          for (int c = 0; c < CPG; ++c) {
+            c0 += l[j][0][c] * r[cy[j][0] + c];
+            c1 += l[j][1][c] * r[cy[j][1] + c];
+          }
+          m[j][tx] = valid ? wy[j][0] * (c0 * inv_cpg) + wy[j][1] * (c1 * inv_cpg) : 0.0f;
+        }
+      }
+    }
+    v4f o;
+    o.x = t.w0 * m[0][0] + t.w1 * m[0][1];
+    o.y = t.w0 * m[1][0] + t.w1 * m[1][1];
+    o.z = t.w0 * m[2][0] + t.w1 * m[2][1];
+    o.w = t.w0 * m[3][0] + t.w1 * m[3][1];
+    if (NT) __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));
+    else *reinterpret_cast<v4f*>(dst) = o;
+    dst += plane;
+    t = tn;
+  }
+}
+
 // Backward.  For a source group g' the output groups that read it are those g with y0(g) == g'
 // (weight wy0(g)) or y0(g)+1 == g' (weight wy1(g)); y0 is monotone in g so there are at most a few.
 //   S(k, w)      = sum_{(g, wy)} wy * gvol[k, w, g]
@@ -487,10 +595,216 @@ gwc_warp_bwd2_kernel(const float* __restrict__ gvol, const float* __restrict__ l
   }
 }
 
+// ---- backward, round 3: the plane stream never stops ---------------------------------------------------------------
+// bwd2 alternates "stream the planes of a run" and "contract the run" with two barriers per run and nothing in flight
+// while it contracts; per batch of planes it pays one full load latency (load, wait, use).  Here
+//   * the planes are read in batches of <= UNR planes of ONE run, two register buffers deep (ping-pong): while a batch is
+//     folded into the tap sums the next one is in flight, and it STAYS in flight across a contraction (the barrier is a
+//     raw s_barrier behind s_waitcnt lgkmcnt(0) -- __syncthreads() would drain vmcnt).  The batch sequence follows from
+//     runend[] (end of the run a plane belongs to: a binary search per plane in the prologue, x0(k) is monotone);
+//   * the tap sums roll: a run with taps (x0, x0 + 1) is followed by one with (x0 - 1, x0) almost everywhere, so the sum
+//     for d = x0 keeps accumulating (as the upper tap) and only the finished one (d = x0 + 1) is contracted -- one
+//     contraction per run instead of two, one barrier each (the exchange buffer S is double-buffered);
+//   * y-taps of weight zero (align_corners: every second one) are dropped from the source lists.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CPG, int UNR>
+__global__ void __launch_bounds__(BWD_MAXTHREADS)
+gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ left, const float* __restrict__ right,
+                     const float* __restrict__ calib, float* __restrict__ part_l, float* __restrict__ part_r,
+                     PlaneChunks chunks, int B, int C, int G, int D, int H, int W, float down, int align_corners) {
+  constexpr int MAXI = BwdCfg<CPG>::MAXI;
+  extern __shared__ __align__(16) float lds[];
+  const int stride = C;                                      // the contraction reads runs of consecutive s: no pad needed
+  float* Lrow = lds;                                         // [W][C]
+  float* Rrow = Lrow + W * stride;                           // [W][C]
+  float* S = Rrow + W * stride;                              // [2][W][G]
+  XTap* taps = reinterpret_cast<XTap*>(S + 2 * W * G);       // [chunk length <= D]
+  int* runend = reinterpret_cast<int*>(taps + D);            // [chunk length]: first plane behind the run of plane i
+  int* src_g = runend + D;                                   // [G][MAX_SRC]
+  float* src_w = reinterpret_cast<float*>(src_g + G * MAX_SRC);
+  int* src_n = reinterpret_cast<int*>(src_w + G * MAX_SRC);  // [G]
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1], len = k_end - k_begin;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nq = W * (G >> 2);                               // quads per plane row
+  const size_t plane4 = (size_t)H * W * G / 4;
+  const v4f* grow = reinterpret_cast<const v4f*>(gvol + (((size_t)b * D) * H + h) * W * G);
+  int q[BWD_MAXQ];
+#pragma unroll
+  for (int it = 0; it < BWD_MAXQ; ++it) q[it] = min(tid + it * nthr, nq - 1);
+  // batch = planes [k, min(k + UNR, ke)) of the run that ends at ke; slots past the batch repeat its last plane
+  v4f bufA[UNR][BWD_MAXQ], bufB[UNR][BWD_MAXQ];
+  auto load = [&](v4f (&buf)[UNR][BWD_MAXQ], int k, int ke) __attribute__((always_inline)) {
+    const int last = min(ke, k_end) - 1;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const v4f* gk = grow + (size_t)max(min(k + u, last), k_begin) * plane4;
+#pragma unroll
+      for (int it = 0; it < BWD_MAXQ; ++it) buf[u][it] = gk[q[it]];
+    }
+  };
+
+  stage_row(left + ((size_t)b * H + h) * W * C, Lrow, W, C, stride);
+  stage_row(right + ((size_t)b * H + h) * W * C, Rrow, W, C, stride);
+  for (int k = tid; k < len; k += nthr) taps[k] = depth_tap(calib[b], k_begin + k, D, down, align_corners);
+  for (int gs = tid; gs < G; gs += nthr) {
+    int n = 0;
+    for (int g = 0; g < G; ++g) {
+      int y0;
+      float w0, w1;
+      group_tap(g, G, align_corners, &y0, &w0, &w1);
+      if (y0 == gs && w0 != 0.0f && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w0; ++n; }
+      if (y0 + 1 == gs && w1 != 0.0f && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w1; ++n; }
+    }
+    src_n[gs] = n;
+  }
+  __syncthreads();
+  for (int i = tid; i < len; i += nthr) {                    // equal taps are contiguous (monotone): binary search for the run end
+    const int xi = taps[i].x0;
+    int lo = i + 1, hi = len;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (taps[mid].x0 == xi) lo = mid + 1; else hi = mid;
+    }
+    runend[i] = k_begin + lo;
+  }
+  __syncthreads();
+
+  // contraction identity of this thread: source group s is the same for all of its items (nthr % G == 0)
+  const int s = tid % G, w_first = tid / G, w_step = nthr / G;
+  int sg[MAX_SRC];
+  float sw[MAX_SRC];
+  int nsrc = 0;                                              // the longest source list, workgroup-uniform: shorter lists are
+  for (int g = 0; g < G; ++g) nsrc = max(nsrc, src_n[g]);    // padded with weight 0 on entry 0 (scalar branches in the contraction)
+  {
+    const int n = src_n[s];
+#pragma unroll
+    for (int i = 0; i < MAX_SRC; ++i) {
+      sg[i] = i < n ? src_g[s * MAX_SRC + i] : 0;
+      sw[i] = i < n ? src_w[s * MAX_SRC + i] : 0.0f;
+    }
+  }
+  float accL[MAXI][CPG], accR[MAXI][CPG];
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) accL[it][c] = accR[it][c] = 0.0f;
+
+  v4f Tlo[BWD_MAXQ], Thi[BWD_MAXQ];                          // tap sums for d = cur and d = cur + 1
+#pragma unroll
+  for (int it = 0; it < BWD_MAXQ; ++it) Tlo[it] = Thi[it] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  int cur = INT32_MIN, flip = 0;
+  const int dmax = min(D, W);
+
+  // the run changes to taps (xn, xn + 1): contract what is finished.  xn == cur - 1: only the upper sum (d = cur + 1), the
+  // lower one becomes the new upper one.  Anything else (first run excepted): both.  ONE copy of the contraction per call
+  // site: a loop of one or two rounds with the operand selected by the (workgroup-uniform) round.
+  auto retire = [&](int xn) __attribute__((always_inline)) {
+    if (cur != INT32_MIN) {
+      const bool roll = xn == cur - 1;
+#pragma nounroll
+      for (int f = 0; f < (roll ? 1 : 2); ++f) {
+        const int d = f ? cur : cur + 1;
+        if (d < 0 || d >= dmax) continue;                    // workgroup-uniform
+        float* Sx = S + flip * W * G;
+        flip ^= 1;
+#pragma unroll
+        for (int it = 0; it < BWD_MAXQ; ++it)
+          if (tid + it * nthr < nq) reinterpret_cast<v4f*>(Sx)[tid + it * nthr] = f ? Tlo[it] : Thi[it];
+        lds_barrier();                                       // readers of the other buffer are past their previous round
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+          const int w = w_first + it * w_step;
+          if (w < W) {
+            if (w >= d) {
+              float gc = 0.0f;
+#pragma unroll
+              for (int i = 0; i < MAX_SRC; ++i)
+                if (i < nsrc) gc += sw[i] * Sx[w * G + sg[i]];
+              const float* r = Rrow + (w - d) * stride + s * CPG;
+#pragma unroll
+              for (int c = 0; c < CPG; ++c) accL[it][c] += gc * r[c];
+            }
+            if (w + d < W) {
+              float gc = 0.0f;
+#pragma unroll
+              for (int i = 0; i < MAX_SRC; ++i)
+                if (i < nsrc) gc += sw[i] * Sx[(w + d) * G + sg[i]];
+              const float* l = Lrow + (w + d) * stride + s * CPG;
+#pragma unroll
+              for (int c = 0; c < CPG; ++c) accR[it][c] += gc * l[c];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < BWD_MAXQ; ++it) {
+        Thi[it] = roll ? Tlo[it] : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        Tlo[it] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+    cur = xn;
+  };
+  auto fold = [&](const v4f (&buf)[UNR][BWD_MAXQ], int k, int ke) __attribute__((always_inline)) {
+    if (k >= k_end) return;
+    const int x0 = taps[k - k_begin].x0;
+    if (x0 != cur) retire(x0);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (k + u < ke) {
+        const XTap t = taps[k + u - k_begin];
+#pragma unroll
+        for (int it = 0; it < BWD_MAXQ; ++it) {
+          Tlo[it] += t.w0 * buf[u][it];
+          Thi[it] += t.w1 * buf[u][it];
+        }
+      }
+    }
+  };
+  auto advance = [&](int& k, int& ke) __attribute__((always_inline)) {   // the batch behind (k, ke)
+    k = min(k + UNR, ke);
+    if (k >= ke && k < k_end) ke = runend[k - k_begin];
+  };
+  int kA = k_begin, keA = runend[0], kB, keB;
+  load(bufA, kA, keA);
+  while (kA < k_end) {
+    kB = kA; keB = keA;
+    advance(kB, keB);
+    load(bufB, kB, keB);
+    fold(bufA, kA, keA);
+    kA = kB; keA = keB;
+    advance(kA, keA);
+    load(bufA, kA, keA);
+    fold(bufB, kB, keB);
+  }
+  retire(INT32_MIN + 7);                                     // no plane follows: both sums are finished
+
+  const float inv_cpg = 1.0f / (float)CPG;
+  const size_t slab = (size_t)B * H * W * C;
+  float* pl = part_l + blockIdx.y * slab + ((size_t)b * H + h) * W * C;
+  float* pr = part_r + blockIdx.y * slab + ((size_t)b * H + h) * W * C;
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int w = w_first + it * w_step;
+    if (w < W) {
+#pragma unroll
+      for (int c = 0; c < CPG; ++c) {
+        pl[(size_t)w * C + s * CPG + c] = accL[it][c] * inv_cpg;
+        pr[(size_t)w * C + s * CPG + c] = accR[it][c] * inv_cpg;
+      }
+    }
+  }
+}
+
 // out[i] = sum over chunks (ascending) of part[chunk][i]; n4 float4 elements per slab
-__global__ void gwc_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, size_t n4) {
+__global__ void gwc_partial_reduce_kernel(const float* __restrict__ part0, float* __restrict__ out0,
+                                          const float* __restrict__ part1, float* __restrict__ out1, int nchunks, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  const float* part = blockIdx.y ? part1 : part0;             // blockIdx.y: left / right view
+  float* out = blockIdx.y ? out1 : out0;
   v4f acc = reinterpret_cast<const v4f*>(part)[i];
   for (int c = 1; c < nchunks; ++c) acc += reinterpret_cast<const v4f*>(part)[(size_t)c * n4 + i];
   reinterpret_cast<v4f*>(out)[i] = acc;
@@ -547,7 +861,30 @@ int env_int(const char* name, int dflt) {
 template <int CPG>
 int launch_fwd(const float* l, const float* r, const float* calib, float* vol, const ssbev_gwc_dims* d,
                hipStream_t st) {
-  static const int variant = env_int("SSBEV_GWC_FWD", 2);          // 1 = per-plane kernel (r1), 2 = fwd4
+  static const int variant = env_int("SSBEV_GWC_FWD", 3);          // 1 = per-plane kernel (r1), 2 = fwd4 (r2), 3 = fwd5
+  if (variant >= 3 && d->G % 4 == 0) {
+    static const int threads = env_int("SSBEV_GWC_FWD_THREADS", 256);
+    static const int wg_target = env_int("SSBEV_GWC_FWD_WGS", 480);
+    static const int nt = env_int("SSBEV_GWC_FWD_NT", 0);
+    static const float run_cost = (float)env_int("SSBEV_GWC_FWD_RUNCOST", 4);
+    int unit = 64, g4 = d->G / 4;                   // block size: a multiple of the wave and of G / 4
+    while (unit % g4 != 0) unit += 64;
+    const int nthreads = std::max(unit, std::min(512, std::max(64, threads)) / unit * unit);
+    const int px = nthreads / g4, ntiles = (int)cdiv(d->W, px);
+    const long groups = (long)d->B * d->H * ntiles;
+    const PlaneChunks ch = make_chunks(d->D, (int)cdiv(wg_target, groups), run_cost, d->D);
+    const size_t lds = (size_t)d->W * (d->C + 4) * 4 + (size_t)d->D * sizeof(XTap);
+    if (lds <= 160 * 1024 && groups <= 0x7fffffffL) {
+      auto kern = nt ? gwc_warp_fwd5_kernel<CPG, true> : gwc_warp_fwd5_kernel<CPG, false>;
+      if (lds > 64 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+              hipSuccess)
+        return SSBEV_ELAUNCH;
+      hipLaunchKernelGGL(kern, dim3((unsigned)groups, ch.n), dim3(nthreads), lds, st, l, r, calib, vol, ch, d->B, d->C,
+                         d->G, d->D, d->H, d->W, d->down, d->align_corners, ntiles);
+      return ssbev_launch_status();
+    }
+  }
   if (variant != 1 && d->G % 4 == 0) {
     static const int threads = env_int("SSBEV_GWC_FWD_THREADS", 256);
     static const int wg_target = env_int("SSBEV_GWC_FWD_WGS", 768);
@@ -623,7 +960,7 @@ Bwd2Plan plan_bwd2(const ssbev_gwc_dims* d) {
   threads = std::max(threads, 256);
   if (threads > BWD_MAXTHREADS) return p;
   p.threads = threads;
-  p.lds = (size_t)2 * d->W * (d->C + 4) * 4 + (size_t)2 * d->W * d->G * 4 + (size_t)d->D * sizeof(XTap) +
+  p.lds = (size_t)2 * d->W * (d->C + 4) * 4 + (size_t)2 * d->W * d->G * 4 + (size_t)d->D * (sizeof(XTap) + 4) +
           (size_t)d->G * MAX_SRC * 8 + (size_t)d->G * 4;
   if (p.lds > 160 * 1024) return p;
   static const int wg_target = env_int("SSBEV_GWC_BWD_WGS", 256);     // one workgroup per CU (LDS-bound occupancy)
@@ -646,9 +983,11 @@ int launch_bwd2(const float* gvol, const float* l, const float* r, const float* 
     pl = static_cast<float*>(ws);
     pr = pl + p.ch.n * slab;
   }
-  static const int unr = env_int("SSBEV_GWC_BWD_UNR", 2), nt = env_int("SSBEV_GWC_BWD_NT", 0);
-  auto kern = unr >= 4 ? (nt ? gwc_warp_bwd2_kernel<CPG, 4, true> : gwc_warp_bwd2_kernel<CPG, 4, false>)
-                       : (nt ? gwc_warp_bwd2_kernel<CPG, 2, true> : gwc_warp_bwd2_kernel<CPG, 2, false>);
+  static const int variant = env_int("SSBEV_GWC_BWD", 3);           // 2 = bwd2 (r2), 3 = bwd3
+  static const int unr = env_int("SSBEV_GWC_BWD_UNR", variant >= 3 ? 4 : 2), nt = env_int("SSBEV_GWC_BWD_NT", 0);
+  auto kern = variant >= 3 ? (unr >= 4 ? gwc_warp_bwd3_kernel<CPG, 4> : (unr >= 2 ? gwc_warp_bwd3_kernel<CPG, 2> : gwc_warp_bwd3_kernel<CPG, 1>))
+              : unr >= 4   ? (nt ? gwc_warp_bwd2_kernel<CPG, 4, true> : gwc_warp_bwd2_kernel<CPG, 4, false>)
+                           : (nt ? gwc_warp_bwd2_kernel<CPG, 2, true> : gwc_warp_bwd2_kernel<CPG, 2, false>);
   if (p.lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
           hipSuccess)
@@ -657,8 +996,7 @@ int launch_bwd2(const float* gvol, const float* l, const float* r, const float* 
                      d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners);
   if (p.ch.n > 1) {
     const size_t n4 = slab / 4;
-    hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, pl, gl, p.ch.n, n4);
-    hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, pr, gr, p.ch.n, n4);
+    hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256), 2), dim3(256), 0, st, pl, gl, pr, gr, p.ch.n, n4);
   }
   return ssbev_launch_status();
 }
