@@ -608,6 +608,8 @@ gwc_warp_bwd2_kernel(const float* __restrict__ gvol, const float* __restrict__ l
 //   * y-taps of weight zero (align_corners: every second one) are dropped from the source lists.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+struct __align__(16) BTap { int x0; float w0, w1; int runend; };   // runend: first plane behind the run of this plane
+
 template <int CPG, int UNR>
 __global__ void __launch_bounds__(BWD_MAXTHREADS)
 gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ left, const float* __restrict__ right,
@@ -616,51 +618,50 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
   constexpr int MAXI = BwdCfg<CPG>::MAXI;
   extern __shared__ __align__(16) float lds[];
   const int stride = C;                                      // the contraction reads runs of consecutive s: no pad needed
-  float* Lrow = lds;                                         // [W][C]
+  // order matters: the contraction reads S[(w + d) * G ..], L[w + d], R[w - d] WITHOUT range checks (a selected 0 multiplies
+  // what comes back), so an overshoot must land in initialised floats: S0 -> S1 -> Lrow <- Rrow (negative) / Lrow -> Rrow
+  float* S = lds;                                            // [2][W][G]
+  float* Lrow = S + 2 * W * G;                               // [W][C]
   float* Rrow = Lrow + W * stride;                           // [W][C]
-  float* S = Rrow + W * stride;                              // [2][W][G]
-  XTap* taps = reinterpret_cast<XTap*>(S + 2 * W * G);       // [chunk length <= D]
-  int* runend = reinterpret_cast<int*>(taps + D);            // [chunk length]: first plane behind the run of plane i
-  int* src_g = runend + D;                                   // [G][MAX_SRC]
+  BTap* taps = reinterpret_cast<BTap*>(Rrow + W * stride);   // [chunk length <= D]
+  int* src_g = reinterpret_cast<int*>(taps + D);             // [G][MAX_SRC]
   float* src_w = reinterpret_cast<float*>(src_g + G * MAX_SRC);
   int* src_n = reinterpret_cast<int*>(src_w + G * MAX_SRC);  // [G]
+  int* ytap_y = src_n + G;                                   // [G]     y-tap of output group g: first source group ...
+  float* ytap_w = reinterpret_cast<float*>(ytap_y + G);      // [G][2]  ... and the two weights
+  int* nsrc_max = reinterpret_cast<int*>(ytap_w + 2 * G);    // [1]
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
   const int k_begin = chunks.start[blockIdx.y], k_end = chunks.start[blockIdx.y + 1], len = k_end - k_begin;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int nq = W * (G >> 2);                               // quads per plane row
   const size_t plane4 = (size_t)H * W * G / 4;
   const v4f* grow = reinterpret_cast<const v4f*>(gvol + (((size_t)b * D) * H + h) * W * G);
-  int q[BWD_MAXQ];
-#pragma unroll
-  for (int it = 0; it < BWD_MAXQ; ++it) q[it] = min(tid + it * nthr, nq - 1);
-  // batch = planes [k, min(k + UNR, ke)) of the run that ends at ke; slots past the batch repeat its last plane
-  v4f bufA[UNR][BWD_MAXQ], bufB[UNR][BWD_MAXQ];
-  auto load = [&](v4f (&buf)[UNR][BWD_MAXQ], int k, int ke) __attribute__((always_inline)) {
-    const int last = min(ke, k_end) - 1;
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const v4f* gk = grow + (size_t)max(min(k + u, last), k_begin) * plane4;
-#pragma unroll
-      for (int it = 0; it < BWD_MAXQ; ++it) buf[u][it] = gk[q[it]];
-    }
-  };
 
   stage_row(left + ((size_t)b * H + h) * W * C, Lrow, W, C, stride);
   stage_row(right + ((size_t)b * H + h) * W * C, Rrow, W, C, stride);
-  for (int k = tid; k < len; k += nthr) taps[k] = depth_tap(calib[b], k_begin + k, D, down, align_corners);
-  for (int gs = tid; gs < G; gs += nthr) {
-    int n = 0;
-    for (int g = 0; g < G; ++g) {
-      int y0;
-      float w0, w1;
-      group_tap(g, G, align_corners, &y0, &w0, &w1);
+  for (int k = tid; k < len; k += nthr) {
+    const XTap t = depth_tap(calib[b], k_begin + k, D, down, align_corners);
+    taps[k].x0 = t.x0; taps[k].w0 = t.w0; taps[k].w1 = t.w1;
+  }
+  for (int g = tid; g < G; g += nthr) {                       // the y-tap of every output group, once (IEEE divisions)
+    int y0;
+    float w0, w1;
+    group_tap(g, G, align_corners, &y0, &w0, &w1);
+    ytap_y[g] = y0; ytap_w[2 * g] = w0; ytap_w[2 * g + 1] = w1;
+  }
+  if (tid == 0) *nsrc_max = 0;
+  __syncthreads();
+  for (int gs = tid; gs < G; gs += nthr) {                    // source lists: who reads source group gs, with which weight
+    int n = 0;                                                // (y0(g) is g - 1 or g in both conventions: +-2 is generous)
+    for (int g = max(gs - 2, 0); g <= min(gs + 2, G - 1); ++g) {
+      const int y0 = ytap_y[g];
+      const float w0 = ytap_w[2 * g], w1 = ytap_w[2 * g + 1];
       if (y0 == gs && w0 != 0.0f && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w0; ++n; }
       if (y0 + 1 == gs && w1 != 0.0f && n < MAX_SRC) { src_g[gs * MAX_SRC + n] = g; src_w[gs * MAX_SRC + n] = w1; ++n; }
     }
     src_n[gs] = n;
+    atomicMax(nsrc_max, n);
   }
-  __syncthreads();
   for (int i = tid; i < len; i += nthr) {                    // equal taps are contiguous (monotone): binary search for the run end
     const int xi = taps[i].x0;
     int lo = i + 1, hi = len;
@@ -668,7 +669,7 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
       const int mid = (lo + hi) >> 1;
       if (taps[mid].x0 == xi) lo = mid + 1; else hi = mid;
     }
-    runend[i] = k_begin + lo;
+    taps[i].runend = k_begin + lo;
   }
   __syncthreads();
 
@@ -676,9 +677,8 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
   const int s = tid % G, w_first = tid / G, w_step = nthr / G;
   int sg[MAX_SRC];
   float sw[MAX_SRC];
-  int nsrc = 0;                                              // the longest source list, workgroup-uniform: shorter lists are
-  for (int g = 0; g < G; ++g) nsrc = max(nsrc, src_n[g]);    // padded with weight 0 on entry 0 (scalar branches in the contraction)
-  {
+  const int nsrc = *nsrc_max;                                // the longest source list, workgroup-uniform: shorter lists are
+  {                                                          // padded with weight 0 on entry 0 (scalar branches below)
     const int n = src_n[s];
 #pragma unroll
     for (int i = 0; i < MAX_SRC; ++i) {
@@ -712,30 +712,40 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
         flip ^= 1;
 #pragma unroll
         for (int it = 0; it < BWD_MAXQ; ++it)
-          if (tid + it * nthr < nq) reinterpret_cast<v4f*>(Sx)[tid + it * nthr] = f ? Tlo[it] : Thi[it];
+          reinterpret_cast<v4f*>(Sx)[tid + it * nthr] = f ? Tlo[it] : Thi[it];
         lds_barrier();                                       // readers of the other buffer are past their previous round
+        // branch-free and clamp-free (the launcher guarantees MAXI * w_step == W): an out-of-range item reads initialised
+        // floats of a neighbouring LDS region and contributes a selected 0, so that the LDS reads go out back to back
+        // (guarded, every item was an exec-mask region with its own LDS latency: 22 of the kernel's 67 us).
+        // (the asm makes the lane's offsets opaque: otherwise LICM precomputes base + it * step + sg[i] for every
+        // (item, source) once per kernel and the register allocator spills the 24 of them)
+        int oS = w_first * G, og[MAX_SRC];
+        asm volatile("" : "+v"(oS));
+#pragma unroll
+        for (int i = 0; i < MAX_SRC; ++i) {
+          og[i] = sg[i];
+          asm volatile("" : "+v"(og[i]));
+        }
+        const float* pSl = Sx + oS;
+        const float* pSr = pSl + d * G;
+        const float* pR = Rrow + (w_first - d) * stride + s * CPG;
+        const float* pL = Lrow + (w_first + d) * stride + s * CPG;
 #pragma unroll
         for (int it = 0; it < MAXI; ++it) {
           const int w = w_first + it * w_step;
-          if (w < W) {
-            if (w >= d) {
-              float gc = 0.0f;
+          float gl = 0.0f, gr = 0.0f;
 #pragma unroll
-              for (int i = 0; i < MAX_SRC; ++i)
-                if (i < nsrc) gc += sw[i] * Sx[w * G + sg[i]];
-              const float* r = Rrow + (w - d) * stride + s * CPG;
-#pragma unroll
-              for (int c = 0; c < CPG; ++c) accL[it][c] += gc * r[c];
+          for (int i = 0; i < MAX_SRC; ++i)
+            if (i < nsrc) {                                  // workgroup-uniform
+              gl += sw[i] * pSl[it * w_step * G + og[i]];
+              gr += sw[i] * pSr[it * w_step * G + og[i]];
             }
-            if (w + d < W) {
-              float gc = 0.0f;
+          gl = w >= d ? gl : 0.0f;
+          gr = w + d < W ? gr : 0.0f;
 #pragma unroll
-              for (int i = 0; i < MAX_SRC; ++i)
-                if (i < nsrc) gc += sw[i] * Sx[(w + d) * G + sg[i]];
-              const float* l = Lrow + (w + d) * stride + s * CPG;
-#pragma unroll
-              for (int c = 0; c < CPG; ++c) accR[it][c] += gc * l[c];
-            }
+          for (int c = 0; c < CPG; ++c) {
+            accL[it][c] += gl * pR[it * w_step * stride + c];
+            accR[it][c] += gr * pL[it * w_step * stride + c];
           }
         }
       }
@@ -747,37 +757,55 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
     }
     cur = xn;
   };
-  auto fold = [&](const v4f (&buf)[UNR][BWD_MAXQ], int k, int ke) __attribute__((always_inline)) {
-    if (k >= k_end) return;
-    const int x0 = taps[k - k_begin].x0;
-    if (x0 != cur) retire(x0);
+
+  // batch = planes [k, min(k + UNR, ke)) of the run that ends at ke; slots past the batch repeat its last plane (so do the
+  // two batches behind the chunk: a conditional load makes hipcc drain vmcnt in the loop, an L2 hit costs nothing).  The
+  // batch's taps travel with it in registers (read when its loads are issued: their LDS latency hides behind the loads)
+  struct Batch { v4f v[UNR][BWD_MAXQ]; int k, ke, x0; float w0[UNR], w1[UNR]; };
+  Batch bA, bB;
+  auto load = [&](Batch& bt, int k, int ke) __attribute__((always_inline)) {
+    bt.k = k; bt.ke = ke;
+    const int last = min(ke, k_end) - 1;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if (k + u < ke) {
-        const XTap t = taps[k + u - k_begin];
+      const int kk = max(min(k + u, last), k_begin);
+      const v4f* gk = grow + (size_t)kk * plane4;
+#pragma unroll
+      for (int it = 0; it < BWD_MAXQ; ++it) bt.v[u][it] = gk[tid + it * nthr];
+      const BTap t = taps[kk - k_begin];
+      if (u == 0) bt.x0 = t.x0;
+      bt.w0[u] = t.w0; bt.w1[u] = t.w1;
+    }
+  };
+  auto fold = [&](const Batch& bt) __attribute__((always_inline)) {
+    if (bt.k >= k_end) return;
+    if (bt.x0 != cur) retire(bt.x0);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (bt.k + u < bt.ke) {
 #pragma unroll
         for (int it = 0; it < BWD_MAXQ; ++it) {
-          Tlo[it] += t.w0 * buf[u][it];
-          Thi[it] += t.w1 * buf[u][it];
+          Tlo[it] += bt.w0[u] * bt.v[u][it];
+          Thi[it] += bt.w1[u] * bt.v[u][it];
         }
       }
     }
   };
   auto advance = [&](int& k, int& ke) __attribute__((always_inline)) {   // the batch behind (k, ke)
     k = min(k + UNR, ke);
-    if (k >= ke && k < k_end) ke = runend[k - k_begin];
+    if (k >= ke && k < k_end) ke = taps[k - k_begin].runend;
   };
-  int kA = k_begin, keA = runend[0], kB, keB;
-  load(bufA, kA, keA);
+  int kA = k_begin, keA = taps[0].runend, kB, keB;
+  load(bA, kA, keA);
   while (kA < k_end) {
     kB = kA; keB = keA;
     advance(kB, keB);
-    load(bufB, kB, keB);
-    fold(bufA, kA, keA);
+    load(bB, kB, keB);
+    fold(bA);
     kA = kB; keA = keB;
     advance(kA, keA);
-    load(bufA, kA, keA);
-    fold(bufB, kB, keB);
+    load(bA, kA, keA);
+    fold(bB);
   }
   retire(INT32_MIN + 7);                                     // no plane follows: both sums are finished
 
@@ -788,12 +816,10 @@ gwc_warp_bwd3_kernel(const float* __restrict__ gvol, const float* __restrict__ l
 #pragma unroll
   for (int it = 0; it < MAXI; ++it) {
     const int w = w_first + it * w_step;
-    if (w < W) {
 #pragma unroll
-      for (int c = 0; c < CPG; ++c) {
-        pl[(size_t)w * C + s * CPG + c] = accL[it][c] * inv_cpg;
-        pr[(size_t)w * C + s * CPG + c] = accR[it][c] * inv_cpg;
-      }
+    for (int c = 0; c < CPG; ++c) {
+      pl[(size_t)w * C + s * CPG + c] = accL[it][c] * inv_cpg;
+      pr[(size_t)w * C + s * CPG + c] = accR[it][c] * inv_cpg;
     }
   }
 }
@@ -960,12 +986,12 @@ Bwd2Plan plan_bwd2(const ssbev_gwc_dims* d) {
   threads = std::max(threads, 256);
   if (threads > BWD_MAXTHREADS) return p;
   p.threads = threads;
-  p.lds = (size_t)2 * d->W * (d->C + 4) * 4 + (size_t)2 * d->W * d->G * 4 + (size_t)d->D * (sizeof(XTap) + 4) +
-          (size_t)d->G * MAX_SRC * 8 + (size_t)d->G * 4;
+  p.lds = (size_t)2 * d->W * (d->C + 4) * 4 + (size_t)2 * d->W * d->G * 4 + (size_t)d->D * sizeof(BTap) +
+          (size_t)d->G * MAX_SRC * 8 + (size_t)d->G * 16 + 16;
   if (p.lds > 160 * 1024) return p;
   static const int wg_target = env_int("SSBEV_GWC_BWD_WGS", 256);     // one workgroup per CU (LDS-bound occupancy)
   const int rows = d->B * d->H;
-  static const float run_cost = (float)env_int("SSBEV_GWC_BWD_RUNCOST", 5);
+  static const float run_cost = (float)env_int("SSBEV_GWC_BWD_RUNCOST", 8);
   p.ch = make_chunks(d->D, std::max(1, wg_target / rows), run_cost, d->D);
   p.ok = true;
   return p;
@@ -984,16 +1010,28 @@ int launch_bwd2(const float* gvol, const float* l, const float* r, const float* 
     pr = pl + p.ch.n * slab;
   }
   static const int variant = env_int("SSBEV_GWC_BWD", 3);           // 2 = bwd2 (r2), 3 = bwd3
-  static const int unr = env_int("SSBEV_GWC_BWD_UNR", variant >= 3 ? 4 : 2), nt = env_int("SSBEV_GWC_BWD_NT", 0);
-  auto kern = variant >= 3 ? (unr >= 4 ? gwc_warp_bwd3_kernel<CPG, 4> : (unr >= 2 ? gwc_warp_bwd3_kernel<CPG, 2> : gwc_warp_bwd3_kernel<CPG, 1>))
-              : unr >= 4   ? (nt ? gwc_warp_bwd2_kernel<CPG, 4, true> : gwc_warp_bwd2_kernel<CPG, 4, false>)
-                           : (nt ? gwc_warp_bwd2_kernel<CPG, 2, true> : gwc_warp_bwd2_kernel<CPG, 2, false>);
-  if (p.lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
-          hipSuccess)
-    return SSBEV_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(d->B * d->H, p.ch.n), dim3(p.threads), p.lds, st, gvol, l, r, calib, pl, pr, p.ch, d->B,
-                     d->C, d->G, d->D, d->H, d->W, d->down, d->align_corners);
+  static const int unr = env_int("SSBEV_GWC_BWD_UNR", variant >= 3 ? 1 : 2), nt = env_int("SSBEV_GWC_BWD_NT", 0);
+  const dim3 grid(d->B * d->H, p.ch.n), block(p.threads);
+  const bool exact = d->W * (d->G / 4) == BWD_MAXQ * p.threads && p.threads % d->G == 0 &&
+                     BwdCfg<CPG>::MAXI * (p.threads / d->G) == d->W;       // bwd3 has no tails (KITTI: 640 threads)
+  if (variant >= 3 && exact) {
+    auto kern = unr >= 2 ? gwc_warp_bwd3_kernel<CPG, 2> : gwc_warp_bwd3_kernel<CPG, 1>;   // 4 planes per batch spill
+    if (p.lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
+            hipSuccess)
+      return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, block, p.lds, st, gvol, l, r, calib, pl, pr, p.ch, d->B, d->C, d->G, d->D, d->H, d->W,
+                       d->down, d->align_corners);
+  } else {
+    auto kern = unr >= 4 ? (nt ? gwc_warp_bwd2_kernel<CPG, 4, true> : gwc_warp_bwd2_kernel<CPG, 4, false>)
+                         : (nt ? gwc_warp_bwd2_kernel<CPG, 2, true> : gwc_warp_bwd2_kernel<CPG, 2, false>);
+    if (p.lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
+            hipSuccess)
+      return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, block, p.lds, st, gvol, l, r, calib, pl, pr, p.ch, d->B, d->C, d->G, d->D, d->H, d->W,
+                       d->down, d->align_corners);
+  }
   if (p.ch.n > 1) {
     const size_t n4 = slab / 4;
     hipLaunchKernelGGL(gwc_partial_reduce_kernel, dim3(cdiv(n4, 256), 2), dim3(256), 0, st, pl, gl, pr, gr, p.ch.n, n4);
