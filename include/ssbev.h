@@ -186,7 +186,12 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
  *   pre_act = 1: the normalised quantity is gelu(x) (exact erf form) -- the Conv3d -> GELU -> GroupNorm triples of CA3D
  *   (attention.py:94-111) without the two elementwise passes of the activation; backward returns the gradient w.r.t. x.
  * ------------------------------------------------------------------------------------------ */
-typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; int pre_act; } ssbev_norm_dims;
+/* ld_y / ld_gy (0 = dense, C floats): row stride of y in _fwd and of gy in _bwd when the operator writes / reads a channel slice
+ * of a wider channels-last tensor -- the branches of a concatenation (SECONDFPN3D, second_fpn3d.py:113-116; ASPP) normalise
+ * straight into their slice of the concatenated tensor and read their slice of its gradient, no torch.cat / slice copies.
+ * Pass y / gy already offset to the first channel of the slice; multiples of 4, >= C.  A strided y/gy of a B > 1 per-sample
+ * GroupNorm is addressed as [(b * S + s) * ld + c]. */
+typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; int pre_act; int64_t ld_y, ld_gy; } ssbev_norm_dims;
 size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d);
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                         float* y, float* mean, float* rstd, const ssbev_norm_dims* d, void* ws,

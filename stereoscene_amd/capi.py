@@ -43,7 +43,7 @@ class ConvDims(C.Structure):
 
 class NormDims(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("G", C.c_int), ("S", C.c_int64), ("eps", C.c_float),
-                ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int)]
+                ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int), ("ld_y", C.c_int64), ("ld_gy", C.c_int64)]
 
 
 class Norm2Dims(C.Structure):

@@ -25,6 +25,8 @@ struct GnGeom {
   float eps;
   int relu;
   int pre;           // 1: u = gelu(x) (exact, erf) is what gets normalised; x is still the tensor in memory
+  long ldy, ldg;     // row strides (floats) of y (forward) and gy (backward): C when dense, the width of the concatenation
+                     // when the operator writes / reads a channel slice of a wider channels-last tensor (ssbev_norm_dims.ld_*)
 };
 
 // GELU in its exact (erf) form, nn.GELU's default, and its derivative from ONE exponential: with z = x / sqrt(2),
@@ -102,7 +104,7 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const float dv = xs[k] - pv[k]; a0[k] += dv; a1[k] += dv * dv; }
       } else {
-        const float4 gv = *reinterpret_cast<const float4*>(gy + off);
+        const float4 gv = *reinterpret_cast<const float4*>(gy + ((size_t)b * g.S + s) * g.ldg + c);
         float gs[4] = {gv.x, gv.y, gv.z, gv.w};
         if (g.relu && mask) {                   // 1 bit per element instead of re-reading y (see gn_apply_fwd_kernel)
           const size_t i4 = off >> 2;
@@ -305,7 +307,8 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
         if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
       }
     }
-    reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    if (g.ldy == g.C) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float4*>(y + (i / q) * g.ldy + (i % q) * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -393,7 +396,8 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
       }
     }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    const float4 gv = reinterpret_cast<const float4*>(gy)[i];
+    const float4 gv = g.ldg == g.C ? reinterpret_cast<const float4*>(gy)[i]
+                                   : *reinterpret_cast<const float4*>(gy + (i / q) * g.ldg + (i % q) * 4);
     float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
     if (g.relu && mask) {
       const unsigned long long* mw = mask + (i >> 6) * 4;
@@ -429,12 +433,16 @@ unsigned apply_blocks(long total4, int q) {
 }
 
 bool gn_ok(const ssbev_norm_dims* d) {
+  if (d && ((d->ld_y != 0 && (d->ld_y < d->C || d->ld_y % 4 != 0)) || (d->ld_gy != 0 && (d->ld_gy < d->C || d->ld_gy % 4 != 0))))
+    return false;
   return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0 && (d->pre_act == 0 || d->pre_act == 1);
 }
 
 GnGeom make_geom(const ssbev_norm_dims* d) {
   GnGeom g;
   g.B = d->B; g.C = d->C; g.G = d->G; g.S = d->S; g.eps = d->eps; g.relu = d->relu; g.pre = d->pre_act;
+  g.ldy = d->ld_y > 0 ? d->ld_y : d->C;
+  g.ldg = d->ld_gy > 0 ? d->ld_gy : d->C;
   // ~768 blocks over the chip (3 per CU), each at least 64 voxels: enough to saturate HBM, few enough that
   // the single-workgroup-per-group finalize pass stays in the 10-us range
   long chunks = 768 / d->B;

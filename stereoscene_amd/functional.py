@@ -411,6 +411,42 @@ def fork(x, n=2):
     return outs
 
 
+class _SpatialMean(torch.autograd.Function):
+    """x.mean over the spatial axes of a channels-last volume, [B, C].  Its data gradient is a per-channel constant: with a
+    gradient slot it is ADDED into the buffer another consumer has already filled (one in-place pass) instead of being
+    materialised as a full tensor and added by autograd (CA3D's squeeze step on the 189 MB activation, ATT:100-104)."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot, ctx.shape = slot, tuple(x.shape)
+        return to_cl(x).mean(dim=tuple(range(1, x.dim() - 1)))
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cch = ctx.shape[0], ctx.shape[1]
+        sp = ctx.shape[2:]
+        n = 1
+        for v in sp:
+            n *= v
+        gb = (g / float(n)).view((B,) + (1,) * len(sp) + (Cch,))
+        buf = ctx.slot.buf if ctx.slot is not None else None
+        if buf is not None and buf.is_contiguous() and buf.numel() == B * n * Cch and buf.shape[-1] == Cch and buf.shape[0] == B:
+            tgt = buf.view((B,) + sp + (Cch,))
+            tgt.add_(gb)
+            return from_cl(tgt), None
+        full = gb.expand((B,) + sp + (Cch,)).contiguous()
+        if ctx.slot is not None:
+            ctx.slot.buf = full
+        return from_cl(full), None
+
+
+def spatial_mean(x):
+    """[B, C, *spatial] -> [B, C] mean; slot-aware (see _SpatialMean)."""
+    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return x.mean(dim=tuple(range(2, x.dim())))
+    return _SpatialMean.apply(x, _slot_of(x))
+
+
 def _slot_of(t):
     return getattr(t, "_ssbev_grad_slot", None) if t is not None else None
 
@@ -1389,6 +1425,102 @@ class _GroupNorm(torch.autograd.Function):
         if has_res and ctx.res_slot is not None and ctx.res_slot.buf is None:
             ctx.res_slot.buf = gres        # first gradient of a forked activation: later consumers accumulate into it
         return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None, None
+
+
+NORM_CAT = os.environ.get("SSBEV_NORM_CAT", "1") != "0"     # concatenations of normalised branches without torch.cat (0 = cat)
+
+
+class _NormCat(torch.autograd.Function):
+    """``torch.cat([relu?(norm_i(x_i)) for i], dim=1)`` with every normalisation writing straight into its channel slice of
+    the concatenated channels-last tensor (``ssbev_norm_dims.ld_y``) and reading its slice of the incoming gradient in place
+    (``ld_gy``): no concatenation pass forward, no slice copies backward (SECONDFPN3D, second_fpn3d.py:113-116: 0.4 GB written
+    and re-read per step; ASPP, BD:404-410).  ``parts``: (groups, eps, as_batch) per branch; tensors: x_i, weight_i, bias_i."""
+
+    @staticmethod
+    def forward(ctx, parts, relu, *tensors):
+        lib = capi.load()
+        ctx.set_materialize_grads(False)
+        n = len(parts)
+        extra = tensors[3 * n] if len(tensors) > 3 * n else None     # an un-normalised last branch (ASPP's image-level one)
+        xs = [to_cl(_f32(tensors[3 * i], "norm_cat")) for i in range(n)]
+        ws_ = [tensors[3 * i + 1].detach().contiguous() for i in range(n)]
+        bs_ = [tensors[3 * i + 2].detach().contiguous() for i in range(n)]
+        Cs = [x.shape[-1] for x in xs]
+        Ctot = sum(Cs) + (extra.shape[1] if extra is not None else 0)
+        out = torch.empty(xs[0].shape[:-1] + (Ctot,), dtype=torch.float32, device=xs[0].device)
+        if extra is not None:
+            out[..., sum(Cs):].copy_(extra.detach().movedim(1, -1))
+        saved, stats, metas = [], [], []
+        c0 = 0
+        for i, (groups, eps, as_batch) in enumerate(parts):
+            x = xs[i]
+            B = 1 if as_batch else x.shape[0]
+            S = x.numel() // (B * Cs[i])
+            d = capi.NormDims(B, Cs[i], groups, S, float(eps), int(relu), 0, 0, Ctot, 0)
+            mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+            ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
+            mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if relu else None
+            with _span("groupnorm", 0.0, 12.0 * x.numel(), f"fwd   N C={Cs[i]} G={groups} S={S} cat@{c0}/{Ctot}"):
+                capi.check(lib.ssbev_groupnorm_fwd_mask(capi.ptr(x), capi.ptr(ws_[i]), capi.ptr(bs_[i]), None,
+                                                        C.c_void_p(out.data_ptr() + 4 * c0), capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask),
+                                                        C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                           "ssbev_groupnorm_fwd_mask")
+            saved += [x, mask, ws_[i], mean, rstd]
+            stats += [mean, rstd]
+            metas.append((B, S, Cs[i], groups, float(eps), c0))
+            c0 += Cs[i]
+        ctx.save_for_backward(*[t for t in saved if t is not None])
+        ctx.has_mask = bool(relu)
+        ctx.metas, ctx.relu, ctx.Ctot = metas, int(relu), Ctot
+        ctx.extra_at = sum(Cs) if extra is not None else None
+        ctx.mark_non_differentiable(*stats)
+        return (from_cl(out), *stats)
+
+    @staticmethod
+    def backward(ctx, gy, *_):
+        lib = capi.load()
+        per = 5 if ctx.has_mask else 4
+        sv = ctx.saved_tensors
+        gcl = to_cl(gy)                                    # the whole concatenated gradient, channels-last
+        grads = []
+        for i, (B, S, Cch, groups, eps, c0) in enumerate(ctx.metas):
+            if ctx.has_mask:
+                x, mask, w, mean, rstd = sv[per * i: per * i + 5]
+            else:
+                (x, w, mean, rstd), mask = sv[per * i: per * i + 4], None
+            d = capi.NormDims(B, Cch, groups, S, eps, ctx.relu, 0, 0, 0, ctx.Ctot)
+            gx = torch.empty_like(x)
+            gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
+            gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
+            ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
+            with _span("groupnorm", 0.0, 20.0 * x.numel(), f"bwd   N C={Cch} G={groups} S={S} cat@{c0}/{ctx.Ctot}"):
+                capi.check(lib.ssbev_groupnorm_bwd_mask(C.c_void_p(gcl.data_ptr() + 4 * c0), capi.ptr(x), capi.ptr(mask), capi.ptr(w),
+                                                        capi.ptr(mean), capi.ptr(rstd), capi.ptr(gx), None, capi.ptr(gg),
+                                                        capi.ptr(gb), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
+                           "ssbev_groupnorm_bwd_mask")
+            grads += [from_cl(gx), gg, gb]
+        if ctx.extra_at is not None:
+            grads.append(gcl[..., ctx.extra_at:].movedim(-1, 1))
+        return (None, None, *grads)
+
+
+def norm_cat(xs, norms, relu=True, extra=None):
+    """Concatenation along the channel axis of relu?(norm_i(x_i)) (+ ``extra`` as it is, behind them): ``norms`` = (weight, bias,
+    groups, eps, as_batch) per branch.  Returns (y, [(mean_i, rstd_i)])."""
+    parts = tuple((int(g), float(e), bool(ab)) for (_, _, g, e, ab) in norms)
+    flat = []
+    for x, (w, b, _, _, _) in zip(xs, norms):
+        flat += [x, w, b]
+    if extra is not None:
+        flat.append(extra)
+    out = _NormCat.apply(parts, bool(relu), *flat)
+    return out[0], [(out[1 + 2 * i], out[2 + 2 * i]) for i in range(len(xs))]
+
+
+def norm_cat_supported(xs):
+    return (NORM_CAT and GN_RELU_MASK and all(x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 for x in xs)
+            and all(x.shape[0] == xs[0].shape[0] and x.shape[2:] == xs[0].shape[2:] for x in xs))
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False, pre_act=None):

@@ -195,6 +195,28 @@ def norm_pair(norm_a, xa, norm_b, xb, relu=True):
     return y
 
 
+def norm_cat(norms, xs, relu=True, extra=None):
+    """torch.cat([relu?(n(x)) for n, x in zip(norms, xs)] (+ [extra]), dim=1) for GroupNorm / training-mode BatchNorm layers:
+    one operator whose branches write their slice of the concatenated tensor (functional.norm_cat); anything else takes the
+    plain form."""
+    def fusable(n):
+        return isinstance(n, GroupNorm) or (isinstance(n, _HipBatchNorm) and n.training)
+    if not (all(fusable(n) for n in norms) and F.norm_cat_supported(list(xs))
+            and (extra is None or (extra.is_cuda and extra.shape[1] % 4 == 0))):
+        ys = [n(x, relu=relu) for n, x in zip(norms, xs)]
+        return torch.cat(ys + ([extra] if extra is not None else []), dim=1)
+    spec = [(n.weight, n.bias, n.num_groups, n.eps, False) if isinstance(n, GroupNorm)
+            else (n.weight, n.bias, n.num_features, n.eps, True) for n in norms]
+    y, stats = F.norm_cat(list(xs), spec, relu=relu, extra=extra)
+    for n, (mean, rstd), x in zip(norms, stats, xs):
+        if isinstance(n, _HipBatchNorm) and n.track_running_stats:
+            with torch.no_grad():
+                m = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked + 1)
+                F.bn_update_running_(n.running_mean, n.running_var, mean, rstd, m, n.eps, x.numel() // x.shape[1])
+                n.num_batches_tracked += 1
+    return y
+
+
 def _last_leaf(m):
     while isinstance(m, nn.Sequential) and len(m) > 0:
         m = m[len(m) - 1]

@@ -21,7 +21,7 @@ import torch.nn.functional as TF
 
 from .. import functional as F
 from ..layers import (BatchNorm2d, BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
-                      fuse_relu_, norm_pair)
+                      fuse_relu_, norm_cat, norm_pair)
 from ..registry import NECKS
 
 GN2 = dict(type="GN", num_groups=2, requires_grad=True)
@@ -113,7 +113,9 @@ class ASPP(nn.Module):
         g = TF.linear(g, self.global_avg_pool[1].weight.flatten(1))  # 1x1 conv on a 1x1 map
         g = torch.relu(self.global_avg_pool[2](g))[..., None, None]
         g = g.expand(-1, -1, x.shape[2], x.shape[3])                 # bilinear(align_corners) of a 1x1 map
-        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), dim=1)
+        branches = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)
+        # the four BatchNorm + ReLU tails write their 640-channel slices of the 3200-channel tensor directly (BD:404-410)
+        y = norm_cat([m.bn for m in branches], [m.atrous_conv(x) for m in branches], relu=True, extra=g)
         return self.dropout(self.bn1(self.conv1(y), relu=True))
 
 
@@ -346,7 +348,11 @@ class CA3D(nn.Module):
             data = self.conv1(x)
         else:
             data = F.group_norm(c1(x), gn1.num_groups, gn1.weight, gn1.bias, gn1.eps, pre_act="gelu")
-        pool = data.mean(dim=(2, 3, 4))
+        if x.is_cuda:
+            dpool, data = F.fork(data)          # squeeze and the last conv: their data gradients meet in one buffer
+            pool = F.spatial_mean(dpool)
+        else:
+            pool = data.mean(dim=(2, 3, 4))
         s = TF.gelu(TF.linear(pool, self.conv2[0].weight.flatten(1), self.conv2[0].bias))
         s = TF.gelu(TF.linear(s, self.conv2[2].weight.flatten(1), self.conv2[2].bias))
         gate = torch.sigmoid(s)

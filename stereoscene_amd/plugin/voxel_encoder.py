@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F
-from ..layers import Conv3d, build_conv_layer, build_norm_layer, build_upsample_layer, fuse_relu_, norm_pair
+from ..layers import Conv3d, GroupNorm, build_conv_layer, build_norm_layer, build_upsample_layer, fuse_relu_, norm_pair
 from ..registry import BACKBONES, HEADS, NECKS
 from . import losses as L
 
@@ -102,7 +102,17 @@ class SECONDFPN3D(nn.Module):
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
-        ups = [blk(f) for blk, f in zip(self.deblocks, x)]
+        norms = [blk[1] for blk in self.deblocks]
+        if (len(x) > 1 and all(isinstance(n, GroupNorm) and n.fused_relu for n in norms)
+                and all(isinstance(blk[2], nn.Identity) for blk in self.deblocks)):
+            raw = [blk[0](f) for blk, f in zip(self.deblocks, x)]
+            if F.norm_cat_supported(raw):
+                # every branch's GroupNorm + ReLU writes its channel slice of the concatenated tensor (FPN:113-116 without
+                # the torch.cat pass and, backward, without the three slice copies)
+                return [F.norm_cat(raw, [(n.weight, n.bias, n.num_groups, n.eps, False) for n in norms], relu=True)[0]]
+            ups = [blk[2](blk[1](r)) for blk, r in zip(self.deblocks, raw)]
+        else:
+            ups = [blk(f) for blk, f in zip(self.deblocks, x)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]
 
 

@@ -249,3 +249,56 @@ def test_side_streams_change_nothing_bit_for_bit(monkeypatch):
         for other in (g_on[n], g_on2[n]):
             # (a gradient that is zero up to cancellation noise, |g| ~ 1e-10, has no relative accuracy on either stream)
             assert (other.double() - ref).norm().item() < 1e-5 * ref.norm().item() + 1e-8 * ref.numel() ** 0.5, n
+
+
+@pytest.mark.parametrize("case", [((64, 32, 128), (8, 4, 32), (3, 4, 5), False, True), ((32, 32), (32, 32), (6, 10), True, True),
+                                   ((16, 8, 8), (2, 2, 1), (4, 4, 4), False, False)])
+def test_norm_cat_equals_cat_of_norms_bit_for_bit(case):
+    """functional.norm_cat (every branch normalises into its slice of the concatenated tensor, reads its slice of the gradient
+    in place) against torch.cat over the separate operators: the same kernels on the same numbers, so everything is equal."""
+    Cs, groups, sp, as_batch, relu = case
+    B = 2
+    xs = [S.hash_normal(f"normcat/x{i}", (B, c) + sp).to(DEV).contiguous(memory_format=torch.channels_last_3d if len(sp) == 3
+                                                                           else torch.channels_last) for i, c in enumerate(Cs)]
+    ws = [S.hash_normal(f"normcat/w{i}", (c,)).to(DEV) + 1.0 for i, c in enumerate(Cs)]
+    bs = [S.hash_normal(f"normcat/b{i}", (c,)).to(DEV) for i, c in enumerate(Cs)]
+    go = S.hash_normal("normcat/go", (B, sum(Cs)) + sp).to(DEV)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in xs + ws + bs]
+        lx, lw, lb = leaves[:len(Cs)], leaves[len(Cs):2 * len(Cs)], leaves[2 * len(Cs):]
+        if fused:
+            assert F.norm_cat_supported(lx)
+            y, stats = F.norm_cat(lx, [(w, b, (x.shape[1] if as_batch else g), 1e-5, as_batch)
+                                       for x, w, b, g in zip(lx, lw, lb, groups)], relu=relu)
+        else:
+            parts = []
+            for x, w, b, g in zip(lx, lw, lb, groups):
+                parts.append(F.batch_norm_train(x, w, b, 1e-5, None, relu)[0] if as_batch
+                             else F.group_norm(x, g, w, b, 1e-5, None, relu))
+            y = torch.cat(parts, dim=1)
+        y.backward(go)
+        return [y.detach()] + [t.grad for t in leaves]
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (i, maxdiff(u, v))
+
+
+def test_second_fpn_uses_norm_cat_and_matches_cat(monkeypatch):
+    from stereoscene_amd import model_zoo
+    cfg = S.CFG_T
+    torch.manual_seed(0)
+    neck = model_zoo.build_detector(cfg).img_bev_encoder_neck.to(DEV).train()
+    feats = [S.hash_normal(f"fpncat/f{i}", (1, c, 16 >> i, 16 >> i, 4 >> min(i, 2))).to(DEV) for i, c in enumerate(neck.in_channels)]
+    go = None
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "NORM_CAT", on)
+        neck.zero_grad(set_to_none=True)
+        xs = [f.clone().requires_grad_(True) for f in feats]
+        y = neck(xs)[0]
+        go = S.hash_normal("fpncat/go", tuple(y.shape)).to(DEV) if go is None else go
+        y.backward(go)
+        res[on] = [y.detach()] + [x.grad for x in xs] + [p.grad.clone() for p in neck.parameters()]
+    for u, v in zip(res[True], res[False]):
+        assert torch.equal(u, v), maxdiff(u, v)

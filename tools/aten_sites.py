@@ -30,12 +30,14 @@ class Log(TorchDispatchMode):
         n = max(numel(out), numel(args))
         name = str(func)
         if n >= MIN and not any(k in name for k in ("view", "empty", "as_strided", "detach", "alias", "reshape", "permute",
-                                                     "transpose", "slice.Tensor", "select.int", "unsqueeze", "squeeze", "expand", "aten.t.default")):
+                                                     "transpose", "slice.Tensor", "select.int", "unsqueeze", "squeeze", "expand", "aten.t.default",
+                                                     "record_stream", "_unsafe_view", "split", "unbind", "chunk", "narrow", "is_", "lift_fresh", "_local_scalar")):
             site = "(autograd engine)"
-            for fr in reversed(traceback.extract_stack()):
-                if "stereoscene_amd" in fr.filename and "tools" not in fr.filename:
-                    site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
-                    break
+            frames = [fr for fr in reversed(traceback.extract_stack())
+                      if "stereoscene_amd" in fr.filename and "tools" not in fr.filename]
+            if frames:
+                depth = int(os.environ.get("ATEN_DEPTH", "1"))
+                site = " < ".join(f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}" for fr in frames[:depth])
             shp = tuple(a.shape for a in args if isinstance(a, torch.Tensor))[:2]
             log[(name, site, str(shp))] += 1
             nbytes[(name, site, str(shp))] += 4 * n
@@ -54,5 +56,5 @@ with Log():
 torch.cuda.synchronize()
 rows = sorted(log.items(), key=lambda kv: -nbytes[kv[0]])
 print(f"{sum(log.values())} large ATen calls")
-for (name, site, shp), c in rows[:120]:
-    print(f"{nbytes[(name, site, shp)] / 1e6:9.1f} MB {c:4d}x  {name:34s} {site:48s} {shp[:100]}")
+for (name, site, shp), c in rows[:int(os.environ.get("ATEN_ROWS", "120"))]:
+    print(f"{nbytes[(name, site, shp)] / 1e6:9.1f} MB {c:4d}x  {name:34s} {site:48s} | {shp[:100]}")
