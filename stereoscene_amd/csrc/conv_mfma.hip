@@ -572,13 +572,13 @@ wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Qt, float* _
 // reads per chunk) and are folded through LDS in row order.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps, int Cq, int Cp,
-                    long total) {
+                    long total, long cstride) {
   __shared__ float part[8][33];
   const int e = threadIdx.x & 31, row = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + e;                 // i over ws-slab order [tap][q][p]
   float s = 0.0f;
   if (i < total)
-    for (int c = row; c < nchunks; c += 8) s += ws[(size_t)c * total + i];
+    for (int c = row; c < nchunks; c += 8) s += ws[(size_t)c * cstride + i];
   part[row][e] = s;
   __syncthreads();
   if (row == 0 && i < total) {
@@ -598,7 +598,7 @@ wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nc
 // reads, transposed through LDS, and written as 32 runs of 8*taps contiguous floats.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_tiled_kernel(const float* __restrict__ ws, float* __restrict__ gw, int nchunks, int taps, int Cq, int Cp,
-                          long total) {
+                          long total, long cstride) {
   extern __shared__ float tile[];                 // [32 p][8 q * taps] with an odd pitch
   const int P = 8 * taps + 1;
   const int e = threadIdx.x & 31, row = threadIdx.x >> 5;
@@ -609,7 +609,7 @@ wgrad_reduce_tiled_kernel(const float* __restrict__ ws, float* __restrict__ gw, 
     if (ok) {
       const float* src = ws + ((size_t)tap * Cq + q0 + row) * Cp + p0 + e;
 #pragma unroll 4
-      for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * total];
+      for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * cstride];
     }
     tile[e * P + row * taps + tap] = s;
   }
@@ -622,14 +622,52 @@ wgrad_reduce_tiled_kernel(const float* __restrict__ ws, float* __restrict__ gw, 
   }
 }
 
-void launch_wgrad_reduce(const float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
+// First stage for the narrow layers: there the partials are the big object (e.g. 27 x 32 x 32 floats x ~700 chunks = 73 MB)
+// and the kernels above walk the chunk axis with a few hundred workgroups of 4-byte lanes -- 53 us per layer at 1.4 TB/s,
+// 26 layers per step.  Here the chunk axis is cut into `nsl` slices: workgroup (x, y) sums slice y of 256 float4 columns,
+// eight independent loads in flight per thread, and writes the result over the FIRST slab of its own slice (the only
+// reader of those bytes is the thread that writes them).  The second stage then folds nsl slabs, per * total apart.
+// Fixed order everywhere: deterministic.
+typedef float wr_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+wgrad_reduce_stage_kernel(float* __restrict__ ws, int nchunks, int per, long total4) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total4) return;
+  const int c0 = blockIdx.y * per, c1 = min(nchunks, c0 + per);
+  wr_f4* base = reinterpret_cast<wr_f4*>(ws) + (size_t)c0 * total4 + j;
+  const wr_f4* p = base;
+  wr_f4 a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = wr_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int c = c0; c < c1; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c + u < c1) a[u] += p[(size_t)u * total4];
+    p += 8 * total4;
+  }
+  *base = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+void launch_wgrad_reduce(float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
   const long total = (long)taps * Cq * Cp;
+  long cstride = total;
+  static const int two_stage = getenv("SSBEV_WGRAD_REDUCE2") ? atoi(getenv("SSBEV_WGRAD_REDUCE2")) : 1;
+  if (two_stage && nchunks >= 64 && total % 4 == 0) {
+    const long total4 = total / 4, bx = cdiv(total4, 256);
+    int nsl = (int)std::min<long>(std::max<long>(cdiv(2048, bx), 1), nchunks / 8);
+    const int per = cdiv(nchunks, nsl);
+    nsl = cdiv(nchunks, per);
+    hipLaunchKernelGGL(wgrad_reduce_stage_kernel, dim3((unsigned)bx, (unsigned)nsl), dim3(256), 0, st, partial, nchunks, per,
+                       total4);
+    nchunks = nsl;
+    cstride = (long)per * total;
+  }
   if (taps <= 32 && (long)cdiv(Cp, 32) * cdiv(Cq, 8) >= 128) {
     hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(cdiv(Cp, 32), cdiv(Cq, 8)), dim3(256),
-                       (size_t)32 * (8 * taps + 1) * sizeof(float), st, partial, gw, nchunks, taps, Cq, Cp, total);
+                       (size_t)32 * (8 * taps + 1) * sizeof(float), st, partial, gw, nchunks, taps, Cq, Cp, total, cstride);
   } else {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, partial, gw, nchunks, taps, Cq, Cp,
-                       total);
+                       total, cstride);
   }
 }
 
@@ -3357,7 +3395,7 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
   else if (c.MQ == 2) launch_wgrad<2, 2, 1, 3>(P, Qt, wsf, g, st);
   else if (c.TH == 3) launch_wgrad<1, 1, 3, 3>(P, Qt, wsf, g, st);
   else launch_wgrad<1, 1, 1, 3>(P, Qt, wsf, g, st);
-  launch_wgrad_reduce(static_cast<const float*>(ws), gw, g.nchunks, taps, g.Cq, g.Cp, st);
+  launch_wgrad_reduce(wsf, gw, g.nchunks, taps, g.Cq, g.Cp, st);
   return ssbev_launch_status();
 }
 
