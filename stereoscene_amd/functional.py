@@ -517,7 +517,7 @@ class _ConvNd(torch.autograd.Function):
     """x logical [B,Cin,D,H,W] (channels-last memory), weight in the torch layout (5-D)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None, relu=False):
         lib = capi.load()
         ctx.slot = slot
         xcl = to_cl(_f32(x, "conv"))
@@ -530,7 +530,7 @@ class _ConvNd(torch.autograd.Function):
         if kpad and not thin_in:   # the K-role channel count must be a multiple of 4 (float4 operand loads)
             xcl = torch.nn.functional.pad(xcl, (0, kpad))
             w5 = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0) + ((0, 0, 0, kpad) if transposed else (0, kpad)))
-        d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), stride, padding, dilation, transposed, output_padding)
+        d = _conv_dims(tuple(xcl.shape), tuple(w5.shape), stride, padding, dilation, transposed, output_padding, relu=int(relu))
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32, device=x.device)
         b = bias.detach().contiguous() if bias is not None else None
         fam = _conv_family(lib, d, 0)
@@ -541,7 +541,9 @@ class _ConvNd(torch.autograd.Function):
                 wp = _packed(w5.detach(), d, 0)
                 capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d),
                                               capi.stream()), "ssbev_conv_fwd")
-        ctx.save_for_backward(xcl, weight)
+        # fused ReLU (the kernels' epilogue): backward masks the incoming gradient with the saved output's sign
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(xcl, weight, *((y,) if relu else ()))
         ctx.cfg = (stride, padding, dilation, transposed, output_padding, 0 if thin_in else kpad, bias is not None)
         ctx.thin_in = thin_in
         ctx.bias_leaf = bias is not None and bias.is_leaf and bias.grad is None
@@ -550,9 +552,12 @@ class _ConvNd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         lib = capi.load()
-        xcl, weight = ctx.saved_tensors
+        xcl, weight = ctx.saved_tensors[:2]
         stride, padding, dilation, transposed, output_padding, kpad, has_bias = ctx.cfg
         args = (stride, padding, dilation, transposed, output_padding)
+        if ctx.relu:
+            ycl = ctx.saved_tensors[2]
+            gy = from_cl(torch.where(ycl > 0, to_cl(gy), torch.zeros((), dtype=gy.dtype, device=gy.device)))
         gcl0 = to_cl(gy)                                    # gradient as it arrives: Cout channels
         Cout_g = gcl0.shape[-1]
         cpad = (-Cout_g) % 4                                # the data gradient's K role is the forward Cout: multiple of 4 ...
@@ -639,16 +644,22 @@ class _ConvNd(torch.autograd.Function):
             gw = weight_gradient()
         if want_gb and not gb_side:
             gb = gcl0.reshape(-1, Cout_g).sum(0)
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 WINOGRAD = os.environ.get("SSBEV_WINOGRAD", "1") != "0"   # wide 3x3x3 stride-1 layers via F(2,3)^3 (0 = direct MFMA conv)
 
 
-def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
     """F.conv3d replacement (groups=1): the MFMA implicit-GEMM kernels, or Winograd F(2x2x2,3x3x3) for the wide
     stride-1 3x3x3 layers."""
     st, pd, dl = _triple(stride, 3), _triple(padding, 3), _triple(dilation, 3)
+    if relu:    # epilogue ReLU of the direct kernels (the MIE block's two conv -> ReLU pairs, VT:250-258); elsewhere a norm follows
+        gemm = (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and tuple(weight.shape[2:]) == (1, 1, 1)
+                and st == (1, 1, 1) and pd == (0, 0, 0) and weight.shape[1] >= GEMM_MIN_CIN)
+        if not x.is_cuda or gemm or (WINOGRAD and TILE_HINT == 0 and wino_conv3d_applicable(x, weight, st, pd, dl)):
+            return torch.relu(conv3d(x, weight, bias, stride, padding, dilation))
+        return _ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0), _slot_of(x), True)
     if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == (1, 1, 1)
             and st == (1, 1, 1) and pd == (0, 0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
         return linear_cl(x, weight, bias)

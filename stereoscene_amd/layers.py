@@ -50,8 +50,8 @@ class _ConvBase(nn.Module):
 
 
 class Conv3d(_ConvBase):
-    def forward(self, x):
-        return F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+    def forward(self, x, relu=False):
+        return F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, relu=relu)
 
 
 class ConvTranspose3d(_ConvBase):

@@ -396,9 +396,9 @@ class volume_interaction(nn.Module):
         s, m = stereo_volume.unsqueeze(1), lss_volume.unsqueeze(1)
         a = self.lss2stereo(q=s, kv=m)
         b = self.stereo2lss(q=m, kv=s)
-        x = torch.relu(self.redir1(torch.cat((a, b), dim=1)))
+        x = self.redir1(torch.cat((a, b), dim=1), relu=True)       # ReLU in the kernels' epilogue
         x = self.CA3D(self.dres1(x))
-        x = torch.relu(self.redir2(x)).squeeze(1)
+        x = self.redir2(x, relu=True).squeeze(1)
         return F.softmax(x, dim=1)
 
 

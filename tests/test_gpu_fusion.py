@@ -302,3 +302,22 @@ def test_second_fpn_uses_norm_cat_and_matches_cat(monkeypatch):
         res[on] = [y.detach()] + [x.grad for x in xs] + [p.grad.clone() for p in neck.parameters()]
     for u, v in zip(res[True], res[False]):
         assert torch.equal(u, v), maxdiff(u, v)
+
+
+@pytest.mark.parametrize("cin,cout", [(2, 32), (32, 1), (32, 32)])
+def test_conv3d_epilogue_relu_equals_relu_of_conv(cin, cout):
+    """conv3d(..., relu=True) (ReLU in the kernels' epilogue, the gradient masked with the saved output's sign) against
+    torch.relu(conv3d(...)) on the thin-in, thin-out and LDS-ring kernels: the same numbers, so everything is equal."""
+    x = S.hash_normal("convrelu/x", (1, cin, 6, 8, 32)).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    w = (S.hash_normal("convrelu/w", (cout, cin, 3, 3, 3)) * 0.2).to(DEV)
+    b = S.hash_normal("convrelu/b", (cout,)).to(DEV)
+    go = S.hash_normal("convrelu/go", (1, cout, 6, 8, 32)).to(DEV)
+    res = []
+    for fused in (True, False):
+        xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = F.conv3d(xs, ws, bs, 1, 1, 1, relu=True) if fused else torch.relu(F.conv3d(xs, ws, bs, 1, 1))
+        y.backward(go)
+        res.append((y.detach(), xs.grad, ws.grad, bs.grad))
+    assert (res[0][0] == 0).any() and (res[0][0] > 0).any()
+    for u, v in zip(*res):
+        assert torch.equal(u, v), maxdiff(u, v)
