@@ -65,6 +65,17 @@ int ssbev_coords_to_vox(const int32_t* coords, int n, int32_t* vox, const ssbev_
 /* CSR build: starts[NV+1], order[n] with NV = B*nx*ny*nz.  Points of voxel v are
  * order[starts[v] .. starts[v+1]) in ASCENDING point index (the canonical summation order,
  * = stable argsort by rank in the upstream op).  Entries with vox<0 are skipped. */
+/* Frustum points -> ego frame: the per-point part of get_geometry (ViewTransformerLSSBEVDepth.py:123-156) in one kernel,
+ *   p = frustum[d,h,w,:] - t0[b,n];  p = m1[b,n] p;  p = (p.x p.z, p.y p.z, p.z);  p -= t2[b,n] (if given);
+ *   p = m2[b,n] p + tr[b,n];  p = m3[b] p (+ t3[b] if given)
+ * with m1 = inv(post_rots), t0 = post_trans, m2 = rots inv(intrins), t2 = intrins[:3,3] (4-column intrinsics), tr = trans,
+ * m3 / t3 = the BEV augmentation; all row-major fp32.  Separately rounded multiplies and adds in the reference's order: the
+ * points (and the voxel indices of ssbev_voxel_index) are bit-identical to the tensor expression.  geom[B,N,D,H,W,3]. */
+typedef struct { int B, N, D, H, W; } ssbev_geom_dims;
+int ssbev_frustum_geometry(const float* frustum, const float* m1, const float* t0, const float* m2, const float* t2,
+                           const float* tr, const float* m3, const float* t3, float* geom, const ssbev_geom_dims* d,
+                           ssbev_stream_t stream);
+
 size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d);
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);

@@ -41,6 +41,10 @@ class ConvDims(C.Structure):
         "pd", "ph", "pw", "dd", "dh", "dw", "transposed", "relu", "accumulate", "tile_hint", "precision")]
 
 
+class GeomDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "N", "D", "H", "W")]
+
+
 class NormDims(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("G", C.c_int), ("S", C.c_int64), ("eps", C.c_float),
                 ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int), ("ld_y", C.c_int64), ("ld_gy", C.c_int64)]
@@ -104,6 +108,7 @@ SIGNATURES = {
     "ssbev_gwc_warp_bwd_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P, C.c_size_t, _P]),
     "ssbev_conv_packed_weight_elems": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_kernel_class": (C.c_int, [C.POINTER(ConvDims), C.c_int]),
+    "ssbev_frustum_geometry": (C.c_int, [_P] * 9 + [C.POINTER(GeomDims), _P]),
     "ssbev_conv_pack_weight": (C.c_int, [_P, _P, C.POINTER(ConvDims), C.c_int, _P]),
     "ssbev_conv_thin_workspace": (C.c_size_t, [C.POINTER(ConvDims), C.c_int]),
     "ssbev_conv_thin_packed_elems": (C.c_size_t, [C.POINTER(ConvDims), C.c_int]),

@@ -51,6 +51,48 @@ __global__ void voxel_index_kernel(const float* __restrict__ geom, int32_t* __re
   }
 }
 
+// ---------------------------------------------------------------- frustum -> ego frame (BD:123-156)
+// The per-point chain of get_geometry -- un-do the image augmentation, lift by depth, camera -> ego, BEV augmentation -- as ONE
+// kernel instead of ~22 broadcast ATen passes over the [B, N, D, H, W, 3] point cloud.  Every product and sum is the separately
+// rounded fp32 operation of the reference's tensor expression, in its order ((m0 x + m1 y) + m2 z; this file is built without FMA
+// contraction), so the points -- and the voxel indices derived from them -- are bit for bit those of the ATen path.
+struct GeomArgs {
+  const float *frustum, *m1, *t0, *m2, *t2, *tr, *m3, *t3;
+  float* out;
+  int B, N, D, H, W;
+};
+
+__device__ __forceinline__ void mat3_apply(const float* __restrict__ m, float x, float y, float z, float& ox, float& oy,
+                                           float& oz) {
+  ox = __fadd_rn(__fadd_rn(__fmul_rn(m[0], x), __fmul_rn(m[1], y)), __fmul_rn(m[2], z));
+  oy = __fadd_rn(__fadd_rn(__fmul_rn(m[3], x), __fmul_rn(m[4], y)), __fmul_rn(m[5], z));
+  oz = __fadd_rn(__fadd_rn(__fmul_rn(m[6], x), __fmul_rn(m[7], y)), __fmul_rn(m[8], z));
+}
+
+__global__ void __launch_bounds__(256) frustum_geometry_kernel(GeomArgs a) {
+  const long dhw = (long)a.D * a.H * a.W, total = (long)a.B * a.N * dhw;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const long f = p % dhw;
+  const int bn = (int)(p / dhw), b = bn / a.N;
+  float x = __fsub_rn(a.frustum[3 * f + 0], a.t0[3 * bn + 0]);
+  float y = __fsub_rn(a.frustum[3 * f + 1], a.t0[3 * bn + 1]);
+  float z = __fsub_rn(a.frustum[3 * f + 2], a.t0[3 * bn + 2]);
+  float u, v, w;
+  mat3_apply(a.m1 + 9 * bn, x, y, z, u, v, w);
+  x = __fmul_rn(u, w); y = __fmul_rn(v, w); z = w;
+  if (a.t2) {
+    x = __fsub_rn(x, a.t2[3 * bn + 0]); y = __fsub_rn(y, a.t2[3 * bn + 1]); z = __fsub_rn(z, a.t2[3 * bn + 2]);
+  }
+  mat3_apply(a.m2 + 9 * bn, x, y, z, u, v, w);
+  x = __fadd_rn(u, a.tr[3 * bn + 0]); y = __fadd_rn(v, a.tr[3 * bn + 1]); z = __fadd_rn(w, a.tr[3 * bn + 2]);
+  mat3_apply(a.m3 + 9 * b, x, y, z, u, v, w);
+  if (a.t3) {
+    u = __fadd_rn(u, a.t3[3 * b + 0]); v = __fadd_rn(v, a.t3[3 * b + 1]); w = __fadd_rn(w, a.t3[3 * b + 2]);
+  }
+  a.out[3 * p + 0] = u; a.out[3 * p + 1] = v; a.out[3 * p + 2] = w;
+}
+
 __global__ void coords_to_vox_kernel(const int32_t* __restrict__ coords, int n, int32_t* __restrict__ vox,
                                      int B, int nx, int ny, int nz) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -832,6 +874,18 @@ int ssbev_voxel_index(const float* geom, int32_t* vox, int32_t* idx3, const ssbe
   hipLaunchKernelGGL(voxel_index_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), geom, vox, idx3,
                      total, d->P, d->nx, d->ny, d->nz, d->origin[0], d->origin[1], d->origin[2], d->dx[0], d->dx[1],
                      d->dx[2]);
+  return ssbev_launch_status();
+}
+
+int ssbev_frustum_geometry(const float* frustum, const float* m1, const float* t0, const float* m2, const float* t2,
+                           const float* tr, const float* m3, const float* t3, float* geom, const ssbev_geom_dims* d,
+                           ssbev_stream_t stream) {
+  if (!d || d->B <= 0 || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || !frustum || !m1 || !t0 || !m2 || !tr || !m3 || !geom)
+    return SSBEV_EINVAL;
+  const long total = (long)d->B * d->N * d->D * d->H * d->W;
+  if (total >= (1L << 31)) return SSBEV_EINVAL;
+  GeomArgs a{frustum, m1, t0, m2, t2, tr, m3, t3, geom, d->B, d->N, d->D, d->H, d->W};
+  hipLaunchKernelGGL(frustum_geometry_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), a);
   return ssbev_launch_status();
 }
 

@@ -174,6 +174,28 @@ def grid_origin(bx, dx):
     return (bx.detach().float().cpu() - dx.detach().float().cpu() / 2.0)
 
 
+GEOM_FUSED = os.environ.get("SSBEV_GEOM_FUSED", "1") != "0"     # per-point chain of get_geometry in one kernel (0 = ATen passes)
+
+
+def frustum_geometry(frustum, m1, t0, m2, t2, tr, m3, t3):
+    """Per-point part of get_geometry (BD:123-156): frustum [D,H,W,3]; m1, m2 [B,N,3,3]; t0, tr (, t2) [B,N,3]; m3 [B,3,3]
+    (, t3 [B,3]) -> geom [B,N,D,H,W,3], bit-identical to the broadcast tensor expression (ssbev_frustum_geometry)."""
+    lib = capi.load()
+    B, N = m1.shape[:2]
+    D, H, W = frustum.shape[:3]
+    dev = m1.device
+
+    def c(t):
+        return None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+    fr, m1, t0, m2, t2, tr, m3, t3 = (c(t) for t in (frustum, m1, t0, m2, t2, tr, m3, t3))
+    out = torch.empty(B, N, D, H, W, 3, dtype=torch.float32, device=dev)
+    d = capi.GeomDims(B, N, D, H, W)
+    capi.check(lib.ssbev_frustum_geometry(capi.ptr(fr), capi.ptr(m1), capi.ptr(t0), capi.ptr(m2), capi.ptr(t2), capi.ptr(tr),
+                                          capi.ptr(m3), capi.ptr(t3), capi.ptr(out), C.byref(d), capi.stream()),
+               "ssbev_frustum_geometry")
+    return out
+
+
 def voxel_index(geom, bx, dx, nx, return_idx=False, grid_host=None):
     """geom [B, ..., 3] fp32 (cuda) -> vox int32 [B*P] (linear voxel or -1) [, idx3 int32 [B*P,3]].
     ``grid_host`` = (origin, dx, n) python lists, if the caller already holds host copies of the grid parameters."""

@@ -501,6 +501,15 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             return torch.inverse(m[..., :3, :3].float().cpu()).to(m.device)      # same 3x3 block the hint inverts
 
         intr_hint = hint_of(intrins)
+        if (F.GEOM_FUSED and trans.is_cuda and self.frustum.is_cuda and all(
+                t.dtype == torch.float32 for t in (rots, trans, intrins, post_rots, post_trans, bda))):
+            # the per-point chain below as ONE kernel (same separately rounded products and sums in the same order: the
+            # points and the voxel indices are bit-identical); only the 3x3 matrix algebra stays in ATen
+            m1 = inv(post_rots, hint_of(post_rots))
+            t2 = intrins[:, :, :3, 3] if intrins.shape[3] == 4 else None
+            m2 = rots.matmul(inv(intrins[:, :, :3, :3] if intrins.shape[3] == 4 else intrins, intr_hint))
+            m3, t3 = (bda[:, :3, :3], bda[:, :3, 3]) if bda.shape[-1] == 4 else (bda, None)
+            return F.frustum_geometry(self.frustum, m1[..., :3, :3], post_trans, m2, t2, trans, m3, t3)
         pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
         pts = self._apply3x3(inv(post_rots, hint_of(post_rots)), pts)
         pts = torch.cat((pts[..., :2] * pts[..., 2:3], pts[..., 2:3]), -1)

@@ -321,3 +321,30 @@ def test_conv3d_epilogue_relu_equals_relu_of_conv(cin, cout):
     assert (res[0][0] == 0).any() and (res[0][0] > 0).any()
     for u, v in zip(*res):
         assert torch.equal(u, v), maxdiff(u, v)
+
+
+@pytest.mark.parametrize("variant", ["3x3", "4x4"])
+def test_fused_frustum_geometry_is_bit_identical_to_the_tensor_expression(variant, monkeypatch):
+    """get_geometry's per-point chain as one kernel (ssbev_frustum_geometry) against the broadcast ATen passes it replaces: the
+    same separately rounded fp32 operations in the same order, so the points are EQUAL -- and with them the voxel indices."""
+    from stereoscene_amd import model_zoo
+    cfg = S.CFG_T
+    vt = model_zoo.build_detector(cfg).img_view_transformer.to(DEV)
+    smp = S.synthetic_sample(cfg, B=2, tag="geomfused")
+    rots, trans, intrins, post_rots, post_trans, bda = [t.to(DEV) for t in smp["geo_l"]]
+    if variant == "4x4":
+        i4 = torch.zeros(intrins.shape[:2] + (4, 4), device=DEV)
+        i4[..., :3, :3] = intrins[..., :3, :3]
+        i4[..., :3, 3] = S.hash_normal("geomfused/it", tuple(intrins.shape[:2]) + (3,)).to(DEV) * 0.01
+        i4[..., 3, 3] = 1.0
+        intrins = i4
+        b4 = torch.eye(4, device=DEV).repeat(bda.shape[0], 1, 1)
+        b4[:, :3, :3] = bda[:, :3, :3]
+        b4[:, :3, 3] = S.hash_normal("geomfused/bt", (bda.shape[0], 3)).to(DEV)
+        bda = b4
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "GEOM_FUSED", on)
+        out[on] = vt.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
+    assert out[True].shape == out[False].shape
+    assert torch.equal(out[True], out[False]), maxdiff(out[True], out[False])

@@ -9,14 +9,14 @@ import collections, csv, json, sys
 
 FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_dfw_kernel",)),
             ("gemm_nn_kernel", ("gemm_nn_kernel",)), ("gemm_tn_kernel", ("gemm_tn_kernel", "gemm_tn_skinny_kernel")),
-            ("gwc_warp_bwd2", ("gwc_warp_bwd2_kernel",)), ("lift_splat_bwd2", ("lift_splat_bwd2_kernel",)),
+            ("gwc_warp_bwd", ("gwc_warp_bwd2_kernel", "gwc_warp_bwd3_kernel")), ("lift_splat_bwd2", ("lift_splat_bwd2_kernel",)),
             ("conv_thinin_kernel", ("conv_thinin_kernel",)), ("conv_thinout_u_kernel", ("conv_thinout_u_kernel",)),
             ("wgrad_thinside_kernel", ("wgrad_thinside_kernel",)), ("softmax_row", ("softmax_row_",)),
             ("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
             ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)),
             ("conv_tap2_kernel", ("conv_tap2_kernel",)), ("conv_tap2up_kernel", ("conv_tap2up_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
-            ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel")),
+            ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel", "gwc_warp_fwd5_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel", "pool_gather5_kernel")),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
             ("gn2_apply_fwd", ("gn2_apply_fwd_kernel",)), ("gn2_partial_bwd", ("gn2_partial_bwd_kernel",)), ("gn2_apply_bwd", ("gn2_apply_bwd_kernel",)),
             ("wino_input_kernel", ("wino_input_kernel", "wino43_input_kernel")),
