@@ -293,6 +293,12 @@ int ssbev_occ_loss_num_sums(void);
 size_t ssbev_occ_loss_workspace(const ssbev_occloss_dims* d);
 int ssbev_occ_loss_fwd(const float* logits, const uint8_t* label, const float* class_weight, double* sums,
                        const ssbev_occloss_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+/* The scalar algebra behind the sums in one launch: out5 (float) = w_ce * CE, w_sem * sem_scal, w_geo * geo_scal (occhead.py:
+ * 291-361, semkitti.py:67-149), completion IoU, mean IoU over classes 1..19; jac[3][41] (double) = the Jacobian of the three
+ * weighted losses w.r.t. (ce_num, sum_p[20], nom[20]) -- backward is jac^T times the three incoming scalars, which is the
+ * `coef` of ssbev_occ_loss_bwd. */
+int ssbev_occ_loss_tail(const double* sums, float w_ce, float w_sem, float w_geo, float* out5, double* jac,
+                        ssbev_stream_t stream);
 size_t ssbev_occ_loss_bwd_workspace(const ssbev_occloss_dims* d);
 int ssbev_occ_loss_bwd(const float* logits, const uint8_t* label, const float* class_weight,
                        const float* coef, float* grad_logits, const ssbev_occloss_dims* d, void* ws,

@@ -203,6 +203,7 @@ SIGNATURES = {
     "ssbev_occ_loss_num_sums": (C.c_int, []),
     "ssbev_occ_loss_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
+    "ssbev_occ_loss_tail": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "ssbev_occ_loss_bwd_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
     "ssbev_grad_norm_workspace": (C.c_size_t, []),

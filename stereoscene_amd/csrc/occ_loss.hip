@@ -183,6 +183,98 @@ occ_loss_bwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ lab
 
 constexpr int FWD_BLOCKS = 2048;
 
+// ---- the scalar algebra behind the sums (occhead.py:291-361, semkitti.py:67-149), one 64-thread block.
+// losses: CE = ce_num / ce_den; sem_scal = mean over the present classes of nll(precision) + nll(recall) + nll(specificity);
+// geo_scal = the same three terms for "occupied" (class 0 = empty complemented); nll(v) = -max(log v, -100)
+// (F.binary_cross_entropy against a target of ones).  Written out as ~110 double-precision ATen ops (forward + autograd) this
+// sat on the turning point of every step with the device idle; here the forward also emits the Jacobian of the three losses
+// w.r.t. the 41 differentiable sums (ce_num, sum_p[20], nom[20]), so backward is three scaled rows.
+__device__ __forceinline__ double nll1(double v, double& dv) {       // value and derivative of -clamp(log v, min = -100)
+  const double l = log(v);
+  if (l > -100.0) { dv = -1.0 / v; return -l; }
+  dv = 0.0;                                     // clamped (or NaN: torch.clamp passes it on with a zero gradient)
+  return l != l ? l : 100.0;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+occ_loss_tail_kernel(const double* __restrict__ sums, float w_ce, float w_sem, float w_geo, float* __restrict__ out,
+                     double* __restrict__ jac) {
+  constexpr int ND = 1 + 2 * NC;                 // differentiable sums: ce_num, sum_p[NC], nom[NC]
+  const int c = threadIdx.x;
+  const double ce_num = sums[0], ce_den = sums[1], M = sums[2];
+  const double* sum_p = sums + 3;
+  const double* nom = sums + 3 + NC;
+  const double* cnt = sums + 3 + 2 * NC;
+  const double* conf = sums + 3 + 3 * NC;        // [gt][pred]
+  // jac[k][j]: k = 0 CE, 1 sem_scal, 2 geo_scal; j = 0 ce_num, 1 + c sum_p[c], 1 + NC + c nom[c]
+  for (int j = c; j < 3 * ND; j += 64) jac[j] = 0.0;
+  __syncthreads();
+  // ---- sem_scal
+  double lc = 0.0, d_sp = 0.0, d_nom = 0.0, present = 0.0;
+  if (c < NC) {
+    const double sp = sum_p[c], nm = nom[c], ct = cnt[c], neg = M - ct;
+    present = ct > 0.0 ? 1.0 : 0.0;
+    double dv;
+    if (sp > 0.0) {                                              // precision nom / sum_p
+      lc += nll1(nm / sp, dv);
+      d_nom += dv / sp; d_sp += dv * (-nm / (sp * sp));
+    }
+    {                                                            // recall nom / max(cnt, 1)
+      const double den = ct < 1.0 ? 1.0 : ct;
+      lc += nll1(nm / den, dv);
+      d_nom += dv / den;
+    }
+    if (neg > 0.0) {                                             // specificity (neg - (sum_p - nom)) / max(neg, 1)
+      const double den = neg < 1.0 ? 1.0 : neg;
+      lc += nll1((neg - (sp - nm)) / den, dv);
+      d_sp += -dv / den; d_nom += dv / den;
+    }
+  }
+  const double npres = wave_sum(present);
+  const double sem = wave_sum(lc * present) / npres;
+  if (c < NC) {
+    jac[1 * ND + 1 + c] = (double)w_sem * present * d_sp / npres;
+    jac[1 * ND + 1 + NC + c] = (double)w_sem * present * d_nom / npres;
+  }
+  // ---- metric (no gradient): completion IoU over "occupied", mean IoU over classes 1..NC-1
+  double tp = 0.0, fp = 0.0, fn = 0.0, iou_c = 0.0;
+  if (c < NC) {
+    double row = 0.0, col = 0.0, rocc = 0.0;                     // row: gt == c, col: pred == c
+    for (int k = 0; k < NC; ++k) {
+      row += conf[c * NC + k]; col += conf[k * NC + c];
+      if (k > 0) rocc += conf[c * NC + k];
+    }
+    const double tpc = conf[c * NC + c];
+    if (c > 0) { tp = rocc; fn = conf[c * NC + 0]; iou_c = tpc / (tpc + (col - tpc) + (row - tpc) + 1e-5); }
+    else fp = rocc;                                              // gt empty, predicted occupied
+  }
+  tp = wave_sum(tp); fp = wave_sum(fp); fn = wave_sum(fn);
+  const double miou = wave_sum(iou_c) / (double)(NC - 1);
+  if (c == 0) {
+    // ---- CE
+    out[0] = (float)(ce_num / ce_den) * w_ce;
+    jac[0] = (double)w_ce / ce_den;
+    out[1] = (float)sem * w_sem;
+    // ---- geo_scal
+    const double sp0 = sum_p[0], nm0 = nom[0], ct0 = cnt[0];
+    const double occ_t = M - ct0, inter = occ_t - (sp0 - nm0);
+    double d1, d2, d3;
+    const double g1 = nll1(inter / (M - sp0), d1), g2 = nll1(inter / occ_t, d2), g3 = nll1(nm0 / ct0, d3);
+    out[2] = (float)(g1 + g2 + g3) * w_geo;
+    // d inter / d sum_p0 = -1, d inter / d nom0 = +1
+    const double den1 = M - sp0;
+    jac[2 * ND + 1 + 0] = (double)w_geo * (d1 * (-1.0 / den1 + inter / (den1 * den1)) + d2 * (-1.0 / occ_t));
+    jac[2 * ND + 1 + NC + 0] = (double)w_geo * (d1 / den1 + d2 / occ_t + d3 / ct0);
+    out[3] = (float)(tp / (tp + fp + fn));
+    out[4] = (float)miou;
+  }
+}
+
 bool occ_ok(const ssbev_occloss_dims* d) {
   return d && d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->C == NC;
 }
@@ -206,6 +298,13 @@ int ssbev_occ_loss_fwd(const float* logits, const uint8_t* label, const float* c
   hipLaunchKernelGGL(occ_loss_fwd_kernel, dim3(FWD_BLOCKS), dim3(256), 0, st, logits, label, class_weight, partial, d->B,
                      d->D, d->H, d->W);
   hipLaunchKernelGGL(occ_loss_reduce_kernel, dim3(NS), dim3(256), 0, st, partial, FWD_BLOCKS, sums);
+  return ssbev_launch_status();
+}
+
+int ssbev_occ_loss_tail(const double* sums, float w_ce, float w_sem, float w_geo, float* out5, double* jac,
+                        ssbev_stream_t stream) {
+  if (!sums || !out5 || !jac) return SSBEV_EINVAL;
+  hipLaunchKernelGGL(occ_loss_tail_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, w_ce, w_sem, w_geo, out5, jac);
   return ssbev_launch_status();
 }
 

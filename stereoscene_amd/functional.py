@@ -1863,6 +1863,46 @@ def occ_loss_sums(logits, label_u8, class_weight):
     return _OccLossSums.apply(logits, label_u8, class_weight)
 
 
+OCC_TAIL = os.environ.get("SSBEV_OCC_TAIL", "1") != "0"      # scalar loss algebra in one launch (0 = ~110 tiny ATen ops)
+
+
+class _OccLossTail(torch.autograd.Function):
+    """(diff [41] f64, aux f64) from _OccLossSums -> the three weighted losses + the two metric scalars (five 0-dim float
+    tensors), ``ssbev_occ_loss_tail``: forward also returns the Jacobian, backward scales its three rows."""
+
+    @staticmethod
+    def forward(ctx, diff, aux, w_ce, w_sem, w_geo):
+        lib = capi.load()
+        ctx.set_materialize_grads(False)
+        nd = diff.numel()
+        nc = (nd - 1) // 2
+        # back to the kernel's layout: ce_num, ce_den, M, sum_p, nom, cnt, conf
+        sums = torch.cat((diff[0:1], aux[0:2], diff[1:], aux[2:])).contiguous()
+        assert sums.numel() == lib.ssbev_occ_loss_num_sums() and nc * 2 + 1 == nd
+        out = torch.empty(5, dtype=torch.float32, device=diff.device)
+        jac = torch.empty(3, nd, dtype=torch.float64, device=diff.device)
+        capi.check(lib.ssbev_occ_loss_tail(capi.ptr(sums), float(w_ce), float(w_sem), float(w_geo), capi.ptr(out), capi.ptr(jac),
+                                           capi.stream()), "ssbev_occ_loss_tail")
+        ctx.save_for_backward(jac)
+        outs = tuple(out[i] for i in range(5))
+        ctx.mark_non_differentiable(outs[3], outs[4])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_ce, g_sem, g_geo, _g3, _g4):
+        (jac,) = ctx.saved_tensors
+        gd = None
+        for k, g in enumerate((g_ce, g_sem, g_geo)):
+            if g is not None:
+                term = jac[k] * g.to(torch.float64)
+                gd = term if gd is None else gd + term
+        return gd, None, None, None, None
+
+
+def occ_loss_tail(diff, aux, w_ce, w_sem, w_geo):
+    return _OccLossTail.apply(diff, aux, w_ce, w_sem, w_geo)
+
+
 # -------------------------------------------------------------------------------------------------
 # Image branch (SURVEY 8(f1)): depthwise conv with "same" padding, Swish, squeeze-excitation pieces
 # -------------------------------------------------------------------------------------------------

@@ -86,10 +86,23 @@ def _nll1(v):
 def occ_losses_fused(logits, gt_occ, class_weights, tag="0", w_ce=1.0, w_sem=1.0, w_geo=1.0, compute_metric=False):
     """Same losses / metric as ``occ_losses`` from the sums of the fused HIP epilogue (one pass over the coarse
     logits; the up-sampled logits, probabilities and one-hot volumes are never materialised)."""
+    from .. import functional as F
     from ..functional import occ_loss_sums
     nc = logits.shape[1]
     label = gt_occ.to(torch.uint8)                      # classes 0..19, 255 = ignore
     diff, aux = occ_loss_sums(logits, label, class_weights)
+    if F.OCC_TAIL:                                      # the algebra below in one launch (+ its Jacobian for backward)
+        ce, sem, geo, iou, miou = F.occ_loss_tail(diff, aux, w_ce, w_sem, w_geo)
+        out = {}
+        if w_ce > 0:
+            out[f"loss_voxel_ce_{tag}"] = ce
+        if w_sem > 0:
+            out[f"loss_voxel_sem_scal_{tag}"] = sem
+        if w_geo > 0:
+            out[f"loss_voxel_geo_scal_{tag}"] = geo
+        if compute_metric:
+            out[f"sc_iou_{tag}"], out[f"ssc_miou_{tag}"] = iou.detach(), miou.detach()
+        return out
     ce_num, sum_p, nom = diff[0], diff[1:1 + nc], diff[1 + nc:1 + 2 * nc]
     ce_den, M, cnt, conf = aux[0], aux[1], aux[2:2 + nc], aux[2 + nc:].view(nc, nc)
     out = {}
