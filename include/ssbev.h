@@ -357,6 +357,18 @@ int ssbev_resize_pil_u8(const uint8_t* src, int Hs, int Ws, int C, const int32_t
                         ssbev_stream_t stream);
 int ssbev_crop_normalize_u8(const uint8_t* src, int Hs, int Ws, float* dst, int x0, int y0, int w, int h, int flip,
                             const float* mean, const float* stdinv, int swap_rb, ssbev_stream_t stream);
+/* Depth BCE loss (ViewTransformerLSSVoxel.py:349-416: get_downsampled_gt_depth + get_depth_loss): gt_depths [BN, fH*ds, fW*ds]
+ * (0 = no LiDAR return), depth_pred [BN, D, fH, fW] (a probability distribution over the D bins per pixel).  out2[0] = weight *
+ * sum of the binary cross entropies over the pixels that have a return / max(their number, 1), out2[1] = that divisor.  The
+ * bin of a pixel is (min over its ds x ds block - c0) / dd in fp32, truncated, with c0 = d0 - dd / 2 computed by the caller as
+ * the reference does (in double, rounded to fp32 once).  The workspace keeps the per-pixel labels for _bwd, which writes
+ * grad_pred = grad_loss[0] * d out2[0] / d depth_pred. */
+size_t ssbev_depth_bce_workspace(int BN, int fH, int fW);
+int ssbev_depth_bce_fwd(const float* gt_depths, const float* depth_pred, float* out2, int BN, int D, int fH, int fW, int ds,
+                        float c0, float dd, float weight, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+int ssbev_depth_bce_bwd(const float* depth_pred, const float* grad_loss, const float* out2, float* grad_pred, int BN, int D, int fH,
+                        int fW, int ds, float c0, float dd, float weight, const void* ws, ssbev_stream_t stream);
+
 size_t ssbev_lidar_depth_workspace(int H, int W);
 int ssbev_lidar_depth_map(const float* points, int n_points, const float* cam, const float* labels, float* uvd,
                           unsigned char* valid, float* depth, float* seg, int H, int W, void* ws, size_t ws_bytes,

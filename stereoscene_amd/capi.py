@@ -134,6 +134,9 @@ SIGNATURES = {
     "ssbev_bn_update_running": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int64, _P]),
     "ssbev_resize_pil_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "ssbev_crop_normalize_u8": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "ssbev_depth_bce_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ssbev_depth_bce_fwd": (C.c_int, [_P, _P, _P] + [C.c_int] * 5 + [C.c_float] * 3 + [_P, C.c_size_t, _P]),
+    "ssbev_depth_bce_bwd": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 5 + [C.c_float] * 3 + [_P, _P]),
     "ssbev_lidar_depth_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "ssbev_lidar_depth_map": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ssbev_dwconv2d_fwd": (C.c_int, [_P, _P, _P, C.POINTER(DwDims), _P]),

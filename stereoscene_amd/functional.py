@@ -1863,6 +1863,46 @@ def occ_loss_sums(logits, label_u8, class_weight):
     return _OccLossSums.apply(logits, label_u8, class_weight)
 
 
+DEPTH_BCE = os.environ.get("SSBEV_DEPTH_BCE", "1") != "0"    # fused depth loss (0 = the ~35 ATen ops of the tensor expression)
+
+
+class _DepthBce(torch.autograd.Function):
+    """weight * BCE(depth_pred, one-hot of the down-sampled LiDAR depth) over the pixels with a return (VT:349-416),
+    ``ssbev_depth_bce_fwd / _bwd``: gt_depths [B, N, H, W], depth_pred [B*N, D, H/ds, W/ds] -> 0-dim loss."""
+
+    @staticmethod
+    def forward(ctx, gt_depths, depth_pred, ds, dbound, weight):
+        lib = capi.load()
+        B, N, H, W = gt_depths.shape
+        BN, D, fH, fW = depth_pred.shape
+        assert BN == B * N and fH * ds == H and fW * ds == W
+        gt = _f32(gt_depths, "depth_bce").contiguous()
+        pred = _f32(depth_pred, "depth_bce").contiguous()
+        c0 = float(dbound[0] - dbound[2] / 2)                      # in double, like the reference's Python expression
+        args = (BN, D, fH, fW, int(ds), c0, float(dbound[2]), float(weight))
+        ws = torch.empty(lib.ssbev_depth_bce_workspace(BN, fH, fW), dtype=torch.uint8, device=pred.device)   # kept for backward
+        out = torch.empty(2, dtype=torch.float32, device=pred.device)
+        capi.check(lib.ssbev_depth_bce_fwd(capi.ptr(gt), capi.ptr(pred), capi.ptr(out), *args, capi.ptr(ws), ws.numel(),
+                                           capi.stream()), "ssbev_depth_bce_fwd")
+        ctx.save_for_backward(pred, out, ws)
+        ctx.args = args
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = capi.load()
+        pred, out, ws = ctx.saved_tensors
+        gp = torch.empty_like(pred)
+        gl = g.to(torch.float32).reshape(1).contiguous()
+        capi.check(lib.ssbev_depth_bce_bwd(capi.ptr(pred), capi.ptr(gl), capi.ptr(out), capi.ptr(gp), *ctx.args, capi.ptr(ws),
+                                           capi.stream()), "ssbev_depth_bce_bwd")
+        return None, gp, None, None, None
+
+
+def depth_bce_loss(gt_depths, depth_pred, ds, dbound, weight):
+    return _DepthBce.apply(gt_depths, depth_pred, ds, dbound, weight)
+
+
 OCC_TAIL = os.environ.get("SSBEV_OCC_TAIL", "1") != "0"      # scalar loss algebra in one launch (0 = ~110 tiny ATen ops)
 
 

@@ -609,6 +609,9 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         """BCE depth loss (VT:375-388,405-416)."""
         if self.loss_depth_type != "bce":
             raise NotImplementedError(self.loss_depth_type)
+        if (F.DEPTH_BCE and depth_preds.is_cuda and depth_preds.dtype == torch.float32 and depth_labels.dtype == torch.float32
+                and depth_preds.shape[1] == self.D):
+            return F.depth_bce_loss(depth_labels, depth_preds, self.downsample, self.grid_config["dbound"], self.loss_depth_weight)
         _, labels = self.get_downsampled_gt_depth(depth_labels)
         preds = depth_preds.float().permute(0, 2, 3, 1).reshape(-1, self.D)
         fg = labels.max(dim=1).values > 0.0

@@ -370,3 +370,25 @@ def test_occ_loss_tail_kernel_equals_the_tensor_algebra(monkeypatch):
     for k, v in res[False][0].items():
         assert abs(res[True][0][k] - v) <= 1e-6 * max(1.0, abs(v)), (k, res[True][0][k], v)
     assert _rel_l2(res[True][1], res[False][1]) < 1e-6
+
+
+def test_fused_depth_bce_loss_equals_the_tensor_expression(monkeypatch):
+    """ssbev_depth_bce_fwd / _bwd against get_downsampled_gt_depth + get_depth_loss written with ATen ops (VT:349-416): the same
+    bins (bit-exact fp32 arithmetic), the same elementwise terms; the sum is taken in double instead of ATen's fp32 tree."""
+    from stereoscene_amd import model_zoo
+    cfg = S.CFG_T
+    vt = model_zoo.build_detector(cfg).img_view_transformer.to(DEV)
+    smp = S.synthetic_sample(cfg, B=2, tag="depthbce")
+    gt = smp["gt_depths"].to(DEV).float()
+    B, N, H, W = gt.shape
+    logits = S.hash_normal("depthbce/p", (B * N, vt.D, H // vt.downsample, W // vt.downsample)).to(DEV)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "DEPTH_BCE", on)
+        x = logits.clone().requires_grad_(True)
+        loss = vt.get_depth_loss(gt, torch.softmax(x, dim=1))
+        (loss * 1.7).backward()
+        res[on] = (float(loss), x.grad.clone())
+    assert res[False][0] > 0
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), res
+    assert _rel_l2(res[True][1], res[False][1]) < 2e-6
