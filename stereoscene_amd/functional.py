@@ -579,7 +579,7 @@ class _ConvNd(torch.autograd.Function):
         args = (stride, padding, dilation, transposed, output_padding)
         if ctx.relu:
             ycl = ctx.saved_tensors[2]
-            gy = from_cl(torch.where(ycl > 0, to_cl(gy), torch.zeros((), dtype=gy.dtype, device=gy.device)))
+            gy = from_cl(torch.ops.aten.threshold_backward(to_cl(gy).contiguous(), ycl, 0.0))     # gy * [y > 0], one pass
         gcl0 = to_cl(gy)                                    # gradient as it arrives: Cout channels
         Cout_g = gcl0.shape[-1]
         cpad = (-Cout_g) % 4                                # the data gradient's K role is the forward Cout: multiple of 4 ...
