@@ -293,6 +293,25 @@ int ssbev_occ_loss_num_sums(void);
 size_t ssbev_occ_loss_workspace(const ssbev_occloss_dims* d);
 int ssbev_occ_loss_fwd(const float* logits, const uint8_t* label, const float* class_weight, double* sums,
                        const ssbev_occloss_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+/* The elementwise shell of a BRI attention block (attention.py:45-86) around its six products, operands [B, D, T] with the token
+ * axis contiguous; every scalar parameter is a DEVICE pointer to one float (the 1x1x1 single-channel convolutions' weight / bias,
+ * gamma).  Forward: Q = q wq + bq, K = kv wk + bk, Vc = (kv wv + bv) conf[b, t]  (pre);  y = gamma out + kv  (post).
+ * Backward: post_bwd writes gout = gy gamma, per-chunk partial column sums delta_part[chunks][B*T] of gout * out (their sum over
+ * the chunk axis is the softmax-backward row term) and partial sums of gy * out (-> d gamma); pre_bwd writes gq, gkv (gres = the
+ * residual branch's gradient, added in), gconf_part[chunks][B*T] and part[..][6] = partial sums for d(wq, bq, wk, bk, wv, bv).
+ * chunks = ssbev_bri_shell_chunks(); part arrays have chunks * ceil(B*T / 256) rows (doubles), summed by the caller. */
+int ssbev_bri_shell_chunks(void);
+int ssbev_bri_shell_pre_fwd(const float* q, const float* kv, const float* conf, const float* wq, const float* bq,
+                            const float* wk, const float* bk, const float* wv, const float* bv, float* Q, float* K, float* Vc,
+                            int B, int D, int T, ssbev_stream_t stream);
+int ssbev_bri_shell_post_fwd(const float* out, const float* kv, const float* gamma, float* y, int B, int D, int T,
+                             ssbev_stream_t stream);
+int ssbev_bri_shell_post_bwd(const float* gy, const float* out, const float* gamma, float* gout, float* delta_part, double* part,
+                             int B, int D, int T, ssbev_stream_t stream);
+int ssbev_bri_shell_pre_bwd(const float* gQ, const float* gK, const float* gVc, const float* q, const float* kv, const float* conf,
+                            const float* gres, const float* wq, const float* wk, const float* wv, const float* bv, float* gq,
+                            float* gkv, float* gconf_part, double* part, int B, int D, int T, ssbev_stream_t stream);
+
 /* The scalar algebra behind the sums in one launch: out5 (float) = w_ce * CE, w_sem * sem_scal, w_geo * geo_scal (occhead.py:
  * 291-361, semkitti.py:67-149), completion IoU, mean IoU over classes 1..19; jac[3][41] (double) = the Jacobian of the three
  * weighted losses w.r.t. (ce_num, sum_p[20], nom[20]) -- backward is jac^T times the three incoming scalars, which is the

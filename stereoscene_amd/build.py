@@ -14,7 +14,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 # Kernels whose results must be BIT-identical to the CPU oracle are built without FMA contraction
 # (hipcc's __fmul_rn/__fadd_rn are plain * and + and would otherwise fuse).
-PER_FILE_FLAGS = {"voxel_pool.hip": ["-ffp-contract=off"], "lidar_depth.hip": ["-ffp-contract=off"]}
+PER_FILE_FLAGS = {"voxel_pool.hip": ["-ffp-contract=off"], "lidar_depth.hip": ["-ffp-contract=off"],
+                  "bri_shell.hip": ["-ffp-contract=off"]}
 
 
 def sources():

@@ -207,6 +207,11 @@ SIGNATURES = {
     "ssbev_occ_loss_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
     "ssbev_occ_loss_tail": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
+    "ssbev_bri_shell_chunks": (C.c_int, []),
+    "ssbev_bri_shell_pre_fwd": (C.c_int, [_P] * 12 + [C.c_int] * 3 + [_P]),
+    "ssbev_bri_shell_post_fwd": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
+    "ssbev_bri_shell_post_bwd": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
+    "ssbev_bri_shell_pre_bwd": (C.c_int, [_P] * 15 + [C.c_int] * 3 + [_P]),
     "ssbev_occ_loss_bwd_workspace": (C.c_size_t, [C.POINTER(UpsampleDims)]),
     "ssbev_occ_loss_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(UpsampleDims), _P, C.c_size_t, _P]),
     "ssbev_grad_norm_workspace": (C.c_size_t, []),

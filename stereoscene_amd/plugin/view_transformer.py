@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from .. import capi
 from .. import functional as F
 from ..layers import (BatchNorm2d, BatchNorm3d, Conv2d, Conv3d, ConvTranspose3d, GroupNorm, build_conv_layer, build_norm_layer,
                       fuse_relu_, norm_cat, norm_pair)
@@ -264,6 +265,10 @@ class attention(nn.Module):
         B, C, D, H, W = kv.shape
         hw = H * W
         conf = F.softmax(q, dim=2).amax(dim=2).view(B, hw)                # [B,HW]
+        if (BRI_SHELL and kv.is_cuda and C == 1 and q.dtype == kv.dtype == torch.float32 and F.own_gemm_site("bri")
+                and os.environ.get("SSBEV_BRI", "gemm") != "flash" and hw % 4 == 0 and hw <= 8192):
+            qc, kc, vc = self.query_conv, self.key_conv, self.value_conv
+            return _BriBlock.apply(q, kv, conf, qc.weight, qc.bias, kc.weight, kc.bias, vc.weight, vc.bias, self.gamma)
         Q = self._affine(self.query_conv, q).view(B, D, hw)                   # [B,D,HW] (tokens contiguous)
         K = self._affine(self.key_conv, kv).view(B, D, hw)
         V = self._affine(self.value_conv, kv).view(B, D, hw)
@@ -276,6 +281,67 @@ class attention(nn.Module):
         else:
             out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
         return self.gamma * out + kv
+
+
+BRI_SHELL = os.environ.get("SSBEV_BRI_SHELL", "1") != "0"   # elementwise shell of the block as four kernels (0 = ~40 ATen ops)
+
+
+class _BriBlock(torch.autograd.Function):
+    """One BRI block end to end for the own-GEMM realisation: ``gamma * BRI(q w_q + b_q, kv w_k + b_k, (kv w_v + b_v) conf) + kv``
+    (ATT:45-86).  The six products are _BriCore's; everything around them -- three scalar-affine convolutions, the key-side
+    re-weight, the residual, and all their gradients incl. the seven scalar parameter gradients -- is csrc/bri_shell.hip
+    (two launches forward, two backward) instead of ~9 + ~30 tensor expressions on 5.9 MB operands."""
+
+    @staticmethod
+    def forward(ctx, q, kv, conf, wq, bq, wk, bk, wv, bv, gamma):
+        lib = capi.load()
+        B, C, D, H, W = kv.shape
+        T = H * W
+        q3, kv3 = q.contiguous().view(B, D, T), kv.contiguous().view(B, D, T)
+        cf = conf.contiguous()
+        ps = [t.detach().reshape(1).contiguous() for t in (wq, bq, wk, bk, wv, bv, gamma)]
+        Q, K, Vc = (torch.empty_like(q3) for _ in range(3))
+        capi.check(lib.ssbev_bri_shell_pre_fwd(capi.ptr(q3), capi.ptr(kv3), capi.ptr(cf), *[capi.ptr(p) for p in ps[:6]],
+                                               capi.ptr(Q), capi.ptr(K), capi.ptr(Vc), B, D, T, capi.stream()), "ssbev_bri_shell_pre_fwd")
+        att = F.softmax_rows_(F.gemm_tn(Q, K, tag="bri energy"))                         # [B,T(i),T(j)]
+        out = F.gemm_nt(Vc, att, tag="bri out")                                         # [B,D,T(i)]
+        y = torch.empty_like(kv3)
+        capi.check(lib.ssbev_bri_shell_post_fwd(capi.ptr(out), capi.ptr(kv3), capi.ptr(ps[6]), capi.ptr(y), B, D, T, capi.stream()),
+                   "ssbev_bri_shell_post_fwd")
+        ctx.save_for_backward(q3, kv3, cf, Q, K, Vc, att, out, *ps)
+        ctx.shapes = (tuple(q.shape), tuple(kv.shape), [tuple(t.shape) for t in (wq, bq, wk, bk, wv, bv, gamma)])
+        return y.view(B, C, D, H, W)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = capi.load()
+        q3, kv3, cf, Q, K, Vc, att, out, *ps = ctx.saved_tensors
+        B, D, T = kv3.shape
+        dev = gy.device
+        g3 = gy.contiguous().view(B, D, T)
+        nch, nblk = lib.ssbev_bri_shell_chunks(), (B * T + 255) // 256
+        gout = torch.empty_like(g3)
+        delta_part = torch.empty(nch, B * T, dtype=torch.float32, device=dev)
+        part_g = torch.empty(nch * nblk, dtype=torch.float64, device=dev)
+        capi.check(lib.ssbev_bri_shell_post_bwd(capi.ptr(g3), capi.ptr(out), capi.ptr(ps[6]), capi.ptr(gout), capi.ptr(delta_part),
+                                                capi.ptr(part_g), B, D, T, capi.stream()), "ssbev_bri_shell_post_bwd")
+        delta = delta_part.sum(0).view(B, T)
+        # the products of _BriCore.backward (softmax backward inside the epilogue of the gatt product)
+        gE = F.gemm_tn(gout, Vc, tag="bri gatt+softmax bwd", ep_mul=att, ep_rowsub=delta)
+        gVc = F.gemm_nn(gout, att, tag="bri gVc")
+        gQ = F.gemm_nt(K, gE, tag="bri gQ")
+        gK = F.gemm_nn(Q, gE, tag="bri gK")
+        gq, gkv = torch.empty_like(q3), torch.empty_like(kv3)
+        gconf_part = torch.empty(nch, B * T, dtype=torch.float32, device=dev)
+        part = torch.empty(nch * nblk, 6, dtype=torch.float64, device=dev)
+        capi.check(lib.ssbev_bri_shell_pre_bwd(capi.ptr(gQ), capi.ptr(gK), capi.ptr(gVc), capi.ptr(q3), capi.ptr(kv3), capi.ptr(cf),
+                                               capi.ptr(g3), capi.ptr(ps[0]), capi.ptr(ps[2]), capi.ptr(ps[4]), capi.ptr(ps[5]),
+                                               capi.ptr(gq), capi.ptr(gkv), capi.ptr(gconf_part), capi.ptr(part), B, D, T,
+                                               capi.stream()), "ssbev_bri_shell_pre_bwd")
+        gconf = gconf_part.sum(0).view(B, T)
+        gp = torch.cat((part.sum(0), part_g.sum().reshape(1))).to(torch.float32)        # d(wq, bq, wk, bk, wv, bv, gamma)
+        qs, ks, pshapes = ctx.shapes
+        return (gq.view(qs), gkv.view(ks), gconf, *[gp[i].view(sh) for i, sh in enumerate(pshapes)])
 
 
 class _BriCore(torch.autograd.Function):

@@ -392,3 +392,34 @@ def test_fused_depth_bce_loss_equals_the_tensor_expression(monkeypatch):
     assert res[False][0] > 0
     assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), res
     assert _rel_l2(res[True][1], res[False][1]) < 2e-6
+
+
+def test_bri_block_shell_kernels_equal_the_tensor_expressions(monkeypatch):
+    """attention.forward through _BriBlock (csrc/bri_shell.hip around the six products) against the same block written with
+    tensor expressions around _BriCore: output, both input gradients and the seven scalar parameter gradients."""
+    from stereoscene_amd.plugin import view_transformer as VT
+    torch.manual_seed(0)
+    att = VT.attention(1).to(DEV)
+    with torch.no_grad():
+        for i, p in enumerate(att.parameters()):
+            p.copy_(S.hash_normal(f"brishell/p{i}", tuple(p.shape)).to(DEV) * 0.5 + 0.3)
+    B, D, H, W = 2, 24, 8, 16
+    q = S.hash_normal("brishell/q", (B, 1, D, H, W)).to(DEV)
+    kv = S.hash_normal("brishell/kv", (B, 1, D, H, W)).to(DEV)
+    go = S.hash_normal("brishell/go", (B, 1, D, H, W)).to(DEV)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(VT, "BRI_SHELL", on)
+        att.zero_grad(set_to_none=True)
+        a, b = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        y = att(a, b)
+        y.backward(go)
+        res[on] = [y.detach(), a.grad, b.grad] + [p.grad.clone() for p in att.parameters()]
+    for i, (u, v) in enumerate(zip(res[True], res[False])):
+        assert u.shape == v.shape
+        # the scalar parameter gradients are sums of ~6 k signed terms: the kernels add them in double, ATen in an fp32 tree
+        # (and d w_k, d b_k vanish analytically -- a shift of the keys does not move a softmax: both sides return rounding noise)
+        if i < 3:
+            assert _rel_l2(u, v) < 2e-5, (i, _rel_l2(u, v))
+        else:
+            assert abs(float(u) - float(v)) <= 2e-4 * abs(float(v)) + 1e-7, (i, float(u), float(v))
