@@ -55,3 +55,33 @@ def test_workspace_queries_and_einval_on_host():
     c = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0)
     assert lib.ssbev_conv_packed_weight_elems(C.byref(c)) >= 27 * 32 * 32      # (the tap-split layout pads to 28 taps)
     assert lib.ssbev_conv_bwd_weight_workspace(C.byref(c)) >= 27 * 32 * 32 * 4
+
+
+def test_round3_entry_points_validate_their_arguments_on_host():
+    """Workspace queries and argument checks of the round-3 entry points (no device work): the fused depth loss, the loss
+    tail, the BRI shell, the frustum geometry, the strided GroupNorm and the cost-volume backward workspace."""
+    import ctypes as C
+    lib = capi.load()
+    npix = 2 * 48 * 160
+    ws = lib.ssbev_depth_bce_workspace(2, 48, 160)
+    assert ws >= npix * 4 + (npix // 256) * lib.ssbev_bri_shell_chunks() * 16          # labels + (bce, count) partials
+    assert lib.ssbev_depth_bce_workspace(0, 48, 160) == 0
+    assert lib.ssbev_depth_bce_fwd(None, None, None, 1, 192, 48, 160, 8, 1.75, 0.5, 1.0, None, 0, None) == capi.EINVAL
+    assert lib.ssbev_depth_bce_bwd(None, None, None, None, 1, 192, 48, 160, 8, 1.75, 0.5, 1.0, None, None) == capi.EINVAL
+    assert lib.ssbev_occ_loss_tail(None, 1.0, 1.0, 1.0, None, None, None) == capi.EINVAL
+    assert lib.ssbev_bri_shell_chunks() >= 1
+    nul = [None] * 12
+    assert lib.ssbev_bri_shell_pre_fwd(*nul, 1, 192, 7680, None) == capi.EINVAL
+    assert lib.ssbev_bri_shell_post_fwd(None, None, None, None, 1, 192, 7680, None) == capi.EINVAL
+    assert lib.ssbev_bri_shell_post_bwd(*[None] * 6, 1, 192, 7680, None) == capi.EINVAL
+    assert lib.ssbev_bri_shell_pre_bwd(*[None] * 15, 0, 192, 7680, None) == capi.EINVAL
+    gd = capi.GeomDims(1, 1, 192, 48, 160)
+    assert lib.ssbev_frustum_geometry(*[None] * 9, C.byref(gd), None) == capi.EINVAL
+    # strided GroupNorm output / gradient: the row stride must hold the slice and keep 16-byte alignment
+    nd = capi.NormDims(1, 128, 32, 1000, 1e-5, 1, 0, 0, 384, 0)
+    assert lib.ssbev_groupnorm_workspace(C.byref(nd)) > 0
+    for bad in (64, 130):
+        nd.ld_y = bad
+        assert lib.ssbev_groupnorm_workspace(C.byref(nd)) == 0
+    g = capi.GwcDims(1, 64, 32, 192, 48, 160, 1.0, 1)
+    assert lib.ssbev_gwc_warp_bwd_workspace(C.byref(g)) >= 2 * 2 * 48 * 160 * 64 * 4   # >= two chunks of both partial gradients
