@@ -258,52 +258,65 @@ class LoadMultiViewImageFromFiles_SemanticKitti:
             raise NotImplementedError("colorjitter / load_depth are off in stereoscene.py and not built")
         self.is_train, self.data_config, self.img_norm_cfg, self.device = is_train, data_config, img_norm_cfg, device
 
-    @staticmethod
-    def get_rot(h):
-        return torch.Tensor([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]])
+    # The image-view augmentation of one sample = five numbers (scale, left, top, mirrored, angle).  TRAIN draws them from
+    # numpy's global RNG; the fixture tests/golden/image_loading.npz pins the ORDER of the draws and the integer truncations
+    # (loading_semkitti.py:138-166), nothing else: each row below is (name, "does it consume the RNG stream?", draw).
+    _DRAWS = (
+        ("jitter", lambda c, st: True, lambda c, st: np.random.uniform(*c["resize"])),
+        ("top_frac", lambda c, st: True, lambda c, st: np.random.uniform(*c["crop_h"])),
+        ("left", lambda c, st: True, lambda c, st: np.random.uniform(0, max(0, st["size"][0] - st["target"][0]))),
+        ("mirrored", lambda c, st: bool(c["flip"]), lambda c, st: np.random.choice([0, 1])),     # no draw when flips are off
+        ("angle", lambda c, st: True, lambda c, st: np.random.uniform(*c["rot"])),
+    )
 
     def sample_augmentation(self, H, W, flip=None, scale=None):
-        fH, fW = self.data_config["input_size"]
+        """-> (resize, (newW, newH), (x0, y0, x1, y1), flip, rotate): one draw per sample, shared by both views."""
+        cfg = self.data_config
+        fH, fW = cfg["input_size"]
+        st = {"target": (fW, fH)}
+        base = float(fW) / float(W)
         if self.is_train:
-            resize = float(fW) / float(W) + np.random.uniform(*self.data_config["resize"])
-            resize_dims = (int(W * resize), int(H * resize))
-            newW, newH = resize_dims
-            crop_h = int((1 - np.random.uniform(*self.data_config["crop_h"])) * newH) - fH
-            crop_w = int(np.random.uniform(0, max(0, newW - fW)))
-            crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
-            flip = self.data_config["flip"] and np.random.choice([0, 1])
-            rotate = np.random.uniform(*self.data_config["rot"])
+            for name, consumes, draw in self._DRAWS:
+                if name == "top_frac":                       # the resized size is known once the scale jitter is drawn
+                    st["scale"] = base + st["jitter"]
+                    st["size"] = (int(W * st["scale"]), int(H * st["scale"]))
+                st[name] = draw(cfg, st) if consumes(cfg, st) else cfg["flip"]
+            top = int((1 - st["top_frac"]) * st["size"][1]) - fH
+            left, mirrored, angle = int(st["left"]), st["mirrored"], st["angle"]
         else:
-            resize = float(fW) / float(W) + self.data_config.get("resize_test", 0.0)
-            if scale is not None:
-                resize = scale
-            resize_dims = (int(W * resize), int(H * resize))
-            newW, newH = resize_dims
-            crop_h = int((1 - np.mean(self.data_config["crop_h"])) * newH) - fH
-            crop_w = int(max(0, newW - fW) / 2)
-            crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
-            flip = False if flip is None else flip
-            rotate = 0
-        return resize, resize_dims, crop, flip, rotate
+            st["scale"] = scale if scale is not None else base + cfg.get("resize_test", 0.0)
+            st["size"] = (int(W * st["scale"]), int(H * st["scale"]))
+            top = int((1 - np.mean(cfg["crop_h"])) * st["size"][1]) - fH
+            left = int(max(0, st["size"][0] - fW) / 2)
+            mirrored, angle = (False if flip is None else flip), 0
+        return st["scale"], st["size"], (left, top, left + fW, top + fH), mirrored, angle
+
+    @staticmethod
+    def _then(step, cur):
+        """Affine maps of image coordinates as (M [2,2], t [2]) fp32 pairs: ``step`` applied after ``cur``."""
+        return step[0].matmul(cur[0]), step[0].matmul(cur[1]) + step[1]
+
+    def pixel_map(self, post_rot, post_tran, resize, crop, flip):
+        """The pixel map raw image -> network input composed onto (post_rot, post_tran): scale, shift by the crop corner,
+        mirror about the crop width (what the reference accumulates at loading_semkitti.py:109-125; a rotation about the crop
+        centre would be the fourth step)."""
+        eye = torch.eye(2)
+        steps = [(eye * resize, torch.zeros(2)),
+                 (eye, -torch.Tensor([crop[0], crop[1]]))]
+        if flip:
+            steps.append((torch.Tensor([[-1, 0], [0, 1]]), torch.Tensor([crop[2] - crop[0], 0])))
+        m = (post_rot, post_tran)
+        for step in steps:
+            m = self._then(step, m)
+        return m
 
     def img_transform(self, img, post_rot, post_tran, resize, resize_dims, crop, flip, rotate):
-        """img: uint8 [H, W, 3] on the GPU -> normalised float [3, fH, fW]; post_rot / post_tran as loading_semkitti.py:109-125."""
+        """img: uint8 [H, W, 3] on the GPU -> normalised float [3, fH, fW] + the updated (post_rot, post_tran)."""
         if rotate != 0:
             raise NotImplementedError("image rotation is off in stereoscene.py (rot = (0, 0)) and not built")
         cfg = self.img_norm_cfg or dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
         out = crop_normalize(resize_u8(img, resize_dims), crop, flip, cfg["mean"], cfg["std"], swap_rb=False)
-        post_rot = post_rot * resize
-        post_tran = post_tran - torch.Tensor(crop[:2])
-        if flip:
-            A = torch.Tensor([[-1, 0], [0, 1]])
-            b = torch.Tensor([crop[2] - crop[0], 0])
-            post_rot = A.matmul(post_rot)
-            post_tran = A.matmul(post_tran) + b
-        A = self.get_rot(rotate / 180 * np.pi)
-        b = torch.Tensor([crop[2] - crop[0], crop[3] - crop[1]]) / 2
-        b = A.matmul(-b) + b
-        post_rot = A.matmul(post_rot)
-        post_tran = A.matmul(post_tran) + b
+        post_rot, post_tran = self.pixel_map(post_rot, post_tran, resize, crop, flip)
         return out, post_rot, post_tran
 
     def _view(self, results, k, augs):

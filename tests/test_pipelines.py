@@ -148,6 +148,32 @@ def test_oracle_image_loading_matches_reference_loader():
             assert np.array_equal(g[pre + "bda"], np.eye(3, dtype=np.float32))          # apply_bda=False: identity in slot 6
 
 
+def test_image_augmentation_draw_and_pixel_map_match_reference_loader():
+    """Host side of the product's image loader (no GPU): the augmentation draw (RNG order, integer truncations) and the 2x3
+    pixel map against what the reference's loader produced for the same seed (tests/golden/image_loading.npz)."""
+    g = load_golden("image_loading")
+    Hs, Ws = stereo_images()[1].shape[:2]
+    for mode, is_train in (("test", False), ("train", True)):
+        step = P.PIPELINES.build(dict(type="LoadMultiViewImageFromFiles_SemanticKitti", data_config=DATA_CONFIG, is_train=is_train,
+                                      device="cpu"))
+        np.random.seed(0)
+        resize, dims, crop, flip, rotate = step.sample_augmentation(H=Hs, W=Ws)
+        assert rotate == 0 and dims == (int(Ws * resize), int(Hs * resize))
+        assert (crop[2] - crop[0], crop[3] - crop[1]) == tuple(DATA_CONFIG["input_size"][::-1])
+        rot2, tran2 = step.pixel_map(torch.eye(2), torch.zeros(2), resize, crop, flip)
+        for name in ("left", "right"):                                       # one draw per sample, shared by both views
+            assert np.abs(rot2.numpy() - g[f"load_{mode}_{name}_post_rot"][0][:2, :2]).max() < 1e-6
+            assert np.abs(tran2.numpy() - g[f"load_{mode}_{name}_post_tran"][0][:2]).max() < 1e-5
+    # flips off in the config: the RNG stream is not consumed for them (the crop after it would move otherwise)
+    cfg = dict(DATA_CONFIG, flip=False)
+    step = P.PIPELINES.build(dict(type="LoadMultiViewImageFromFiles_SemanticKitti", data_config=cfg, is_train=True, device="cpu"))
+    np.random.seed(3)
+    a = step.sample_augmentation(H=Hs, W=Ws)
+    np.random.seed(3)
+    u = [np.random.uniform(*cfg["resize"]), np.random.uniform(*cfg["crop_h"])]
+    assert a[3] is False and abs(a[0] - (cfg["input_size"][1] / Ws + u[0])) < 1e-12
+
+
 def test_bev_transform_and_annotation_loader_host_logic():
     from stereoscene_amd import synthetic as S
     g = load_golden("image_loading")
