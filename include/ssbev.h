@@ -9,8 +9,12 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no torch types.
- *   - all data pointers are DEVICE pointers owned by the caller; the library never allocates,
- *     frees, synchronises or keeps state; work is enqueued on `stream` (a hipStream_t).
+ *   - all data pointers are DEVICE pointers owned by the caller; the library never allocates or frees
+ *     device memory, never synchronises and keeps no state that changes a result; work is enqueued
+ *     on `stream` (a hipStream_t).  The one thing it remembers is host-side memoisation of launch
+ *     PLANS (chunking searches of a few 10k iterations keyed by the problem shape: a mutex-guarded
+ *     std::map in csrc/conv_mfma.hip, plan_wgrad_lds): same inputs -> same plan -> same bits, with
+ *     or without the cache.
  *   - return 0 on success, <0 on error (no exceptions cross the boundary):
  *       SSBEV_EINVAL      bad dims / null pointer / unsupported configuration
  *       SSBEV_EWORKSPACE  workspace smaller than ssbev_*_workspace() says

@@ -744,6 +744,8 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
                               float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
                               size_t ws_bytes, ssbev_stream_t stream) {
   if (!gn_ok(d) || !x || !gamma || !beta || !y || !mean || !rstd || !ws) return SSBEV_EINVAL;
+  // a strided output (ld_y) is a slice of a concatenation: the residual operand has no stride of its own -> refused together
+  if (residual && d->ld_y != 0 && d->ld_y != d->C) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
@@ -801,6 +803,10 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
                               ssbev_stream_t stream) {
   if (!gn_ok(d) || !gy || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !ws) return SSBEV_EINVAL;
   if (d->relu && !y && !mask) return SSBEV_EINVAL;
+  // row strides are honoured for gy (ld_gy) on the paths that exist for them: the saved y of the non-mask ReLU path and the
+  // residual gradient are dense tensors -> a strided call that would need them is refused instead of mis-read
+  const bool strided = (d->ld_gy != 0 && d->ld_gy != d->C) || (d->ld_y != 0 && d->ld_y != d->C);
+  if (strided && ((d->relu && !mask) || gresidual)) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);

@@ -95,13 +95,33 @@ class FlatGradAllReduce:
         self._handles = []
         self.no_grad_ranges = []          # [(start, end)] element ranges of the flat buffer without a gradient this step
         self.bytes_exchanged = 0
+        self._home = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _home_stream(self):
+        """The stream the flat buffer belongs to: the caller's stream at ``zero_grad()`` (or at construction).  Packing and
+        the exchange always run THERE, whatever stream the autograd hook happens to fire on (DepthNet's backward -- and with
+        it the AccumulateGrad nodes of its parameters and this hook -- runs on the side stream, streams.py)."""
+        if self._home is None:
+            self._home = torch.cuda.current_stream(self.flat.device)
+        return self._home
 
     def _pack(self, b):
         """Move the stolen gradient tensors of bucket b into the flat buffer (one multi-tensor copy)."""
-        if self.flat.is_cuda:
-            from . import streams
-            streams.join(self.flat.device)      # weight gradients computed on the side stream (streams.py) are read here
+        if not self.flat.is_cuda:
+            return self._pack_on_current(b)
+        from . import streams
+        home = self._home_stream()
+        here = torch.cuda.current_stream(self.flat.device)
+        if here != home:
+            home.wait_stream(here)              # gradients produced by the node whose hook this is
+        # ... and everything the side stream has been given so far: weight gradients sent there by the convolution wrappers
+        # AND gradients computed there in place (DepthNet's), which never mark it dirty
+        streams.wait_side(home)
+        with torch.cuda.stream(home):
+            self._pack_on_current(b, foreign=here if here != home else None)
+
+    def _pack_on_current(self, b, foreign=None):
         dst, src = [], []
         for p in self._members[b]:
             view = self._views[p]
@@ -114,6 +134,10 @@ class FlatGradAllReduce:
                 src.append(p.grad.detach().reshape(view.shape))
             p.grad = view
         if dst:
+            if self.flat.is_cuda:
+                home = torch.cuda.current_stream(self.flat.device)
+                for t in src:                      # allocated on another stream, read here: tell the caching allocator
+                    t.record_stream(home)
             torch._foreach_copy_(dst, src)
         self._packed[b] = True
 
@@ -147,14 +171,23 @@ class FlatGradAllReduce:
         self._arrived[b] += 1
         if self._arrived[b] == self.buckets[b][2]:
             self._pack(b)
-            if self.timeline is not None and self.flat.is_cuda:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                self.timeline.append((b, ev))
-            if self.active:
-                self._handles += self._exchange(b, async_op=True)
+            if not self.flat.is_cuda:
+                if self.active:
+                    self._handles += self._exchange(b, async_op=True)
+                return
+            with torch.cuda.stream(self._home_stream()):       # the collective is ordered behind the pack on the home stream
+                if self.timeline is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.timeline.append((b, ev))
+                if self.active:
+                    self._handles += self._exchange(b, async_op=True)
 
     def zero_grad(self):
+        if self.flat.is_cuda:
+            from . import streams
+            self._home = torch.cuda.current_stream(self.flat.device)
+            streams.new_step()
         for p in self.params:
             p.grad = None                          # autograd will hand over its tensors; nothing to clear
         self._arrived = [0] * len(self.buckets)

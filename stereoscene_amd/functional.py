@@ -470,7 +470,16 @@ def spatial_mean(x):
 
 
 def _slot_of(t):
-    return getattr(t, "_ssbev_grad_slot", None) if t is not None else None
+    """The gradient slot an alias from ``fork`` carries -- handed out ONCE: the consumer that asks takes it off the alias.  A
+    second slot-aware consumer of the same alias gets None and returns a fresh gradient tensor, which autograd adds as usual
+    (with the slot still attached it would have accumulated into the shared buffer AND returned it: autograd's own sum of the
+    alias' two gradients would then count that buffer twice without any error)."""
+    if t is None:
+        return None
+    slot = getattr(t, "_ssbev_grad_slot", None)
+    if slot is not None:
+        t._ssbev_grad_slot = None
+    return slot
 
 
 def _slot_target(slot, like):
@@ -542,6 +551,7 @@ class _ConvNd(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None, relu=False):
         lib = capi.load()
         ctx.slot = slot
+        streams.note_use(weight)
         xcl = to_cl(_f32(x, "conv"))
         kpad = (-xcl.shape[-1]) % 4
         w5 = weight
@@ -1158,6 +1168,7 @@ class _WinoConvDF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, slot=None):
         ctx.slot = slot
+        streams.note_use(weight)
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout = weight.shape[0]
@@ -1230,6 +1241,7 @@ class _WinoConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, slot=None):
         ctx.slot = slot
+        streams.note_use(weight)
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout, three_d = weight.shape[0], weight.shape[2] == 3

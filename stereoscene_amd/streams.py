@@ -20,8 +20,9 @@ Contract (what keeps this safe with autograd and the caching allocator):
     dp.FlatGradAllReduce._pack (gradient bucket complete) and an end-of-backward callback queued on the autograd engine, so
     after ``backward()`` returns every gradient is ordered before later work on the caller's stream.
   * a weight gradient is only computed on the side stream when autograd will merely STORE it (a leaf parameter whose
-    ``.grad is None``); an existing ``.grad`` would be read by AccumulateGrad on the caller's stream straight away, and so
-    would the gradient of a non-leaf weight by the node that produced it.
+    ``.grad is None``, used ONCE in the graph, without tensor hooks); an existing ``.grad`` would be read by AccumulateGrad
+    on the caller's stream straight away, so would the gradient of a non-leaf weight by the node that produced it, and the
+    two gradients of a weight used twice are summed by the engine on the caller's stream (``note_use`` / ``wgrad_on_side``).
 """
 import os
 
@@ -46,8 +47,31 @@ def join(device=None):
     """Make the current stream wait for the side stream(s) (no-op when they are idle)."""
     for idx in list(_DIRTY):
         if device is None or device.index in (None, idx):
-            torch.cuda.current_stream(idx).wait_stream(_SIDE[idx])
+            cur = torch.cuda.current_stream(idx)
+            if cur == _SIDE[idx]:
+                continue        # called from work that lives ON the side stream: nothing was ordered for the caller's stream
+            cur.wait_stream(_SIDE[idx])
             _DIRTY.discard(idx)
+
+
+def wait_side(stream):
+    """Unconditionally order ``stream`` behind everything queued on its device's side stream so far (dp._pack: the gradients
+    of a bucket may have been produced there inline -- DepthNet's backward -- without ever marking it dirty)."""
+    idx = stream.device.index
+    st = _SIDE.get(idx)
+    if st is not None and st != stream:
+        stream.wait_stream(st)
+        if torch.cuda.current_stream(idx) == stream:
+            _DIRTY.discard(idx)
+
+
+def new_step():
+    """Start of an optimisation step (dp.FlatGradAllReduce.zero_grad): forget per-graph state that a failed or abandoned
+    backward may have left behind -- the engine drops its callbacks when backward() raises, and forward passes whose graph was
+    never run backward leave their weight-use counts."""
+    global _EPOCH
+    _CB_QUEUED.clear()
+    _EPOCH += 1
 
 
 def _end_of_backward():
@@ -94,8 +118,38 @@ class on_side:
         return False
 
 
+# ---- how often does one graph use a weight? -----------------------------------------------------------------------------
+# A gradient computed on the side stream is only safe while autograd merely STORES it.  A weight that feeds two convolution
+# calls of one graph gets its two gradients summed in the engine's input buffer on the caller's stream, unordered against the
+# side stream.  The convolution wrappers therefore count the uses of a weight in forward (``note_use``) and backward asks
+# ``wgrad_on_side``: more than one use since the weight's counter was last at rest -> every one of them stays on the caller's
+# stream.  The counter rests again when all counted uses have run backward, or at the next ``new_step()``.
+_EPOCH = 0
+
+
+def note_use(weight):
+    """Forward of a convolution wrapper that may send this weight's gradient to the side stream."""
+    if not (WGRAD_STREAM and weight.requires_grad and torch.is_grad_enabled()):
+        return
+    st = getattr(weight, "_ssbev_uses", None)
+    if st is None or st[0] != _EPOCH:
+        st = weight._ssbev_uses = [_EPOCH, 0, False]          # epoch, uses not yet run backward, shared?
+    st[1] += 1
+    if st[1] > 1:
+        st[2] = True
+
+
 def wgrad_on_side(weight):
     """Should this weight gradient go to the side stream?  (Only when autograd will merely store it, see above.)"""
     # a LEAF parameter: its gradient goes to AccumulateGrad, which keeps the tensor when .grad is None; the gradient of a
     # computed weight (CA3D folds its channel gate into the weights) is read by the next backward node at once
-    return WGRAD_STREAM and weight.is_cuda and weight.is_leaf and weight.grad is None
+    shared = False
+    st = getattr(weight, "_ssbev_uses", None)
+    if st is not None:
+        shared = st[2]
+        st[1] -= 1
+        if st[1] <= 0:
+            st[1], st[2] = 0, False
+    # tensor hooks on the weight read the gradient on the caller's stream before AccumulateGrad sees it
+    hooked = bool(getattr(weight, "_backward_hooks", None))
+    return WGRAD_STREAM and weight.is_cuda and weight.is_leaf and weight.grad is None and not shared and not hooked

@@ -251,6 +251,73 @@ def test_side_streams_change_nothing_bit_for_bit(monkeypatch):
             assert (other.double() - ref).norm().item() < 1e-5 * ref.norm().item() + 1e-8 * ref.numel() ** 0.5, n
 
 
+def test_flat_gradient_buffer_identical_with_and_without_side_streams(monkeypatch):
+    """the gradient bucket pack of dp.FlatGradAllReduce must be ordered behind BOTH streams -- DepthNet's
+    backward (and with it the autograd hooks of its parameters) runs on the side stream, the stereo net's GN affine gradients on
+    the caller's, and the two share buckets.  The packed flat buffer of a KITTI-size step is compared with the streams on and
+    off (twice each: the race would be timing dependent), small buckets so that many packs happen mid-backward."""
+    from stereoscene_amd import dp, model_zoo, streams
+    from stereoscene_amd.plugin import view_transformer as VTM
+    cfg = S.CFG_K112
+    model = model_zoo.build_detector(cfg).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    smp = S.synthetic_sample(cfg, B=1, tag="flatgrad")
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    gt = smp["gt_occ"].to(DEV)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    red = dp.FlatGradAllReduce(model, bucket_mb=4)
+    assert len(red.buckets) > 20
+    names = {p: n for n, p in model.named_parameters()}
+    loose_rng = [(red._offsets[p], red._offsets[p] + p.numel()) for p in red.params if "depth_net" in names[p]]
+
+    def step(on):
+        monkeypatch.setattr(VTM, "VT_STREAMS", on)
+        monkeypatch.setattr(streams, "WGRAD_STREAM", on)
+        model.load_state_dict(sd0)
+        red.zero_grad()
+        losses = model.forward_train(img_inputs=inputs, gt_occ=gt)
+        sum(v for k, v in losses.items() if k.startswith("loss")).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        return red.flat.detach().clone()
+
+    f_off, f_on, f_on2, f_off2 = step(False), step(True), step(True), step(False)
+    strict = torch.ones_like(f_off, dtype=torch.bool)
+    for a, b in loose_rng:                      # behind the DCN's float atomics: reproducible to rounding only (see the test above)
+        strict[a:b] = False
+    for other in (f_on, f_on2, f_off2):
+        assert torch.equal(other[strict], f_off[strict])
+        d = (other.double() - f_off.double())[~strict]
+        assert d.norm().item() < 1e-5 * f_off.double()[~strict].norm().item()
+    red.remove()
+
+
+def test_weight_used_twice_keeps_its_gradients_off_the_side_stream():
+    """the two gradients of a weight that feeds two convolution calls of one graph are summed by the
+    autograd engine on the caller's stream -- they must not be produced on the side stream.  streams.note_use counts the uses."""
+    from stereoscene_amd import streams
+    w = (S.hash_normal("shared/w", (32, 32, 3, 3, 3)) * 0.1).to(DEV).requires_grad_(True)
+    x = S.hash_normal("shared/x", (1, 32, 24, 16, 64)).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    for _ in range(3):
+        w.grad = None
+        y = F.conv3d(F.conv3d(x, w, None, 1, 1), w, None, 1, 1)          # the same weight twice
+        assert w._ssbev_uses[1] == 2 and w._ssbev_uses[2]
+        y.square().mean().backward()
+        assert w._ssbev_uses[1] == 0 and not w._ssbev_uses[2]
+        g = w.grad.clone()
+        w.grad = None
+        w2 = w.detach().clone().requires_grad_(True)
+        y2 = torch.nn.functional.conv3d(torch.nn.functional.conv3d(x, w2, None, 1, 1), w2, None, 1, 1)
+        y2.square().mean().backward()
+        assert (g - w2.grad).norm().item() < 2e-5 * w2.grad.norm().item()
+    # a single use still goes to the side stream
+    w.grad = None
+    y = F.conv3d(x, w, None, 1, 1)
+    assert w._ssbev_uses[1] == 1 and not w._ssbev_uses[2] and streams.WGRAD_STREAM
+
+
 @pytest.mark.parametrize("case", [((64, 32, 128), (8, 4, 32), (3, 4, 5), False, True), ((32, 32), (32, 32), (6, 10), True, True),
                                    ((16, 8, 8), (2, 2, 1), (4, 4, 4), False, False)])
 def test_norm_cat_equals_cat_of_norms_bit_for_bit(case):
