@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--skip-serial-replay", action="store_true",
                     help="do not append the serial replay (side streams off) that measures the dominant kernel without co-scheduled "
                          "kernels (profiling runs: keeps the per-kernel averages of the timed schedule clean)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_operands"],
                     help="fp32 = the BASELINE metric (default); bf16 = BASELINE configs[3] (never the headline)")
     ap.add_argument("--ablation", default="full", choices=["full", "bev_only", "stereo_only"],
                     help="BASELINE configs[4]: depth distribution from the MIE fusion | monocular DepthNet only | stereo volume only")

@@ -152,7 +152,15 @@ typedef struct {
   int precision;       /* 0 = fp32 MFMA (exact fp32 products, the parity contract);
                         * 1 = forward / data gradient round their operands to bf16 in registers (nearest even) and use
                         *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[3]); tensors in memory
-                        *     stay fp32, the weight gradient kernels stay on the fp32 MFMA                          */
+                        *     stay fp32, the weight gradient kernels stay on the fp32 MFMA;
+                        * 2 = bf16 STORAGE (round 4; the configs[3] path proper, csrc/conv_bf16.hip): the source tensor (x in
+                        *     ssbev_conv_fwd, gy in ssbev_conv_bwd_data; both in ssbev_conv_bwd_weight) AND the result (y / gx)
+                        *     are bf16 channels-last tensors (raw 16-bit patterns behind the float pointers), the packed
+                        *     weights hold bf16 operands, accumulation is fp32, gw is fp32.  Needs Cin % 8 == 0 (and
+                        *     Cout % 8 == 0 wherever the Cout-channel tensor is a source); bias stays fp32;
+                        * 3 = as 2 with an fp32 RESULT (the layer in front of an fp32 island, e.g. the logits conv)
+                        *     ssbev_conv_kernel_class answers 16 (generic gather), 17 (LDS-ring tap kernel), 18 (weight
+                        *     gradient) for these modes                                                              */
 } ssbev_conv_dims;
 
 /* weight packing: src is the torch layout  conv: [Cout,Cin,kd,kh,kw]  deconv: [Cin,Cout,kd,kh,kw]
@@ -206,7 +214,11 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
  * straight into their slice of the concatenated tensor and read their slice of its gradient, no torch.cat / slice copies.
  * Pass y / gy already offset to the first channel of the slice; multiples of 4, >= C.  A strided y/gy of a B > 1 per-sample
  * GroupNorm is addressed as [(b * S + s) * ld + c]. */
-typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; int pre_act; int64_t ld_y, ld_gy; } ssbev_norm_dims;
+/* io_dtype (round 4, BASELINE configs[3]): 0 = the activation tensors x / residual / y (and gy / gx / gresidual) are fp32, 1 = they
+ * hold bf16 bit patterns (pass the pointers cast to float*; ld_y / ld_gy then count bf16 elements).  Statistics, gamma / beta and their
+ * gradients, and all arithmetic stay fp32.  ABI note: ld_y / ld_gy (round 3) and io_dtype (round 4) were appended to the struct; a
+ * binding built against an older, shorter struct must be rebuilt -- the library reads all fields. */
+typedef struct { int B, C, G; int64_t S; float eps; int relu; int stats_given; int pre_act; int64_t ld_y, ld_gy; int io_dtype; } ssbev_norm_dims;
 size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d);
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                         float* y, float* mean, float* rstd, const ssbev_norm_dims* d, void* ws,
@@ -234,7 +246,7 @@ int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* re
  * when G == C).  The apply pass reads the two raw tensors once and writes the sum once; backward reads (gy, mask, xa, xb) twice
  * instead of eleven tensor passes for the two separate operators.  C % 4 == 0, C <= 1024; relu_mask as in ssbev_groupnorm_*_mask
  * (required when relu = 1).  Statistics are outputs of _fwd and inputs of _bwd. */
-typedef struct { int B, C, Ga, Gb; int64_t S; float eps_a, eps_b; int relu; int a_batch, b_batch; } ssbev_norm2_dims;
+typedef struct { int B, C, Ga, Gb; int64_t S; float eps_a, eps_b; int relu; int a_batch, b_batch; int io_dtype; /* as in ssbev_norm_dims */ } ssbev_norm2_dims;
 size_t ssbev_groupnorm2_workspace(const ssbev_norm2_dims* d);
 int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
                          const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
@@ -452,6 +464,14 @@ int ssbev_wino_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_win
 int ssbev_wino2d_input_transform_bf16(const float* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_transform_bf16(const uint16_t* M, float* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
 int ssbev_wino2d_output_adjoint_bf16(const float* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+/* `_bf16a` (round 4, bf16 STORAGE mode): the activation side (x, gy, y) is a bf16 channels-last tensor too -- every pass of the
+ * F(2,3) pipeline then moves 16-bit elements only. */
+int ssbev_wino_input_transform_bf16a(const uint16_t* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_transform_bf16a(const uint16_t* M, uint16_t* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino_output_adjoint_bf16a(const uint16_t* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_input_transform_bf16a(const uint16_t* x, uint16_t* V, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_transform_bf16a(const uint16_t* M, uint16_t* y, const ssbev_wino_dims* d, ssbev_stream_t stream);
+int ssbev_wino2d_output_adjoint_bf16a(const uint16_t* gy, uint16_t* Z, const ssbev_wino_dims* d, ssbev_stream_t stream);
 /* F(2x4x4, 3x3x3) / F(4x4, 3x3): 4-wide tiles along h and w (Lavin & Gray's F(4,3)), 2-deep along d.  144 (2-D: 36)
  * frequencies, xi = (a*6 + e)*6 + f; T = B * D/2 * H/4 * W/4 (2-D: B * D * H/4 * W/4); needs H % 4 == W % 4 == 0
  * (3-D: D % 2 == 0).  Transformed domain 4.5x (2.25x) the activation instead of 8x (4x), GEMM stage 6x (4x) fewer

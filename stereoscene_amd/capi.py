@@ -47,12 +47,13 @@ class GeomDims(C.Structure):
 
 class NormDims(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("G", C.c_int), ("S", C.c_int64), ("eps", C.c_float),
-                ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int), ("ld_y", C.c_int64), ("ld_gy", C.c_int64)]
+                ("relu", C.c_int), ("stats_given", C.c_int), ("pre_act", C.c_int), ("ld_y", C.c_int64), ("ld_gy", C.c_int64),
+                ("io_dtype", C.c_int)]
 
 
 class Norm2Dims(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("Ga", C.c_int), ("Gb", C.c_int), ("S", C.c_int64), ("eps_a", C.c_float),
-                ("eps_b", C.c_float), ("relu", C.c_int), ("a_batch", C.c_int), ("b_batch", C.c_int)]
+                ("eps_b", C.c_float), ("relu", C.c_int), ("a_batch", C.c_int), ("b_batch", C.c_int), ("io_dtype", C.c_int)]
 
 
 class DcnDims(C.Structure):
@@ -199,6 +200,12 @@ SIGNATURES = {
     "ssbev_wino2d_input_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_transform_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_wino2d_output_adjoint_bf16": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_input_transform_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_transform_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino_output_adjoint_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_input_transform_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_output_transform_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
+    "ssbev_wino2d_output_adjoint_bf16a": (C.c_int, [_P, _P, C.POINTER(WinoDims), _P]),
     "ssbev_softmax_axis_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_softmax_axis_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int64, _P]),
     "ssbev_softmax_rows_fwd": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),

@@ -1,0 +1,850 @@
+// bf16-STORAGE convolution family for gfx950 (BASELINE configs[3]: "bf16 mixed precision, MFMA 3D-conv path").
+//
+// Rounds 1-3 had a "bf16 mode" that kept every tensor fp32 in HBM and only rounded the MFMA operands in registers: the
+// direct kernels stayed operand-delivery-bound and nothing HBM-bound got cheaper.  Here the activations and their
+// gradients ARE bf16 in memory (channels-last [B, D, H, W, C], C a multiple of 8), which is what the 32x32x16 bf16 MFMA
+// wants to eat: ONE 16-byte load (global or LDS) = 8 consecutive channels = the k-slice a lane supplies to
+// v_mfma_f32_32x32x16_bf16 -- no v_cvt, half the bytes, 4x the multiply-adds per operand byte of the fp32 path.
+// Accumulation is fp32; weights stay fp32 masters and are packed to bf16 operand order per launch (a few microseconds);
+// weight gradients are produced in fp32.  The reference mechanism this realises is mmcv's Fp16OptimizerHook / auto_fp16
+// (reference: projects/mmdet3d_plugin/occupancy/apis/mmdet_train.py:131-134, tools/fp16/train.py:224-226), with bf16 in
+// place of fp16 (same 16-bit storage, fp32 exponent range: no loss scaling needed, kept available in train.LossScaler).
+//
+// Kernels:
+//   conv_gather16_kernel<MT,NT,YT>   forward / data gradient of ANY conv / transposed conv (stride, dilation, 1x1, k == s):
+//                                    implicit GEMM, A operand straight from L1/L2 as 16-byte voxel-line pieces (the
+//                                    design of conv_gather_kernel in conv_mfma.hip, parity-class walk for the transposed form).
+//   conv_tap16_kernel<YT>            the <= 32-channel stride-1 3x3x3 layers of the cost-volume stack: input rows in an LDS
+//                                    ring of bf16 voxel lines (global_load_lds), weights in registers, taps split over 4 waves.
+//   wgrad16_kernel<MQ,MP,TH,TW>      weight gradient of any of them.  The reduction axis is the VOXEL axis, i.e. the MFMA
+//                                    operands are the transposes of what lies in memory: every wave stages 16-voxel x
+//                                    32-channel tiles through its own slice of LDS (one 16-byte load + one ds_write_b128 per
+//                                    lane) and reads them back with ds_read_b64_tr_b16, gfx950's transposing LDS read,
+//                                    which hands each lane 4 consecutive VOXELS of its channel: two of them = one operand.
+#include "conv_bf16.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace ssbev_detail {
+void wgrad_reduce(float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st);   // conv_mfma.hip
+}
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ const uint4 kZero16 = {0u, 0u, 0u, 0u};
+
+int pad16(int c) { return (c + 15) & ~15; }
+int pad32(int c) { return (c + 31) & ~31; }
+
+struct Geom16 {
+  int B, Cin, Cout, KP, CoutPad;       // K = Cin of THIS gather (multiple of 8), KP = ceil(Cin / 16) operand groups, N = Cout
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int form;                            // 0 conv gather, 1 transposed gather (parity classes)
+  int relu, accumulate;
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// dst (bf16) [tap][p][lk][n][t] = W[k = 16 p + 8 lk + t][n][tap]: lane (n, lk) of the B operand reads 16 bytes.
+//   layout 0: src [A0, A1, taps] with K = A1, N = A0;   layout 1: K = A0, N = A1   (as pack_weight_kernel, conv_mfma.hip)
+__global__ void pack16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int N, int KP, int NPad,
+                              int taps, int layout, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long r = i;
+  const int t = (int)(r & 7); r >>= 3;
+  const int n = (int)(r % NPad); r /= NPad;
+  const int lk = (int)(r & 1); r >>= 1;
+  const int p = (int)(r % KP);
+  const int tap = (int)(r / KP);
+  const int k = 16 * p + 8 * lk + t;
+  float v = 0.0f;
+  if (k < K && n < N) {
+    const size_t a0 = layout == 0 ? n : k, a1 = layout == 0 ? k : n;
+    const size_t A1 = layout == 0 ? K : N;
+    v = src[(a0 * A1 + a1) * taps + tap];
+  }
+  dst[i] = f2bf(v);
+}
+
+// ------------------------------------------------------------------------------------------------ generic gather
+// One wave: (MT * 32 voxels) x (NT * 32 channels); see conv_gather_kernel (conv_mfma.hip) for the tap walk, the parity
+// classes of the transposed form and the XCD-aware tile order -- this is that kernel for bf16 tensors.
+template <int MT, int NT, typename YT>
+__global__ void __launch_bounds__(256)
+conv_gather16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+                     YT* __restrict__ y, Geom16 g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  int par_d = 0, par_h = 0, par_w = 0;
+  int Dc = g.Do, Hc = g.Ho, Wc = g.Wo;
+  if (g.form == 1) {
+    int cls = (int)gridDim.z - 1 - (int)blockIdx.z;       // heaviest parity class first
+    par_w = cls % g.sw; cls /= g.sw;
+    par_h = cls % g.sh; cls /= g.sh;
+    par_d = cls;
+    Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
+  }
+  const long Mtot = (long)g.B * Dc * Hc * Wc;
+  int bx, by;
+  {
+    const unsigned n = gridDim.x * gridDim.y;
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    bx = (int)(Lp / gridDim.y);
+    by = (int)(Lp % gridDim.y);
+  }
+  const long m_wave = ((long)bx * 4 + wave) * (MT * 32);
+  const int n0 = by * (NT * 32);
+  if (m_wave >= Mtot) return;
+
+  int ob[MT], od[MT], oh[MT], ow[MT];
+  bool mok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long m = m_wave + mt * 32 + li;
+    mok[mt] = m < Mtot;
+    if (!mok[mt]) m = 0;
+    ow[mt] = (int)(m % Wc); m /= Wc;
+    oh[mt] = (int)(m % Hc); m /= Hc;
+    od[mt] = (int)(m % Dc);
+    ob[mt] = (int)(m / Dc);
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  const int P = g.KP;
+  const size_t w_tap_stride = (size_t)P * 2 * g.CoutPad * 8;
+  const bf16_t* wlane = wp + ((size_t)lk * g.CoutPad + n0 + li) * 8;
+
+  int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
+  if (g.form == 1) {
+    kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
+    kds = g.sd; khs = g.sh; kws = g.sw;
+  }
+  const int nkd = (g.kd - kd0 + kds - 1) / kds, nkh = (g.kh - kh0 + khs - 1) / khs, nkw = (g.kw - kw0 + kws - 1) / kws;
+  const int ntaps = (kd0 < g.kd && kh0 < g.kh && kw0 < g.kw) ? nkd * nkh * nkw : 0;
+  int step_d, step_h, step_w;
+  if (g.form == 0) { step_d = g.dd; step_h = g.dh; step_w = g.dw; }
+  else { step_d = -(kds * g.dd) / g.sd; step_h = -(khs * g.dh) / g.sh; step_w = -(kws * g.dw) / g.sw; }
+  const bf16_t* pbase[MT];
+  unsigned vmask[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int bd, bh, bw;
+    if (g.form == 0) {
+      bd = od[mt] * g.sd - g.pd; bh = oh[mt] * g.sh - g.ph; bw = ow[mt] * g.sw - g.pw;
+    } else {
+      bd = od[mt] + (par_d + g.pd - kd0 * g.dd) / g.sd;
+      bh = oh[mt] + (par_h + g.ph - kh0 * g.dh) / g.sh;
+      bw = ow[mt] + (par_w + g.pw - kw0 * g.dw) / g.sw;
+    }
+    unsigned m = 0;
+    for (int i = 0; i < nkd && i < 8; ++i) { const int v = bd + i * step_d; m |= (v >= 0 && v < g.Di) ? (1u << i) : 0u; }
+    for (int i = 0; i < nkh && i < 8; ++i) { const int v = bh + i * step_h; m |= (v >= 0 && v < g.Hi) ? (1u << (8 + i)) : 0u; }
+    for (int i = 0; i < nkw && i < 8; ++i) { const int v = bw + i * step_w; m |= (v >= 0 && v < g.Wi) ? (1u << (16 + i)) : 0u; }
+    vmask[mt] = mok[mt] ? m : 0u;
+    pbase[mt] = x + ((((long)ob[mt] * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin + 8 * lk;
+  }
+
+  for (int ti = 0; ti < ntaps; ++ti) {
+    const int ic = ti % nkw, ib = (ti / nkw) % nkh, ia = ti / (nkw * nkh);
+    const int c = kw0 + ic * kws, bq = kh0 + ib * khs, a = kd0 + ia * kds;
+    const int tap = (a * g.kh + bq) * g.kw + c;
+    const long toff = (((long)ia * step_d * g.Hi + (long)ib * step_h) * g.Wi + (long)ic * step_w) * g.Cin;   // wave-uniform
+    const unsigned need = (1u << ia) | (1u << (8 + ib)) | (1u << (16 + ic));
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = ((vmask[mt] & need) == need) ? pbase[mt] + toff : nullptr;
+    const bf16_t* wt = wlane + (size_t)tap * w_tap_stride;
+    for (int p0 = 0; p0 < P; p0 += 2) {
+      uint4 av[2][MT], bv[2][NT];
+      const bool two = p0 + 1 < P;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = p0 + u;
+        const bool pok = u == 0 || two;
+        const bool cok = pok && (16 * p + 8 * lk) < g.Cin;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          av[u][mt] = (ap[mt] && cok) ? *reinterpret_cast<const uint4*>(ap[mt] + 16 * p) : kZero16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bv[u][nt] = (pok && n0 + nt * 32 < g.CoutPad)
+                          ? *reinterpret_cast<const uint4*>(wt + ((size_t)p * 2 * g.CoutPad + nt * 32) * 8) : kZero16;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(av[0][mt], bv[0][nt], acc[mt][nt]);
+      if (two) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(av[1][mt], bv[1][nt], acc[mt][nt]);
+      }
+    }
+  }
+
+  // epilogue: accumulator row r of sub-tile mt = voxel of lane (r & 3) + 8 (r >> 2) + 4 lk, column = channel n0 + 32 nt + li
+  auto row_vox = [&](int mt, int r, bool& rok) -> size_t {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int rb = __shfl(ob[mt], row, 64), rd = __shfl(od[mt], row, 64);
+    const int rh = __shfl(oh[mt], row, 64), rw = __shfl(ow[mt], row, 64);
+    rok = __shfl((int)mok[mt], row, 64) != 0;
+    if (g.form == 0) return (((size_t)rb * g.Do + rd) * g.Ho + rh) * g.Wo + rw;
+    return (((size_t)rb * g.Do + (rd * g.sd + par_d)) * g.Ho + (rh * g.sh + par_h)) * g.Wo + (rw * g.sw + par_w);
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (g.accumulate) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float oldv[8][NT];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          bool rok;
+          const size_t vox = row_vox(mt, r0 + r, rok);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = n0 + nt * 32 + li;
+            oldv[r][nt] = (rok && co < g.Cout) ? ld1(y + vox * g.Cout + co) : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r0 + r] += oldv[r][nt];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bool rok;
+      const size_t vox = row_vox(mt, r, rok);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + nt * 32 + li;
+        if (rok && co < g.Cout) {
+          float v = acc[mt][nt][r];
+          if (bias) v += bias[co];
+          if (g.relu) v = fmaxf(v, 0.0f);
+          st1(y + vox * g.Cout + co, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-ring tap kernel
+// 3x3x3 / stride 1 / pad 1, K <= 32 input and N <= 32 output channels (multiples of 8): conv_tap_kernel (conv_mfma.hip) with
+// bf16 voxel lines.  Ring [3 planes][4 row slots][34 voxels][32 channels] of bf16: a voxel line is 64 bytes = four 16-byte
+// items; MFMA roles rows = output channel (A = this wave's taps, in registers), columns = voxel (B = one ds_read_b128 per
+// 8 channels), k = input channel.  Four voxel lines share a 256-byte bank row, so the physical item of (voxel u, channel
+// octet q) is q ^ ((u >> 2) & 3): the 16 lanes of a ds_read_b128 lane group then hit 16 different 16-byte slots for every
+// kw shift (applied on the GLOBAL side of the LDS load, whose LDS side must stay lane-contiguous).
+struct Tap16Geom {
+  int B, D, H, W, K, N;
+  int nseg, NG, gpc;
+  int relu, has_bias, accumulate;
+};
+
+constexpr int kT16Wseg = 32, kT16Cols = kT16Wseg + 2;
+constexpr int kT16RowB = kT16Cols * 64;                  // bytes per ring row
+constexpr int kT16Slots = 4, kT16PlaneB = kT16Slots * kT16RowB, kT16RingB = 3 * kT16PlaneB;
+constexpr size_t kT16LdsBytes = (size_t)kT16RingB + 4 * 16 * 64 * sizeof(float);
+constexpr int kT16PackedU4 = 4 * 7 * 2 * 64;             // uint4 items
+
+// wp (uint4 items) [((wave * 7 + tt) * 2 + j) * 64 + lane] = 8 bf16: Weff[n = lane & 31][k = 16 j + 8 (lane >> 5) + t][tap = wave + 4 tt]
+//   mode 0: Weff[n][k][tap] = w[n][k][tap];  mode 1 (data gradient): Weff[n][k][tap] = w[k][n][26 - tap]
+__global__ void __launch_bounds__(256)
+pack_tap16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kT16PackedU4 * 8) return;
+  const int t = i & 7, lane = (i >> 3) & 63, j = (i >> 9) & 1, wt = i >> 10;
+  const int tt = wt % 7, wave = wt / 7;
+  const int tap = wave + 4 * tt, n = lane & 31, k = 16 * j + 8 * (lane >> 5) + t;
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (tap < 27 && n < N && k < K)
+    v = mode == 0 ? w[((size_t)n * Cin + k) * 27 + tap] : w[((size_t)k * Cin + n) * 27 + (26 - tap)];
+  wp[i] = f2bf(v);
+}
+
+template <typename YT>
+__global__ void __launch_bounds__(256)
+conv_tap16_kernel(const bf16_t* __restrict__ X, const uint4* __restrict__ wp, const float* __restrict__ bias,
+                  YT* __restrict__ Y, Tap16Geom g) {
+  extern __shared__ __align__(16) unsigned char tl[];
+  unsigned char* ring = tl;
+  float* red = reinterpret_cast<float*>(tl + kT16RingB);      // [4 waves][16 rows][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+
+  uint4 wb[7][2];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wb[tt][j] = wp[((wave * 7 + tt) * 2 + j) * 64 + lane];
+  const int ntap = wave < 3 ? 7 : 6;
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int w0 = seg * kT16Wseg;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+
+  // staging entries: one entry = 64 consecutive 16-byte items of one (plane, row); item j = (voxel u = j >> 2, physical
+  // octet j & 3), source octet (j & 3) ^ ((u >> 2) & 3)
+  constexpr int items = kT16Cols * 4, nxc = (items + 63) / 64;           // 136 items, 3 entries per row
+  int xoff[3], xmeta[3];
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int q = wave + n * 4;
+    int off = -2, meta = -1;
+    if (q < 3 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < items) {
+        const int u = j >> 2, c = (((j & 3) ^ ((u >> 2) & 3)) << 3), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kT16PlaneB + ch * 1024) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  auto stage_row = [&](int b, int d, int hp) {
+    const bf16_t* base = X + ((long)(b * g.D + d - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = d - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      unsigned char* dst = ring + (meta >> 4) + (hp & 3) * kT16RowB;
+      const int off = xoff[n];
+      const void* src = (rowok && off >= 0) ? static_cast<const void*>(base + off) : static_cast<const void*>(&kZero16);
+      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+
+  int tp_plane[7], tp_kh[7], tp_kw[7];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    const int t = min(wave + 4 * tt, 26);
+    tp_plane[tt] = (t / 9) * kT16PlaneB; tp_kh[tt] = (t / 3) % 3; tp_kw[tt] = t % 3;
+  }
+  const int nb = 8 * wave + 4 * lk;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
+  }
+
+  bool fresh = true;
+  int h = g_begin % g.H, d, b;
+  {
+    const int bd = g_begin / g.H;
+    b = bd / g.D; d = bd % g.D;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    if (fresh) {
+      stage_row(b, d, h); stage_row(b, d, h + 1); stage_row(b, d, h + 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const bool same_plane = G + 1 < g_end && h + 1 < g.H;
+    if (same_plane) stage_row(b, d, h + 3);
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[q][r] = 0.0f;
+    uint4 xa[2], xb2[2];
+    auto fetch = [&](int tt, uint4 (&xv)[2]) {
+      const int u = li + tp_kw[tt];
+      const unsigned char* rowp = ring + tp_plane[tt] + ((h + tp_kh[tt]) & 3) * kT16RowB + u * 64;
+      const int key = (u >> 2) & 3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xv[j] = *reinterpret_cast<const uint4*>(rowp + (((2 * j + lk) ^ key) << 4));
+    };
+    fetch(0, xa);
+#pragma unroll
+    for (int tt = 0; tt < 7; tt += 2) {
+      if (tt < ntap) {
+        acc2[0] = mfma16(wb[tt][0], xa[0], acc2[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 1 < 7 && tt + 1 < ntap) fetch(tt + 1, xb2);
+        __builtin_amdgcn_sched_barrier(0);
+        acc2[1] = mfma16(wb[tt][1], xa[1], acc2[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tt + 1 < 7 && tt + 1 < ntap) {
+        acc2[0] = mfma16(wb[tt + 1][0], xb2[0], acc2[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 2 < 7 && tt + 2 < ntap) fetch(tt + 2, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        acc2[1] = mfma16(wb[tt + 1][1], xb2[1], acc2[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        o[i] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+               red[(3 * 16 + r) * 64 + lane] + bv[i];
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      const int wv = w0 + li;
+      if (wv < g.W && nb < g.N) {
+        YT* dst = Y + (((long)(b * g.D + d) * g.H + h) * g.W + wv) * g.N + nb;
+        if (g.accumulate) { const float4 t = ld4(dst); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+        st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+      }
+    }
+    __syncthreads();
+    fresh = !same_plane;
+    if (++h == g.H) {
+      h = 0;
+      if (++d == g.D) { d = 0; ++b; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// gw[tap][cq][cp] = sum_m Q[pos(m, tap)][cq] * P[m][cp]   (m over the small grid; conv: P = gy, Q = x; transposed: P = x, Q = gy)
+// One wave: (32 MQ q-channels) x (32 MP p-channels) x (TH x TW taps of one kd slice) over its own chunk of voxels, 16 voxels
+// (one MFMA k-step) per trip.  Lane l loads 16 bytes = 8 channels of voxel l >> 2 for every operand tile (a whole 1 KB tile
+// per wave instruction), parks it in the wave's LDS slice as [16 voxels][32 channels], and the transposing read returns
+// [channel = l & 31][voxels 8 (l >> 5) .. + 7] -- the MFMA operand.  LDS is in-order per wave: no barrier anywhere.
+struct Wg16Geom {
+  int B, Cp, Cq;
+  int Ds, Hs, Ws;
+  int Dq, Hq, Wq;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int chunk, nchunks;
+};
+
+__device__ __forceinline__ uint4 tr_operand(const unsigned char* tile, int trbase) {
+  typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + trbase));
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + trbase + 4 * 64));
+  uint4 r;
+  r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return r;
+}
+
+template <int MQ, int MP, int TH, int TW>
+__global__ void __launch_bounds__(256)
+wgrad16_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, float* __restrict__ ws, Wg16Geom g) {
+  constexpr int NQ = MQ * TH * TW, NTILE = MP + NQ;
+  extern __shared__ __align__(16) unsigned char wl[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int chunk_id = blockIdx.x * 4 + wave;
+  if (chunk_id >= g.nchunks) return;
+  unsigned char* my = wl + (size_t)wave * NTILE * 1024;
+  const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
+  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
+  const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
+  int tg = blockIdx.z;
+  const int kwg = tg % kw_groups; tg /= kw_groups;
+  const int khg = tg % kh_groups;
+  const int kdi = tg / kh_groups;
+
+  f32x16 acc[MQ][MP][TH][TW];
+#pragma unroll
+  for (int a = 0; a < MQ; ++a)
+#pragma unroll
+    for (int e = 0; e < MP; ++e)
+#pragma unroll
+      for (int c = 0; c < TH; ++c)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][e][c][t][r] = 0.0f;
+
+  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
+  const long m_begin = (long)chunk_id * g.chunk;
+  const long m_end = min(Mtot, m_begin + g.chunk);
+  const int j = lane >> 2, c8 = (lane & 3) * 8;           // staging role: voxel j of the trip, channel octet c8
+  // transposing-read address of this lane inside a tile (+ 4 rows for the second half)
+  const int trbase = (8 * lk + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  int w, h, d, b;
+  {
+    long r = min(m_begin + j, Mtot - 1);
+    w = (int)(r % g.Ws); r /= g.Ws;
+    h = (int)(r % g.Hs); r /= g.Hs;
+    d = (int)(r % g.Ds);
+    b = (int)(r / g.Ds);
+  }
+  int pch[MP], qch[MQ];
+#pragma unroll
+  for (int e = 0; e < MP; ++e) pch[e] = (pt * MP + e) * 32 + c8;
+#pragma unroll
+  for (int a = 0; a < MQ; ++a) qch[a] = (qt * MQ + a) * 32 + c8;
+
+  for (long m0 = m_begin; m0 < m_end; m0 += 16) {
+    const long m = m0 + j;
+    const bool mok = m < m_end;
+    uint4 pv[MP], qv[TH][TW][MQ];
+#pragma unroll
+    for (int e = 0; e < MP; ++e)
+      pv[e] = (mok && pch[e] < g.Cp) ? *reinterpret_cast<const uint4*>(P + (size_t)m * g.Cp + pch[e]) : kZero16;
+    const int id = d * g.sd - g.pd + kdi * g.dd;
+    const bool dok = mok && id >= 0 && id < g.Dq;
+    const int iw0 = w * g.sw - g.pw + (kwg * TW) * g.dw;
+#pragma unroll
+    for (int c = 0; c < TH; ++c) {
+      const int khi = khg * TH + c;
+      const int ih = h * g.sh - g.ph + khi * g.dh;
+      const bool rok = dok && khi < g.kh && ih >= 0 && ih < g.Hq;
+      const size_t rowbase = (((size_t)b * g.Dq + id) * g.Hq + ih) * g.Wq;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const int iw = iw0 + t * g.dw;
+        const bool ok = rok && (kwg * TW + t) < g.kw && iw >= 0 && iw < g.Wq;
+#pragma unroll
+        for (int a = 0; a < MQ; ++a)
+          qv[c][t][a] = (ok && qch[a] < g.Cq) ? *reinterpret_cast<const uint4*>(Q + (rowbase + iw) * g.Cq + qch[a]) : kZero16;
+      }
+    }
+    // advance this lane's voxel by 16
+    w += 16;
+    while (w >= g.Ws) {
+      w -= g.Ws;
+      if (++h >= g.Hs) { h = 0; if (++d >= g.Ds) { d = 0; ++b; } }
+    }
+    // park the tiles (lane-contiguous 1 KB each), read them back transposed
+#pragma unroll
+    for (int e = 0; e < MP; ++e) *reinterpret_cast<uint4*>(my + e * 1024 + lane * 16) = pv[e];
+#pragma unroll
+    for (int c = 0; c < TH; ++c)
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int a = 0; a < MQ; ++a)
+          *reinterpret_cast<uint4*>(my + (MP + (c * TW + t) * MQ + a) * 1024 + lane * 16) = qv[c][t][a];
+    uint4 pb[MP];
+#pragma unroll
+    for (int e = 0; e < MP; ++e) pb[e] = tr_operand(my + e * 1024, trbase);
+#pragma unroll
+    for (int c = 0; c < TH; ++c)
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int a = 0; a < MQ; ++a) {
+          const uint4 qa = tr_operand(my + (MP + (c * TW + t) * MQ + a) * 1024, trbase);
+#pragma unroll
+          for (int e = 0; e < MP; ++e) acc[a][e][c][t] = mfma16(qa, pb[e], acc[a][e][c][t]);
+        }
+  }
+
+  const int taps = g.kd * g.kh * g.kw;
+#pragma unroll
+  for (int c = 0; c < TH; ++c)
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const int khi = khg * TH + c, kwi = kwg * TW + t;
+      if (khi >= g.kh || kwi >= g.kw) continue;
+      const int tap = (kdi * g.kh + khi) * g.kw + kwi;
+      float* dst = ws + (((size_t)chunk_id * taps + tap) * g.Cq) * g.Cp;
+#pragma unroll
+      for (int a = 0; a < MQ; ++a)
+#pragma unroll
+        for (int e = 0; e < MP; ++e) {
+          const int pc = (pt * MP + e) * 32 + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (qt * MQ + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = acc[a][e][c][t][r];
+          }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool basic_ok(const ssbev_conv_dims* d) {
+  if (!d || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
+  if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || d->kd > 8 || d->kh > 8 || d->kw > 8) return false;
+  return true;
+}
+
+bool tap16_applicable(const ssbev_conv_dims* d, int mode) {
+  static const bool enabled = !(getenv("SSBEV_TAP16") && atoi(getenv("SSBEV_TAP16")) == 0);       // A/B hook
+  if (!enabled && d->tile_hint != 9) return false;
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->tile_hint == 8) return false;
+  if (d->Cin > 32 || d->Cout > 32 || d->Cin % 8 || d->Cout % 8) return false;
+  const int K = mode == 0 ? d->Cin : d->Cout;
+  if (K < 16 && d->tile_hint != 9) return false;
+  if ((long)d->Ho * d->Wo * K >= (1L << 30)) return false;
+  return d->tile_hint == 9 || (long)d->B * d->Do * d->Ho * ((d->Wo + kT16Wseg - 1) / kT16Wseg) >= 1024L * 16;
+}
+
+Geom16 make_geom(const ssbev_conv_dims* d, int mode) {
+  Geom16 g;
+  g.B = d->B;
+  if (mode == 0) {
+    g.Cin = d->Cin; g.Cout = d->Cout;
+    g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo;
+    g.form = d->transposed ? 1 : 0; g.relu = d->relu;
+  } else {     // data gradient: roles swapped, the gradient of a conv gathers like a transposed conv and vice versa
+    g.Cin = d->Cout; g.Cout = d->Cin;
+    g.Di = d->Do; g.Hi = d->Ho; g.Wi = d->Wo; g.Do = d->Di; g.Ho = d->Hi; g.Wo = d->Wi;
+    g.form = d->transposed ? 0 : 1; g.relu = 0;
+  }
+  g.KP = pad16(g.Cin) / 16; g.CoutPad = pad32(g.Cout);
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  g.accumulate = d->accumulate;
+  return g;
+}
+
+long gather_blocks(const Geom16& g, int MT, int NT) {
+  long M = (long)g.B * g.Do * g.Ho * g.Wo;
+  long classes = 1;
+  if (g.form == 1) {
+    classes = (long)g.sd * g.sh * g.sw;
+    M = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  return ((M + 4 * MT * 32 - 1) / (4 * MT * 32)) * ((g.Cout + NT * 32 - 1) / (NT * 32)) * classes;
+}
+
+template <int MT, int NT, typename YT>
+int launch_gather16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st) {
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  int classes = 1;
+  if (g.form == 1) {
+    classes = g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  dim3 grid(cdiv(Mtot, 4 * MT * 32), cdiv(g.Cout, NT * 32), classes), block(256);
+  hipLaunchKernelGGL((conv_gather16_kernel<MT, NT, YT>), grid, block, 0, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
+template <typename YT>
+int dispatch_gather16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, int hint, hipStream_t st) {
+  int mt, nt;
+  if (hint >= 10) { mt = hint / 10; nt = hint % 10; }
+  else {
+    // the fp32 kernel's measured choices (dispatch_gather, conv_mfma.hip): wide column tiles when Cout allows and the grid
+    // still fills the chip, two row tiles unless that leaves too few workgroups
+    nt = (g.Cout % 192 == 0 && gather_blocks(g, 2, 6) >= 256) ? 6 : (g.Cout % 128 == 0) ? 4 : (g.Cout > 32 ? 2 : 1);
+    if (nt == 4 && gather_blocks(g, 2, 4) < 256) nt = 2;
+    mt = gather_blocks(g, 2, nt) >= 160 ? 2 : 1;
+    if (g.form == 1 && g.sd * g.sh * g.sw > 1) { mt = 1; nt = nt > 2 ? 2 : nt; }     // parity classes: short loops, small tiles
+  }
+  switch (mt * 10 + nt) {
+    case 11: return launch_gather16<1, 1, YT>(x, wp, bias, y, g, st);
+    case 12: return launch_gather16<1, 2, YT>(x, wp, bias, y, g, st);
+    case 14: return launch_gather16<1, 4, YT>(x, wp, bias, y, g, st);
+    case 21: return launch_gather16<2, 1, YT>(x, wp, bias, y, g, st);
+    case 22: return launch_gather16<2, 2, YT>(x, wp, bias, y, g, st);
+    case 24: return launch_gather16<2, 4, YT>(x, wp, bias, y, g, st);
+    case 26: return launch_gather16<2, 6, YT>(x, wp, bias, y, g, st);
+    default: return SSBEV_EINVAL;
+  }
+}
+
+template <typename YT>
+int launch_tap16(const bf16_t* x, const float* wp, const float* bias, YT* y, const ssbev_conv_dims* d, int mode, hipStream_t st) {
+  Tap16Geom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + kT16Wseg - 1) / kT16Wseg;
+  g.NG = g.B * g.D * g.H;
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
+  // three workgroups per CU (42.5 KB of LDS each): whole rounds of 768 workgroups, >= 24 rows each
+  long nranges = 768 / g.nseg;
+  for (long rounds = 8; rounds >= 1; --rounds) {
+    const long nr = (768 * rounds) / g.nseg;
+    if (nr >= 1 && (g.NG + nr - 1) / nr >= 24) { nranges = nr; break; }
+  }
+  if (const char* e = getenv("SSBEV_TAP16_RANGES")) { const long v = atol(e); if (v > 0) nranges = v; }   // tuning hook
+  if (nranges < 1) nranges = 1;
+  g.gpc = (int)((g.NG + nranges - 1) / nranges);
+  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  auto kern = conv_tap16_kernel<YT>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nranges * g.nseg)), dim3(256), kT16LdsBytes, st, x, reinterpret_cast<const uint4*>(wp),
+                     bias, y, g);
+  return ssbev_launch_status();
+}
+
+struct WgCfg16 { int MQ, MP, TH, TW; };
+
+WgCfg16 wg_cfg(int Cp, int Cq, int kh, int kw) {
+  if (kh * kw == 1) return (Cp <= 32 && Cq <= 32) ? WgCfg16{1, 1, 1, 1} : WgCfg16{2, 2, 1, 1};
+  if (Cp <= 32 && Cq <= 32) return {1, 1, 3, 3};
+  return {2, 2, 1, 3};
+}
+
+Wg16Geom make_wg_geom(const ssbev_conv_dims* d) {
+  Wg16Geom g;
+  g.B = d->B;
+  if (!d->transposed) {
+    g.Cp = d->Cout; g.Cq = d->Cin;
+    g.Ds = d->Do; g.Hs = d->Ho; g.Ws = d->Wo; g.Dq = d->Di; g.Hq = d->Hi; g.Wq = d->Wi;
+  } else {
+    g.Cp = d->Cin; g.Cq = d->Cout;
+    g.Ds = d->Di; g.Hs = d->Hi; g.Ws = d->Wi; g.Dq = d->Do; g.Hq = d->Ho; g.Wq = d->Wo;
+  }
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+  const long Mtot = (long)g.B * g.Ds * g.Hs * g.Ws;
+  const WgCfg16 c = wg_cfg(g.Cp, g.Cq, g.kh, g.kw);
+  const long tiles = (long)cdiv(g.Cp, 32 * c.MP) * cdiv(g.Cq, 32 * c.MQ) * g.kd * cdiv(g.kh, c.TH) * cdiv(g.kw, c.TW);
+  // ~4096 wave-tasks in total (2 waves per SIMD x 2 rounds), chunks of at least 256 voxels, partial slabs bounded to 256 MB
+  long want = std::max(1L, 4096 / std::max(1L, tiles));
+  if (const char* e = getenv("SSBEV_WG16_WAVES")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / std::max(1L, tiles)); }
+  const long slab = (long)g.kd * g.kh * g.kw * g.Cp * g.Cq * 4;
+  want = std::min(want, std::max(1L, (256L << 20) / slab));
+  long chunk = (Mtot + want - 1) / want;
+  if (chunk < 256) chunk = 256;
+  chunk = (chunk + 15) & ~15L;
+  g.chunk = (int)chunk;
+  g.nchunks = (int)((Mtot + chunk - 1) / chunk);
+  return g;
+}
+
+template <int MQ, int MP, int TH, int TW>
+int launch_wg16(const bf16_t* P, const bf16_t* Q, float* ws, const Wg16Geom& g, hipStream_t st) {
+  const int ytiles = cdiv(g.Cq, 32 * MQ) * cdiv(g.Cp, 32 * MP);
+  dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * cdiv(g.kh, TH) * cdiv(g.kw, TW));
+  const size_t lds = (size_t)4 * (MP + MQ * TH * TW) * 1024;
+  hipLaunchKernelGGL((wgrad16_kernel<MQ, MP, TH, TW>), grid, dim3(256), lds, st, P, Q, ws, g);
+  return ssbev_launch_status();
+}
+
+}  // namespace
+
+namespace ssbev_bf16 {
+
+bool storage_mode(const ssbev_conv_dims* d) { return d && (d->precision == 2 || d->precision == 3); }
+
+bool dims_ok(const ssbev_conv_dims* d, int mode) {
+  if (!basic_ok(d) || !storage_mode(d)) return false;
+  if (d->Cin % 8 != 0) return false;                        // 16-byte voxel-line pieces of the bf16 source tensor
+  if (mode != 0 && d->Cout % 8 != 0) return false;          // ... and the gradient tensor is a source in modes 1 / 2
+  if (mode == 2 && d->precision != 2) return false;
+  if ((long)d->B * d->Do * d->Ho * d->Wo >= (1L << 31) || (long)d->B * d->Di * d->Hi * d->Wi >= (1L << 31)) return false;
+  return true;
+}
+
+int kernel_class(const ssbev_conv_dims* d, int mode) {
+  if (mode == 2) return 18;
+  return tap16_applicable(d, mode) ? 17 : 16;
+}
+
+size_t packed_elems(const ssbev_conv_dims* d) {
+  if (!basic_ok(d)) return 0;
+  const size_t taps = (size_t)d->kd * d->kh * d->kw;
+  const size_t a = (size_t)pad16(d->Cin) * pad32(d->Cout), b = (size_t)pad16(d->Cout) * pad32(d->Cin);
+  const size_t generic_bf16 = taps * (a > b ? a : b);
+  const size_t bf = std::max(generic_bf16, (size_t)kT16PackedU4 * 8);
+  return (bf + 1) / 2 + 8;                                  // bf16 elements -> floats
+}
+
+int pack(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode, hipStream_t st) {
+  if (!dims_ok(d, mode) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(w_packed);
+  if (tap16_applicable(d, mode)) {
+    hipLaunchKernelGGL(pack_tap16_kernel, dim3(cdiv(kT16PackedU4 * 8, 256)), dim3(256), 0, st, w_src, dst, d->Cout, d->Cin, mode);
+    return ssbev_launch_status();
+  }
+  const int taps = d->kd * d->kh * d->kw;
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  const int layout = (mode == 0) == (d->transposed == 0) ? 0 : 1;
+  const int KP = pad16(K) / 16, NPad = pad32(N);
+  const long total = (long)taps * KP * 2 * NPad * 8;
+  hipLaunchKernelGGL(pack16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_src, dst, K, N, KP, NPad, taps, layout, total);
+  return ssbev_launch_status();
+}
+
+static int run(const void* src, const float* wp, const float* bias, void* dst, const ssbev_conv_dims* d, int mode, hipStream_t st) {
+  const bf16_t* x = static_cast<const bf16_t*>(src);
+  const bool y16 = d->precision == 2;
+  if (tap16_applicable(d, mode))
+    return y16 ? launch_tap16(x, wp, bias, static_cast<bf16_t*>(dst), d, mode, st)
+               : launch_tap16(x, wp, bias, static_cast<float*>(dst), d, mode, st);
+  const Geom16 g = make_geom(d, mode);
+  const bf16_t* w16 = reinterpret_cast<const bf16_t*>(wp);
+  const int hint = d->tile_hint >= 10 ? d->tile_hint : 0;
+  return y16 ? dispatch_gather16(x, w16, bias, static_cast<bf16_t*>(dst), g, hint, st)
+             : dispatch_gather16(x, w16, bias, static_cast<float*>(dst), g, hint, st);
+}
+
+int forward(const void* x, const float* wp, const float* bias, void* y, const ssbev_conv_dims* d, hipStream_t st) {
+  if (!dims_ok(d, 0) || !x || !wp || !y) return SSBEV_EINVAL;
+  return run(x, wp, bias, y, d, 0, st);
+}
+
+int backward_data(const void* gy, const float* wp, void* gx, const ssbev_conv_dims* d, hipStream_t st) {
+  if (!dims_ok(d, 1) || !gy || !wp || !gx) return SSBEV_EINVAL;
+  return run(gy, wp, nullptr, gx, d, 1, st);
+}
+
+size_t wgrad_workspace(const ssbev_conv_dims* d) {
+  if (!dims_ok(d, 2)) return 0;
+  const Wg16Geom g = make_wg_geom(d);
+  return (size_t)g.nchunks * d->kd * d->kh * d->kw * g.Cp * g.Cq * sizeof(float);
+}
+
+int backward_weight(const void* x, const void* gy, float* gw, const ssbev_conv_dims* d, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!dims_ok(d, 2) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
+  if (ws_bytes < wgrad_workspace(d)) return SSBEV_EWORKSPACE;
+  const Wg16Geom g = make_wg_geom(d);
+  const bf16_t* P = static_cast<const bf16_t*>(d->transposed ? x : gy);
+  const bf16_t* Q = static_cast<const bf16_t*>(d->transposed ? gy : x);
+  float* partial = static_cast<float*>(ws);
+  const WgCfg16 c = wg_cfg(g.Cp, g.Cq, g.kh, g.kw);
+  int rc;
+  if (c.TH == 3) rc = launch_wg16<1, 1, 3, 3>(P, Q, partial, g, st);
+  else if (c.TW == 3) rc = launch_wg16<2, 2, 1, 3>(P, Q, partial, g, st);
+  else if (c.MQ == 2) rc = launch_wg16<2, 2, 1, 1>(P, Q, partial, g, st);
+  else rc = launch_wg16<1, 1, 1, 1>(P, Q, partial, g, st);
+  if (rc != SSBEV_OK) return rc;
+  ssbev_detail::wgrad_reduce(partial, gw, g.nchunks, g.kd * g.kh * g.kw, g.Cq, g.Cp, st);
+  return ssbev_launch_status();
+}
+
+}  // namespace ssbev_bf16

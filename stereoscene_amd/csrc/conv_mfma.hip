@@ -25,6 +25,7 @@
 // The wide (>= 64 channel) stride-1 3x3(x3) layers normally do not come here at all: functional.conv3d / conv2d route them
 // through the Winograd path (winograd.hip).
 #include "common.h"
+#include "conv_bf16.h"
 #include "conv_thin_mfma.h"
 
 #include <algorithm>
@@ -3175,10 +3176,18 @@ void launch_wgrad(const float* P, const float* Qt, float* ws, const WgradGeom& g
 
 }  // namespace
 
+namespace ssbev_detail {
+// fixed-order fold of per-chunk partial weight gradients [chunk][tap][Cq][Cp] into the torch layout (shared with conv_bf16.hip)
+void wgrad_reduce(float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
+  launch_wgrad_reduce(partial, gw, nchunks, taps, Cq, Cp, st);
+}
+}  // namespace ssbev_detail
+
 extern "C" {
 
 int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (!conv_dims_ok(d) || mode < 0 || mode > 2) return SSBEV_EINVAL;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::dims_ok(d, mode) ? ssbev_bf16::kernel_class(d, mode) : SSBEV_EINVAL;
   if (mode == 2) return ssbev_thin::wgrad_applicable(d) ? 6 : 0;      // weight gradient: 6 = wgrad_thinside_kernel (unpadded thin side)
   if (ssbev_thin::thinin_applicable(d, mode)) return 4;
   if (ssbev_thin::thinout_applicable(d, mode)) return 5;     // ssbev_conv_thin_* (caller-owned workspace); ssbev_conv_fwd falls back to class 3 / 0
@@ -3192,6 +3201,7 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
 
 size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::packed_elems(d);
   // big enough for either role assignment (forward or data-gradient operand)
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
@@ -3203,6 +3213,7 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
 int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode,
                            ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !w_src || !w_packed || (mode != 0 && mode != 1)) return SSBEV_EINVAL;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::pack(w_src, w_packed, d, mode, as_stream(stream));
   if (ssbev_thin::thinin_applicable(d, mode)) return ssbev_thin::thinin_pack(w_src, w_packed, d, mode, as_stream(stream));
   if (conv_thin_applicable(d, mode)) {       // <= 4 output channels: LDS-resident [tap][n][k] table (conv_thin_kernel)
     hipLaunchKernelGGL(pack_thin_kernel, dim3(cdiv(27 * kThinNP * 32, 256)), dim3(256), 0, as_stream(stream), w_src,
@@ -3246,6 +3257,7 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                    const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::forward(x, w_packed, bias, y, d, as_stream(stream));
   if (ssbev_thin::thinin_applicable(d, 0)) return ssbev_thin::thinin_launch(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
@@ -3267,6 +3279,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::backward_data(gy, w_packed_t, gx, d, as_stream(stream));
   if (ssbev_thin::thinin_applicable(d, 1)) return ssbev_thin::thinin_launch(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
@@ -3287,6 +3300,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
 
 size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
   if (!conv_dims_ok(d)) return 0;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::wgrad_workspace(d);
   if (ssbev_thin::wgrad_applicable(d)) return ssbev_thin::wgrad_workspace(d);
   {
     const WgradThinPlan tp = plan_wgrad_thin(d);
@@ -3316,6 +3330,7 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
 int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_conv_dims* d,
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
+  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::backward_weight(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
   if (ssbev_thin::wgrad_applicable(d)) return ssbev_thin::wgrad_launch(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
   {

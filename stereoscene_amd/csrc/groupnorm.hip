@@ -52,9 +52,9 @@ __device__ __forceinline__ float gelu_f(float x) {
 
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): (sum g, sum g * xhat) with g = gy * [y > 0] when relu is fused.
-template <int MODE, bool PRE, int RM = 0>                   // RM: where the fused ReLU's sign comes from (0 none, 1 bit mask, 2 y)
+template <int MODE, bool PRE, int RM = 0, typename T = float>   // RM: where the fused ReLU's sign comes from (0 none, 1 bit mask, 2 y)
 __global__ void __launch_bounds__(NT)
-gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ y,
+gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ y,
                   const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
                   const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g) {
   extern __shared__ float lds[];                       // [rows][Cs][2]
@@ -85,7 +85,7 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
     // in double -- E[u^2] - mean^2 from plain fp32 partials cancels catastrophically when |mean| >> std
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 0) {
-      const float4 p4 = *reinterpret_cast<const float4*>(x + base + c);
+      const float4 p4 = ld4(x + base + c);
       pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
       if (PRE) {
 #pragma unroll
@@ -125,15 +125,15 @@ gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, con
     auto fetch = [&](long s, size_t& off, float4& xv, float4& gv, float4& yv, unsigned long long (&mw)[4])
         __attribute__((always_inline)) {
       off = base + (size_t)s * g.C + c;
-      xv = *reinterpret_cast<const float4*>(x + off);
+      xv = ld4(x + off);
       if (MODE == 1) {
-        gv = *reinterpret_cast<const float4*>(gy + ((size_t)b * g.S + s) * g.ldg + c);
+        gv = ld4(gy + ((size_t)b * g.S + s) * g.ldg + c);
         if (RM == 1) {
           const unsigned long long* mp = mask + ((off >> 2) >> 6) * 4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) mw[k] = mp[k];
         } else if (RM == 2) {
-          yv = *reinterpret_cast<const float4*>(y + off);
+          yv = ld4(y + off);
         }
       }
     };
@@ -184,8 +184,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& q, double* s0, dou
 
 // forward finalize: one thread block per (b, group): mean / rstd in double.  Only B*G workgroups exist (2 for GN(2) at
 // B = 1), so the kernel is pure latency: 1024 threads, 8-byte loads, four independent partial sums per thread.
+template <typename T>
 __global__ void __launch_bounds__(FT)
-gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+gn_finalize_fwd_kernel(const float* __restrict__ partial, const T* __restrict__ x, float* __restrict__ mean,
                        float* __restrict__ rstd, GnGeom g) {
   __shared__ double s0[FT], s1[FT];
   __shared__ float piv[FT];                           // pivots of this group's channels (when cpg <= FT)
@@ -193,7 +194,7 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restric
   const int cpg = g.C / g.G, n_el = g.chunks * cpg;
   const bool lds_piv = cpg <= FT;
   if (lds_piv && (int)threadIdx.x < cpg) {
-    float pf = x[(size_t)b * g.S * g.C + grp * cpg + threadIdx.x];
+    float pf = ld1(x + (size_t)b * g.S * g.C + grp * cpg + threadIdx.x);
     piv[threadIdx.x] = g.pre ? gelu_f(pf) : pf;
   }
   __syncthreads();
@@ -207,7 +208,7 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const float* __restric
         const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
         // shifted partials (pivot = the channel's value at voxel 0, see gn_partial_kernel): sum u = sum d + n p,
         // sum u^2 = sum d^2 + 2 p sum d + n p^2, with n = voxels of this chunk
-        float pf = lds_piv ? piv[i % cpg] : x[(size_t)b * g.S * g.C + c];
+        float pf = lds_piv ? piv[i % cpg] : ld1(x + (size_t)b * g.S * g.C + c);
         if (!lds_piv && g.pre) pf = gelu_f(pf);
         const double pd = pf;
         const double n = (double)(min(g.S, (long)(chunk + 1) * g.chunk_len) - (long)chunk * g.chunk_len);
@@ -237,8 +238,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const T* __restrict__ x, float* __restrict__ mean,
                             float* __restrict__ rstd, GnGeom g) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= g.B * g.C) return;
@@ -251,7 +253,7 @@ bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const float* __re
   a = wave_sum_d(a); q = wave_sum_d(q);
   if (lane == 0) {
     // one channel per group: the statistics of the SHIFTED values d = u - p directly (mean = p + E[d], var = var(d))
-    float pf = x[(size_t)b * g.S * g.C + c];
+    float pf = ld1(x + (size_t)b * g.S * g.C + c);
     if (g.pre) pf = gelu_f(pf);
     const double n = (double)g.S, md = a / n;
     double var = q / n - md * md;
@@ -286,11 +288,11 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
 }
 
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
-template <bool PRE>
+template <bool PRE, typename T = float>
 __global__ void __launch_bounds__(NT)
-gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                    const float* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    float* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total4) {
+gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    const T* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
+                    T* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;            // see gn_apply_bwd_kernel
@@ -314,14 +316,14 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
         mu[k] = mean[grp]; rs[k] = rstd[grp];
       }
     }
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 xv = ld4(x + 4 * i);
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
     if (PRE) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
     }
     float rr[4] = {0, 0, 0, 0};
-    if (res) { const float4 t = reinterpret_cast<const float4*>(res)[i]; rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+    if (res) { const float4 t = ld4(res + 4 * i); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
@@ -337,8 +339,8 @@ gn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
         if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
       }
     }
-    if (g.ldy == g.C) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
-    else *reinterpret_cast<float4*>(y + (i / q) * g.ldy + (i % q) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    if (g.ldy == g.C) st4(y + 4 * i, make_float4(v[0], v[1], v[2], v[3]));
+    else st4(y + (i / q) * g.ldy + (i % q) * 4, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
@@ -394,11 +396,11 @@ gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restric
 }
 
 // gx = (gamma * g - xhat * ds/n - db/n) * rstd ;  gres = g  (g = gy masked by the fused ReLU)
-template <bool PRE>
+template <bool PRE, typename T = float>
 __global__ void __launch_bounds__(NT)
-gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ y,
+gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    const float* __restrict__ coef, float* __restrict__ gx, float* __restrict__ gres,
+                    const float* __restrict__ coef, T* __restrict__ gx, T* __restrict__ gres,
                     const unsigned long long* __restrict__ mask, GnGeom g, long total4) {
   const int q = g.C >> 2, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
@@ -425,9 +427,8 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
         mu[k] = mean[grp]; rs[k] = rstd[grp]; c0[k] = coef[grp * 2]; c1[k] = coef[grp * 2 + 1];
       }
     }
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    const float4 gv = g.ldg == g.C ? reinterpret_cast<const float4*>(gy)[i]
-                                   : *reinterpret_cast<const float4*>(gy + (i / q) * g.ldg + (i % q) * 4);
+    const float4 xv = ld4(x + 4 * i);
+    const float4 gv = g.ldg == g.C ? ld4(gy + 4 * i) : ld4(gy + (i / q) * g.ldg + (i % q) * 4);
     float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
     if (g.relu && mask) {
       const unsigned long long* mw = mask + (i >> 6) * 4;
@@ -435,7 +436,7 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
     } else if (g.relu) {
-      const float4 yv = reinterpret_cast<const float4*>(y)[i];
+      const float4 yv = ld4(y + 4 * i);
       gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
       gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
     }
@@ -447,8 +448,8 @@ gn_apply_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, c
       const float xh = (u - mu[k]) * rs[k];
       o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
     }
-    reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
-    if (gres) reinterpret_cast<float4*>(gres)[i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    st4(gx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    if (gres) st4(gres + 4 * i, make_float4(gs[0], gs[1], gs[2], gs[3]));
   }
 }
 
@@ -465,7 +466,8 @@ unsigned apply_blocks(long total4, int q) {
 bool gn_ok(const ssbev_norm_dims* d) {
   if (d && ((d->ld_y != 0 && (d->ld_y < d->C || d->ld_y % 4 != 0)) || (d->ld_gy != 0 && (d->ld_gy < d->C || d->ld_gy % 4 != 0))))
     return false;
-  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0 && (d->pre_act == 0 || d->pre_act == 1);
+  return d && d->B > 0 && d->S > 0 && d->C > 0 && d->G > 0 && d->C % d->G == 0 && d->C % 4 == 0 && (d->pre_act == 0 || d->pre_act == 1) &&
+         (d->io_dtype == 0 || d->io_dtype == 1);
 }
 
 GnGeom make_geom(const ssbev_norm_dims* d) {
@@ -534,11 +536,12 @@ __device__ __forceinline__ void gn2_load_stats(const Gn2Geom& g, int b, int c, c
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(NT)
-gn2_apply_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
-                     const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const float* __restrict__ xb,
+gn2_apply_fwd_kernel(const T* __restrict__ xa, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                     const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                      const float* __restrict__ gamma_b, const float* __restrict__ beta_b, const float* __restrict__ mean_b,
-                     const float* __restrict__ rstd_b, float* __restrict__ y, unsigned long long* __restrict__ mask, Gn2Geom g,
+                     const float* __restrict__ rstd_b, T* __restrict__ y, unsigned long long* __restrict__ mask, Gn2Geom g,
                      long total4) {
   const int q = g.C >> 2;
   const long stride = (long)gridDim.x * NT;
@@ -559,8 +562,8 @@ gn2_apply_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ gam
       bcur = b;
       gn2_load_stats<false>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
     }
-    const float4 av = reinterpret_cast<const float4*>(xa)[i];
-    const float4 bv = reinterpret_cast<const float4*>(xb)[i];
+    const float4 av = ld4(xa + 4 * i);
+    const float4 bv = ld4(xb + 4 * i);
     const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
     float v[4];
 #pragma unroll
@@ -576,15 +579,16 @@ gn2_apply_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ gam
         if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
       }
     }
-    reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    st4(y + 4 * i, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
 // per-chunk (sum g, sum g xhat_a) -> pa, (sum g, sum g xhat_b) -> pb, both in gn_partial_kernel<1>'s layout (so the
 // finalize kernels of the single-norm operator serve unchanged); g = gy masked by the fused ReLU
+template <typename T>
 __global__ void __launch_bounds__(NT)
-gn2_partial_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __restrict__ mask, const float* __restrict__ xa,
-                       const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const float* __restrict__ xb,
+gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
+                       const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                        const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float* __restrict__ pa,
                        float* __restrict__ pb, Gn2Geom g) {
   extern __shared__ float lds[];                       // [rows][C][3]
@@ -600,9 +604,9 @@ gn2_partial_bwd_kernel(const float* __restrict__ gy, const unsigned long long* _
     const size_t base = (size_t)b * g.S * g.C;
     for (long s = s0 + r; s < s1; s += rows) {
       const size_t off = base + (size_t)s * g.C + c;
-      const float4 gv = *reinterpret_cast<const float4*>(gy + off);
-      const float4 av = *reinterpret_cast<const float4*>(xa + off);
-      const float4 bv = *reinterpret_cast<const float4*>(xb + off);
+      const float4 gv = ld4(gy + off);
+      const float4 av = ld4(xa + off);
+      const float4 bv = ld4(xb + off);
       float gs[4] = {gv.x, gv.y, gv.z, gv.w};
       const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
       if (g.relu) {
@@ -638,12 +642,13 @@ gn2_partial_bwd_kernel(const float* __restrict__ gy, const unsigned long long* _
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(NT)
-gn2_apply_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __restrict__ mask, const float* __restrict__ xa,
+gn2_apply_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
                      const float* __restrict__ gamma_a, const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
-                     const float* __restrict__ coef_a, const float* __restrict__ xb, const float* __restrict__ gamma_b,
+                     const float* __restrict__ coef_a, const T* __restrict__ xb, const float* __restrict__ gamma_b,
                      const float* __restrict__ mean_b, const float* __restrict__ rstd_b, const float* __restrict__ coef_b,
-                     float* __restrict__ gxa, float* __restrict__ gxb, Gn2Geom g, long total4) {
+                     T* __restrict__ gxa, T* __restrict__ gxb, Gn2Geom g, long total4) {
   const int q = g.C >> 2;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;
@@ -663,9 +668,9 @@ gn2_apply_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __r
       bcur = b;
       gn2_load_stats<true>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, coef_a, coef_b, mua, rsa, mub, rsb, c0a, c1a, c0b, c1b);
     }
-    const float4 gv = reinterpret_cast<const float4*>(gy)[i];
-    const float4 av = reinterpret_cast<const float4*>(xa)[i];
-    const float4 bv = reinterpret_cast<const float4*>(xb)[i];
+    const float4 gv = ld4(gy + 4 * i);
+    const float4 av = ld4(xa + 4 * i);
+    const float4 bv = ld4(xb + 4 * i);
     float gs[4] = {gv.x, gv.y, gv.z, gv.w};
     const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
     if (g.relu) {
@@ -680,8 +685,8 @@ gn2_apply_bwd_kernel(const float* __restrict__ gy, const unsigned long long* __r
       oa[k] = (ga[k] * gs[k] - (as[k] - mua[k]) * rsa[k] * c0a[k] - c1a[k]) * rsa[k];
       ob[k] = (gb[k] * gs[k] - (bs[k] - mub[k]) * rsb[k] * c0b[k] - c1b[k]) * rsb[k];
     }
-    reinterpret_cast<float4*>(gxa)[i] = make_float4(oa[0], oa[1], oa[2], oa[3]);
-    reinterpret_cast<float4*>(gxb)[i] = make_float4(ob[0], ob[1], ob[2], ob[3]);
+    st4(gxa + 4 * i, make_float4(oa[0], oa[1], oa[2], oa[3]));
+    st4(gxb + 4 * i, make_float4(ob[0], ob[1], ob[2], ob[3]));
   }
 }
 
@@ -695,7 +700,8 @@ ssbev_norm_dims gn2_side(const ssbev_norm2_dims* d, int side) {
   ssbev_norm_dims n;
   const bool batch = side ? d->b_batch : d->a_batch;
   n.B = batch ? 1 : d->B; n.C = d->C; n.G = side ? d->Gb : d->Ga; n.S = batch ? d->S * d->B : d->S;
-  n.eps = side ? d->eps_b : d->eps_a; n.relu = d->relu; n.stats_given = 0; n.pre_act = 0;
+  n.eps = side ? d->eps_b : d->eps_a; n.relu = d->relu; n.stats_given = 0; n.pre_act = 0; n.ld_y = 0; n.ld_gy = 0;
+  n.io_dtype = d->io_dtype;
   return n;
 }
 
@@ -740,13 +746,11 @@ size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d) {
   return ((total4 + 63) / 64) * 4;
 }
 
-static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                              float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
-                              size_t ws_bytes, ssbev_stream_t stream) {
-  if (!gn_ok(d) || !x || !gamma || !beta || !y || !mean || !rstd || !ws) return SSBEV_EINVAL;
-  // a strided output (ld_y) is a slice of a concatenation: the residual operand has no stride of its own -> refused together
-  if (residual && d->ld_y != 0 && d->ld_y != d->C) return SSBEV_EINVAL;
-  if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
+extern "C++" {
+template <typename T>
+static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y,
+                           float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
+                           ssbev_stream_t stream) {
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
@@ -754,25 +758,39 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
     if (g.pre)
-      hipLaunchKernelGGL((gn_partial_kernel<0, true>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr,
-                         nullptr, nullptr, nullptr, partial, g);
+      hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, (const T*)nullptr,
+                         (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     else
-      hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, nullptr, nullptr,
-                         nullptr, nullptr, nullptr, partial, g);
+      hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, (const T*)nullptr,
+                         (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g);
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g);
     else
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
   }
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
   if (g.pre)
-    hipLaunchKernelGGL(gn_apply_fwd_kernel<true>, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+    hipLaunchKernelGGL((gn_apply_fwd_kernel<true, T>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
                        d->relu ? mask : nullptr, g, total4);
   else
-    hipLaunchKernelGGL(gn_apply_fwd_kernel<false>, dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+    hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
                        d->relu ? mask : nullptr, g, total4);
   return ssbev_launch_status();
+}
+}  // extern "C++"
+
+static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                              float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
+                              size_t ws_bytes, ssbev_stream_t stream) {
+  if (!gn_ok(d) || !x || !gamma || !beta || !y || !mean || !rstd || !ws) return SSBEV_EINVAL;
+  // a strided output (ld_y) is a slice of a concatenation: the residual operand has no stride of its own -> refused together
+  if (residual && d->ld_y != 0 && d->ld_y != d->C) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
+  if (d->io_dtype == 1)     // x, residual, y hold bf16 bit patterns (statistics, affine parameters and arithmetic stay fp32)
+    return groupnorm_fwd_t(reinterpret_cast<const bf16_t*>(x), gamma, beta, reinterpret_cast<const bf16_t*>(residual),
+                           reinterpret_cast<bf16_t*>(y), mean, rstd, mask, d, ws, stream);
+  return groupnorm_fwd_t(x, gamma, beta, residual, y, mean, rstd, mask, d, ws, stream);
 }
 
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
@@ -797,17 +815,11 @@ int ssbev_bn_update_running(const float* mean, const float* rstd, float* running
   return ssbev_launch_status();
 }
 
-static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, const unsigned long long* mask,
-                              const float* gamma, const float* mean, const float* rstd, float* gx, float* gresidual,
-                              float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
-                              ssbev_stream_t stream) {
-  if (!gn_ok(d) || !gy || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !ws) return SSBEV_EINVAL;
-  if (d->relu && !y && !mask) return SSBEV_EINVAL;
-  // row strides are honoured for gy (ld_gy) on the paths that exist for them: the saved y of the non-mask ReLU path and the
-  // residual gradient are dense tensors -> a strided call that would need them is refused instead of mis-read
-  const bool strided = (d->ld_gy != 0 && d->ld_gy != d->C) || (d->ld_y != 0 && d->ld_y != d->C);
-  if (strided && ((d->relu && !mask) || gresidual)) return SSBEV_EINVAL;
-  if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
+extern "C++" {
+template <typename T>
+static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned long long* mask,
+                           const float* gamma, const float* mean, const float* rstd, T* gx, T* gresidual,
+                           float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, ssbev_stream_t stream) {
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
@@ -818,7 +830,7 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
     const dim3 grid(g.chunks, g.B, gn_slabs(g));
     const int rm = !g.relu ? 0 : (mask ? 1 : 2);
 #define SSBEV_GNP(PRE_, RM_) \
-    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_>), grid, dim3(NT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
+    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T>), grid, dim3(NT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
     if (g.pre) { if (rm == 0) SSBEV_GNP(true, 0); else if (rm == 1) SSBEV_GNP(true, 1); else SSBEV_GNP(true, 2); }
     else { if (rm == 0) SSBEV_GNP(false, 0); else if (rm == 1) SSBEV_GNP(false, 1); else SSBEV_GNP(false, 2); }
 #undef SSBEV_GNP
@@ -830,12 +842,32 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
   const long total4 = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(total4, g.C / 4);
   if (g.pre)
-    hipLaunchKernelGGL(gn_apply_bwd_kernel<true>, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+    hipLaunchKernelGGL((gn_apply_bwd_kernel<true, T>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
                        gresidual, mask, g, total4);
   else
-    hipLaunchKernelGGL(gn_apply_bwd_kernel<false>, dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+    hipLaunchKernelGGL((gn_apply_bwd_kernel<false, T>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
                        gresidual, mask, g, total4);
   return ssbev_launch_status();
+}
+}  // extern "C++"
+
+static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, const unsigned long long* mask,
+                              const float* gamma, const float* mean, const float* rstd, float* gx, float* gresidual,
+                              float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
+                              ssbev_stream_t stream) {
+  if (!gn_ok(d) || !gy || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !ws) return SSBEV_EINVAL;
+  if (d->relu && !y && !mask) return SSBEV_EINVAL;
+  // row strides are honoured for gy (ld_gy) on the paths that exist for them: the saved y of the non-mask ReLU path and the
+  // residual gradient are dense tensors -> a strided call that would need them is refused instead of mis-read
+  const bool strided = (d->ld_gy != 0 && d->ld_gy != d->C) || (d->ld_y != 0 && d->ld_y != d->C);
+  if (strided && ((d->relu && !mask) || gresidual)) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
+  if (d->io_dtype == 1) {
+    typedef const bf16_t* cb;
+    return groupnorm_bwd_t(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean, rstd,
+                           reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws, stream);
+  }
+  return groupnorm_bwd_t(gy, x, y, mask, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, stream);
 }
 
 int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* mean,
@@ -863,15 +895,13 @@ size_t ssbev_groupnorm2_workspace(const ssbev_norm2_dims* d) {
   return fwd > bwd ? fwd : bwd;
 }
 
-int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
-                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
-                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
-  if (!gn2_ok(d) || !xa || !gamma_a || !beta_a || !mean_a || !rstd_a || !xb || !gamma_b || !beta_b || !mean_b || !rstd_b || !y || !ws)
-    return SSBEV_EINVAL;
-  if (d->relu && !relu_mask) return SSBEV_EINVAL;
-  if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
+extern "C++" {
+template <typename T>
+static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                            const T* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, T* y,
+                            uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream) {
   hipStream_t st = as_stream(stream);
-  const float* xs[2] = {xa, xb};
+  const T* xs[2] = {xa, xb};
   float* means[2] = {mean_a, mean_b};
   float* rstds[2] = {rstd_a, rstd_b};
   char* wsp = static_cast<char*>(ws);
@@ -881,32 +911,43 @@ int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* bet
     const size_t lds = lds_bytes(g);
     if (lds > 64 * 1024) return SSBEV_EINVAL;
     float* partial = reinterpret_cast<float*>(wsp);
-    hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, xs[side], nullptr, nullptr,
-                       nullptr, nullptr, nullptr, partial, g);
+    hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, xs[side],
+                       (const T*)nullptr, (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, xs[side], means[side],
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, xs[side], means[side],
                          rstds[side], g);
     else
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(g.B * g.G), dim3(FT), 0, st, partial, xs[side], means[side], rstds[side], g);
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, xs[side], means[side], rstds[side], g);
     wsp += ssbev_groupnorm_workspace(&n);
   }
   const Gn2Geom g2 = make_geom2(d);
   const long total4 = (long)g2.B * g2.S * (g2.C / 4);
-  hipLaunchKernelGGL(gn2_apply_fwd_kernel, dim3(apply_blocks(total4, g2.C / 4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a, rstd_a,
+  hipLaunchKernelGGL(gn2_apply_fwd_kernel<T>, dim3(apply_blocks(total4, g2.C / 4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a, rstd_a,
                      xb, gamma_b, beta_b, mean_b, rstd_b, y, d->relu ? reinterpret_cast<unsigned long long*>(relu_mask) : nullptr, g2,
                      total4);
   return ssbev_launch_status();
 }
+}  // extern "C++"
 
-int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
-                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
-                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
-                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
-  if (!gn2_ok(d) || !gy || !xa || !gamma_a || !mean_a || !rstd_a || !xb || !gamma_b || !mean_b || !rstd_b || !gxa || !gxb ||
-      !ggamma_a || !gbeta_a || !ggamma_b || !gbeta_b || !ws)
+int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!gn2_ok(d) || !xa || !gamma_a || !beta_a || !mean_a || !rstd_a || !xb || !gamma_b || !beta_b || !mean_b || !rstd_b || !y || !ws)
     return SSBEV_EINVAL;
   if (d->relu && !relu_mask) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
+  if (d->io_dtype == 1)
+    return groupnorm2_fwd_t(reinterpret_cast<const bf16_t*>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<const bf16_t*>(xb),
+                            gamma_b, beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
+  return groupnorm2_fwd_t(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, stream);
+}
+
+extern "C++" {
+template <typename T>
+static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa, const float* gamma_a, const float* mean_a,
+                            const float* rstd_a, const T* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                            T* gxa, T* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                            const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream) {
   hipStream_t st = as_stream(stream);
   const Gn2Geom g = make_geom2(d);
   const size_t part = (size_t)g.B * g.chunks * g.C * 2;
@@ -917,14 +958,34 @@ int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float
   const int q = g.C >> 2, rows = NT / q > 0 ? NT / q : 1;
   const size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(relu_mask);
-  hipLaunchKernelGGL(gn2_partial_bwd_kernel, dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b, rstd_b, pa,
+  hipLaunchKernelGGL(gn2_partial_bwd_kernel<T>, dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b, rstd_b, pa,
                      pb, g);
   gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
   gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
   const long total4 = (long)g.B * g.S * (g.C / 4);
-  hipLaunchKernelGGL(gn2_apply_bwd_kernel, dim3(apply_blocks(total4, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a, rstd_a,
+  hipLaunchKernelGGL(gn2_apply_bwd_kernel<T>, dim3(apply_blocks(total4, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a, rstd_a,
                      coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, total4);
   return ssbev_launch_status();
+}
+}  // extern "C++"
+
+int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!gn2_ok(d) || !gy || !xa || !gamma_a || !mean_a || !rstd_a || !xb || !gamma_b || !mean_b || !rstd_b || !gxa || !gxb ||
+      !ggamma_a || !gbeta_a || !ggamma_b || !gbeta_b || !ws)
+    return SSBEV_EINVAL;
+  if (d->relu && !relu_mask) return SSBEV_EINVAL;
+  if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
+  if (d->io_dtype == 1) {
+    typedef const bf16_t* cb;
+    return groupnorm2_bwd_t(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
+                            reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
+                            reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+  }
+  return groupnorm2_bwd_t(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a, gbeta_a,
+                          ggamma_b, gbeta_b, d, ws, stream);
 }
 
 }  // extern "C"

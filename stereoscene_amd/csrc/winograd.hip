@@ -37,9 +37,9 @@ __device__ __forceinline__ void a4(float* v, int s) {         // A g : 2 -> 4 va
   v[0] = g0; v[s] = g0 + g1; v[2 * s] = g0 - g1; v[3 * s] = -g1;
 }
 
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
+wino_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -60,7 +60,7 @@ wino_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, l
       for (int f = 0; f < 4; ++f) {
         const int w = 2 * tw - 1 + f;
         const bool ok = d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
-        v[(a * 4 + e) * 4 + f] = ok ? x[((((long)b * g.D + d) * g.H + h) * g.W + w) * g.C + c] : 0.0f;
+        v[(a * 4 + e) * 4 + f] = ok ? ld1(x + ((((long)b * g.D + d) * g.H + h) * g.W + w) * g.C + c) : 0.0f;
       }
     }
   }
@@ -77,9 +77,9 @@ wino_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, l
   for (int xi = 0; xi < 64; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+wino_output_kernel(const TF* __restrict__ M, TA* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -118,14 +118,14 @@ wino_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, 
                   m3 = r2[(3 * 2 + e) * 2 + f];
       const float y0 = m0 + m1 + m2, y1 = m1 - m2 - m3;
       const long base = ((((long)b * g.D + 2 * td) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c;
-      y[base] = y0;
-      y[base + (long)g.H * g.W * g.C] = y1;
+      st1(y + base, y0);
+      st1(y + base + (long)g.H * g.W * g.C, y1);
     }
 }
 
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
+wino_output_adjoint_kernel(const TA* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -142,7 +142,7 @@ wino_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, Win
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int f = 0; f < 2; ++f)
-        v[(a * 4 + e) * 4 + f] = gy[((((long)b * g.D + 2 * td + a) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c];
+        v[(a * 4 + e) * 4 + f] = ld1(gy + ((((long)b * g.D + 2 * td + a) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -159,9 +159,9 @@ wino_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, Win
 }
 
 // ---- 2-D variant, F(2x2, 3x3): 16 frequencies, tiles over (h, w); the D axis of the dims struct is a batch axis ----
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino2d_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
+wino2d_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -178,7 +178,7 @@ wino2d_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g,
     for (int f = 0; f < 4; ++f) {
       const int w = 2 * tw - 1 + f;
       const bool ok = h >= 0 && h < g.H && w >= 0 && w < g.W;
-      v[e * 4 + f] = ok ? x[((bd * g.H + h) * g.W + w) * g.C + c] : 0.0f;
+      v[e * 4 + f] = ok ? ld1(x + ((bd * g.H + h) * g.W + w) * g.C + c) : 0.0f;
     }
   }
 #pragma unroll
@@ -190,9 +190,9 @@ wino2d_input_kernel(const float* __restrict__ x, TF* __restrict__ V, WinoGeom g,
   for (int xi = 0; xi < 16; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
 }
 
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino2d_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g, long total) {
+wino2d_output_kernel(const TF* __restrict__ M, TA* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -216,22 +216,22 @@ wino2d_output_kernel(const TF* __restrict__ M, float* __restrict__ y, WinoGeom g
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-      oldv[2 * f] = y[base];
-      oldv[2 * f + 1] = y[base + (long)g.W * g.C];
+      oldv[2 * f] = ld1(y + base);
+      oldv[2 * f + 1] = ld1(y + base + (long)g.W * g.C);
     }
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const float y0 = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f], y1 = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f];
     const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-    y[base] = y0 + oldv[2 * f];
-    y[base + (long)g.W * g.C] = y1 + oldv[2 * f + 1];
+    st1(y + base, y0 + oldv[2 * f]);
+    st1(y + base + (long)g.W * g.C, y1 + oldv[2 * f + 1]);
   }
 }
 
-template <typename TF>
+template <typename TF, typename TA = float>
 __global__ void __launch_bounds__(256)
-wino2d_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
+wino2d_output_adjoint_kernel(const TA* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % g.C);
@@ -244,7 +244,7 @@ wino2d_output_adjoint_kernel(const float* __restrict__ gy, TF* __restrict__ Z, W
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) v[e * 4 + f] = gy[((bd * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c];
+    for (int f = 0; f < 2; ++f) v[e * 4 + f] = ld1(gy + ((bd * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c);
 #pragma unroll
   for (int e = 0; e < 2; ++e) a4(v + e * 4, 1);
 #pragma unroll
@@ -1050,6 +1050,14 @@ int ssbev_wino43_weight_grad(const float* gU, float* gw, int Cout, int Cin, int 
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16, wino2d_input_kernel<bf16_bits>, float, uint16_t)
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform_bf16, wino2d_output_kernel<bf16_bits>, uint16_t, float)
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint_bf16, wino2d_output_adjoint_kernel<bf16_bits>, float, uint16_t)
+
+// bf16 ACTIVATIONS on the tensor side as well (round 4, bf16 storage mode): x / gy / y are bf16 channels-last tensors
+SSBEV_WINO_ENTRY(ssbev_wino_input_transform_bf16a, (wino_input_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+SSBEV_WINO_ENTRY(ssbev_wino_output_transform_bf16a, (wino_output_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint_bf16a, (wino_output_adjoint_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16a, (wino2d_input_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform_bf16a, (wino2d_output_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint_bf16a, (wino2d_output_adjoint_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
 
 SSBEV_WINO_ENTRY(ssbev_wino_input_transform_bf16, wino_input_kernel<bf16_bits>, float, uint16_t)
 SSBEV_WINO_ENTRY(ssbev_wino_output_transform_bf16, wino_output_kernel<bf16_bits>, uint16_t, float)

@@ -146,9 +146,22 @@ def from_cl(buf):
 
 
 def _f32(t, what):
+    """Input of an fp32 operator.  In the bf16 storage mode a bf16 activation is widened here (an fp32 island: the autograd
+    engine narrows the gradient the operator returns back to the input's dtype); anything else is an error."""
+    if t.dtype == torch.bfloat16 and PRECISION == "bf16":
+        return t.float()
     if t.dtype != torch.float32:
         raise capi.SsbevError(f"{what}: fp32 expected, got {t.dtype}")
     return t
+
+
+def _act(t, what):
+    """Input of an operator with fp32 AND bf16 kernels: returns (tensor, io_dtype code of the C ABI)."""
+    if t.dtype == torch.bfloat16:
+        return t, 1
+    if t.dtype != torch.float32:
+        raise capi.SsbevError(f"{what}: fp32 or bf16 expected, got {t.dtype}")
+    return t, 0
 
 
 def _ws(nbytes, device):
@@ -440,8 +453,8 @@ class _SpatialMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, slot):
-        ctx.slot, ctx.shape = slot, tuple(x.shape)
-        return to_cl(x).mean(dim=tuple(range(1, x.dim() - 1)))
+        ctx.slot, ctx.shape, ctx.dtype = slot, tuple(x.shape), x.dtype
+        return to_cl(x).mean(dim=tuple(range(1, x.dim() - 1)), dtype=torch.float32)     # fp32 vector also for bf16 activations
 
     @staticmethod
     def backward(ctx, g):
@@ -456,7 +469,7 @@ class _SpatialMean(torch.autograd.Function):
             tgt = buf.view((B,) + sp + (Cch,))
             tgt.add_(gb)
             return from_cl(tgt), None
-        full = gb.expand((B,) + sp + (Cch,)).contiguous()
+        full = gb.to(ctx.dtype).expand((B,) + sp + (Cch,)).contiguous()
         if ctx.slot is not None:
             ctx.slot.buf = full
         return from_cl(full), None
@@ -465,7 +478,7 @@ class _SpatialMean(torch.autograd.Function):
 def spatial_mean(x):
     """[B, C, *spatial] -> [B, C] mean; slot-aware (see _SpatialMean)."""
     if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
-        return x.mean(dim=tuple(range(2, x.dim())))
+        return x.mean(dim=tuple(range(2, x.dim())), dtype=torch.float32 if x.is_floating_point() else None)
     return _SpatialMean.apply(x, _slot_of(x))
 
 
@@ -521,7 +534,7 @@ def _conv_dims(xshape_cl, wshape, stride, padding, dilation, transposed, output_
         outs = [(i + 2 * p - dl * (k - 1) - 1) // s + 1
                 for i, s, p, dl, k in zip((Di, Hi, Wi), stride, padding, dilation, (kd, kh, kw))]
     d = capi.ConvDims(B, Cin, Cout, Di, Hi, Wi, outs[0], outs[1], outs[2], kd, kh, kw, *stride, *padding, *dilation,
-                      int(transposed), int(relu), int(accumulate), int(TILE_HINT), 1 if PRECISION == "bf16" else 0)
+                      int(transposed), int(relu), int(accumulate), int(TILE_HINT), 1 if PRECISION == "bf16_operands" else 0)
     return d
 
 
@@ -551,7 +564,8 @@ class _ConvNd(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None, relu=False):
         lib = capi.load()
         ctx.slot = slot
-        streams.note_use(weight)
+        if ctx.needs_input_grad[1]:
+            streams.note_use(weight)
         xcl = to_cl(_f32(x, "conv"))
         kpad = (-xcl.shape[-1]) % 4
         w5 = weight
@@ -679,13 +693,124 @@ class _ConvNd(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
+class _ConvNd16(torch.autograd.Function):
+    """Convolution / transposed convolution in the bf16 STORAGE mode (csrc/conv_bf16.hip, ssbev_conv_dims.precision = 2 / 3):
+    x and y (and gy, gx) are bf16 channels-last tensors, the weight stays an fp32 master (packed to bf16 operands per launch),
+    its gradient comes back in fp32.  ``out_fp32``: fp32 result (the layer in front of an fp32 island)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding, slot=None, relu=False, out_fp32=False):
+        lib = capi.load()
+        ctx.slot = slot
+        if ctx.needs_input_grad[1]:
+            streams.note_use(weight)
+        xcl = to_cl(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+        d = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding, relu=int(relu))
+        d.precision = 3 if out_fp32 else 2
+        y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        with _span("conv_bf16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "fwd")):
+            wp = _packed(weight.detach(), d, 0)
+            capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d), capi.stream()),
+                       "ssbev_conv_fwd[bf16]")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(xcl, weight, *((y,) if relu else ()))
+        ctx.cfg = (stride, padding, dilation, transposed, output_padding, bias is not None)
+        ctx.bias_leaf = bias is not None and bias.is_leaf and bias.grad is None
+        return from_cl(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = capi.load()
+        xcl, weight = ctx.saved_tensors[:2]
+        stride, padding, dilation, transposed, output_padding, has_bias = ctx.cfg
+        gcl = to_cl(gy)
+        if ctx.relu:
+            gcl = torch.ops.aten.threshold_backward(gcl.contiguous(), ctx.saved_tensors[2], 0.0)
+        if gcl.dtype != torch.bfloat16:
+            gcl = gcl.to(torch.bfloat16)
+        Cout_g = gcl.shape[-1]
+        d = _conv_dims(tuple(xcl.shape), tuple(weight.shape), stride, padding, dilation, transposed, output_padding)
+        d.precision = 2
+        want_gx, want_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = gw = gb = None
+
+        def weight_gradient():
+            gwp = torch.empty(tuple(weight.shape), dtype=torch.float32, device=gy.device)
+            ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
+            with _span("conv_bf16_wgrad", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
+                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d), capi.ptr(ws),
+                                                     ws.numel(), capi.stream()), "ssbev_conv_bwd_weight[bf16]")
+            return gwp
+
+        gw_side = want_gw and streams.wgrad_on_side(weight)
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        gb_side = gw_side and want_gb and ctx.bias_leaf
+        if gw_side:
+            with streams.on_side(gy.device, xcl, gcl) as side:
+                gw = weight_gradient()
+                if gb_side:
+                    gb = gcl.reshape(-1, Cout_g).sum(0, dtype=torch.float32)
+                side.publish(gw, gb)
+        if want_gx:
+            into = _slot_target(ctx.slot, xcl)
+            if into is not None:
+                d.accumulate = 1
+            gxcl = into if into is not None else torch.empty_like(xcl)
+            with _span("conv_bf16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "dgrad")):
+                wpt = _packed(weight.detach(), d, 1)
+                capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d), capi.stream()),
+                           "ssbev_conv_bwd_data[bf16]")
+            d.accumulate = 0
+            if ctx.slot is not None:
+                ctx.slot.buf = gxcl
+            gx = from_cl(gxcl)
+        if want_gw and not gw_side:
+            gw = weight_gradient()
+        if want_gb and not gb_side:
+            gb = gcl.reshape(-1, Cout_g).sum(0, dtype=torch.float32)
+        return gx, gw, gb, None, None, None, None, None, None, None, None
+
+
+def _conv16_route(x, weight5, bias, st, pd, dl, transposed, op, relu=False):
+    """bf16 storage mode: the convolution on csrc/conv_bf16.hip when its channel counts allow 16-byte bf16 voxel-line pieces
+    (Cin % 8 == 0 and Cout % 8 == 0), else None (the caller keeps its fp32 island: the 1- / 2- / 20-channel layers)."""
+    if not (storage_bf16() and x.is_cuda and TILE_HINT in (0, 9)):
+        return None
+    cin = weight5.shape[0] if transposed else weight5.shape[1]
+    cout = weight5.shape[1] if transposed else weight5.shape[0]
+    if cin % 8 != 0 or cout % 8 != 0:        # (the Cout-channel gradient is a bf16 SOURCE in backward)
+        return None
+    return _ConvNd16.apply(x, weight5, bias, st, pd, dl, transposed, op, _slot_of(x), bool(relu), False)
+
+
+def _to_act(y):
+    """Result of an fp32-island convolution on its way back into the bf16 chain (channel counts that cannot be bf16 sources --
+    the 1-channel volumes -- stay fp32)."""
+    if storage_bf16() and y.dtype == torch.float32 and y.shape[1] % 8 == 0:
+        return y.to(torch.bfloat16)
+    return y
+
+
 WINOGRAD = os.environ.get("SSBEV_WINOGRAD", "1") != "0"   # wide 3x3x3 stride-1 layers via F(2,3)^3 (0 = direct MFMA conv)
+# bf16 storage mode: wide stride-1 3x3(x3) layers on the F(2,3) Winograd pipeline with bf16 tensors on both sides (1), or on the
+# direct bf16 MFMA kernels (0): 3.4x / 2.25x fewer multiply-adds against 8x / 4x larger transformed tensors
+WINO_BF16S = os.environ.get("SSBEV_WINO_BF16S", "1") != "0"
 
 
 def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
     """F.conv3d replacement (groups=1): the MFMA implicit-GEMM kernels, or Winograd F(2x2x2,3x3x3) for the wide
     stride-1 3x3x3 layers."""
     st, pd, dl = _triple(stride, 3), _triple(padding, 3), _triple(dilation, 3)
+    if storage_bf16() and x.is_cuda and TILE_HINT in (0, 9):
+        if WINOGRAD and WINO_BF16S and wino_conv3d_applicable(x, weight, st, pd, dl):
+            y = _WinoConv.apply(x, weight, _slot_of(x))
+            y = y if bias is None else y + _like_act(bias, y).view(1, -1, 1, 1, 1)
+            return torch.relu(y) if relu else y
+        y = _conv16_route(x, weight, bias, st, pd, dl, False, (0, 0, 0), relu)
+        if y is not None:
+            return y
+        return _to_act(_ConvNd.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0), None, bool(relu)))
     if relu:    # epilogue ReLU of the direct kernels (the MIE block's two conv -> ReLU pairs, VT:250-258); elsewhere a norm follows
         gemm = (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and tuple(weight.shape[2:]) == (1, 1, 1)
                 and st == (1, 1, 1) and pd == (0, 0, 0) and weight.shape[1] >= GEMM_MIN_CIN)
@@ -949,6 +1074,11 @@ def _deconv_k_eq_s_gemm(x, weight, bias, k):
 def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0):
     """F.conv_transpose3d replacement (weight [Cin, Cout, kd, kh, kw])."""
     st, pd, op = _triple(stride, 3), _triple(padding, 3), _triple(output_padding, 3)
+    if storage_bf16() and x.is_cuda and TILE_HINT in (0, 9):
+        y = _conv16_route(x, weight, bias, st, pd, (1, 1, 1), True, op)
+        if y is not None:
+            return y
+        return _to_act(_ConvNd.apply(x, weight, bias, st, pd, (1, 1, 1), True, op))
     if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == tuple(st)
             and pd == (0, 0, 0) and op == (0, 0, 0) and weight.shape[0] >= 128):
         return _deconv_k_eq_s_gemm(x, weight, bias, tuple(st))
@@ -982,6 +1112,20 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """F.conv2d replacement: a depth-1 volume through the same kernels (groups=1); wide 3x3 stride-1 layers via
     Winograd F(2x2,3x3)."""
     s, p, dl = _triple(stride, 2), _triple(padding, 2), _triple(dilation, 2)
+    if storage_bf16() and x.is_cuda and TILE_HINT in (0, 9):
+        x5, w5 = x.unsqueeze(2), weight.unsqueeze(2)
+        if (DILATED_POLYPHASE and WINOGRAD and WINO_BF16S and tuple(weight.shape[2:]) == (3, 3) and s == (1, 1) and dl[0] == dl[1]
+                and dl[0] > 1 and p == dl and min(weight.shape[0], weight.shape[1]) >= 64):
+            y = _dilated_polyphase(x, weight, dl[0])
+            if y is not None:
+                return y if bias is None else y + _like_act(bias, y).view(1, -1, 1, 1)
+        if WINOGRAD and WINO_BF16S and wino_conv3d_applicable(x5, w5, (1,) + s, (0,) + p, (1,) + dl):
+            y = _WinoConv.apply(x5, w5, _slot_of(x)).squeeze(2)
+            return y if bias is None else y + _like_act(bias, y).view(1, -1, 1, 1)
+        y = _conv16_route(x5, w5, bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0))
+        if y is None:
+            y = _to_act(_ConvNd.apply(x5, w5, bias, (1,) + s, (0,) + p, (1,) + dl, False, (0, 0, 0)))
+        return y.squeeze(2)
     if (GEMM_LAYERS and TILE_HINT == 0 and PRECISION == "fp32" and x.is_cuda and tuple(weight.shape[2:]) == (1, 1)
             and s == (1, 1) and p == (0, 0) and weight.shape[1] >= GEMM_MIN_CIN):
         return linear_cl(x, weight, bias)           # wide pointwise conv = plain GEMM on the channels-last buffer
@@ -1012,18 +1156,38 @@ def _wino_g(device):
     return _WINO_G
 
 
-# BASELINE configs[3] ("bf16 mixed precision, MFMA 3D-conv path"): "bf16" stores the Winograd-domain tensors of the wide
-# 3x3(x3) layers (70 % of the step's convolution FLOPs) as bf16 and runs their frequency GEMMs on the bf16 matrix pipe with
-# fp32 accumulation; weights, activations, gradients, normalisation and losses stay fp32.  Default "fp32" (the parity
-# contract of the headline metric); never switched implicitly.
+# BASELINE configs[3] ("bf16 mixed precision, MFMA 3D-conv path").  Three modes, never switched implicitly:
+#   "fp32"           the parity contract of the headline metric (default);
+#   "bf16"           (round 4) bf16 STORAGE: activations and activation gradients are bf16 channels-last tensors between the
+#                    layers (convolutions on csrc/conv_bf16.hip, normalisations with bf16 I/O, the F(2,3) Winograd pipeline with
+#                    bf16 on both sides); fp32 islands: parameters and their gradients (masters), normalisation statistics,
+#                    softmaxes, the BRI attention, the scatter, the losses -- what mmcv's Fp16OptimizerHook / auto_fp16 keep
+#                    in fp32 (reference mmdet_train.py:131-134), with bf16 in place of fp16;
+#   "bf16_operands"  (rounds 1-3) tensors stay fp32 in HBM, the MFMA operands are rounded to bf16 in registers and the
+#                    Winograd-domain tensors are stored as bf16: kept for A/B runs.
 PRECISION = os.environ.get("SSBEV_PRECISION", "fp32")
+_MODES = ("fp32", "bf16", "bf16_operands")
 
 
 def set_precision(mode):
     global PRECISION
-    if mode not in ("fp32", "bf16"):
-        raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode!r}")
+    if mode not in _MODES:
+        raise ValueError(f"precision must be one of {_MODES}, got {mode!r}")
     PRECISION = mode
+
+
+def storage_bf16():
+    """Are activations stored as bf16 between layers (precision mode "bf16")?"""
+    return PRECISION == "bf16"
+
+
+def act_dtype():
+    return torch.bfloat16 if PRECISION == "bf16" else torch.float32
+
+
+def _like_act(y, ref):
+    """A broadcast parameter (bias) in the dtype of the activation it is added to (bf16 + fp32 would promote the sum)."""
+    return y if y.dtype == ref.dtype else y.to(ref.dtype)
 
 
 def _wino_call(name, src, dims, out_shape, dtype=torch.float32):
@@ -1168,7 +1332,8 @@ class _WinoConvDF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, slot=None):
         ctx.slot = slot
-        streams.note_use(weight)
+        if ctx.needs_input_grad[1]:
+            streams.note_use(weight)
         xcl = to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout = weight.shape[0]
@@ -1241,11 +1406,13 @@ class _WinoConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, slot=None):
         ctx.slot = slot
-        streams.note_use(weight)
-        xcl = to_cl(_f32(x, "wino_conv"))
+        if ctx.needs_input_grad[1]:
+            streams.note_use(weight)
+        bf = PRECISION != "fp32"
+        a16 = storage_bf16()              # bf16 tensors on the activation side too (`_bf16a` transforms)
+        xcl = to_cl(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)) if a16 else to_cl(_f32(x, "wino_conv"))
         B, D, H, W, Cin = xcl.shape
         Cout, three_d = weight.shape[0], weight.shape[2] == 3
-        bf = PRECISION == "bf16"
         f43, pre, nf, th, red = _WinoConv._plan(three_d, D, H, W, bf, Cin)
         T = B * (D // (4 if f43 == 4 else 2) if three_d else D) * (H // th) * (W // th)
         lib = capi.load()
@@ -1264,23 +1431,28 @@ class _WinoConv(torch.autograd.Function):
                 y = _wino_depth_fused(xcl, w, B, D, H, W, Cin, Cout, 0)
                 V = None
             elif bf:
-                V = _wino_call(pre + "input_transform_bf16", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin), torch.bfloat16)
+                sfx = "_bf16a" if a16 else "_bf16"
+                V = _wino_call(pre + "input_transform" + sfx, xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin), torch.bfloat16)
                 M = torch.bmm(V, U.to(torch.bfloat16))
-                y = _wino_call(pre + "output_transform_bf16", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
+                y = _wino_call(pre + "output_transform" + sfx, M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout),
+                               torch.bfloat16 if a16 else torch.float32)
             else:
                 V = _wino_call(pre + "input_transform", xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                 M = _wino_bgemm(V, w, Cout, Cin, 0) if (three_d and WINO_OWN_GEMM and not f43) else (gemm_nn(V, U, tag=tag + " gemm") if own_gemm_site("wino") else torch.bmm(V, U))
                 y = _wino_call(pre + "output_transform", M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout))
         ctx.save_for_backward(xcl if fused else V, weight)
-        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red)
+        ctx.geom = (B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red, a16)
         return from_cl(y)
 
     @staticmethod
     def backward(ctx, gy):
         V, weight = ctx.saved_tensors            # (depth-fused path: V is the channels-last input, transformed below)
-        B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red = ctx.geom
-        sfx, fdt = ("_bf16", torch.bfloat16) if bf else ("", torch.float32)
+        B, D, H, W, Cin, Cout, T, three_d, fl, fused, bf, f43, pre, nf, red, a16 = ctx.geom
+        sfx, fdt = (("_bf16a" if a16 else "_bf16"), torch.bfloat16) if bf else ("", torch.float32)
         gcl = to_cl(gy)
+        if a16 and gcl.dtype != torch.bfloat16:
+            gcl = gcl.to(torch.bfloat16)
+        adt = torch.bfloat16 if a16 else torch.float32          # dtype of the activation-side tensors
         lib = capi.load()
         w = weight.detach().contiguous()
         nd = 4 if f43 == 4 else (3 if three_d else 2)
@@ -1307,7 +1479,7 @@ class _WinoConv(torch.autograd.Function):
                     capi.check(getattr(lib, acc_fn)(capi.ptr(Mx), capi.ptr(into), C.byref(odims), capi.stream()), acc_fn)
                     gxcl = into
                 else:
-                    gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin))
+                    gxcl = _wino_call(pre + "output_transform" + sfx, Mx, capi.WinoDims(B, D, H, W, Cin), (B, D, H, W, Cin), adt)
                 if ctx.slot is not None:
                     ctx.slot.buf = gxcl
             gx = from_cl(gxcl)
@@ -1416,19 +1588,19 @@ class _GroupNorm(torch.autograd.Function):
         lib = capi.load()
         ctx.res_slot = res_slot
         ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) statistics outputs
-        xcl = to_cl(_f32(x, "group_norm"))
+        xcl, io = _act(to_cl(x), "group_norm")
         Cch = xcl.shape[-1]
         B = 1 if as_batch else xcl.shape[0]
         S = xcl.numel() // (B * Cch)
-        rcl = to_cl(residual) if residual is not None else None
+        rcl = to_cl(residual if residual.dtype == xcl.dtype else residual.to(xcl.dtype)) if residual is not None else None
         given = given_mean is not None
-        d = capi.NormDims(B, Cch, groups, S, float(eps), int(relu), int(given), int(pre_act))
+        d = capi.NormDims(B, Cch, groups, S, float(eps), int(relu), int(given), int(pre_act), 0, 0, io)
         y = torch.empty_like(xcl)
         mean = given_mean.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = given_rstd.contiguous() if given else torch.empty(B * groups, dtype=torch.float32, device=x.device)
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
         w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        nb = 4.0 * xcl.numel() * (3 + (residual is not None) - 2 * given)      # stats read + apply read/write
+        nb = float(xcl.element_size()) * xcl.numel() * (3 + (residual is not None) - 2 * given)      # stats read + apply read/write
         use_mask = bool(relu) and GN_RELU_MASK and not given and any(ctx.needs_input_grad[:4])
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if use_mask else None
         with _span("groupnorm", 0.0, nb, f"fwd   N C={Cch} G={groups} S={S} res={int(residual is not None)}"):
@@ -1442,7 +1614,7 @@ class _GroupNorm(torch.autograd.Function):
                                                    capi.stream()), "ssbev_groupnorm_fwd")
         ctx.save_for_backward(xcl, (mask if use_mask else y) if relu else None, w, mean, rstd)
         ctx.use_mask = use_mask
-        ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given, int(pre_act))
+        ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given, int(pre_act), io)
         ctx.mark_non_differentiable(mean, rstd)
         return from_cl(y), mean, rstd
 
@@ -1450,18 +1622,18 @@ class _GroupNorm(torch.autograd.Function):
     def backward(ctx, gy, _gm, _gr):
         lib = capi.load()
         xcl, y, w, mean, rstd = ctx.saved_tensors
-        B, S, Cch, groups, eps, relu, has_res, given, pre_act = ctx.meta
+        B, S, Cch, groups, eps, relu, has_res, given, pre_act, io = ctx.meta
         if given:
             raise capi.SsbevError("eval-mode (given statistics) normalisation has no HIP backward; use torch for it")
-        gcl = to_cl(gy)
-        d = capi.NormDims(B, Cch, groups, S, eps, relu, 0, pre_act)
+        gcl = to_cl(gy if gy.dtype == xcl.dtype else gy.to(xcl.dtype))
+        d = capi.NormDims(B, Cch, groups, S, eps, relu, 0, pre_act, 0, 0, io)
         gx = torch.empty_like(xcl)
         gres = torch.empty_like(xcl) if has_res else None
         gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
         # stats: x, gy (, y); apply: x, gy (, y) -> gx (, gres); the ReLU bit mask replaces both y reads
-        nb = 4.0 * xcl.numel() * (5 + (relu and not ctx.use_mask) + has_res)
+        nb = float(xcl.element_size()) * xcl.numel() * (5 + (relu and not ctx.use_mask) + has_res)
         with _span("groupnorm", 0.0, nb, f"bwd   N C={Cch} G={groups} S={S} res={int(has_res)}"):
             fn = lib.ssbev_groupnorm_bwd_mask if ctx.use_mask else lib.ssbev_groupnorm_bwd
             capi.check(fn(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
@@ -1487,12 +1659,15 @@ class _NormCat(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         n = len(parts)
         extra = tensors[3 * n] if len(tensors) > 3 * n else None     # an un-normalised last branch (ASPP's image-level one)
-        xs = [to_cl(_f32(tensors[3 * i], "norm_cat")) for i in range(n)]
+        xs = [to_cl(tensors[3 * i]) for i in range(n)]
+        adt = xs[0].dtype if all(x.dtype == xs[0].dtype for x in xs) else torch.float32      # one storage type for the whole cat
+        xs = [_act(x if x.dtype == adt else x.to(adt), "norm_cat")[0] for x in xs]
+        io, esz = (1, 2) if adt == torch.bfloat16 else (0, 4)
         ws_ = [tensors[3 * i + 1].detach().contiguous() for i in range(n)]
         bs_ = [tensors[3 * i + 2].detach().contiguous() for i in range(n)]
         Cs = [x.shape[-1] for x in xs]
         Ctot = sum(Cs) + (extra.shape[1] if extra is not None else 0)
-        out = torch.empty(xs[0].shape[:-1] + (Ctot,), dtype=torch.float32, device=xs[0].device)
+        out = torch.empty(xs[0].shape[:-1] + (Ctot,), dtype=adt, device=xs[0].device)
         if extra is not None:
             out[..., sum(Cs):].copy_(extra.detach().movedim(1, -1))
         saved, stats, metas = [], [], []
@@ -1501,14 +1676,14 @@ class _NormCat(torch.autograd.Function):
             x = xs[i]
             B = 1 if as_batch else x.shape[0]
             S = x.numel() // (B * Cs[i])
-            d = capi.NormDims(B, Cs[i], groups, S, float(eps), int(relu), 0, 0, Ctot, 0)
+            d = capi.NormDims(B, Cs[i], groups, S, float(eps), int(relu), 0, 0, Ctot, 0, io)
             mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
             rstd = torch.empty(B * groups, dtype=torch.float32, device=x.device)
             ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
             mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if relu else None
-            with _span("groupnorm", 0.0, 12.0 * x.numel(), f"fwd   N C={Cs[i]} G={groups} S={S} cat@{c0}/{Ctot}"):
+            with _span("groupnorm", 0.0, 3.0 * esz * x.numel(), f"fwd   N C={Cs[i]} G={groups} S={S} cat@{c0}/{Ctot}"):
                 capi.check(lib.ssbev_groupnorm_fwd_mask(capi.ptr(x), capi.ptr(ws_[i]), capi.ptr(bs_[i]), None,
-                                                        C.c_void_p(out.data_ptr() + 4 * c0), capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask),
+                                                        C.c_void_p(out.data_ptr() + esz * c0), capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask),
                                                         C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_groupnorm_fwd_mask")
             saved += [x, mask, ws_[i], mean, rstd]
@@ -1517,7 +1692,7 @@ class _NormCat(torch.autograd.Function):
             c0 += Cs[i]
         ctx.save_for_backward(*[t for t in saved if t is not None])
         ctx.has_mask = bool(relu)
-        ctx.metas, ctx.relu, ctx.Ctot = metas, int(relu), Ctot
+        ctx.metas, ctx.relu, ctx.Ctot, ctx.io = metas, int(relu), Ctot, io
         ctx.extra_at = sum(Cs) if extra is not None else None
         ctx.mark_non_differentiable(*stats)
         return (from_cl(out), *stats)
@@ -1527,20 +1702,21 @@ class _NormCat(torch.autograd.Function):
         lib = capi.load()
         per = 5 if ctx.has_mask else 4
         sv = ctx.saved_tensors
-        gcl = to_cl(gy)                                    # the whole concatenated gradient, channels-last
+        adt, esz = (torch.bfloat16, 2) if ctx.io else (torch.float32, 4)
+        gcl = to_cl(gy if gy.dtype == adt else gy.to(adt))    # the whole concatenated gradient, channels-last
         grads = []
         for i, (B, S, Cch, groups, eps, c0) in enumerate(ctx.metas):
             if ctx.has_mask:
                 x, mask, w, mean, rstd = sv[per * i: per * i + 5]
             else:
                 (x, w, mean, rstd), mask = sv[per * i: per * i + 4], None
-            d = capi.NormDims(B, Cch, groups, S, eps, ctx.relu, 0, 0, 0, ctx.Ctot)
+            d = capi.NormDims(B, Cch, groups, S, eps, ctx.relu, 0, 0, 0, ctx.Ctot, ctx.io)
             gx = torch.empty_like(x)
             gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
             gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
-            with _span("groupnorm", 0.0, 20.0 * x.numel(), f"bwd   N C={Cch} G={groups} S={S} cat@{c0}/{ctx.Ctot}"):
-                capi.check(lib.ssbev_groupnorm_bwd_mask(C.c_void_p(gcl.data_ptr() + 4 * c0), capi.ptr(x), capi.ptr(mask), capi.ptr(w),
+            with _span("groupnorm", 0.0, 5.0 * esz * x.numel(), f"bwd   N C={Cch} G={groups} S={S} cat@{c0}/{ctx.Ctot}"):
+                capi.check(lib.ssbev_groupnorm_bwd_mask(C.c_void_p(gcl.data_ptr() + esz * c0), capi.ptr(x), capi.ptr(mask), capi.ptr(w),
                                                         capi.ptr(mean), capi.ptr(rstd), capi.ptr(gx), None, capi.ptr(gg),
                                                         capi.ptr(gb), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
                            "ssbev_groupnorm_bwd_mask")
@@ -1564,7 +1740,7 @@ def norm_cat(xs, norms, relu=True, extra=None):
 
 
 def norm_cat_supported(xs):
-    return (NORM_CAT and GN_RELU_MASK and all(x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 for x in xs)
+    return (NORM_CAT and GN_RELU_MASK and all(x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 4 == 0 for x in xs)
             and all(x.shape[0] == xs[0].shape[0] and x.shape[2:] == xs[0].shape[2:] for x in xs))
 
 
@@ -1604,12 +1780,13 @@ class _DualNorm(torch.autograd.Function):
     def forward(ctx, xa, wa, ba, xb, wb, bb, ga, gb, eps_a, eps_b, relu, a_batch, b_batch):
         lib = capi.load()
         ctx.set_materialize_grads(False)
-        acl, bcl = to_cl(_f32(xa, "dual_norm")), to_cl(_f32(xb, "dual_norm"))
+        acl, io = _act(to_cl(xa), "dual_norm")
+        bcl = to_cl(xb if xb.dtype == acl.dtype else xb.to(acl.dtype))
         if acl.shape != bcl.shape:
             raise capi.SsbevError(f"dual_norm: shapes differ, {tuple(acl.shape)} vs {tuple(bcl.shape)}")
         B, Cch = acl.shape[0], acl.shape[-1]
         S = acl.numel() // (B * Cch)
-        d = capi.Norm2Dims(B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch))
+        d = capi.Norm2Dims(B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch), io)
         dev = xa.device
         y = torch.empty_like(acl)
         mean_a = torch.empty((1 if a_batch else B) * ga, dtype=torch.float32, device=dev)
@@ -1623,13 +1800,13 @@ class _DualNorm(torch.autograd.Function):
         nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0)
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(nd)), dtype=torch.int64, device=dev) if relu else None
         wa_, ba_, wb_, bb_ = (t.detach().contiguous() for t in (wa, ba, wb, bb))
-        with _span("groupnorm", 0.0, 4.0 * acl.numel() * 5, f"fwd   N2 C={Cch} Ga={ga} Gb={gb} S={S}"):
+        with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 5, f"fwd   N2 C={Cch} Ga={ga} Gb={gb} S={S}"):
             capi.check(lib.ssbev_groupnorm2_fwd(capi.ptr(acl), capi.ptr(wa_), capi.ptr(ba_), capi.ptr(mean_a), capi.ptr(rstd_a),
                                                 capi.ptr(bcl), capi.ptr(wb_), capi.ptr(bb_), capi.ptr(mean_b), capi.ptr(rstd_b),
                                                 capi.ptr(y), capi.ptr(mask), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
                        "ssbev_groupnorm2_fwd")
         ctx.save_for_backward(acl, bcl, mask, wa_, wb_, mean_a, rstd_a, mean_b, rstd_b)
-        ctx.meta = (B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch))
+        ctx.meta = (B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch), io)
         ctx.mark_non_differentiable(mean_a, rstd_a, mean_b, rstd_b)
         return from_cl(y), mean_a, rstd_a, mean_b, rstd_b
 
@@ -1639,11 +1816,11 @@ class _DualNorm(torch.autograd.Function):
         acl, bcl, mask, wa_, wb_, mean_a, rstd_a, mean_b, rstd_b = ctx.saved_tensors
         d = capi.Norm2Dims(*ctx.meta)
         Cch, dev = ctx.meta[1], gy.device
-        gcl = to_cl(gy)
+        gcl = to_cl(gy if gy.dtype == acl.dtype else gy.to(acl.dtype))
         gxa, gxb = torch.empty_like(acl), torch.empty_like(bcl)
         gga, gba, ggb, gbb = (torch.empty(Cch, dtype=torch.float32, device=dev) for _ in range(4))
         ws = _ws(lib.ssbev_groupnorm2_workspace(C.byref(d)), dev)
-        with _span("groupnorm", 0.0, 4.0 * acl.numel() * 8, f"bwd   N2 C={Cch} Ga={ctx.meta[2]} Gb={ctx.meta[3]} S={ctx.meta[4]}"):
+        with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 8, f"bwd   N2 C={Cch} Ga={ctx.meta[2]} Gb={ctx.meta[3]} S={ctx.meta[4]}"):
             capi.check(lib.ssbev_groupnorm2_bwd(capi.ptr(gcl), capi.ptr(mask), capi.ptr(acl), capi.ptr(wa_), capi.ptr(mean_a),
                                                 capi.ptr(rstd_a), capi.ptr(bcl), capi.ptr(wb_), capi.ptr(mean_b), capi.ptr(rstd_b),
                                                 capi.ptr(gxa), capi.ptr(gxb), capi.ptr(gga), capi.ptr(gba), capi.ptr(ggb),

@@ -129,7 +129,7 @@ _EPOCH = 0
 
 def note_use(weight):
     """Forward of a convolution wrapper that may send this weight's gradient to the side stream."""
-    if not (WGRAD_STREAM and weight.requires_grad and torch.is_grad_enabled()):
+    if not WGRAD_STREAM:                  # (callers ask only when this graph needs the weight's gradient)
         return
     st = getattr(weight, "_ssbev_uses", None)
     if st is None or st[0] != _EPOCH:

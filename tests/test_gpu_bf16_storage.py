@@ -1,0 +1,189 @@
+"""BASELINE configs[3], the bf16 STORAGE mode (functional.set_precision("bf16"), csrc/conv_bf16.hip, bf16 I/O of the normalisation
+and Winograd kernels): kernel-level error budgets.  References are fp32 ATen operators evaluated on the SAME bf16-rounded inputs
+and weights, so what is measured is the kernels' own error: fp32 accumulation order and the one rounding of the stored result
+(2^-9 relative).  Weight gradients are fp32 results of exact bf16 products: tight gates."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from stereoscene_amd import functional as F
+from stereoscene_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _err(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30), ((a - b).norm() / max(b.norm().item(), 1e-30)).item()
+
+
+# kind, Cin, Cout, (D, H, W), k, stride, pad, dilation, tile_hint, winograd allowed
+CASES = [
+    ("conv3d", 32, 32, (6, 8, 36), 3, 1, 1, 1, 0, False),        # generic gather kernel (small grid)
+    ("conv3d", 32, 32, (6, 8, 36), 3, 1, 1, 1, 9, False),        # LDS-ring tap kernel forced (two w-segments, ragged second)
+    ("conv3d", 24, 16, (4, 6, 32), 3, 1, 1, 1, 9, False),        # tap kernel with K, N < 32
+    ("conv3d", 32, 64, (8, 8, 16), 3, 2, 1, 1, 0, False),        # stride 2
+    ("deconv", 64, 32, (4, 4, 8), 3, 2, 1, 1, 0, False),         # transposed k3 s2 p1 op1: parity classes
+    ("conv3d", 64, 64, (4, 8, 8), 3, 1, 1, 1, 0, False),         # wide layer on the direct kernel
+    ("conv3d", 64, 64, (4, 8, 8), 3, 1, 1, 1, 0, True),          # ... and on the F(2,3) pipeline with bf16 on both sides
+    ("conv3d", 128, 128, (4, 6, 10), 1, 1, 0, 1, 0, False),      # pointwise, ragged voxel count (240)
+    ("deconv", 256, 128, (2, 4, 4), 2, 2, 0, 1, 0, False),       # k == s
+    ("conv3d", 24, 40, (3, 5, 20), 3, 1, 1, 1, 0, False),        # channel counts that are multiples of 8 only, W % 16 != 0
+    ("conv2d", 64, 48, (1, 12, 20), 3, 1, 2, 2, 0, False),       # dilated 2-D
+    ("conv2d", 640, 128, (1, 12, 40), 3, 1, 1, 1, 0, True),      # DepthNet-like 2-D Winograd layer
+    ("conv3d", 384, 192, (2, 4, 8), 3, 1, 1, 1, 0, False),       # six column tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16_storage_error_budget(case, monkeypatch):
+    kind, Cin, Cout, (D, H, W), k, st, pad, dil, hint, wino = case
+    nd = 2 if kind == "conv2d" else 3
+    B = 2
+    xs = (B, Cin, H, W) if nd == 2 else (B, Cin, D, H, W)
+    ws = ((Cin, Cout) if kind == "deconv" else (Cout, Cin)) + (k,) * nd
+    x = _r16(S.hash_normal(f"s16/x{case}", xs))
+    w = _r16(S.hash_uniform(f"s16/w{case}", ws, -1, 1) * (3.0 / (Cin * k ** nd)) ** 0.5)
+    bias = S.hash_normal(f"s16/b{case}", (Cout,)) * 0.1
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    op = 1 if (kind == "deconv" and k == 3 and st == 2) else 0
+    if kind == "deconv":
+        want = TF.conv_transpose3d(xc, wc, bc, st, pad, op)
+    elif nd == 2:
+        want = TF.conv2d(xc, wc, bc, st, pad, dil)
+    else:
+        want = TF.conv3d(xc, wc, bc, st, pad, dil)
+    go = _r16(S.hash_normal(f"s16/go{case}", tuple(want.shape)))
+    want.backward(go)
+    mf = torch.channels_last if nd == 2 else torch.channels_last_3d
+    xg = x.to(DEV).to(torch.bfloat16).contiguous(memory_format=mf).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    monkeypatch.setattr(F, "WINO_BF16S", wino)
+    monkeypatch.setattr(F, "TILE_HINT", hint)
+    F.set_precision("bf16")
+    try:
+        if kind == "deconv":
+            got = F.conv_transpose3d(xg, wg, bg, st, pad, op)
+        elif nd == 2:
+            got = F.conv2d(xg, wg, bg, st, pad, dil)
+        else:
+            got = F.conv3d(xg, wg, bg, st, pad, dil)
+        assert got.dtype == torch.bfloat16
+        got.backward(go.to(DEV).to(torch.bfloat16))
+    finally:
+        F.set_precision("fp32")
+    assert xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    # y, gx: one bf16 rounding of the result (the Winograd pipeline rounds V and M as well); gw, gb: fp32 results
+    tol = (3e-2, 1e-2) if wino else (8e-3, 3e-3)
+    for name, a, b in (("y", got, want), ("gx", xg.grad, xc.grad)):
+        rel_max, rel_l2 = _err(a, b)
+        assert rel_max < tol[0] and rel_l2 < tol[1], (name, rel_max, rel_l2)
+    rel_max, rel_l2 = _err(wg.grad, wc.grad)
+    assert rel_max < (2e-2 if wino else 2e-4) and rel_l2 < (1e-2 if wino else 1e-4), ("gw", rel_max, rel_l2)
+    rel_max, rel_l2 = _err(bg.grad, bc.grad)
+    assert rel_l2 < (5e-3 if wino else 1e-3), ("gb", rel_l2)      # (the Winograd route adds the bias as a bf16 tensor op)
+
+
+def test_conv_bf16_storage_relu_epilogue_slot_and_fallbacks():
+    """ReLU epilogue + gradient slots (two consumers accumulate into one bf16 buffer) + the fp32 islands: a 2 -> 32 layer (thin
+    input) and a 32 -> 1 layer keep their fp32 kernels inside the bf16 mode, their wide side re-enters the chain as bf16."""
+    x = _r16(S.hash_normal("s16r/x", (1, 32, 6, 8, 32)))
+    w1 = _r16(S.hash_uniform("s16r/w1", (32, 32, 3, 3, 3), -1, 1) * 0.06)
+    w2 = _r16(S.hash_uniform("s16r/w2", (32, 32, 1, 1, 1), -1, 1) * 0.2)
+    wt = S.hash_uniform("s16r/wt", (1, 32, 3, 3, 3), -1, 1) * 0.06
+    wi = S.hash_uniform("s16r/wi", (32, 2, 3, 3, 3), -1, 1) * 0.2
+
+    def run(conv, xin, ws):
+        a, b = F.fork(xin) if conv is F.conv3d else (xin, xin)
+        y = conv(a, ws[0], None, 1, 1, relu=True) if conv is F.conv3d else torch.relu(conv(a, ws[0], None, 1, 1))
+        z = conv(b, ws[1], None, 1, 0)
+        thin = conv(y + z, ws[2], None, 1, 1)
+        return (y + z), thin
+
+    xc = x.clone().requires_grad_(True)
+    wc = [t.clone().requires_grad_(True) for t in (w1, w2, wt)]
+    yw, tw = run(TF.conv3d, xc, wc)
+    (yw.square().mean() + tw.square().mean()).backward()
+    F.set_precision("bf16")
+    try:
+        xg = x.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        wg = [t.to(DEV).requires_grad_(True) for t in (w1, w2, wt)]
+        yg, tg = run(F.conv3d, xg, wg)
+        assert yg.dtype == torch.bfloat16 and tg.dtype == torch.float32          # the 1-channel volume stays fp32
+        (yg.float().square().mean() + tg.square().mean()).backward()
+        x2 = S.hash_normal("s16r/x2", (1, 2, 6, 8, 32)).to(DEV)
+        wig = wi.to(DEV).requires_grad_(True)
+        yi = F.conv3d(x2, wig, None, 1, 1)
+        assert yi.dtype == torch.bfloat16                                        # thin-input island re-enters as bf16
+        want_i = TF.conv3d(x2.cpu(), wi, None, 1, 1)
+    finally:
+        F.set_precision("fp32")
+    assert _err(yi, want_i)[1] < 4e-3
+    assert _err(yg, yw)[1] < 5e-3 and _err(tg, tw)[1] < 1e-2
+    assert _err(xg.grad, xc.grad)[1] < 2e-2
+    for a, b in zip(wg, wc):
+        assert _err(a.grad, b.grad)[1] < 2e-2
+
+
+@pytest.mark.parametrize("case", [(2, 32, 2, (4, 6, 16), True, True, False), (1, 64, 2, (3, 5, 8), False, True, False),
+                                  (2, 128, 32, (4, 4, 4), True, False, False), (2, 32, 32, (6, 4, 8), True, True, True),
+                                  (1, 32, 1, (4, 6, 16), False, False, False)])
+def test_norms_with_bf16_io(case):
+    """GroupNorm / train-mode BatchNorm with bf16 tensors in and out (ssbev_norm_dims.io_dtype = 1): statistics and arithmetic
+    stay fp32, so against the fp32 operator on the same bf16 inputs only the stored results round."""
+    B, Cch, G, sp, relu, with_res, as_batch = case
+    x = _r16(S.hash_normal(f"n16/x{case}", (B, Cch) + sp) * 2.0 + 0.5)
+    r = _r16(S.hash_normal(f"n16/r{case}", (B, Cch) + sp)) if with_res else None
+    gam, bet = S.hash_normal(f"n16/g{case}", (Cch,)) * 0.3 + 1.0, S.hash_normal(f"n16/b{case}", (Cch,)) * 0.2
+    go = _r16(S.hash_normal(f"n16/go{case}", (B, Cch) + sp))
+
+    def run(dt):
+        xs = x.to(DEV).to(dt).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        rs = r.to(DEV).to(dt).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) if with_res else None
+        g_, b_ = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+        if as_batch:
+            y = F.batch_norm_train(xs, g_, b_, 1e-5, rs, relu)[0]
+        else:
+            y = F.group_norm(xs, G, g_, b_, 1e-5, rs, relu)
+        y.backward(go.to(DEV).to(dt))
+        return y, xs.grad, (rs.grad if with_res else None), g_.grad, b_.grad
+
+    y32, gx32, gr32, gg32, gb32 = run(torch.float32)
+    y16, gx16, gr16, gg16, gb16 = run(torch.bfloat16)
+    assert y16.dtype == torch.bfloat16 and gx16.dtype == torch.bfloat16 and gg16.dtype == torch.float32
+    assert _err(y16, y32)[0] < 8e-3 and _err(gx16, gx32)[0] < 8e-3
+    if with_res:
+        assert _err(gr16, gr32)[0] < 8e-3
+    assert _err(gg16, gg32)[1] < 1e-5 and _err(gb16, gb32)[1] < 1e-5        # same fp32 sums of the same values
+
+
+def test_dual_norm_and_norm_cat_with_bf16_io():
+    sp = (4, 6, 8)
+    xa, xb = (_r16(S.hash_normal(f"d16/{n}", (2, 32) + sp) * 1.5) for n in "ab")
+    ga, ba, gb_, bb = (S.hash_normal(f"d16/p{i}", (32,)) * 0.3 + (1.0 if i % 2 == 0 else 0.0) for i in range(4))
+    go = _r16(S.hash_normal("d16/go", (2, 32) + sp))
+    cat_go = _r16(S.hash_normal("d16/cgo", (2, 64) + sp))
+
+    def run(dt):
+        ts = [t.to(DEV).to(dt).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for t in (xa, xb)]
+        ps = [t.to(DEV).requires_grad_(True) for t in (ga, ba, gb_, bb)]
+        y, _, _ = F.dual_norm(ts[0], ps[0], ps[1], 2, 1e-5, ts[1], ps[2], ps[3], 32, 1e-5, relu=True, b_batch=True)
+        y.backward(go.to(DEV).to(dt))
+        g1 = [t.grad.clone() for t in ts] + [p.grad.clone() for p in ps]
+        for t in ts + ps:
+            t.grad = None
+        yc, _ = F.norm_cat(ts, [(ps[0], ps[1], 2, 1e-5, False), (ps[2], ps[3], 4, 1e-5, False)], relu=True)
+        yc.backward(cat_go.to(DEV).to(dt))
+        return y, g1, yc, [t.grad for t in ts] + [p.grad for p in ps]
+
+    y32, g32, c32, cg32 = run(torch.float32)
+    y16, g16, c16, cg16 = run(torch.bfloat16)
+    assert y16.dtype == torch.bfloat16 and c16.dtype == torch.bfloat16 and c16.shape[1] == 64
+    assert _err(y16, y32)[0] < 8e-3 and _err(c16, c32)[0] < 8e-3
+    for a, b in list(zip(g16, g32)) + list(zip(cg16, cg32)):
+        assert _err(a, b)[0] < (8e-3 if a.dtype == torch.bfloat16 else 1e-4)

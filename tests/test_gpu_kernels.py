@@ -825,7 +825,7 @@ def test_winograd_bf16_mode_error_budget(case):
     go = S.hash_normal(f"wbf/go{case}", tuple(want.shape))
     want.backward(go)
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    F.set_precision("bf16")
+    F.set_precision("bf16_operands")          # the rounds 1-3 mode: fp32 tensors, bf16 operands / transformed-domain tensors
     f43 = F.WINO_F43
     F.WINO_F43 = False                                          # F(2,3) transforms (the F(4,3) ones: test_winograd_f43_tiles)
     try:
@@ -967,7 +967,7 @@ def test_direct_conv_bf16_mode_error_budget(case):
     go = S.hash_normal(f"dbf/go{case}", tuple(want.shape))
     want.backward(go)
     xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    F.set_precision("bf16")
+    F.set_precision("bf16_operands")
     F.TILE_HINT = hint
     wino = F.WINOGRAD
     F.WINOGRAD = False
