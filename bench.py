@@ -44,10 +44,15 @@ EXECUTED_NOTE = {
     "conv_tap_h": "in-kernel Winograd F(2,3) along h: 2/3 of the direct convolution's",
     "conv_wino_fused": "F(4,3)^2 over (h, w) in memory and F(2,3) along d in registers: 1/6 of the direct convolution's; "
                        "bytes = the kernel's own operands P / Mo (2.25x the activations) and packed weights",
+    "conv_tap16": "direct convolution on v_mfma_f32_32x32x16_bf16, bf16 tensors: all of the direct convolution's",
+    "wgrad16": "direct weight gradient on v_mfma_f32_32x32x16_bf16 (all template instances of wgrad16_kernel): all of the operator's",
 }
 SINGLE_KERNEL_FAMILIES = {
     "conv_tap_h": ("conv_taph_kernel", "mfma"),
     "conv_wino_fused": ("wino_df_kernel", "mfma"),
+    # bf16 storage mode (--precision bf16, BASELINE configs[3]): priced against the dense bf16 MFMA peak
+    "conv_tap16": ("conv_tap16_kernel", "mfma"),
+    "wgrad16": ("wgrad16_kernel", "mfma"),
 }
 
 
@@ -454,7 +459,10 @@ def main():
                f"voxels/sec fwd+bwd ({args.config})",
                "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate, fp32 norms/losses)",
+               "dtype": "f32" if args.precision == "fp32" else ("bf16 (bf16 activations and activation gradients in HBM, bf16 MFMA with fp32 "
+                                                                "accumulation; fp32 master weights, weight gradients, norm statistics, "
+                                                                "softmaxes, scatter and losses)" if args.precision == "bf16" else
+                                                                "bf16 operands (fp32 tensors in HBM; the rounds 1-3 mode)"),
                "data": "synthetic",
                "config": {"workload": f"{args.config}: stereo pair features 2x[B,640,48,160] -> 256x256x32 occupancy, "
                                       f"D={model.img_view_transformer.D}, fwd+bwd incl. 4 losses"

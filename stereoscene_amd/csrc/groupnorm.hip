@@ -301,10 +301,28 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
   float gam[4], bet[4], mu[4], rs[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
-  for (; i < total4; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  // (U = 2 -- two grid-stride elements loaded before either is processed, to give the 8-byte bf16 accesses the bytes in
+  // flight of the fp32 kernel's 16-byte ones -- was measured SLOWER in both apply kernels: 41 -> 45 us forward, 60 -> 74 us
+  // backward per launch, profiles/r4d_summary_bf16_storage_b2.txt; the passes are latency-bound on their per-voxel constants)
+  constexpr int U = 1;
+  for (; i < total4; i += U * stride) {
+    float4 xin[U], rin[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long iu = i + u * stride;
+      xin[u] = make_float4(0.f, 0.f, 0.f, 0.f); rin[u] = xin[u];
+      if (iu < total4) {
+        xin[u] = ld4(x + 4 * iu);
+        if (res) rin[u] = ld4(res + 4 * iu);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const long iu = i + u * stride;
+    if (iu >= total4) break;
+    const int b = (int)(iu / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(i % q) * 4;
+      c = (int)(iu % q) * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
     }
@@ -316,14 +334,13 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
         mu[k] = mean[grp]; rs[k] = rstd[grp];
       }
     }
-    const float4 xv = ld4(x + 4 * i);
+    const float4 xv = xin[u];
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
     if (PRE) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
     }
-    float rr[4] = {0, 0, 0, 0};
-    if (res) { const float4 t = ld4(res + 4 * i); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+    const float rr[4] = {rin[u].x, rin[u].y, rin[u].z, rin[u].w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
@@ -336,11 +353,12 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned long long bal = __ballot(v[k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
+        if ((threadIdx.x & 63) == 0) mask[(iu >> 6) * 4 + k] = bal;
       }
     }
-    if (g.ldy == g.C) st4(y + 4 * i, make_float4(v[0], v[1], v[2], v[3]));
-    else st4(y + (i / q) * g.ldy + (i % q) * 4, make_float4(v[0], v[1], v[2], v[3]));
+    if (g.ldy == g.C) st4(y + 4 * iu, make_float4(v[0], v[1], v[2], v[3]));
+    else st4(y + (iu / q) * g.ldy + (iu % q) * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
   }
 }
 
@@ -412,10 +430,34 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
   float gam[4], mu[4], rs[4], c0[4], c1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; mu[k] = 0.f; rs[k] = 0.f; c0[k] = 0.f; c1[k] = 0.f; }
-  for (; i < total4; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  constexpr int U = 1;                             // see gn_apply_fwd_kernel
+  for (; i < total4; i += U * stride) {
+    float4 xin[U], gin[U], yin[U];
+    unsigned long long mw[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long iu = i + u * stride;
+      xin[u] = make_float4(0.f, 0.f, 0.f, 0.f); gin[u] = xin[u]; yin[u] = xin[u];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mw[u][k] = 0ull;
+      if (iu < total4) {
+        xin[u] = ld4(x + 4 * iu);
+        gin[u] = g.ldg == g.C ? ld4(gy + 4 * iu) : ld4(gy + (iu / q) * g.ldg + (iu % q) * 4);
+        if (g.relu && mask) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mw[u][k] = mask[(iu >> 6) * 4 + k];
+        } else if (g.relu) {
+          yin[u] = ld4(y + 4 * iu);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const long iu = i + u * stride;
+    if (iu >= total4) break;
+    const int b = (int)(iu / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(i % q) * 4;
+      c = (int)(iu % q) * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) gam[k] = gamma[c + k];
     }
@@ -427,29 +469,28 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
         mu[k] = mean[grp]; rs[k] = rstd[grp]; c0[k] = coef[grp * 2]; c1[k] = coef[grp * 2 + 1];
       }
     }
-    const float4 xv = ld4(x + 4 * i);
-    const float4 gv = g.ldg == g.C ? ld4(gy + 4 * i) : ld4(gy + (i / q) * g.ldg + (i % q) * 4);
+    const float4 xv = xin[u], gv = gin[u];
     float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
     if (g.relu && mask) {
-      const unsigned long long* mw = mask + (i >> 6) * 4;
-      const int sh = (int)(i & 63);
+      const int sh = (int)(iu & 63);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      for (int k = 0; k < 4; ++k) gs[k] = ((mw[u][k] >> sh) & 1ull) ? gs[k] : 0.0f;
     } else if (g.relu) {
-      const float4 yv = ld4(y + 4 * i);
+      const float4 yv = yin[u];
       gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
       gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
     }
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float u = xs[k], du = 1.0f;
-      if (PRE) gelu_both(xs[k], u, du);
-      const float xh = (u - mu[k]) * rs[k];
+      float uu = xs[k], du = 1.0f;
+      if (PRE) gelu_both(xs[k], uu, du);
+      const float xh = (uu - mu[k]) * rs[k];
       o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
     }
-    st4(gx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
-    if (gres) st4(gres + 4 * i, make_float4(gs[0], gs[1], gs[2], gs[3]));
+    st4(gx + 4 * iu, make_float4(o[0], o[1], o[2], o[3]));
+    if (gres) st4(gres + 4 * iu, make_float4(gs[0], gs[1], gs[2], gs[3]));
+    }
   }
 }
 

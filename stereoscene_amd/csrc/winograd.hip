@@ -37,19 +37,64 @@ __device__ __forceinline__ void a4(float* v, int s) {         // A g : 2 -> 4 va
   v[0] = g0; v[s] = g0 + g1; v[2 * s] = g0 - g1; v[3 * s] = -g1;
 }
 
-template <typename TF, typename TA = float>
+// NV channels per thread (consecutive: one packed access).  NV = 2 is used by the all-bf16 variants: a thread moves 4 bytes per
+// access like the fp32 kernels do with NV = 1 (2-byte lanes left the streaming passes instruction-bound: the bf16 input transform
+// took 346 us where the fp32 one takes 185 -- profiles/r4c_summary_bf16_storage_b2_first.txt).
+template <int NV, typename T>
+__device__ __forceinline__ void ldv(const T* p, float (&o)[NV]) {
+  if constexpr (NV == 1) {
+    o[0] = ld1(p);
+  } else if constexpr (sizeof(T) == 2) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    o[0] = __uint_as_float(u << 16); o[1] = __uint_as_float(u & 0xffff0000u);
+  } else {
+    const float2 f = *reinterpret_cast<const float2*>(p);
+    o[0] = f.x; o[1] = f.y;
+  }
+}
+template <int NV, typename T>
+__device__ __forceinline__ void stv(T* p, const float (&v)[NV]) {
+  if constexpr (NV == 1) {
+    st1(p, v[0]);
+  } else if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<unsigned*>(p) = pack_bf2(v[0], v[1]);
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  }
+}
+
+// decode thread i -> (channel c, tile, td, th, tw, b) for the 3-D tilings / (c, tile, th, tw, bd) for the 2-D ones
+template <int NV>
+__device__ __forceinline__ void wino_decode3(long i, const WinoGeom& g, int& c, long& tile, int& tw, int& th, int& td, int& b) {
+  const int cq = g.C / NV;
+  c = NV * (int)(i % cq);
+  long t = i / cq;
+  tile = t;
+  tw = (int)(t % (g.W / 2)); t /= g.W / 2;
+  th = (int)(t % (g.H / 2)); t /= g.H / 2;
+  td = (int)(t % (g.D / 2));
+  b = (int)(t / (g.D / 2));
+}
+template <int NV>
+__device__ __forceinline__ void wino_decode2(long i, const WinoGeom& g, int& c, long& tile, int& tw, int& th, long& bd) {
+  const int cq = g.C / NV;
+  c = NV * (int)(i % cq);
+  long t = i / cq;
+  tile = t;
+  tw = (int)(t % (g.W / 2)); t /= g.W / 2;
+  th = (int)(t % (g.H / 2));
+  bd = t / (g.H / 2);
+}
+
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2)); t /= g.H / 2;
-  const int td = (int)(t % (g.D / 2));
-  const int b = (int)(t / (g.D / 2));
-  float v[64];
+  int c, tw, th, td, b;
+  long tile;
+  wino_decode3<NV>(i, g, c, tile, tw, th, td, b);
+  float v[NV][64];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int d = 2 * td - 1 + a;
@@ -60,117 +105,149 @@ wino_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, long
       for (int f = 0; f < 4; ++f) {
         const int w = 2 * tw - 1 + f;
         const bool ok = d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
-        v[(a * 4 + e) * 4 + f] = ok ? ld1(x + ((((long)b * g.D + d) * g.H + h) * g.W + w) * g.C + c) : 0.0f;
+        float t[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) t[n] = 0.0f;
+        if (ok) ldv<NV>(x + ((((long)b * g.D + d) * g.H + h) * g.W + w) * g.C + c, t);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v[n][(a * 4 + e) * 4 + f] = t[n];
       }
     }
   }
 #pragma unroll
-  for (int p = 0; p < 16; ++p) bt4(v + p * 4, 1);                              // along w
+  for (int n = 0; n < NV; ++n) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int p = 0; p < 16; ++p) bt4(v[n] + p * 4, 1);                            // along w
 #pragma unroll
-    for (int f = 0; f < 4; ++f) bt4(v + a * 16 + f, 4);                          // along h
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-  for (int p = 0; p < 16; ++p) bt4(v + p, 16);                                 // along d
-  const long T = total / g.C;
+      for (int f = 0; f < 4; ++f) bt4(v[n] + a * 16 + f, 4);                        // along h
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
+    for (int p = 0; p < 16; ++p) bt4(v[n] + p, 16);                               // along d
+  }
+  const long T = total / (g.C / NV);
+#pragma unroll
+  for (int xi = 0; xi < 64; ++xi) {
+    float t[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) t[n] = v[n][xi];
+    stv<NV>(V + ((long)xi * T + tile) * g.C + c, t);
+  }
 }
 
-template <typename TF, typename TA = float>
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino_output_kernel(const TF* __restrict__ M, TA* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2)); t /= g.H / 2;
-  const int td = (int)(t % (g.D / 2));
-  const int b = (int)(t / (g.D / 2));
-  const long T = total / g.C;
-  float m[64];
+  int c, tw, th, td, b;
+  long tile;
+  wino_decode3<NV>(i, g, c, tile, tw, th, td, b);
+  const long T = total / (g.C / NV);
+  float m[NV][64];
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) m[xi] = fload(M + ((long)xi * T + tile) * g.C + c);
-  // A^T along w: 4 -> 2   (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3)
-  float r1[32];
+  for (int xi = 0; xi < 64; ++xi) {
+    float t[NV];
+    ldv<NV>(M + ((long)xi * T + tile) * g.C + c, t);
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    r1[p * 2 + 0] = m[p * 4] + m[p * 4 + 1] + m[p * 4 + 2];
-    r1[p * 2 + 1] = m[p * 4 + 1] - m[p * 4 + 2] - m[p * 4 + 3];
+    for (int n = 0; n < NV; ++n) m[n][xi] = t[n];
   }
-  float r2[16];                                  // along h: index (a*4 + e)*2 + f -> (a*2 + e')*2 + f
+  float out[NV][8];                                  // (dz, e, f)
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int n = 0; n < NV; ++n) {
+    // A^T along w: 4 -> 2   (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3)
+    float r1[32];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const float m0 = r1[(a * 4 + 0) * 2 + f], m1 = r1[(a * 4 + 1) * 2 + f], m2 = r1[(a * 4 + 2) * 2 + f],
-                  m3 = r1[(a * 4 + 3) * 2 + f];
-      r2[(a * 2 + 0) * 2 + f] = m0 + m1 + m2;
-      r2[(a * 2 + 1) * 2 + f] = m1 - m2 - m3;
+    for (int p = 0; p < 16; ++p) {
+      r1[p * 2 + 0] = m[n][p * 4] + m[n][p * 4 + 1] + m[n][p * 4 + 2];
+      r1[p * 2 + 1] = m[n][p * 4 + 1] - m[n][p * 4 + 2] - m[n][p * 4 + 3];
     }
+    float r2[16];                                  // along h: index (a*4 + e)*2 + f -> (a*2 + e')*2 + f
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const float m0 = r2[(0 * 2 + e) * 2 + f], m1 = r2[(1 * 2 + e) * 2 + f], m2 = r2[(2 * 2 + e) * 2 + f],
-                  m3 = r2[(3 * 2 + e) * 2 + f];
-      const float y0 = m0 + m1 + m2, y1 = m1 - m2 - m3;
-      const long base = ((((long)b * g.D + 2 * td) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c;
-      st1(y + base, y0);
-      st1(y + base + (long)g.H * g.W * g.C, y1);
-    }
+      for (int f = 0; f < 2; ++f) {
+        const float m0 = r1[(a * 4 + 0) * 2 + f], m1 = r1[(a * 4 + 1) * 2 + f], m2 = r1[(a * 4 + 2) * 2 + f],
+                    m3 = r1[(a * 4 + 3) * 2 + f];
+        r2[(a * 2 + 0) * 2 + f] = m0 + m1 + m2;
+        r2[(a * 2 + 1) * 2 + f] = m1 - m2 - m3;
+      }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float m0 = r2[(0 * 2 + e) * 2 + f], m1 = r2[(1 * 2 + e) * 2 + f], m2 = r2[(2 * 2 + e) * 2 + f],
+                    m3 = r2[(3 * 2 + e) * 2 + f];
+        out[n][(0 * 2 + e) * 2 + f] = m0 + m1 + m2;
+        out[n][(1 * 2 + e) * 2 + f] = m1 - m2 - m3;
+      }
+  }
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float t[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) t[n] = out[n][(dz * 2 + e) * 2 + f];
+        stv<NV>(y + ((((long)b * g.D + 2 * td + dz) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c, t);
+      }
 }
 
-template <typename TF, typename TA = float>
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino_output_adjoint_kernel(const TA* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2)); t /= g.H / 2;
-  const int td = (int)(t % (g.D / 2));
-  const int b = (int)(t / (g.D / 2));
-  float v[64];
+  int c, tw, th, td, b;
+  long tile;
+  wino_decode3<NV>(i, g, c, tile, tw, th, td, b);
+  float v[NV][64];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-        v[(a * 4 + e) * 4 + f] = ld1(gy + ((((long)b * g.D + 2 * td + a) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c);
+      for (int f = 0; f < 2; ++f) {
+        float t[NV];
+        ldv<NV>(gy + ((((long)b * g.D + 2 * td + a) * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c, t);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+        for (int n = 0; n < NV; ++n) v[n][(a * 4 + e) * 4 + f] = t[n];
+      }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) a4(v + (a * 4 + e) * 4, 1);                      // along w: 2 -> 4
+  for (int n = 0; n < NV; ++n) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) a4(v + a * 16 + f, 4);                           // along h
+      for (int e = 0; e < 2; ++e) a4(v[n] + (a * 4 + e) * 4, 1);                    // along w: 2 -> 4
 #pragma unroll
-  for (int p = 0; p < 16; ++p) a4(v + p, 16);                                  // along d
-  const long T = total / g.C;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-  for (int xi = 0; xi < 64; ++xi) fstore(Z + ((long)xi * T + tile) * g.C + c, v[xi]);
+      for (int f = 0; f < 4; ++f) a4(v[n] + a * 16 + f, 4);                         // along h
+#pragma unroll
+    for (int p = 0; p < 16; ++p) a4(v[n] + p, 16);                                // along d
+  }
+  const long T = total / (g.C / NV);
+#pragma unroll
+  for (int xi = 0; xi < 64; ++xi) {
+    float t[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) t[n] = v[n][xi];
+    stv<NV>(Z + ((long)xi * T + tile) * g.C + c, t);
+  }
 }
 
 // ---- 2-D variant, F(2x2, 3x3): 16 frequencies, tiles over (h, w); the D axis of the dims struct is a batch axis ----
-template <typename TF, typename TA = float>
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino2d_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2));
-  const long bd = t / (g.H / 2);                     // b * D + d
-  float v[16];
+  int c, tw, th;
+  long tile, bd;
+  wino_decode2<NV>(i, g, c, tile, tw, th, bd);
+  float v[NV][16];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int h = 2 * th - 1 + e;
@@ -178,80 +255,117 @@ wino2d_input_kernel(const TA* __restrict__ x, TF* __restrict__ V, WinoGeom g, lo
     for (int f = 0; f < 4; ++f) {
       const int w = 2 * tw - 1 + f;
       const bool ok = h >= 0 && h < g.H && w >= 0 && w < g.W;
-      v[e * 4 + f] = ok ? ld1(x + ((bd * g.H + h) * g.W + w) * g.C + c) : 0.0f;
+      float t[NV];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) t[n] = 0.0f;
+      if (ok) ldv<NV>(x + ((bd * g.H + h) * g.W + w) * g.C + c, t);
+#pragma unroll
+      for (int n = 0; n < NV; ++n) v[n][e * 4 + f] = t[n];
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bt4(v + e * 4, 1);
+  for (int n = 0; n < NV; ++n) {
 #pragma unroll
-  for (int f = 0; f < 4; ++f) bt4(v + f, 4);
-  const long T = total / g.C;
+    for (int e = 0; e < 4; ++e) bt4(v[n] + e * 4, 1);
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) fstore(V + ((long)xi * T + tile) * g.C + c, v[xi]);
+    for (int f = 0; f < 4; ++f) bt4(v[n] + f, 4);
+  }
+  const long T = total / (g.C / NV);
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) {
+    float t[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) t[n] = v[n][xi];
+    stv<NV>(V + ((long)xi * T + tile) * g.C + c, t);
+  }
 }
 
-template <typename TF, typename TA = float>
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino2d_output_kernel(const TF* __restrict__ M, TA* __restrict__ y, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2));
-  const long bd = t / (g.H / 2);
-  const long T = total / g.C;
-  float m[16];
+  int c, tw, th;
+  long tile, bd;
+  wino_decode2<NV>(i, g, c, tile, tw, th, bd);
+  const long T = total / (g.C / NV);
+  float m[NV][16];
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) m[xi] = fload(M + ((long)xi * T + tile) * g.C + c);
-  float r[8];
+  for (int xi = 0; xi < 16; ++xi) {
+    float t[NV];
+    ldv<NV>(M + ((long)xi * T + tile) * g.C + c, t);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    r[e * 2 + 0] = m[e * 4] + m[e * 4 + 1] + m[e * 4 + 2];
-    r[e * 2 + 1] = m[e * 4 + 1] - m[e * 4 + 2] - m[e * 4 + 3];
+    for (int n = 0; n < NV; ++n) m[n][xi] = t[n];
   }
-  float oldv[4] = {0.f, 0.f, 0.f, 0.f};
+  float oldv[NV][4];
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oldv[n][k] = 0.0f;
   if (g.acc) {                                       // y += result: old values first, then the stores
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-      oldv[2 * f] = ld1(y + base);
-      oldv[2 * f + 1] = ld1(y + base + (long)g.W * g.C);
+      float t0[NV], t1[NV];
+      ldv<NV>(y + base, t0);
+      ldv<NV>(y + base + (long)g.W * g.C, t1);
+#pragma unroll
+      for (int n = 0; n < NV; ++n) { oldv[n][2 * f] = t0[n]; oldv[n][2 * f + 1] = t1[n]; }
     }
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const float y0 = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f], y1 = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f];
+    float y0[NV], y1[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[e * 2 + 0] = m[n][e * 4] + m[n][e * 4 + 1] + m[n][e * 4 + 2];
+        r[e * 2 + 1] = m[n][e * 4 + 1] - m[n][e * 4 + 2] - m[n][e * 4 + 3];
+      }
+      y0[n] = r[0 * 2 + f] + r[1 * 2 + f] + r[2 * 2 + f] + oldv[n][2 * f];
+      y1[n] = r[1 * 2 + f] - r[2 * 2 + f] - r[3 * 2 + f] + oldv[n][2 * f + 1];
+    }
     const long base = ((bd * g.H + 2 * th) * g.W + 2 * tw + f) * g.C + c;
-    st1(y + base, y0 + oldv[2 * f]);
-    st1(y + base + (long)g.W * g.C, y1 + oldv[2 * f + 1]);
+    stv<NV>(y + base, y0);
+    stv<NV>(y + base + (long)g.W * g.C, y1);
   }
 }
 
-template <typename TF, typename TA = float>
+template <typename TF, typename TA = float, int NV = 1>
 __global__ void __launch_bounds__(256)
 wino2d_output_adjoint_kernel(const TA* __restrict__ gy, TF* __restrict__ Z, WinoGeom g, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % g.C);
-  long t = i / g.C;
-  const long tile = t;
-  const int tw = (int)(t % (g.W / 2)); t /= g.W / 2;
-  const int th = (int)(t % (g.H / 2));
-  const long bd = t / (g.H / 2);
-  float v[16];
+  int c, tw, th;
+  long tile, bd;
+  wino_decode2<NV>(i, g, c, tile, tw, th, bd);
+  float v[NV][16];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) v[e * 4 + f] = ld1(gy + ((bd * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c);
+    for (int f = 0; f < 2; ++f) {
+      float t[NV];
+      ldv<NV>(gy + ((bd * g.H + 2 * th + e) * g.W + 2 * tw + f) * g.C + c, t);
 #pragma unroll
-  for (int e = 0; e < 2; ++e) a4(v + e * 4, 1);
+      for (int n = 0; n < NV; ++n) v[n][e * 4 + f] = t[n];
+    }
 #pragma unroll
-  for (int f = 0; f < 4; ++f) a4(v + f, 4);
-  const long T = total / g.C;
+  for (int n = 0; n < NV; ++n) {
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) fstore(Z + ((long)xi * T + tile) * g.C + c, v[xi]);
+    for (int e = 0; e < 2; ++e) a4(v[n] + e * 4, 1);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) a4(v[n] + f, 4);
+  }
+  const long T = total / (g.C / NV);
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) {
+    float t[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) t[n] = v[n][xi];
+    stv<NV>(Z + ((long)xi * T + tile) * g.C + c, t);
+  }
 }
 
 bool wino2d_ok(const ssbev_wino_dims* d) {
@@ -1051,13 +1165,26 @@ SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16, wino2d_input_kernel<bf16_b
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform_bf16, wino2d_output_kernel<bf16_bits>, uint16_t, float)
 SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint_bf16, wino2d_output_adjoint_kernel<bf16_bits>, float, uint16_t)
 
-// bf16 ACTIVATIONS on the tensor side as well (round 4, bf16 storage mode): x / gy / y are bf16 channels-last tensors
-SSBEV_WINO_ENTRY(ssbev_wino_input_transform_bf16a, (wino_input_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
-SSBEV_WINO_ENTRY(ssbev_wino_output_transform_bf16a, (wino_output_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
-SSBEV_WINO_ENTRY(ssbev_wino_output_adjoint_bf16a, (wino_output_adjoint_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_input_transform_bf16a, (wino2d_input_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_transform_bf16a, (wino2d_output_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
-SSBEV_WINO2D_ENTRY(ssbev_wino2d_output_adjoint_bf16a, (wino2d_output_adjoint_kernel<bf16_bits, bf16_bits>), uint16_t, uint16_t)
+// bf16 ACTIVATIONS on the tensor side as well (round 4, bf16 storage mode): x / gy / y are bf16 channels-last tensors; two
+// channels per thread (packed 4-byte accesses) whenever C is even
+#define SSBEV_WINO16_ENTRY(NAME, KERNEL, DIV_D, OK)                                                                   \
+  int NAME(const uint16_t* src, uint16_t* dst, const ssbev_wino_dims* d, ssbev_stream_t stream) {                    \
+    if (!OK(d) || !src || !dst) return SSBEV_EINVAL;                                                                  \
+    const int nv = d->C % 2 == 0 ? 2 : 1;                                                                             \
+    const long total = (long)d->B * (d->D / DIV_D) * (d->H / 2) * (d->W / 2) * (d->C / nv);                           \
+    const WinoGeom g{d->B, d->D, d->H, d->W, d->C};                                                                   \
+    if (nv == 2)                                                                                                      \
+      hipLaunchKernelGGL((KERNEL<bf16_bits, bf16_bits, 2>), dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((KERNEL<bf16_bits, bf16_bits, 1>), dim3(cdiv((size_t)total, 256)), dim3(256), 0, as_stream(stream), src, dst, g, total); \
+    return ssbev_launch_status();                                                                                     \
+  }
+SSBEV_WINO16_ENTRY(ssbev_wino_input_transform_bf16a, wino_input_kernel, 2, wino_ok)
+SSBEV_WINO16_ENTRY(ssbev_wino_output_transform_bf16a, wino_output_kernel, 2, wino_ok)
+SSBEV_WINO16_ENTRY(ssbev_wino_output_adjoint_bf16a, wino_output_adjoint_kernel, 2, wino_ok)
+SSBEV_WINO16_ENTRY(ssbev_wino2d_input_transform_bf16a, wino2d_input_kernel, 1, wino2d_ok)
+SSBEV_WINO16_ENTRY(ssbev_wino2d_output_transform_bf16a, wino2d_output_kernel, 1, wino2d_ok)
+SSBEV_WINO16_ENTRY(ssbev_wino2d_output_adjoint_bf16a, wino2d_output_adjoint_kernel, 1, wino2d_ok)
 
 SSBEV_WINO_ENTRY(ssbev_wino_input_transform_bf16, wino_input_kernel<bf16_bits>, float, uint16_t)
 SSBEV_WINO_ENTRY(ssbev_wino_output_transform_bf16, wino_output_kernel<bf16_bits>, uint16_t, float)

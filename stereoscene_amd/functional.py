@@ -709,7 +709,8 @@ class _ConvNd16(torch.autograd.Function):
         d.precision = 3 if out_fp32 else 2
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        with _span("conv_bf16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "fwd")):
+        fam = "conv_tap16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 0) == 17) else "conv_gather16"
+        with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "fwd")):
             wp = _packed(weight.detach(), d, 0)
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d), capi.stream()),
                        "ssbev_conv_fwd[bf16]")
@@ -738,7 +739,7 @@ class _ConvNd16(torch.autograd.Function):
         def weight_gradient():
             gwp = torch.empty(tuple(weight.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            with _span("conv_bf16_wgrad", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
+            with _span("wgrad16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
                 capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d), capi.ptr(ws),
                                                      ws.numel(), capi.stream()), "ssbev_conv_bwd_weight[bf16]")
             return gwp
@@ -757,7 +758,8 @@ class _ConvNd16(torch.autograd.Function):
             if into is not None:
                 d.accumulate = 1
             gxcl = into if into is not None else torch.empty_like(xcl)
-            with _span("conv_bf16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "dgrad")):
+            fam = "conv_tap16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 1) == 17) else "conv_gather16"
+            with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "dgrad")):
                 wpt = _packed(weight.detach(), d, 1)
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d), capi.stream()),
                            "ssbev_conv_bwd_data[bf16]")
