@@ -50,114 +50,141 @@ __device__ __forceinline__ float gelu_f(float x) {
   return u;
 }
 
+// VW consecutive channels per lane: 4 (one 16-byte fp32 access, or 8 bytes of bf16) or -- bf16 tensors with C % 8 == 0 -- 8
+// (one 16-byte bf16 access).  With 8-byte accesses the bf16 passes ran at half the bytes per second of the fp32 ones (round 4:
+// 17.3 -> 14.3 ms per two-sample step instead of -> 9); the ReLU bit mask keeps one bit per element, VW words per 64 lanes.
+template <int VW, typename T>
+__device__ __forceinline__ void ldn(const T* p, float (&o)[VW]) {
+  if constexpr (VW == 4) {
+    const float4 v = ld4(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    static_assert(sizeof(T) == 2, "8 channels per lane: bf16 tensors only");
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+}
+template <int VW, typename T>
+__device__ __forceinline__ void stn(T* p, const float (&v)[VW]) {
+  if constexpr (VW == 4) {
+    st4(p, make_float4(v[0], v[1], v[2], v[3]));
+  } else {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  }
+}
+
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): (sum g, sum g * xhat) with g = gy * [y > 0] when relu is fused.
-template <int MODE, bool PRE, int RM = 0, typename T = float>   // RM: where the fused ReLU's sign comes from (0 none, 1 bit mask, 2 y)
+template <int MODE, bool PRE, int RM = 0, typename T = float, int VW = 4>   // RM: source of the fused ReLU's sign (0 none, 1 bit mask, 2 y)
 __global__ void __launch_bounds__(NT)
 gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ y,
                   const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
                   const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g) {
   extern __shared__ float lds[];                       // [rows][Cs][2]
-  // channel slab of this block (blockIdx.z): up to NT float4 lanes = 1024 channels (the image branch's BatchNorms
+  // channel slab of this block (blockIdx.z): up to NT lanes of VW channels (the image branch's BatchNorms
   // reach 3840 channels; everything on the voxel path fits one slab)
-  const int q0 = blockIdx.z * NT;                      // first float4 lane of the slab
-  const int q = min((g.C >> 2) - q0, NT);              // float4 lanes per voxel in this slab
-  const int Cs = q * 4;
+  const int q0 = blockIdx.z * NT;                      // first lane of the slab
+  const int q = min(g.C / VW - q0, NT);                // lanes per voxel in this slab
+  const int Cs = q * VW;
   const int rows = NT / q > 0 ? NT / q : 1;            // voxels handled per block iteration
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const long s0 = (long)chunk * g.chunk_len;
   const long s1 = min(g.S, s0 + g.chunk_len);
-  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  float a0[VW], a1[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) { a0[k] = 0.0f; a1[k] = 0.0f; }
   const int c4 = tid % q, r = tid / q;
   if (r < rows) {
-    const int c = (q0 + c4) * 4;
+    const int c = (q0 + c4) * VW;
     const int cpg = g.C / g.G;
-    float mu4[4] = {0.f, 0.f, 0.f, 0.f}, rs4[4] = {1.f, 1.f, 1.f, 1.f};      // this thread's channels never change
+    float mu4[VW], rs4[VW];                             // this thread's channels never change
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { mu4[k] = 0.0f; rs4[k] = 1.0f; }
     if (MODE == 1) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { mu4[k] = mean[b * g.G + (c + k) / cpg]; rs4[k] = rstd[b * g.G + (c + k) / cpg]; }
+      for (int k = 0; k < VW; ++k) { mu4[k] = mean[b * g.G + (c + k) / cpg]; rs4[k] = rstd[b * g.G + (c + k) / cpg]; }
     }
-    // a float4 never straddles groups when cpg % 4 == 0; otherwise handled per component below
     const size_t base = (size_t)b * g.S * g.C;
     // MODE 0 accumulates SHIFTED sums, sum (u - p) and sum (u - p)^2 with the pivot p = the channel's value at voxel 0 of
     // the sample: the fp32 partials then hold no large common offset, and the finalize kernels rebuild sum u and sum u^2
     // in double -- E[u^2] - mean^2 from plain fp32 partials cancels catastrophically when |mean| >> std
-    float pv[4] = {0.f, 0.f, 0.f, 0.f};
+    float pv[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) pv[k] = 0.0f;
     if (MODE == 0) {
-      const float4 p4 = ld4(x + base + c);
-      pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+      ldn<VW>(x + base + c, pv);
       if (PRE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pv[k] = gelu_f(pv[k]);
+        for (int k = 0; k < VW; ++k) pv[k] = gelu_f(pv[k]);
       }
     }
     // UB voxels per trip: all their loads are issued before the first sum (the plain loop kept ~2 loads per thread in flight
     // and ran at 3.4 TB/s); the sums themselves stay in voxel order, so the partials are bit for bit what they were
     constexpr int UB = 4;
-    auto accumulate = [&](const size_t off, const float4 xv, const float4 gv, const float4 yv, const unsigned long long (&mw)[4])
-        __attribute__((always_inline)) {
-      float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      if (PRE) {
+    struct Item { size_t off; float xv[VW], gv[VW], yv[VW]; unsigned long long mw[4]; };
+    auto accumulate = [&](const Item& it) __attribute__((always_inline)) {
+      float xs[VW];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xs[k] = gelu_f(xs[k]);
-      }
+      for (int k = 0; k < VW; ++k) xs[k] = PRE ? gelu_f(it.xv[k]) : it.xv[k];
       if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const float dv = xs[k] - pv[k]; a0[k] += dv; a1[k] += dv * dv; }
+        for (int k = 0; k < VW; ++k) { const float dv = xs[k] - pv[k]; a0[k] += dv; a1[k] += dv * dv; }
       } else {
-        float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-        if (RM == 1) {                          // 1 bit per element instead of re-reading y (see gn_apply_fwd_kernel)
-          const int sh = (int)((off >> 2) & 63);
+        float gs[VW];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+        for (int k = 0; k < VW; ++k) gs[k] = it.gv[k];
+        if (RM == 1) {                          // 1 bit per element instead of re-reading y (see gn_apply_fwd_kernel)
+          // the mask is laid out per channel QUAD (word (quad / 64) * 4 + component, bit quad % 64) whatever VW is: an
+          // 8-channel lane reads two neighbouring bits (its first quad index is even) of the same four words
+          const int sh = (int)((it.off >> 2) & 63);
+#pragma unroll
+          for (int k = 0; k < VW; ++k) gs[k] = ((it.mw[k & 3] >> (sh + (k >> 2))) & 1ull) ? gs[k] : 0.0f;
         } else if (RM == 2) {
-          gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
-          gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) gs[k] = it.yv[k] > 0.0f ? gs[k] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VW; ++k) {
           a0[k] += gs[k];
           a1[k] += gs[k] * (xs[k] - mu4[k]) * rs4[k];
         }
       }
     };
-    auto fetch = [&](long s, size_t& off, float4& xv, float4& gv, float4& yv, unsigned long long (&mw)[4])
-        __attribute__((always_inline)) {
-      off = base + (size_t)s * g.C + c;
-      xv = ld4(x + off);
+    auto fetch = [&](long s, Item& it) __attribute__((always_inline)) {
+      it.off = base + (size_t)s * g.C + c;
+      ldn<VW>(x + it.off, it.xv);
       if (MODE == 1) {
-        gv = ld4(gy + ((size_t)b * g.S + s) * g.ldg + c);
+        ldn<VW>(gy + ((size_t)b * g.S + s) * g.ldg + c, it.gv);
         if (RM == 1) {
-          const unsigned long long* mp = mask + ((off >> 2) >> 6) * 4;
+          const unsigned long long* mp = mask + ((it.off >> 2) >> 6) * 4;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) mw[k] = mp[k];
+          for (int k = 0; k < 4; ++k) it.mw[k] = mp[k];
         } else if (RM == 2) {
-          yv = ld4(y + off);
+          ldn<VW>(y + it.off, it.yv);
         }
       }
     };
     long s = s0 + r;
     for (; s + (long)(UB - 1) * rows < s1; s += (long)UB * rows) {
-      size_t off[UB];
-      float4 xv[UB], gv[UB], yv[UB];
-      unsigned long long mw[UB][4];
+      Item it[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) fetch(s + (long)u * rows, off[u], xv[u], gv[u], yv[u], mw[u]);
+      for (int u = 0; u < UB; ++u) fetch(s + (long)u * rows, it[u]);
 #pragma unroll
-      for (int u = 0; u < UB; ++u) accumulate(off[u], xv[u], gv[u], yv[u], mw[u]);
+      for (int u = 0; u < UB; ++u) accumulate(it[u]);
     }
     for (; s < s1; s += rows) {
-      size_t off;
-      float4 xv, gv, yv;
-      unsigned long long mw[4];
-      fetch(s, off, xv, gv, yv, mw);
-      accumulate(off, xv, gv, yv, mw);
+      Item it;
+      fetch(s, it);
+      accumulate(it);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      lds[((size_t)r * Cs + c4 * 4 + k) * 2 + 0] = a0[k];
-      lds[((size_t)r * Cs + c4 * 4 + k) * 2 + 1] = a1[k];
+    for (int k = 0; k < VW; ++k) {
+      lds[((size_t)r * Cs + c4 * VW + k) * 2 + 0] = a0[k];
+      lds[((size_t)r * Cs + c4 * VW + k) * 2 + 1] = a1[k];
     }
   }
   __syncthreads();
@@ -165,7 +192,7 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __
   for (int t = tid; t < 2 * Cs; t += NT) {
     float s = 0.0f;
     for (int rr = 0; rr < rows; ++rr) s += lds[(size_t)rr * Cs * 2 + t];
-    partial[((size_t)(b * g.chunks + chunk) * g.C + q0 * 4) * 2 + t] = s;
+    partial[((size_t)(b * g.chunks + chunk) * g.C + q0 * VW) * 2 + t] = s;
   }
 }
 
@@ -288,77 +315,60 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
 }
 
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
-template <bool PRE, typename T = float>
+template <bool PRE, typename T = float, int VW = 4>
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const T* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
-                    T* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total4) {
-  const int q = g.C >> 2, cpg = g.C / g.G;
+                    T* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long totalv) {
+  const int q = g.C / VW, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;            // see gn_apply_bwd_kernel
   long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * 4, bcur = -1;
-  float gam[4], bet[4], mu[4], rs[4];
+  int c = (int)(i % q) * VW, bcur = -1;
+  float gam[VW], bet[VW], mu[VW], rs[VW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
-  // (U = 2 -- two grid-stride elements loaded before either is processed, to give the 8-byte bf16 accesses the bytes in
-  // flight of the fp32 kernel's 16-byte ones -- was measured SLOWER in both apply kernels: 41 -> 45 us forward, 60 -> 74 us
-  // backward per launch, profiles/r4d_summary_bf16_storage_b2.txt; the passes are latency-bound on their per-voxel constants)
-  constexpr int U = 1;
-  for (; i < total4; i += U * stride) {
-    float4 xin[U], rin[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long iu = i + u * stride;
-      xin[u] = make_float4(0.f, 0.f, 0.f, 0.f); rin[u] = xin[u];
-      if (iu < total4) {
-        xin[u] = ld4(x + 4 * iu);
-        if (res) rin[u] = ld4(res + 4 * iu);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-    const long iu = i + u * stride;
-    if (iu >= total4) break;
-    const int b = (int)(iu / ((long)q * g.S));
+  for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
+  for (; i < totalv; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(iu % q) * 4;
+      c = (int)(i % q) * VW;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
+      for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
     }
     if (!fixed || b != bcur) {
       bcur = b;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VW; ++k) {
         const int grp = b * g.G + (c + k) / cpg;
         mu[k] = mean[grp]; rs[k] = rstd[grp];
       }
     }
-    const float4 xv = xin[u];
-    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+    float v[VW], rr[VW];
+    ldn<VW>(x + (size_t)VW * i, v);
     if (PRE) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+      for (int k = 0; k < VW; ++k) v[k] = gelu_f(v[k]);
     }
-    const float rr[4] = {rin[u].x, rin[u].y, rin[u].z, rin[u].w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < VW; ++k) rr[k] = 0.0f;
+    if (res) ldn<VW>(res + (size_t)VW * i, rr);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
       float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
       v[k] = g.relu ? fmaxf(o, 0.0f) : o;
     }
     if (mask) {
-      // ReLU mask for the backward pass: word (i / 64) * 4 + k holds bit (i % 64) = [component k of float4 i is > 0].  The 64
-      // lanes of a wave own 64 consecutive float4s (block offsets and the grid stride are multiples of 256), so one ballot
-      // per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
+      // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
+      // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
+      // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VW; ++k) {
         const unsigned long long bal = __ballot(v[k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) mask[(iu >> 6) * 4 + k] = bal;
+        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
       }
     }
-    if (g.ldy == g.C) st4(y + 4 * iu, make_float4(v[0], v[1], v[2], v[3]));
-    else st4(y + (iu / q) * g.ldy + (iu % q) * 4, make_float4(v[0], v[1], v[2], v[3]));
-    }
+    if (g.ldy == g.C) stn<VW>(y + (size_t)VW * i, v);
+    else stn<VW>(y + (i / q) * g.ldy + (i % q) * VW, v);
   }
 }
 
@@ -414,83 +424,62 @@ gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restric
 }
 
 // gx = (gamma * g - xhat * ds/n - db/n) * rstd ;  gres = g  (g = gy masked by the fused ReLU)
-template <bool PRE, typename T = float>
+template <bool PRE, typename T = float, int VW = 4>
 __global__ void __launch_bounds__(NT)
 gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ coef, T* __restrict__ gx, T* __restrict__ gres,
-                    const unsigned long long* __restrict__ mask, GnGeom g, long total4) {
-  const int q = g.C >> 2, cpg = g.C / g.G;
+                    const unsigned long long* __restrict__ mask, GnGeom g, long totalv) {
+  const int q = g.C / VW, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
-  // the launch makes `stride` a multiple of q whenever it can: a thread then always owns the same four channels and
+  // the launch makes `stride` a multiple of q whenever it can: a thread then always owns the same channels and
   // the per-channel / per-group constants leave the streaming loop
   const bool fixed = stride % q == 0;
   long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * 4, bcur = -1;
-  float gam[4], mu[4], rs[4], c0[4], c1[4];
+  int c = (int)(i % q) * VW, bcur = -1;
+  float gam[VW], mu[VW], rs[VW], c0[VW], c1[VW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { gam[k] = gamma[c + k]; mu[k] = 0.f; rs[k] = 0.f; c0[k] = 0.f; c1[k] = 0.f; }
-  constexpr int U = 1;                             // see gn_apply_fwd_kernel
-  for (; i < total4; i += U * stride) {
-    float4 xin[U], gin[U], yin[U];
-    unsigned long long mw[U][4];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long iu = i + u * stride;
-      xin[u] = make_float4(0.f, 0.f, 0.f, 0.f); gin[u] = xin[u]; yin[u] = xin[u];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) mw[u][k] = 0ull;
-      if (iu < total4) {
-        xin[u] = ld4(x + 4 * iu);
-        gin[u] = g.ldg == g.C ? ld4(gy + 4 * iu) : ld4(gy + (iu / q) * g.ldg + (iu % q) * 4);
-        if (g.relu && mask) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) mw[u][k] = mask[(iu >> 6) * 4 + k];
-        } else if (g.relu) {
-          yin[u] = ld4(y + 4 * iu);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-    const long iu = i + u * stride;
-    if (iu >= total4) break;
-    const int b = (int)(iu / ((long)q * g.S));
+  for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; mu[k] = 0.f; rs[k] = 0.f; c0[k] = 0.f; c1[k] = 0.f; }
+  for (; i < totalv; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(iu % q) * 4;
+      c = (int)(i % q) * VW;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gam[k] = gamma[c + k];
+      for (int k = 0; k < VW; ++k) gam[k] = gamma[c + k];
     }
     if (!fixed || b != bcur) {
       bcur = b;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VW; ++k) {
         const int grp = b * g.G + (c + k) / cpg;
         mu[k] = mean[grp]; rs[k] = rstd[grp]; c0[k] = coef[grp * 2]; c1[k] = coef[grp * 2 + 1];
       }
     }
-    const float4 xv = xin[u], gv = gin[u];
-    float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float xs[VW], gs[VW];
+    ldn<VW>(x + (size_t)VW * i, xs);
+    if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, gs);
+    else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
     if (g.relu && mask) {
-      const int sh = (int)(iu & 63);
+      const unsigned long long* mw = mask + (i >> 6) * VW;
+      const int sh = (int)(i & 63);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gs[k] = ((mw[u][k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
     } else if (g.relu) {
-      const float4 yv = yin[u];
-      gs[0] = yv.x > 0.0f ? gs[0] : 0.0f; gs[1] = yv.y > 0.0f ? gs[1] : 0.0f;
-      gs[2] = yv.z > 0.0f ? gs[2] : 0.0f; gs[3] = yv.w > 0.0f ? gs[3] : 0.0f;
-    }
-    float o[4];
+      float yv[VW];
+      ldn<VW>(y + (size_t)VW * i, yv);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float uu = xs[k], du = 1.0f;
-      if (PRE) gelu_both(xs[k], uu, du);
-      const float xh = (uu - mu[k]) * rs[k];
+      for (int k = 0; k < VW; ++k) gs[k] = yv[k] > 0.0f ? gs[k] : 0.0f;
+    }
+    float o[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      float u = xs[k], du = 1.0f;
+      if (PRE) gelu_both(xs[k], u, du);
+      const float xh = (u - mu[k]) * rs[k];
       o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
     }
-    st4(gx + 4 * iu, make_float4(o[0], o[1], o[2], o[3]));
-    if (gres) st4(gres + 4 * iu, make_float4(gs[0], gs[1], gs[2], gs[3]));
-    }
+    stn<VW>(gx + (size_t)VW * i, o);
+    if (gres) stn<VW>(gres + (size_t)VW * i, gs);
   }
 }
 
@@ -527,13 +516,19 @@ GnGeom make_geom(const ssbev_norm_dims* d) {
   return g;
 }
 
-size_t lds_bytes(const GnGeom& g) {
-  const int q = std::min(g.C >> 2, NT);               // widest slab; narrower ones need rows * q <= NT entries too
+size_t lds_bytes(const GnGeom& g, int vw = 4) {
+  const int q = std::min(g.C / vw, NT);               // widest slab; narrower ones need rows * q <= NT entries too
   const int rows = NT / q > 0 ? NT / q : 1;
-  return (size_t)std::max(rows * q, NT) * 4 * 2 * sizeof(float);
+  return (size_t)std::max(rows * q, NT) * vw * 2 * sizeof(float);
 }
 
-unsigned gn_slabs(const GnGeom& g) { return cdiv((size_t)(g.C >> 2), NT); }
+unsigned gn_slabs(const GnGeom& g, int vw = 4) { return cdiv((size_t)(g.C / vw), NT); }
+
+// channels per lane of the STATISTICS passes: 8 for bf16 tensors whose channel count allows 16-byte lanes, else 4 (round 4,
+// measured per launch on the two-sample step: statistics passes 47 -> 32 us and 18.6 -> 19.6 us with 8; the apply passes got
+// SLOWER with 8 -- 41 -> 56 us forward, 60 -> 74 us backward: twice the registers for the per-channel constants, half the
+// waves in flight -- and stay at 4.  The ReLU bit mask has ONE layout, per channel quad, read by both widths.)
+int gn_vw(int io_dtype, int C) { return (io_dtype == 1 && C % 8 == 0) ? 8 : 4; }
 
 // running statistics of a training-mode BatchNorm (nn.BatchNorm semantics: unbiased variance in the running buffer)
 __global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -563,109 +558,109 @@ struct Gn2Geom {
   int relu, a_batch, b_batch;
 };
 
-template <bool BWD>
+template <bool BWD, int VW>
 __device__ __forceinline__ void gn2_load_stats(const Gn2Geom& g, int b, int c, const float* mean_a, const float* rstd_a,
                                                const float* mean_b, const float* rstd_b, const float* coef_a, const float* coef_b,
-                                               float (&mua)[4], float (&rsa)[4], float (&mub)[4], float (&rsb)[4],
-                                               float (&c0a)[4], float (&c1a)[4], float (&c0b)[4], float (&c1b)[4]) {
+                                               float (&mua)[VW], float (&rsa)[VW], float (&mub)[VW], float (&rsb)[VW],
+                                               float (&c0a)[VW], float (&c1a)[VW], float (&c0b)[VW], float (&c1b)[VW]) {
   const int cpa = g.C / g.Ga, cpb = g.C / g.Gb;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < VW; ++k) {
     const int ia = (g.a_batch ? 0 : b) * g.Ga + (c + k) / cpa, ib = (g.b_batch ? 0 : b) * g.Gb + (c + k) / cpb;
     mua[k] = mean_a[ia]; rsa[k] = rstd_a[ia]; mub[k] = mean_b[ib]; rsb[k] = rstd_b[ib];
     if (BWD) { c0a[k] = coef_a[ia * 2]; c1a[k] = coef_a[ia * 2 + 1]; c0b[k] = coef_b[ib * 2]; c1b[k] = coef_b[ib * 2 + 1]; }
   }
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void __launch_bounds__(NT)
 gn2_apply_fwd_kernel(const T* __restrict__ xa, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
                      const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                      const float* __restrict__ gamma_b, const float* __restrict__ beta_b, const float* __restrict__ mean_b,
                      const float* __restrict__ rstd_b, T* __restrict__ y, unsigned long long* __restrict__ mask, Gn2Geom g,
-                     long total4) {
-  const int q = g.C >> 2;
+                     long totalv) {
+  const int q = g.C / VW;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;
   long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * 4, bcur = -1;
-  float ga[4], ba[4], gb[4], bb[4], mua[4], rsa[4], mub[4], rsb[4], d0[4], d1[4], d2[4], d3[4];
+  int c = (int)(i % q) * VW, bcur = -1;
+  float ga[VW], ba[VW], gb[VW], bb[VW], mua[VW], rsa[VW], mub[VW], rsb[VW], d0[VW], d1[VW], d2[VW], d3[VW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
-  for (; i < total4; i += stride) {
+  for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
+  for (; i < totalv; i += stride) {
     const int b = (int)(i / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(i % q) * 4;
+      c = (int)(i % q) * VW;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
+      for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
     }
     if (!fixed || b != bcur) {
       bcur = b;
-      gn2_load_stats<false>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
+      gn2_load_stats<false, VW>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
     }
-    const float4 av = ld4(xa + 4 * i);
-    const float4 bv = ld4(xb + 4 * i);
-    const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
-    float v[4];
+    float as[VW], bs[VW], v[VW];
+    ldn<VW>(xa + (size_t)VW * i, as);
+    ldn<VW>(xb + (size_t)VW * i, bs);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < VW; ++k) {
       // the same association as gn_apply_fwd_kernel with the other norm's output as its residual
       const float o = (as[k] - mua[k]) * rsa[k] * ga[k] + ba[k] + ((bs[k] - mub[k]) * rsb[k] * gb[k] + bb[k]);
       v[k] = g.relu ? fmaxf(o, 0.0f) : o;
     }
     if (mask) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VW; ++k) {
         const unsigned long long bal = __ballot(v[k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
+        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
       }
     }
-    st4(y + 4 * i, make_float4(v[0], v[1], v[2], v[3]));
+    stn<VW>(y + (size_t)VW * i, v);
   }
 }
 
 // per-chunk (sum g, sum g xhat_a) -> pa, (sum g, sum g xhat_b) -> pb, both in gn_partial_kernel<1>'s layout (so the
 // finalize kernels of the single-norm operator serve unchanged); g = gy masked by the fused ReLU
-template <typename T>
+template <typename T, int VW>
 __global__ void __launch_bounds__(NT)
 gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
                        const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                        const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float* __restrict__ pa,
                        float* __restrict__ pb, Gn2Geom g) {
   extern __shared__ float lds[];                       // [rows][C][3]
-  const int q = g.C >> 2, rows = NT / q > 0 ? NT / q : 1;
+  const int q = g.C / VW, rows = NT / q > 0 ? NT / q : 1;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
   const long s0 = (long)chunk * g.chunk_len, s1 = min(g.S, s0 + g.chunk_len);
   const int c4 = tid % q, r = tid / q;
   if (r < rows) {
-    const int c = c4 * 4;
-    float mua[4], rsa[4], mub[4], rsb[4], d0[4], d1[4], d2[4], d3[4];
-    gn2_load_stats<false>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
-    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const int c = c4 * VW;
+    float mua[VW], rsa[VW], mub[VW], rsb[VW], d0[VW], d1[VW], d2[VW], d3[VW];
+    gn2_load_stats<false, VW>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, nullptr, nullptr, mua, rsa, mub, rsb, d0, d1, d2, d3);
+    float a0[VW], a1[VW], a2[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { a0[k] = 0.0f; a1[k] = 0.0f; a2[k] = 0.0f; }
     const size_t base = (size_t)b * g.S * g.C;
     for (long s = s0 + r; s < s1; s += rows) {
       const size_t off = base + (size_t)s * g.C + c;
-      const float4 gv = ld4(gy + off);
-      const float4 av = ld4(xa + off);
-      const float4 bv = ld4(xb + off);
-      float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-      const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
-      if (g.relu) {
+      float gs[VW], as[VW], bs[VW];
+      ldn<VW>(gy + off, gs);
+      ldn<VW>(xa + off, as);
+      ldn<VW>(xb + off, bs);
+      if (g.relu) {                                     // quad-layout mask, see gn_partial_kernel
         const size_t i4 = off >> 2;
         const unsigned long long* mw = mask + (i4 >> 6) * 4;
         const int sh = (int)(i4 & 63);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+        for (int k = 0; k < VW; ++k) gs[k] = ((mw[k & 3] >> (sh + (k >> 2))) & 1ull) ? gs[k] : 0.0f;
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < VW; ++k) {
         a0[k] += gs[k];
         a1[k] += gs[k] * (as[k] - mua[k]) * rsa[k];
         a2[k] += gs[k] * (bs[k] - mub[k]) * rsb[k];
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < VW; ++k) {
       float* l = lds + ((size_t)r * g.C + c + k) * 3;
       l[0] = a0[k]; l[1] = a1[k]; l[2] = a2[k];
     }
@@ -683,51 +678,50 @@ gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __res
   }
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void __launch_bounds__(NT)
 gn2_apply_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
                      const float* __restrict__ gamma_a, const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
                      const float* __restrict__ coef_a, const T* __restrict__ xb, const float* __restrict__ gamma_b,
                      const float* __restrict__ mean_b, const float* __restrict__ rstd_b, const float* __restrict__ coef_b,
-                     T* __restrict__ gxa, T* __restrict__ gxb, Gn2Geom g, long total4) {
-  const int q = g.C >> 2;
+                     T* __restrict__ gxa, T* __restrict__ gxb, Gn2Geom g, long totalv) {
+  const int q = g.C / VW;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;
   long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * 4, bcur = -1;
-  float ga[4], gb[4], mua[4], rsa[4], mub[4], rsb[4], c0a[4], c1a[4], c0b[4], c1b[4];
+  int c = (int)(i % q) * VW, bcur = -1;
+  float ga[VW], gb[VW], mua[VW], rsa[VW], mub[VW], rsb[VW], c0a[VW], c1a[VW], c0b[VW], c1b[VW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
-  for (; i < total4; i += stride) {
+  for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
+  for (; i < totalv; i += stride) {
     const int b = (int)(i / ((long)q * g.S));
     if (!fixed) {
-      c = (int)(i % q) * 4;
+      c = (int)(i % q) * VW;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
+      for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
     }
     if (!fixed || b != bcur) {
       bcur = b;
-      gn2_load_stats<true>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, coef_a, coef_b, mua, rsa, mub, rsb, c0a, c1a, c0b, c1b);
+      gn2_load_stats<true, VW>(g, b, c, mean_a, rstd_a, mean_b, rstd_b, coef_a, coef_b, mua, rsa, mub, rsb, c0a, c1a, c0b, c1b);
     }
-    const float4 gv = ld4(gy + 4 * i);
-    const float4 av = ld4(xa + 4 * i);
-    const float4 bv = ld4(xb + 4 * i);
-    float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    const float as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+    float gs[VW], as[VW], bs[VW];
+    ldn<VW>(gy + (size_t)VW * i, gs);
+    ldn<VW>(xa + (size_t)VW * i, as);
+    ldn<VW>(xb + (size_t)VW * i, bs);
     if (g.relu) {
-      const unsigned long long* mw = mask + (i >> 6) * 4;
+      const unsigned long long* mw = mask + (i >> 6) * VW;
       const int sh = (int)(i & 63);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
     }
-    float oa[4], ob[4];
+    float oa[VW], ob[VW];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < VW; ++k) {
       oa[k] = (ga[k] * gs[k] - (as[k] - mua[k]) * rsa[k] * c0a[k] - c1a[k]) * rsa[k];
       ob[k] = (gb[k] * gs[k] - (bs[k] - mub[k]) * rsb[k] * c0b[k] - c1b[k]) * rsb[k];
     }
-    st4(gxa + 4 * i, make_float4(oa[0], oa[1], oa[2], oa[3]));
-    st4(gxb + 4 * i, make_float4(ob[0], ob[1], ob[2], ob[3]));
+    stn<VW>(gxa + (size_t)VW * i, oa);
+    stn<VW>(gxb + (size_t)VW * i, ob);
   }
 }
 
@@ -783,43 +777,51 @@ size_t ssbev_groupnorm_workspace(const ssbev_norm_dims* d) {
 
 size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d) {
   if (!gn_ok(d)) return 0;
-  const size_t total4 = (size_t)d->B * d->S * (d->C / 4);
+  const size_t total4 = (size_t)d->B * d->S * (d->C / 4);      // one bit per element, four words per 64 channel quads
   return ((total4 + 63) / 64) * 4;
 }
 
 extern "C++" {
-template <typename T>
+template <typename T, int VW>
 static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y,
                            float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
                            ssbev_stream_t stream) {
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
-  const size_t lds = lds_bytes(g);
+  const size_t lds = lds_bytes(g, VW);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
     if (g.pre)
-      hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, (const T*)nullptr,
+      hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, x, (const T*)nullptr,
                          (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     else
-      hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, x, (const T*)nullptr,
+      hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, x, (const T*)nullptr,
                          (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
       hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g);
     else
       hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
   }
-  const long total4 = (long)g.B * g.S * (g.C / 4);
-  const unsigned blocks = apply_blocks(total4, g.C / 4);
+  const long totalv = (long)g.B * g.S * (g.C / 4);
+  const unsigned blocks = apply_blocks(totalv, g.C / 4);
   if (g.pre)
-    hipLaunchKernelGGL((gn_apply_fwd_kernel<true, T>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
-                       d->relu ? mask : nullptr, g, total4);
+    hipLaunchKernelGGL((gn_apply_fwd_kernel<true, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                       d->relu ? mask : nullptr, g, totalv);
   else
-    hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
-                       d->relu ? mask : nullptr, g, total4);
+    hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                       d->relu ? mask : nullptr, g, totalv);
   return ssbev_launch_status();
 }
 }  // extern "C++"
+
+// 16-byte lanes of bf16 tensors need 16-byte aligned rows
+static bool gn_rows16(const ssbev_norm_dims* d, const void* const* ptrs, int n) {
+  if ((d->ld_y != 0 && d->ld_y % 8 != 0) || (d->ld_gy != 0 && d->ld_gy % 8 != 0)) return false;
+  for (int i = 0; i < n; ++i)
+    if (ptrs[i] && reinterpret_cast<uintptr_t>(ptrs[i]) % 16 != 0) return false;
+  return true;
+}
 
 static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                               float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
@@ -828,10 +830,18 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
   // a strided output (ld_y) is a slice of a concatenation: the residual operand has no stride of its own -> refused together
   if (residual && d->ld_y != 0 && d->ld_y != d->C) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
-  if (d->io_dtype == 1)     // x, residual, y hold bf16 bit patterns (statistics, affine parameters and arithmetic stay fp32)
-    return groupnorm_fwd_t(reinterpret_cast<const bf16_t*>(x), gamma, beta, reinterpret_cast<const bf16_t*>(residual),
-                           reinterpret_cast<bf16_t*>(y), mean, rstd, mask, d, ws, stream);
-  return groupnorm_fwd_t(x, gamma, beta, residual, y, mean, rstd, mask, d, ws, stream);
+  if (d->io_dtype == 1) {   // x, residual, y hold bf16 bit patterns (statistics, affine parameters and arithmetic stay fp32)
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(x);
+    const bf16_t* r16 = reinterpret_cast<const bf16_t*>(residual);
+    bf16_t* y16 = reinterpret_cast<bf16_t*>(y);
+    if (gn_vw(1, d->C) == 8) {
+      const void* ps[1] = {x};
+      if (!gn_rows16(d, ps, 1)) return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
+      return groupnorm_fwd_t<bf16_t, 8>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
+    }
+    return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
+  }
+  return groupnorm_fwd_t<float, 4>(x, gamma, beta, residual, y, mean, rstd, mask, d, ws, stream);
 }
 
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
@@ -857,7 +867,7 @@ int ssbev_bn_update_running(const float* mean, const float* rstd, float* running
 }
 
 extern "C++" {
-template <typename T>
+template <typename T, int VW>
 static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned long long* mask,
                            const float* gamma, const float* mean, const float* rstd, T* gx, T* gresidual,
                            float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, ssbev_stream_t stream) {
@@ -865,13 +875,13 @@ static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned l
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
-  const size_t lds = lds_bytes(g);
+  const size_t lds = lds_bytes(g, VW);
   if (lds > 64 * 1024) return SSBEV_EINVAL;
   {
-    const dim3 grid(g.chunks, g.B, gn_slabs(g));
+    const dim3 grid(g.chunks, g.B, gn_slabs(g, VW));
     const int rm = !g.relu ? 0 : (mask ? 1 : 2);
 #define SSBEV_GNP(PRE_, RM_) \
-    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T>), grid, dim3(NT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
+    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T, VW>), grid, dim3(NT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
     if (g.pre) { if (rm == 0) SSBEV_GNP(true, 0); else if (rm == 1) SSBEV_GNP(true, 1); else SSBEV_GNP(true, 2); }
     else { if (rm == 0) SSBEV_GNP(false, 0); else if (rm == 1) SSBEV_GNP(false, 1); else SSBEV_GNP(false, 2); }
 #undef SSBEV_GNP
@@ -880,14 +890,14 @@ static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned l
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
-  const long total4 = (long)g.B * g.S * (g.C / 4);
-  const unsigned blocks = apply_blocks(total4, g.C / 4);
+  const long totalv = (long)g.B * g.S * (g.C / 4);
+  const unsigned blocks = apply_blocks(totalv, g.C / 4);
   if (g.pre)
-    hipLaunchKernelGGL((gn_apply_bwd_kernel<true, T>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
-                       gresidual, mask, g, total4);
+    hipLaunchKernelGGL((gn_apply_bwd_kernel<true, T, 4>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+                       gresidual, mask, g, totalv);
   else
-    hipLaunchKernelGGL((gn_apply_bwd_kernel<false, T>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
-                       gresidual, mask, g, total4);
+    hipLaunchKernelGGL((gn_apply_bwd_kernel<false, T, 4>), dim3(blocks), dim3(NT), 0, st, gy, x, y, gamma, mean, rstd, coef, gx,
+                       gresidual, mask, g, totalv);
   return ssbev_launch_status();
 }
 }  // extern "C++"
@@ -905,10 +915,17 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
   if (ws_bytes < ssbev_groupnorm_workspace(d)) return SSBEV_EWORKSPACE;
   if (d->io_dtype == 1) {
     typedef const bf16_t* cb;
-    return groupnorm_bwd_t(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean, rstd,
-                           reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws, stream);
+    if (gn_vw(1, d->C) == 8) {
+      const void* ps[3] = {gy, x, y};
+      if (gn_rows16(d, ps, 3))
+        return groupnorm_bwd_t<bf16_t, 8>(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean,
+                                        rstd, reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws,
+                                        stream);
+    }
+    return groupnorm_bwd_t<bf16_t, 4>(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean, rstd,
+                                      reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws, stream);
   }
-  return groupnorm_bwd_t(gy, x, y, mask, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, stream);
+  return groupnorm_bwd_t<float, 4>(gy, x, y, mask, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, stream);
 }
 
 int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* mean,
@@ -937,7 +954,7 @@ size_t ssbev_groupnorm2_workspace(const ssbev_norm2_dims* d) {
 }
 
 extern "C++" {
-template <typename T>
+template <typename T, int VW>
 static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
                             const T* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, T* y,
                             uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream) {
@@ -949,10 +966,10 @@ static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta
   for (int side = 0; side < 2; ++side) {
     const ssbev_norm_dims n = gn2_side(d, side);
     const GnGeom g = make_geom(&n);
-    const size_t lds = lds_bytes(g);
+    const size_t lds = lds_bytes(g, VW);
     if (lds > 64 * 1024) return SSBEV_EINVAL;
     float* partial = reinterpret_cast<float*>(wsp);
-    hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T>), dim3(g.chunks, g.B, gn_slabs(g)), dim3(NT), lds, st, xs[side],
+    hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, xs[side],
                        (const T*)nullptr, (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
     if (g.G == g.C)
       hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, xs[side], means[side],
@@ -962,10 +979,10 @@ static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta
     wsp += ssbev_groupnorm_workspace(&n);
   }
   const Gn2Geom g2 = make_geom2(d);
-  const long total4 = (long)g2.B * g2.S * (g2.C / 4);
-  hipLaunchKernelGGL(gn2_apply_fwd_kernel<T>, dim3(apply_blocks(total4, g2.C / 4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a, rstd_a,
-                     xb, gamma_b, beta_b, mean_b, rstd_b, y, d->relu ? reinterpret_cast<unsigned long long*>(relu_mask) : nullptr, g2,
-                     total4);
+  const long totalv = (long)g2.B * g2.S * (g2.C / 4);
+  hipLaunchKernelGGL((gn2_apply_fwd_kernel<T, 4>), dim3(apply_blocks(totalv, g2.C / 4)), dim3(NT), 0, st, xa, gamma_a, beta_a, mean_a,
+                     rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, d->relu ? reinterpret_cast<unsigned long long*>(relu_mask) : nullptr,
+                     g2, totalv);
   return ssbev_launch_status();
 }
 }  // extern "C++"
@@ -977,14 +994,22 @@ int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* bet
     return SSBEV_EINVAL;
   if (d->relu && !relu_mask) return SSBEV_EINVAL;
   if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
-  if (d->io_dtype == 1)
-    return groupnorm2_fwd_t(reinterpret_cast<const bf16_t*>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<const bf16_t*>(xb),
-                            gamma_b, beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
-  return groupnorm2_fwd_t(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, stream);
+  if (d->io_dtype == 1) {
+    typedef const bf16_t* cb;
+    const bool al = reinterpret_cast<uintptr_t>(xa) % 16 == 0 && reinterpret_cast<uintptr_t>(xb) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    if (gn_vw(1, d->C) == 8 && al) {
+      return groupnorm2_fwd_t<bf16_t, 8>(reinterpret_cast<cb>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<cb>(xb), gamma_b,
+                                         beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
+    }
+    return groupnorm2_fwd_t<bf16_t, 4>(reinterpret_cast<cb>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<cb>(xb), gamma_b,
+                                       beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
+  }
+  return groupnorm2_fwd_t<float, 4>(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, stream);
 }
 
 extern "C++" {
-template <typename T>
+template <typename T, int VW>
 static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa, const float* gamma_a, const float* mean_a,
                             const float* rstd_a, const T* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
                             T* gxa, T* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
@@ -996,16 +1021,16 @@ static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa,
   float* pb = pa + part;
   float* coef_a = pb + part;
   float* coef_b = coef_a + (size_t)g.B * g.C * 2 + 64;
-  const int q = g.C >> 2, rows = NT / q > 0 ? NT / q : 1;
+  const int q = g.C / VW, rows = NT / q > 0 ? NT / q : 1;
   const size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(relu_mask);
-  hipLaunchKernelGGL(gn2_partial_bwd_kernel<T>, dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b, rstd_b, pa,
-                     pb, g);
+  hipLaunchKernelGGL((gn2_partial_bwd_kernel<T, VW>), dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b,
+                     rstd_b, pa, pb, g);
   gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
   gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
-  const long total4 = (long)g.B * g.S * (g.C / 4);
-  hipLaunchKernelGGL(gn2_apply_bwd_kernel<T>, dim3(apply_blocks(total4, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a, rstd_a,
-                     coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, total4);
+  const long totalv = (long)g.B * g.S * (g.C / 4);
+  hipLaunchKernelGGL((gn2_apply_bwd_kernel<T, 4>), dim3(apply_blocks(totalv, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a,
+                     rstd_a, coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, totalv);
   return ssbev_launch_status();
 }
 }  // extern "C++"
@@ -1021,12 +1046,20 @@ int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float
   if (ws_bytes < ssbev_groupnorm2_workspace(d)) return SSBEV_EWORKSPACE;
   if (d->io_dtype == 1) {
     typedef const bf16_t* cb;
-    return groupnorm2_bwd_t(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
-                            reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
-                            reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+    bool al = true;
+    for (const void* q : {(const void*)gy, (const void*)xa, (const void*)xb, (const void*)gxa, (const void*)gxb})
+      al = al && reinterpret_cast<uintptr_t>(q) % 16 == 0;
+    if (gn_vw(1, d->C) == 8 && al) {
+      return groupnorm2_bwd_t<bf16_t, 8>(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
+                                         reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
+                                         reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+    }
+    return groupnorm2_bwd_t<bf16_t, 4>(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
+                                       reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
+                                       reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
   }
-  return groupnorm2_bwd_t(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a, gbeta_a,
-                          ggamma_b, gbeta_b, d, ws, stream);
+  return groupnorm2_bwd_t<float, 4>(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a,
+                                    gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
 }
 
 }  // extern "C"

@@ -1663,6 +1663,8 @@ class _NormCat(torch.autograd.Function):
         extra = tensors[3 * n] if len(tensors) > 3 * n else None     # an un-normalised last branch (ASPP's image-level one)
         xs = [to_cl(tensors[3 * i]) for i in range(n)]
         adt = xs[0].dtype if all(x.dtype == xs[0].dtype for x in xs) else torch.float32      # one storage type for the whole cat
+        if adt == torch.bfloat16 and (any(x.shape[-1] % 8 for x in xs) or (extra is not None and extra.shape[1] % 8)):
+            adt = torch.float32            # 16-byte bf16 lanes need channel slices that start and end on multiples of 8
         xs = [_act(x if x.dtype == adt else x.to(adt), "norm_cat")[0] for x in xs]
         io, esz = (1, 2) if adt == torch.bfloat16 else (0, 4)
         ws_ = [tensors[3 * i + 1].detach().contiguous() for i in range(n)]
@@ -1799,7 +1801,7 @@ class _DualNorm(torch.autograd.Function):
         if nbytes == 0:
             raise capi.SsbevError("dual_norm: unsupported dims (C % 4, C <= 1024, C % G)")
         ws = _ws(nbytes, dev)
-        nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0)
+        nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0, 0, 0, io)
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(nd)), dtype=torch.int64, device=dev) if relu else None
         wa_, ba_, wb_, bb_ = (t.detach().contiguous() for t in (wa, ba, wb, bb))
         with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 5, f"fwd   N2 C={Cch} Ga={ga} Gb={gb} S={S}"):
