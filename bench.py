@@ -45,6 +45,8 @@ EXECUTED_NOTE = {
     "conv_wino_fused": "F(4,3)^2 over (h, w) in memory and F(2,3) along d in registers: 1/6 of the direct convolution's; "
                        "bytes = the kernel's own operands P / Mo (2.25x the activations) and packed weights",
     "conv_tap16": "direct convolution on v_mfma_f32_32x32x16_bf16, bf16 tensors: all of the direct convolution's",
+    "conv_wide16": "direct convolution on v_mfma_f32_32x32x16_bf16 (LDS-ring implicit GEMM, all template instances): all of the "
+                   "direct convolution's",
     "wgrad16": "direct weight gradient on v_mfma_f32_32x32x16_bf16 (all template instances of wgrad16_kernel): all of the operator's",
 }
 SINGLE_KERNEL_FAMILIES = {
@@ -52,6 +54,7 @@ SINGLE_KERNEL_FAMILIES = {
     "conv_wino_fused": ("wino_df_kernel", "mfma"),
     # bf16 storage mode (--precision bf16, BASELINE configs[3]): priced against the dense bf16 MFMA peak
     "conv_tap16": ("conv_tap16_kernel", "mfma"),
+    "conv_wide16": ("conv_wide16_kernel", "mfma"),
     "wgrad16": ("wgrad16_kernel", "mfma"),
 }
 

@@ -442,6 +442,169 @@ conv_tap16_kernel(const bf16_t* __restrict__ X, const uint4* __restrict__ wp, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wide LDS-ring kernel
+// 3x3x3 / stride 1 / pad 1 with K % 32 == 0 input and N % 64 == 0 output channels on grids whose W is a multiple of 16: the
+// voxel encoder's 128 -> 128 layers and the 384 -> 192 head conv at 128 x 128 x 16, the 64 -> 64 layers of the cost-volume
+// hourglasses.  In the bf16 mode these ran on the F(2,3)^3 Winograd pipeline + library GEMMs: HBM-bound on its 8x larger
+// transformed tensors (4.5 GB per 128 -> 128 layer against 0.27 GB of operands, 334 TF/s operator rate), while the direct
+// contraction is MFMA-bound (232 GF = 0.09 ms at the bf16 peak).  This kernel is the implicit GEMM with the A operand in LDS:
+//   * a workgroup owns 16 rows x 16 voxels of one depth plane x NTL * 32 output channels; wave w owns rows 4w .. 4w+3 as two
+//     32-voxel MFMA row groups (2 rows x 16 voxels), i.e. a 64 voxel x NTL * 32 channel register tile (2 x NTL accumulators);
+//   * the input arrives 32 channels (one 64-byte voxel line piece) at a time: 3 planes x 18 rows x 18 voxels x 64 bytes = 61 KB
+//     by global_load_lds, item swizzle as in conv_tap16_kernel; each staged chunk feeds 27 taps x 2 k-steps x 2 NTL MFMAs per
+//     wave (432 for NTL = 4) between two barriers; two workgroups per CU, so one stages while the other contracts;
+//   * the B operand (weights, pack16 layout) is read straight from L1/L2 -- 16 bytes per lane feeding two MFMAs -- one k-step
+//     ahead of its use (ping-pong registers).
+// Data gradient = the same walk with the channel roles swapped by the packing and the taps mirrored (26 - tap).
+struct Wide16Geom {
+  int B, D, H, W, K, N, KP, NPad;
+  int nth, ntw, ntn;               // tiles along h, along w, along the output channels
+  int relu, accumulate, mirror;
+};
+
+constexpr int kW16Rows = 16, kW16RR = kW16Rows + 2, kW16RC = 18;
+constexpr int kW16RowB = kW16RC * 64, kW16PlaneB = kW16RR * kW16RowB, kW16RingB = 3 * kW16PlaneB;      // 1152, 20736, 62208
+constexpr int kW16Items = 3 * kW16RR * kW16RC * 4, kW16Entries = (kW16Items + 63) / 64;                // 3888, 61
+
+template <int NTL, typename YT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_wide16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+                   YT* __restrict__ Y, Wide16Geom g) {
+  extern __shared__ __align__(16) unsigned char ring[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  int mtile, ntile;
+  {   // XCD-aware order: the column tiles of one voxel tile, then neighbouring voxel tiles, share an L2
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    mtile = (int)(Lp / g.ntn); ntile = (int)(Lp % g.ntn);
+  }
+  int t = mtile;
+  const int wt_ = t % g.ntw; t /= g.ntw;
+  const int ht = t % g.nth; t /= g.nth;
+  const int d = t % g.D;
+  const int b = t / g.D;
+  const int h0 = ht * kW16Rows, w0 = wt_ * 16;
+  const int n0 = ntile * (NTL * 32);
+
+  // ---- staging: entry e = wave + 4 n covers LDS items [64 e, 64 e + 64); item = (plane, row, voxel u, physical octet).  The
+  // decode is redone per chunk (a few dozen VALU instructions against 432 MFMAs) rather than kept in 16 registers
+  const bf16_t* xbase = X + ((((long)b * g.D + (d - 1)) * g.H + (h0 - 1)) * g.W + (w0 - 1)) * (long)g.K;
+  auto stage = [&](int c) {
+#pragma unroll 4
+    for (int n = 0; n < (kW16Entries + 3) / 4; ++n) {
+      const int e = wave + 4 * n;
+      if (e >= kW16Entries) break;
+      const int L = e * 64 + lane;
+      if (L < kW16Items) {
+        const int pl = L / (kW16RR * kW16RC * 4), rem = L % (kW16RR * kW16RC * 4);
+        const int row = rem / (kW16RC * 4), it = rem % (kW16RC * 4);
+        const int u = it >> 2, so = (it & 3) ^ ((u >> 2) & 3);
+        const int ds = d - 1 + pl, hs = h0 - 1 + row, ws = w0 - 1 + u;
+        const bool ok = ds >= 0 && ds < g.D && hs >= 0 && hs < g.H && ws >= 0 && ws < g.W;
+        const void* src = ok ? static_cast<const void*>(xbase + (((long)pl * g.H + row) * g.W + u) * g.K + so * 8 + c * 32)
+                             : static_cast<const void*>(&kZero16);
+        __builtin_amdgcn_global_load_lds(src, ring + e * 1024, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- A operand: lane = (row r2 of its 2-row group, voxel wq)
+  const int r2 = li >> 4, wq = li & 15;
+  const int rowb0 = (4 * wave + r2) * kW16RowB;             // row group mt: + 2 mt rows
+
+  const size_t w_tap_stride = (size_t)g.KP * 2 * g.NPad * 8;
+  const size_t w_p_stride = (size_t)2 * g.NPad * 8;
+  const bf16_t* wlane = wp + ((size_t)lk * g.NPad + n0 + li) * 8;
+
+  f32x16 acc[2][NTL];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  const int nchunks = g.K >> 5;
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                                   // every wave is done with the previous chunk
+    stage(c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // 27 taps x 2 halves of the 32-channel chunk; the operands of a step are requested one step ahead (ping-pong registers)
+    uint4 a0[2], b0[NTL], a1[2], b1[NTL];
+    auto load = [&](int kd, int kh, int kw, int tap, int j, uint4 (&av)[2], uint4 (&bv)[NTL]) __attribute__((always_inline)) {
+      const int u = wq + kw;
+      const unsigned char* ap = ring + kd * kW16PlaneB + kh * kW16RowB + rowb0 + u * 64 + (((2 * j + lk) ^ ((u >> 2) & 3)) << 4);
+      av[0] = *reinterpret_cast<const uint4*>(ap);
+      av[1] = *reinterpret_cast<const uint4*>(ap + 2 * kW16RowB);
+      const bf16_t* wt = wlane + (size_t)(g.mirror ? 26 - tap : tap) * w_tap_stride + (size_t)(2 * c + j) * w_p_stride;
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) bv[nt] = *reinterpret_cast<const uint4*>(wt + nt * 32 * 8);
+    };
+    auto mma = [&](const uint4 (&av)[2], const uint4 (&bv)[NTL]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16(av[mt], bv[nt], acc[mt][nt]);
+    };
+    load(0, 0, 0, 0, 0, a0, b0);
+    int kd = 0, kh = 0, kw = 0;
+    for (int tap = 0; tap < 27; ++tap) {
+      load(kd, kh, kw, tap, 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      // next tap (uniform counters)
+      if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; ++kd; } }
+      if (tap + 1 < 27) load(kd, kh, kw, tap + 1, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: accumulator row rr of group mt = voxel (row 4 wave + 2 mt + (vi >> 4), w = vi & 15), vi = (rr & 3) + 8 (rr >> 2) + 4 lk
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+      float oldv[8][NTL];
+      if (g.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int vi = ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lk;
+          const int h = h0 + 4 * wave + 2 * mt + (vi >> 4), w = w0 + (vi & 15);
+          const size_t vox = (((size_t)b * g.D + d) * g.H + h) * g.W + w;
+#pragma unroll
+          for (int nt = 0; nt < NTL; ++nt)
+            oldv[r][nt] = h < g.H ? ld1(Y + vox * g.N + n0 + nt * 32 + li) : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int vi = ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lk;
+        const int h = h0 + 4 * wave + 2 * mt + (vi >> 4), w = w0 + (vi & 15);
+        const size_t vox = (((size_t)b * g.D + d) * g.H + h) * g.W + w;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+          const int co = n0 + nt * 32 + li;
+          if (h < g.H) {
+            float v = acc[mt][nt][r0 + r];
+            if (g.accumulate) v += oldv[r][nt];
+            if (bias) v += bias[co];
+            if (g.relu) v = fmaxf(v, 0.0f);
+            st1(Y + vox * g.N + co, v);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // gw[tap][cq][cp] = sum_m Q[pos(m, tap)][cq] * P[m][cp]   (m over the small grid; conv: P = gy, Q = x; transposed: P = x, Q = gy)
 // One wave: (32 MQ q-channels) x (32 MP p-channels) x (TH x TW taps of one kd slice) over its own chunk of voxels, 16 voxels
@@ -617,6 +780,41 @@ bool tap16_applicable(const ssbev_conv_dims* d, int mode) {
   return d->tile_hint == 9 || (long)d->B * d->Do * d->Ho * ((d->Wo + kT16Wseg - 1) / kT16Wseg) >= 1024L * 16;
 }
 
+int wide16_ntl(const ssbev_conv_dims* d, int mode) {        // 0 = not applicable, else 32-channel column tiles per wave
+  static const bool enabled = !(getenv("SSBEV_WIDE16") && atoi(getenv("SSBEV_WIDE16")) == 0);      // A/B hook
+  if (!enabled && d->tile_hint != 7) return 0;
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return 0;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return 0;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->tile_hint == 8) return 0;
+  const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  if (K % 32 != 0 || (N % 64 != 0 && N % 96 != 0) || K < 64 || d->Wo % 16 != 0) return 0;
+  if ((long)d->Ho * d->Wo * K >= (1L << 29)) return 0;
+  // worth it when the tiles fill the chip (512 resident workgroups); tile_hint 7 forces it on small problems (tests)
+  const int ntl = N % 128 == 0 ? 4 : (N % 96 == 0 ? 3 : 2);      // (six tiles of 32: 256 VGPRs + spills; 192 = 2 x 96)
+  const long tiles = (long)d->B * d->Do * ((d->Ho + kW16Rows - 1) / kW16Rows) * (d->Wo / 16) * (N / (32 * ntl));
+  if (d->tile_hint != 7 && tiles < 512) return 0;
+  return ntl;
+}
+
+template <int NTL, typename YT>
+int launch_wide16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const ssbev_conv_dims* d, int mode, hipStream_t st) {
+  Wide16Geom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.KP = pad16(g.K) / 16; g.NPad = pad32(g.N);
+  g.nth = (g.H + kW16Rows - 1) / kW16Rows; g.ntw = g.W / 16; g.ntn = g.N / (32 * NTL);
+  g.relu = mode == 0 ? d->relu : 0;
+  g.accumulate = d->accumulate;
+  g.mirror = mode == 1 ? 1 : 0;
+  auto kern = conv_wide16_kernel<NTL, YT>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kW16RingB) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  const long blocks = (long)g.B * g.D * g.nth * g.ntw * g.ntn;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kW16RingB, st, x, wp, mode == 0 ? bias : nullptr, y, g);
+  return ssbev_launch_status();
+}
+
 Geom16 make_geom(const ssbev_conv_dims* d, int mode) {
   Geom16 g;
   g.B = d->B;
@@ -772,6 +970,7 @@ bool dims_ok(const ssbev_conv_dims* d, int mode) {
 
 int kernel_class(const ssbev_conv_dims* d, int mode) {
   if (mode == 2) return 18;
+  if (wide16_ntl(d, mode)) return 19;
   return tap16_applicable(d, mode) ? 17 : 16;
 }
 
@@ -793,6 +992,7 @@ int pack(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode
   }
   const int taps = d->kd * d->kh * d->kw;
   const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+  // (the wide kernel takes the generic layout too: its data gradient swaps the channel roles here and mirrors the taps itself)
   const int layout = (mode == 0) == (d->transposed == 0) ? 0 : 1;
   const int KP = pad16(K) / 16, NPad = pad32(N);
   const long total = (long)taps * KP * 2 * NPad * 8;
@@ -806,8 +1006,14 @@ static int run(const void* src, const float* wp, const float* bias, void* dst, c
   if (tap16_applicable(d, mode))
     return y16 ? launch_tap16(x, wp, bias, static_cast<bf16_t*>(dst), d, mode, st)
                : launch_tap16(x, wp, bias, static_cast<float*>(dst), d, mode, st);
-  const Geom16 g = make_geom(d, mode);
   const bf16_t* w16 = reinterpret_cast<const bf16_t*>(wp);
+  if (const int ntl = wide16_ntl(d, mode)) {
+#define SSBEV_W16(NTL_) (y16 ? launch_wide16<NTL_>(x, w16, bias, static_cast<bf16_t*>(dst), d, mode, st) \
+                             : launch_wide16<NTL_>(x, w16, bias, static_cast<float*>(dst), d, mode, st))
+    return ntl == 4 ? SSBEV_W16(4) : (ntl == 3 ? SSBEV_W16(3) : SSBEV_W16(2));
+#undef SSBEV_W16
+  }
+  const Geom16 g = make_geom(d, mode);
   const int hint = d->tile_hint >= 10 ? d->tile_hint : 0;
   return y16 ? dispatch_gather16(x, w16, bias, static_cast<bf16_t*>(dst), g, hint, st)
              : dispatch_gather16(x, w16, bias, static_cast<float*>(dst), g, hint, st);

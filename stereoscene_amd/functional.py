@@ -709,7 +709,7 @@ class _ConvNd16(torch.autograd.Function):
         d.precision = 3 if out_fp32 else 2
         y = torch.empty(d.B, d.Do, d.Ho, d.Wo, d.Cout, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        fam = "conv_tap16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 0) == 17) else "conv_gather16"
+        fam = {17: "conv_tap16", 19: "conv_wide16"}.get(lib.ssbev_conv_kernel_class(C.byref(d), 0), "conv_gather16") if KERNEL_TIMER is not None else "conv_gather16"
         with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "fwd")):
             wp = _packed(weight.detach(), d, 0)
             capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d), capi.stream()),
@@ -737,6 +737,10 @@ class _ConvNd16(torch.autograd.Function):
         gx = gw = gb = None
 
         def weight_gradient():
+            if (WIDE16_WGRAD == "wino" and not transposed and lib.ssbev_conv_kernel_class(C.byref(d), 0) == 19
+                    and all(int(n) % 2 == 0 for n in xcl.shape[1:4])):
+                with _span("conv_winograd_wgrad", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad(wino)"), conv_flops(d) / 3.375):
+                    return _wino_wgrad_bf16(xcl, gcl, weight)
             gwp = torch.empty(tuple(weight.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
             with _span("wgrad16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
@@ -758,7 +762,7 @@ class _ConvNd16(torch.autograd.Function):
             if into is not None:
                 d.accumulate = 1
             gxcl = into if into is not None else torch.empty_like(xcl)
-            fam = "conv_tap16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 1) == 17) else "conv_gather16"
+            fam = {17: "conv_tap16", 19: "conv_wide16"}.get(lib.ssbev_conv_kernel_class(C.byref(d), 1), "conv_gather16") if KERNEL_TIMER is not None else "conv_gather16"
             with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "dgrad")):
                 wpt = _packed(weight.detach(), d, 1)
                 capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d), capi.stream()),
@@ -777,13 +781,46 @@ class _ConvNd16(torch.autograd.Function):
 def _conv16_route(x, weight5, bias, st, pd, dl, transposed, op, relu=False):
     """bf16 storage mode: the convolution on csrc/conv_bf16.hip when its channel counts allow 16-byte bf16 voxel-line pieces
     (Cin % 8 == 0 and Cout % 8 == 0), else None (the caller keeps its fp32 island: the 1- / 2- / 20-channel layers)."""
-    if not (storage_bf16() and x.is_cuda and TILE_HINT in (0, 9)):
+    if not (storage_bf16() and x.is_cuda and TILE_HINT in (0, 7, 9)):
         return None
     cin = weight5.shape[0] if transposed else weight5.shape[1]
     cout = weight5.shape[1] if transposed else weight5.shape[0]
     if cin % 8 != 0 or cout % 8 != 0:        # (the Cout-channel gradient is a bf16 SOURCE in backward)
         return None
     return _ConvNd16.apply(x, weight5, bias, st, pd, dl, transposed, op, _slot_of(x), bool(relu), False)
+
+
+# bf16 storage mode: the wide stride-1 3x3x3 layers on grids with W % 16 == 0 (voxel encoder level 0, head conv, the 64 -> 64
+# hourglass layers) run on conv_wide16_kernel (LDS-ring implicit GEMM) instead of the F(2,3) Winograd pipeline (0 = Winograd)
+WIDE16 = os.environ.get("SSBEV_WIDE16", "1") != "0"
+# ... and their weight gradient on the Winograd-domain product (input transform + adjoint + batched bf16 GEMM: 551 TF/s operator
+# rate on 128 -> 128) rather than on the generic wgrad16_kernel ("direct")
+WIDE16_WGRAD = os.environ.get("SSBEV_WIDE16_WGRAD", "wino")
+
+
+def _wide16_applicable(x, weight, st, pd, dl):
+    if x.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or st != (1, 1, 1) or pd != (1, 1, 1) or dl != (1, 1, 1):
+        return False
+    if weight.shape[0] % 8 or weight.shape[1] % 8:
+        return False
+    d = _conv_dims((x.shape[0], x.shape[2], x.shape[3], x.shape[4], x.shape[1]), tuple(weight.shape), st, pd, dl, False, (0, 0, 0))
+    d.precision = 2
+    return capi.load().ssbev_conv_kernel_class(C.byref(d), 0) == 19
+
+
+def _wino_wgrad_bf16(xcl, gcl, weight):
+    """Weight gradient of a 3x3x3 / stride 1 / pad 1 layer in the F(2,3)^3 Winograd domain, bf16 tensors on both sides:
+    gU[xi] = V[xi]^T Z[xi] (batched bf16 GEMM, fp32 result), gw = G^T gU G."""
+    lib = capi.load()
+    B, D, H, W, Cin = xcl.shape
+    Cout = gcl.shape[-1]
+    T = B * (D // 2) * (H // 2) * (W // 2)
+    V = _wino_call("ssbev_wino_input_transform_bf16a", xcl, capi.WinoDims(B, D, H, W, Cin), (64, T, Cin), torch.bfloat16)
+    Z = _wino_call("ssbev_wino_output_adjoint_bf16a", gcl, capi.WinoDims(B, D, H, W, Cout), (64, T, Cout), torch.bfloat16)
+    gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32)
+    gwt = torch.empty(tuple(weight.shape), dtype=torch.float32, device=xcl.device)
+    capi.check(lib.ssbev_wino_weight_grad(capi.ptr(gU), capi.ptr(gwt), Cout, Cin, 3, capi.stream()), "ssbev_wino_weight_grad")
+    return gwt
 
 
 def _to_act(y):
@@ -804,7 +841,9 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
     """F.conv3d replacement (groups=1): the MFMA implicit-GEMM kernels, or Winograd F(2x2x2,3x3x3) for the wide
     stride-1 3x3x3 layers."""
     st, pd, dl = _triple(stride, 3), _triple(padding, 3), _triple(dilation, 3)
-    if storage_bf16() and x.is_cuda and TILE_HINT in (0, 9):
+    if storage_bf16() and x.is_cuda and TILE_HINT in (0, 7, 9):
+        if WIDE16 and _wide16_applicable(x, weight, st, pd, dl):
+            return _ConvNd16.apply(x, weight, bias, st, pd, dl, False, (0, 0, 0), _slot_of(x), bool(relu), False)
         if WINOGRAD and WINO_BF16S and wino_conv3d_applicable(x, weight, st, pd, dl):
             y = _WinoConv.apply(x, weight, _slot_of(x))
             y = y if bias is None else y + _like_act(bias, y).view(1, -1, 1, 1, 1)

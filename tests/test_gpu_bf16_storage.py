@@ -37,6 +37,9 @@ CASES = [
     ("conv2d", 64, 48, (1, 12, 20), 3, 1, 2, 2, 0, False),       # dilated 2-D
     ("conv2d", 640, 128, (1, 12, 40), 3, 1, 1, 1, 0, True),      # DepthNet-like 2-D Winograd layer
     ("conv3d", 384, 192, (2, 4, 8), 3, 1, 1, 1, 0, False),       # six column tiles
+    ("conv3d", 128, 128, (4, 20, 16), 3, 1, 1, 1, 7, False),     # LDS-ring wide kernel forced (four column tiles per wave, ragged rows)
+    ("conv3d", 64, 64, (3, 16, 32), 3, 1, 1, 1, 7, False),       # ... two column tiles, two w-tiles
+    ("conv3d", 96, 192, (2, 18, 16), 3, 1, 1, 1, 7, False),      # ... three column tiles x two workgroup columns, three channel chunks
 ]
 
 
@@ -84,7 +87,8 @@ def test_conv_bf16_storage_error_budget(case, monkeypatch):
         rel_max, rel_l2 = _err(a, b)
         assert rel_max < tol[0] and rel_l2 < tol[1], (name, rel_max, rel_l2)
     rel_max, rel_l2 = _err(wg.grad, wc.grad)
-    assert rel_max < (2e-2 if wino else 2e-4) and rel_l2 < (1e-2 if wino else 1e-4), ("gw", rel_max, rel_l2)
+    wino_w = wino or hint == 7               # the wide kernel's weight gradient is formed in the Winograd domain (bf16 V, Z)
+    assert rel_max < (2e-2 if wino_w else 2e-4) and rel_l2 < (1e-2 if wino_w else 1e-4), ("gw", rel_max, rel_l2)
     rel_max, rel_l2 = _err(bg.grad, bc.grad)
     assert rel_l2 < (5e-3 if wino else 1e-3), ("gb", rel_l2)      # (the Winograd route adds the bias as a bf16 tensor op)
 
