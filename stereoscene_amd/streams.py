@@ -35,11 +35,36 @@ _DIRTY = set()          # device indices whose side stream holds work the caller
 _CB_QUEUED = set()
 
 
+# Optional CU mask of the side stream ("stop the side stream from taxing the critical path"): the weight
+# gradient / DepthNet kernels are then confined to a subset of the 256 CUs (hipExtStreamCreateWithCUMask) and leave the rest to the
+# data-gradient chain.  SSBEV_SIDE_CU_MASK = "<n>" (the n lowest mask bits) or "<n>s" (n bits spread evenly over the 256);
+# unset = an ordinary stream.  Measured in round 4: profiles/r4_side_stream_cu_mask.txt.
+SIDE_CU_MASK = os.environ.get("SSBEV_SIDE_CU_MASK", "")
+
+
+def _masked_stream(idx, spec):
+    import ctypes
+    n = int(spec.rstrip("s"))
+    total = torch.cuda.get_device_properties(idx).multi_processor_count
+    bits = [0] * ((total + 31) // 32)
+    picks = [int(i * total / n) for i in range(n)] if spec.endswith("s") else list(range(n))
+    for c in picks:
+        bits[c // 32] |= 1 << (c % 32)
+    arr = (ctypes.c_uint32 * len(bits))(*bits)
+    hip = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(bits)), arr)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=idx)
+
+
 def side_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _SIDE.get(idx)
     if st is None:
-        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+        st = _SIDE[idx] = _masked_stream(idx, SIDE_CU_MASK) if SIDE_CU_MASK else torch.cuda.Stream(device=idx)
     return idx, st
 
 
