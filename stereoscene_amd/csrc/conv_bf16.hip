@@ -760,6 +760,136 @@ wgrad16_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-ring weight gradient
+// Stride-1 3x3x3 "same" layers on grids with W % 16 == 0 (the 32 -> 32 cost-volume layers, the wide encoder / head layers):
+// wgrad16_kernel stages every operand tile of every tap per wave (global -> registers -> LDS -> transposing read).  Here the
+// workgroup's four waves share ONE staged copy: the Q rows (the tensor the taps slide over) of an 8-row x 16-voxel tile plus
+// halo and the matching P rows arrive by global_load_lds, and every wave takes its operands straight out of that ring with
+// ds_read_b64_tr_b16 -- a tap is an LDS address offset.  One MFMA k-step = the 16 voxels of one row.
+//   NARROW (Cq, Cp <= 32): three Q planes staged, the 27 taps dealt to the waves (7 / 7 / 7 / 6 accumulators);
+//   wide: blockIdx.z = kd (one Q plane staged), blockIdx.y = (32-channel Q tile, group of four 32-channel P tiles), wave = P tile,
+//         nine (kh, kw) accumulators per wave.
+// A workgroup walks a chunk of tiles with its accumulators live and leaves ONE partial slab entry; wgrad_reduce folds the chunks.
+struct WgRingGeom {
+  int B, D, H, W, Cp, Cq;
+  int nth, ntw, ntiles, tpc, nchunks;
+  int ncqt;                        // wide: 32-channel Q tiles (blockIdx.y = cqt + ncqt * cp group)
+};
+
+constexpr int kWrRows = 8, kWrQR = kWrRows + 2, kWrQC = 18;
+constexpr int kWrQRowB = kWrQC * 64, kWrQPlaneB = kWrQR * kWrQRowB;          // 1152, 11520
+
+__device__ __forceinline__ uint4 tr_operand2(const unsigned char* base, int rowstride, int lane) {
+  typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+  const unsigned char* p = base + ((8 * (lane >> 5) + ((lane & 15) >> 2)) * rowstride) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)p);
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(p + 4 * rowstride));
+  uint4 r;
+  r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return r;
+}
+
+template <bool NARROW>
+__global__ void __launch_bounds__(256)
+wgrad_ring16_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, float* __restrict__ ws, WgRingGeom g) {
+  constexpr int NKD = NARROW ? 3 : 1;
+  constexpr int NACC = NARROW ? 7 : 9;
+  constexpr int PVB = NARROW ? 64 : 256;                 // bytes of one staged P voxel line (32 / 128 channels)
+  constexpr int QB = NKD * kWrQPlaneB;
+  extern __shared__ __align__(16) unsigned char wr[];
+  unsigned char* qr = wr;                                // [NKD][10 rows][18 voxels][32 ch]
+  unsigned char* pr = wr + QB;                           // [8 rows][16 voxels][PVB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int chunk = blockIdx.x;
+  const int cqt = NARROW ? 0 : (int)blockIdx.y % g.ncqt, cpg = NARROW ? 0 : (int)blockIdx.y / g.ncqt;
+  const int kdz = NARROW ? 0 : (int)blockIdx.z;
+  const int cq0 = cqt * 32, cp0 = cpg * 128;
+  const int ntap = NARROW ? (wave < 3 ? 7 : 6) : 9;
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  const int t_begin = chunk * g.tpc, t_end = min(g.ntiles, t_begin + g.tpc);
+  for (int t = t_begin; t < t_end; ++t) {
+    int tt = t;
+    const int wt = tt % g.ntw; tt /= g.ntw;
+    const int ht = tt % g.nth; tt /= g.nth;
+    const int d = tt % g.D;
+    const int b = tt / g.D;
+    const int h0 = ht * kWrRows, w0 = wt * 16;
+    __syncthreads();                                     // the previous tile's operands have been read
+    // ---- Q: NKD planes x 10 rows x 18 voxels x 4 items of 8 channels
+    {
+      constexpr int items = NKD * kWrQR * kWrQC * 4;
+      for (int e = wave; e * 64 < items; e += 4) {
+        const int L = e * 64 + lane;
+        if (L < items) {
+          const int pl = L / (kWrQR * kWrQC * 4), rem = L % (kWrQR * kWrQC * 4);
+          const int row = rem / (kWrQC * 4), it = rem % (kWrQC * 4);
+          const int u = it >> 2, c = cq0 + (it & 3) * 8;
+          const int ds = d - 1 + (NARROW ? pl : kdz), hs = h0 - 1 + row, wsrc = w0 - 1 + u;
+          const bool ok = ds >= 0 && ds < g.D && hs >= 0 && hs < g.H && wsrc >= 0 && wsrc < g.W && c < g.Cq;
+          const void* src = ok ? static_cast<const void*>(Q + ((((long)b * g.D + ds) * g.H + hs) * g.W + wsrc) * (long)g.Cq + c)
+                               : static_cast<const void*>(&kZero16);
+          __builtin_amdgcn_global_load_lds(src, qr + e * 1024, 16, 0, 0);
+        }
+      }
+    }
+    // ---- P: 8 rows x 16 voxels x (PVB / 16) items
+    {
+      constexpr int ipv = PVB / 16, items = kWrRows * 16 * ipv;
+      for (int e = wave; e * 64 < items; e += 4) {
+        const int L = e * 64 + lane;
+        const int row = L / (16 * ipv), rem = L % (16 * ipv);
+        const int u = rem / ipv, c = cp0 + (rem % ipv) * 8;
+        const int hs = h0 + row;
+        const bool ok = hs < g.H && c < g.Cp;
+        const void* src = ok ? static_cast<const void*>(P + ((((long)b * g.D + d) * g.H + hs) * g.W + (w0 + u)) * (long)g.Cp + c)
+                             : static_cast<const void*>(&kZero16);
+        __builtin_amdgcn_global_load_lds(src, pr + e * 1024, 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int r = 0; r < kWrRows; ++r) {
+      const uint4 bop = tr_operand2(pr + r * (16 * PVB) + (NARROW ? 0 : wave * 64), PVB, lane);
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        if (i < ntap) {
+          int kd, kh, kw;
+          if (NARROW) { const int tp = wave + 4 * i; kd = tp / 9; kh = (tp / 3) % 3; kw = tp % 3; }
+          else { kd = 0; kh = i / 3; kw = i % 3; }
+          const uint4 aop = tr_operand2(qr + kd * kWrQPlaneB + (r + kh) * kWrQRowB + kw * 64, 64, lane);
+          acc[i] = mfma16(aop, bop, acc[i]);
+        }
+      }
+    }
+  }
+
+  // partial slab of this chunk: ws[chunk][tap][cq][cp]
+  const int cpt = NARROW ? 0 : cpg * 4 + wave;
+  const int pc = cpt * 32 + li;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    if (i >= ntap) continue;
+    const int tap = NARROW ? wave + 4 * i : kdz * 9 + i;
+    float* dst = ws + (((size_t)chunk * 27 + tap) * g.Cq) * g.Cp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cq0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < g.Cq && pc < g.Cp) dst[(size_t)row * g.Cp + pc] = acc[i][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool basic_ok(const ssbev_conv_dims* d) {
   if (!d || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
@@ -953,6 +1083,49 @@ int launch_wg16(const bf16_t* P, const bf16_t* Q, float* ws, const Wg16Geom& g, 
   return ssbev_launch_status();
 }
 
+bool wg_ring_applicable(const ssbev_conv_dims* d) {
+  static const bool enabled = !(getenv("SSBEV_WGRING16") && atoi(getenv("SSBEV_WGRING16")) == 0);    // A/B hook
+  if (!enabled && d->tile_hint != 7 && d->tile_hint != 9) return false;
+  if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->tile_hint == 8) return false;
+  if (d->Wo % 16 != 0 || d->Cin % 8 != 0 || d->Cout % 8 != 0 || d->Cin < 16 || d->Cout < 16) return false;
+  const long tiles = (long)d->B * d->Do * ((d->Ho + kWrRows - 1) / kWrRows) * (d->Wo / 16);
+  return d->tile_hint == 7 || d->tile_hint == 9 || tiles >= 2048;
+}
+
+WgRingGeom make_wr_geom(const ssbev_conv_dims* d) {
+  WgRingGeom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo; g.Cp = d->Cout; g.Cq = d->Cin;
+  g.nth = (g.H + kWrRows - 1) / kWrRows; g.ntw = g.W / 16;
+  g.ntiles = g.B * g.D * g.nth * g.ntw;
+  const bool narrow = g.Cq <= 32 && g.Cp <= 32;
+  g.ncqt = narrow ? 1 : (g.Cq + 31) / 32;
+  const long types = narrow ? 1 : (long)g.ncqt * ((g.Cp + 127) / 128) * 3;
+  // ~1024 workgroups in all (two resident per CU, two rounds), at least 4 tiles per chunk, partial slabs bounded to 256 MB
+  long want = std::max(1L, 1024 / types);
+  if (const char* e = getenv("SSBEV_WGRING16_WGS")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / types); }
+  const long slab = 27L * g.Cq * g.Cp * 4;
+  want = std::min(want, std::max(1L, (256L << 20) / slab));
+  long tpc = (g.ntiles + want - 1) / want;
+  if (tpc < 4) tpc = std::min<long>(4, g.ntiles);
+  g.tpc = (int)tpc;
+  g.nchunks = (int)((g.ntiles + tpc - 1) / tpc);
+  return g;
+}
+
+int launch_wg_ring(const bf16_t* P, const bf16_t* Q, float* ws, const WgRingGeom& g, hipStream_t st) {
+  const bool narrow = g.Cq <= 32 && g.Cp <= 32;
+  if (narrow) {
+    const size_t lds = 3 * kWrQPlaneB + kWrRows * 16 * 64;
+    hipLaunchKernelGGL(wgrad_ring16_kernel<true>, dim3(g.nchunks), dim3(256), lds, st, P, Q, ws, g);
+  } else {
+    const size_t lds = kWrQPlaneB + kWrRows * 16 * 256;
+    hipLaunchKernelGGL(wgrad_ring16_kernel<false>, dim3(g.nchunks, g.ncqt * ((g.Cp + 127) / 128), 3), dim3(256), lds, st, P, Q, ws, g);
+  }
+  return ssbev_launch_status();
+}
+
 }  // namespace
 
 namespace ssbev_bf16 {
@@ -969,7 +1142,7 @@ bool dims_ok(const ssbev_conv_dims* d, int mode) {
 }
 
 int kernel_class(const ssbev_conv_dims* d, int mode) {
-  if (mode == 2) return 18;
+  if (mode == 2) return wg_ring_applicable(d) ? 20 : 18;
   if (wide16_ntl(d, mode)) return 19;
   return tap16_applicable(d, mode) ? 17 : 16;
 }
@@ -1031,6 +1204,10 @@ int backward_data(const void* gy, const float* wp, void* gx, const ssbev_conv_di
 
 size_t wgrad_workspace(const ssbev_conv_dims* d) {
   if (!dims_ok(d, 2)) return 0;
+  if (wg_ring_applicable(d)) {
+    const WgRingGeom r = make_wr_geom(d);
+    return (size_t)r.nchunks * 27 * r.Cq * r.Cp * sizeof(float);
+  }
   const Wg16Geom g = make_wg_geom(d);
   return (size_t)g.nchunks * d->kd * d->kh * d->kw * g.Cp * g.Cq * sizeof(float);
 }
@@ -1038,10 +1215,17 @@ size_t wgrad_workspace(const ssbev_conv_dims* d) {
 int backward_weight(const void* x, const void* gy, float* gw, const ssbev_conv_dims* d, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!dims_ok(d, 2) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
   if (ws_bytes < wgrad_workspace(d)) return SSBEV_EWORKSPACE;
+  float* partial = static_cast<float*>(ws);
+  if (wg_ring_applicable(d)) {
+    const WgRingGeom r = make_wr_geom(d);
+    const int rc = launch_wg_ring(static_cast<const bf16_t*>(gy), static_cast<const bf16_t*>(x), partial, r, st);
+    if (rc != SSBEV_OK) return rc;
+    ssbev_detail::wgrad_reduce(partial, gw, r.nchunks, 27, r.Cq, r.Cp, st);
+    return ssbev_launch_status();
+  }
   const Wg16Geom g = make_wg_geom(d);
   const bf16_t* P = static_cast<const bf16_t*>(d->transposed ? x : gy);
   const bf16_t* Q = static_cast<const bf16_t*>(d->transposed ? gy : x);
-  float* partial = static_cast<float*>(ws);
   const WgCfg16 c = wg_cfg(g.Cp, g.Cq, g.kh, g.kw);
   int rc;
   if (c.TH == 3) rc = launch_wg16<1, 1, 3, 3>(P, Q, partial, g, st);

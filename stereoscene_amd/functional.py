@@ -793,9 +793,9 @@ def _conv16_route(x, weight5, bias, st, pd, dl, transposed, op, relu=False):
 # bf16 storage mode: the wide stride-1 3x3x3 layers on grids with W % 16 == 0 (voxel encoder level 0, head conv, the 64 -> 64
 # hourglass layers) run on conv_wide16_kernel (LDS-ring implicit GEMM) instead of the F(2,3) Winograd pipeline (0 = Winograd)
 WIDE16 = os.environ.get("SSBEV_WIDE16", "1") != "0"
-# ... and their weight gradient on the Winograd-domain product (input transform + adjoint + batched bf16 GEMM: 551 TF/s operator
-# rate on 128 -> 128) rather than on the generic wgrad16_kernel ("direct")
-WIDE16_WGRAD = os.environ.get("SSBEV_WIDE16_WGRAD", "wino")
+# ... and their weight gradient on the LDS-ring kernel wgrad_ring16_kernel ("direct", default) or on the Winograd-domain product
+# (input transform + adjoint + batched bf16 library GEMM: "wino", kept for A/B runs)
+WIDE16_WGRAD = os.environ.get("SSBEV_WIDE16_WGRAD", "direct")
 
 
 def _wide16_applicable(x, weight, st, pd, dl):
