@@ -48,6 +48,8 @@ EXECUTED_NOTE = {
     "conv_wide16": "direct convolution on v_mfma_f32_32x32x16_bf16 (LDS-ring implicit GEMM, all template instances): all of the "
                    "direct convolution's",
     "wgrad16": "direct weight gradient on v_mfma_f32_32x32x16_bf16 (all template instances of wgrad16_kernel): all of the operator's",
+    "wgrad_ring16": "direct weight gradient on v_mfma_f32_32x32x16_bf16, operands by transposing LDS reads out of a shared ring "
+                    "(both template instances): all of the operator's",
 }
 SINGLE_KERNEL_FAMILIES = {
     "conv_tap_h": ("conv_taph_kernel", "mfma"),
@@ -56,7 +58,19 @@ SINGLE_KERNEL_FAMILIES = {
     "conv_tap16": ("conv_tap16_kernel", "mfma"),
     "conv_wide16": ("conv_wide16_kernel", "mfma"),
     "wgrad16": ("wgrad16_kernel", "mfma"),
+    "wgrad_ring16": ("wgrad_ring16_kernel", "mfma"),
 }
+
+
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*.hip, *.h, include/ssbev.h): ties a PMC traffic file to the tree it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "stereoscene_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/ssbev.h"]:
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -120,8 +134,17 @@ def cpu_baseline(mode, cfg_full):
     from stereoscene_amd import model_zoo, synthetic as S
     ncores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
+    # pinned (the unpinned baseline moved by +-40 % between boxes and runs): the process -- and with it ATen's
+    # OpenMP team -- is confined to `ncores` logical CPUs of ONE L3 / NUMA neighbourhood (the first ncores ids of the allowed set)
+    pinned = None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        pinned = allowed[:ncores]
+        os.sched_setaffinity(0, set(pinned))
+    except (AttributeError, OSError):
+        allowed = None
 
-    def protocol(cfg, timed=3):
+    def protocol(cfg, timed=5):
         m = model_zoo.build_detector(cfg, device="cpu")       # parameter container only; never run on CPU
         sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and v.dim() > 0 and "running" not in k
                   and not k.endswith(("frustum", ".dx", ".bx", ".nx")) else v) for k, v in m.state_dict().items()}
@@ -144,16 +167,21 @@ def cpu_baseline(mode, cfg_full):
         med = statistics.median(times)
         return vox / med, med, times
 
-    v, med, times = protocol(S.CFG_S)
-    sample = f"1 warm-up + 3 timed fwd+bwd steps of configs[0] (64x64x16 grid, D=48, B=1), median {med:.2f} s"
-    cfg_name = "configs[0]"
-    if mode == "full" or (mode == "auto" and med * 25 * 4 < 140):      # full size ~25x the small step
-        v, med, times = protocol(cfg_full)
-        sample = f"1 warm-up + 3 timed fwd+bwd steps of {cfg_full['name']} (256x256x32 grid, B=1), median {med:.1f} s"
-        cfg_name = cfg_full["name"]
+    try:
+        v, med, times = protocol(S.CFG_S)
+        sample = f"1 warm-up + 5 timed fwd+bwd steps of configs[0] (64x64x16 grid, D=48, B=1), median {med:.2f} s"
+        cfg_name = "configs[0]"
+        if mode == "full" or (mode == "auto" and med * 25 * 6 < 210):      # full size ~25x the small step
+            v, med, times = protocol(cfg_full)
+            sample = f"1 warm-up + 5 timed fwd+bwd steps of {cfg_full['name']} (256x256x32 grid, B=1), median {med:.1f} s"
+            cfg_name = cfg_full["name"]
+    finally:
+        if allowed is not None:
+            os.sched_setaffinity(0, set(allowed))
     return {"value": v, "unit": "voxels/s", "cores": ncores, "kind": "port", "sample": sample, "workload": cfg_name,
-            "step_seconds": [round(t, 3) for t in times], "cpu": _cpu_model(), "host_threads_available": os.cpu_count(),
-            "threads_source": "profiles/r2_cpu_thread_sweep.txt"}
+            "step_seconds": [round(t, 3) for t in times], "step_seconds_min_median_max": [round(min(times), 3), round(med, 3), round(max(times), 3)],
+            "spread": round((max(times) - min(times)) / med, 3), "pinned_cpus": pinned,
+            "cpu": _cpu_model(), "host_threads_available": os.cpu_count(), "threads_source": "profiles/r2_cpu_thread_sweep.txt"}
 
 
 def exchange_microbench(reducer, dist, iters=5):
@@ -374,16 +402,18 @@ def main():
             avg_s = k["ms"] * 1e-3 / n
             exec_tf = k["executed"] / n / avg_s / 1e12
             oper_tf = k["flops"] / n / avg_s / 1e12
-            traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
-            if not os.path.exists(tfile):
-                tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-            if os.path.exists(tfile) and args.config == "kitti_d192" and args.batch == 1:
-                # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (committed
-                # summary of the same tree; PMC collection cannot run inside the timed process)
-                t = json.load(open(tfile))["kernels"].get(tname)
+            traffic, traffic_src, traffic_fresh = None, None, None
+            cands = (["r4_pmc_traffic_bf16.json"] if args.precision != "fp32" else ["r4_pmc_traffic.json", "r3_pmc_traffic.json"])
+            tfile = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
+            if tfile and args.config == "kitti_d192" and args.batch == 1:
+                # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (PMC collection cannot run
+                # inside the timed process).  `traffic_matches_tree`: the file records a hash of csrc/ at collection time
+                # (tools/pmc_traffic.py); it is compared with the tree this process runs ("a HEAD-hash check")
+                tj = json.load(open(tfile))
+                t = tj["kernels"].get(tname)
                 if t:
                     traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
+                    traffic_fresh = (tj.get("csrc_sha16") == csrc_sha16()) if tj.get("csrc_sha16") else None
             return {"bound": bound, "kernel": kname,
                     "achieved": exec_tf, "peak": peak, "unit": "TFLOP/s", "frac": exec_tf / peak,
                     "flop_convention": "achieved / frac count the multiply-adds the kernel EXECUTES (" + EXECUTED_NOTE[base] +
@@ -398,6 +428,7 @@ def main():
                     "algorithmic_bytes_per_launch": k["bytes"] / n,
                     "ms_per_step_in_kernel": k["ms"] / nsteps,
                     "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
+                    "traffic_matches_tree": traffic_fresh,
                     "timing": timing or ("HIP events on the launch stream around every launch inside the timed region"
                                          + ("; the step runs on TWO streams (weight gradients / DepthNet on the second), so a "
                                             "launch's event-to-event time includes the CU share of co-scheduled kernels -- see "

@@ -159,8 +159,10 @@ typedef struct {
                         *     weights hold bf16 operands, accumulation is fp32, gw is fp32.  Needs Cin % 8 == 0 (and
                         *     Cout % 8 == 0 wherever the Cout-channel tensor is a source); bias stays fp32;
                         * 3 = as 2 with an fp32 RESULT (the layer in front of an fp32 island, e.g. the logits conv)
-                        *     ssbev_conv_kernel_class answers 16 (generic gather), 17 (LDS-ring tap kernel), 18 (weight
-                        *     gradient) for these modes                                                              */
+                        *     ssbev_conv_kernel_class answers, for these modes: 16 generic gather (conv_gather16_kernel), 17
+                        *     LDS-ring tap kernel (<= 32 channels, conv_tap16_kernel), 19 LDS-ring implicit GEMM for the wide
+                        *     stride-1 3x3x3 layers (conv_wide16_kernel); mode 2: 18 generic weight gradient (wgrad16_kernel),
+                        *     20 LDS-ring weight gradient (wgrad_ring16_kernel)                                       */
 } ssbev_conv_dims;
 
 /* weight packing: src is the torch layout  conv: [Cout,Cin,kd,kh,kw]  deconv: [Cin,Cout,kd,kh,kw]

@@ -12,7 +12,7 @@ namespace ssbev_bf16 {
 
 bool storage_mode(const ssbev_conv_dims* d);                       // precision 2 or 3
 bool dims_ok(const ssbev_conv_dims* d, int mode);                  // channel multiples the kernels need (mode 0 fwd, 1 dgrad, 2 wgrad)
-int kernel_class(const ssbev_conv_dims* d, int mode);              // 16 generic gather, 17 LDS-ring tap kernel, 18 LDS weight gradient
+int kernel_class(const ssbev_conv_dims* d, int mode);              // 16 / 17 / 19 forward + data gradient kernels, 18 / 20 weight gradient (ssbev.h)
 size_t packed_elems(const ssbev_conv_dims* d);                     // in floats (the buffer holds bf16 operands)
 int pack(const float* w_src, float* w_packed, const ssbev_conv_dims* d, int mode, hipStream_t st);
 int forward(const void* x, const float* wp, const float* bias, void* y, const ssbev_conv_dims* d, hipStream_t st);

@@ -53,7 +53,10 @@ class FlatGradAllReduce:
         # xGMI) and widened back into the fp32 flat buffer.  The SUM then happens in bf16 on the wire: relative error of the
         # averaged gradient <= ~2^-8 per element (tests/test_dp_gloo.py measures it) -- opt-in, like the reference's fp16
         # all-reduce under Fp16OptimizerHook; master gradients / moments stay fp32.
-        cd = comm_dtype or os.environ.get("SSBEV_DP_COMM_DTYPE", "fp32")
+        # default: fp32 on the wire in the fp32 mode, bf16 in the bf16 storage mode ("bf16 exchange on by default in that
+        # mode" -- the counterpart of the reference's fp16 gradient all-reduce under Fp16OptimizerHook, mmdet_train.py:131-134)
+        from . import functional as _F
+        cd = comm_dtype or os.environ.get("SSBEV_DP_COMM_DTYPE", "bf16" if _F.storage_bf16() else "fp32")
         if cd not in ("fp32", "bf16"):
             raise ValueError(f"comm_dtype must be 'fp32' or 'bf16', got {cd!r}")
         self.comm_dtype = cd

@@ -743,7 +743,8 @@ class _ConvNd16(torch.autograd.Function):
                     return _wino_wgrad_bf16(xcl, gcl, weight)
             gwp = torch.empty(tuple(weight.shape), dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
-            with _span("wgrad16", conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
+            fam = "wgrad_ring16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 2) == 20) else "wgrad16"
+            with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
                 capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d), capi.ptr(ws),
                                                      ws.numel(), capi.stream()), "ssbev_conv_bwd_weight[bf16]")
             return gwp

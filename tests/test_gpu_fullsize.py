@@ -178,6 +178,42 @@ def test_full_size_forward_batch2_vs_oracle():
     assert (logits[0] - logits[1]).abs().max().item() > 1e-2          # the two samples really differ
 
 
+@pytest.mark.parametrize("mode", ["bev_only", "stereo_only"])
+def test_full_size_ablation_modes_vs_oracle(mode):
+    """BASELINE configs[4] at the KITTI size (the ablation modes were compared with the oracle only at the tiny
+    config): kitti_d112, eval mode.  The reference has no ablation switch, so the expected lifted volume is composed from the
+    oracle's own pieces -- its monocular (bev_only) / stereo (stereo_only) depth distribution pushed through its lift + splat;
+    gates as for the full path: depth distribution 1e-4, BEV volume 1e-3 of its scale."""
+    import torch
+    cfg = S.CONFIGS["kitti_d112"]
+    model = model_zoo.build_detector(cfg).eval()
+    vt = model.img_view_transformer
+    smp = S.synthetic_sample(cfg, B=1, tag="fsabl")
+    sd = {k: v.detach().cpu().clone() for k, v in vt.state_dict().items()}
+    oin = _oracle_inputs(smp)
+    taps = {}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(32, nt))
+    try:
+        with torch.no_grad():
+            O.view_transformer(sd, "", oin, dict(D=vt.D, numC_Trans=128, warp_align_corners=True), taps=taps)
+            dist_ref = taps["lss_volume"] if mode == "bev_only" else taps["stereo_volume"]
+            bev_ref = O.lift_splat(dist_ref, taps["img_feat"], taps["geom"], sd["dx"], sd["bx"], sd["nx"])
+    finally:
+        torch.set_num_threads(nt)
+    vt.ablation = mode
+    try:
+        with torch.no_grad():
+            bev, dp = vt([t.cuda() for t in oin])
+    finally:
+        vt.ablation = "full"
+    e_d = (dp.cpu() - dist_ref).abs().max().item()
+    e_b = (bev.cpu() - bev_ref).abs().max().item()
+    scale = bev_ref.abs().max().item()
+    print(f"kitti_d112 ablation {mode}: depth distribution max-abs {e_d:.2e}, BEV volume max-abs {e_b:.2e} (scale {scale:.2f})")
+    assert bev.shape == bev_ref.shape and e_d < 1e-4 and e_b < 1e-3 * max(1.0, scale)
+
+
 @pytest.mark.parametrize("cfg_name,B", [("kitti_d192", 1), ("kitti_d112", 2), ("kitti_d192", 2)])
 def test_full_size_bf16_mode_vs_oracle(cfg_name, B):
     """BASELINE configs[3] at the KITTI size: the bf16 STORAGE mode (round 4: bf16 activations between the layers, bf16 MFMA

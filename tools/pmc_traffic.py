@@ -7,7 +7,10 @@ streaming kernels of this path (gwc_warp_fwd writes 188.7 MB, pool_gather 134.2 
 it is doubled."""
 import collections, csv, json, sys
 
-FAMILIES = [("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_dfw_kernel",)),
+FAMILIES = [("conv_wide16_kernel", ("conv_wide16_kernel",)), ("conv_tap16_kernel", ("conv_tap16_kernel",)),
+            ("conv_gather16_kernel", ("conv_gather16_kernel",)), ("wgrad16_kernel", ("wgrad16_kernel", "wgrad_ring16_kernel")),
+            ("wgrad_ring16_kernel", ("wgrad_ring16_kernel",)),
+            ("wino_df_kernel", ("wino_df_kernel",)), ("wino_dfw_kernel", ("wino_dfw_kernel",)),
             ("gemm_nn_kernel", ("gemm_nn_kernel",)), ("gemm_tn_kernel", ("gemm_tn_kernel", "gemm_tn_skinny_kernel")),
             ("gwc_warp_bwd", ("gwc_warp_bwd2_kernel", "gwc_warp_bwd3_kernel")), ("lift_splat_bwd2", ("lift_splat_bwd2_kernel",)),
             ("conv_thinin_kernel", ("conv_thinin_kernel",)), ("conv_thinout_u_kernel", ("conv_thinout_u_kernel",)),
@@ -31,7 +34,10 @@ def load(path):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-out = {"_doc": __doc__, "kernels": {}}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16                      # the tree the counters were collected on (bench.py checks it against its own)
+out = {"_doc": __doc__, "csrc_sha16": csrc_sha16(), "kernels": {}}
 for fam, keys in FAMILIES:
     f = [v for k, vs in fetch.items() if any(s in k for s in keys) for v in vs]
     w = [v for k, vs in write.items() if any(s in k for s in keys) for v in vs]
