@@ -66,9 +66,6 @@ int ssbev_voxel_index(const float* geom, int32_t* vox, int32_t* idx3, const ssbe
 int ssbev_coords_to_vox(const int32_t* coords, int n, int32_t* vox, const ssbev_pool_dims* d,
                         ssbev_stream_t stream);
 
-/* CSR build: starts[NV+1], order[n] with NV = B*nx*ny*nz.  Points of voxel v are
- * order[starts[v] .. starts[v+1]) in ASCENDING point index (the canonical summation order,
- * = stable argsort by rank in the upstream op).  Entries with vox<0 are skipped. */
 /* Frustum points -> ego frame: the per-point part of get_geometry (ViewTransformerLSSBEVDepth.py:123-156) in one kernel,
  *   p = frustum[d,h,w,:] - t0[b,n];  p = m1[b,n] p;  p = (p.x p.z, p.y p.z, p.z);  p -= t2[b,n] (if given);
  *   p = m2[b,n] p + tr[b,n];  p = m3[b] p (+ t3[b] if given)
@@ -80,6 +77,12 @@ int ssbev_frustum_geometry(const float* frustum, const float* m1, const float* t
                            const float* tr, const float* m3, const float* t3, float* geom, const ssbev_geom_dims* d,
                            ssbev_stream_t stream);
 
+/* CSR build: starts[NV+1], order[n] with NV = B*nx*ny*nz.  Points of voxel v are
+ * order[starts[v] .. starts[v+1]) in ASCENDING point index (the canonical summation order,
+ * = stable argsort by rank in the upstream op).  Entries with vox<0 (or >= NV) are skipped: order[] holds starts[NV] ids,
+ * its tail is left untouched.  Own two-level counting sort (csrc/voxel_pool.hip, "CSR build"): a stable partition by the
+ * high digit of the voxel id, then one wavefront per 2^lo-voxel bucket that counts, scans (= starts) and places; five
+ * launches for NV <= 2^22, no device-wide library sort.  SSBEV_POOL_MAX_DIGIT_BITS (2..11) narrows the digit (tests). */
 size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d);
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);

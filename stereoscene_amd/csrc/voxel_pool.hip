@@ -2,17 +2,14 @@
 //
 // Design (MI355X-first, not a translation of BEVFusion's bev_pool CUDA op):
 //   * the scatter is turned into a GATHER over a CSR table (voxel -> ascending point list) that
-//     is built on the device with a histogram / scan (segment starts) and one stable radix sort of
-//     (voxel id, point id) pairs (hipCUB's device-wide LSD sort: the only library primitive in this file);
-//     no float atomics anywhere, sums are sequential fp32 in a fixed order => bit-reproducible
+//     is built on the device by an own two-level stable counting sort of (voxel id, point id) pairs
+//     ("CSR build" below; no library primitive in this file); no float atomics anywhere, sums are sequential fp32 in a fixed order => bit-reproducible
 //     and bit-identical to the CPU oracle;
 //   * one wavefront owns one voxel and streams its C channels with 8-byte lanes (C=128 ->
 //     one 512-B line per point, one 512-B store per voxel): the kernel is bound by the
 //     [B,nx,ny,nz,C] output write (134 MB at the KITTI config), everything else stays in L2;
 //   * Lift (depth x feature outer product, 755 MB at D=192) is fused in: never materialised.
 #include "common.h"
-
-#include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
 
@@ -103,103 +100,334 @@ __global__ void coords_to_vox_kernel(const int32_t* __restrict__ coords, int n, 
 }
 
 // ---------------------------------------------------------------- CSR build
-__global__ void histogram_kernel(const int32_t* __restrict__ vox, int n, int32_t* __restrict__ counts) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int v = vox[i];
-  if (v >= 0) atomicAdd(&counts[v], 1);
-}
+// The table (starts[NV + 1], order[n]: the points of voxel v in ASCENDING point id) is a stable sort of the points by voxel
+// id.  Own two-level counting sort (round 4; hipCUB's three onesweep passes + a global-atomics histogram took 166 us for the
+// 1.47 M points of the KITTI frustum):
+//   level 1  stable partition by the HIGH digit of the voxel id (<= 11 bits): per-tile digit counts in LDS (csr_hist), one
+//            workgroup per digit turns its row of tile counts into output offsets (csr_scan), then every tile places its
+//            points (csr_partition): a wave owns a contiguous quarter of the tile and walks it 64 points at a time; the rank
+//            of a point among the lanes with the same digit is a popcount of a match mask (one ballot per digit bit), the
+//            running offsets live in LDS.  No sorting network, no global atomics on the data path, stable by construction.
+//   level 2  one WAVE per high-digit bucket (512 voxels at the KITTI grid, a few thousand points): counts its points per
+//            LOW digit in LDS, scans them -- that IS starts[] for its voxels, written as coalesced lines, so the 262 144-bin
+//            histogram of the old path is gone -- and places the point ids with the same match-mask ranking.
+// Voxel grids above 2^22 cells take more than one level-1 pass (LSD over the high part; bucket bounds by binary search).
+constexpr int CSR_T = 256;                 // threads of a level-1 workgroup
+constexpr int CSR_WAVES = CSR_T / 64;
+constexpr int CSR_MAX_DIGIT_BITS = 11;
 
-constexpr int SCAN_T = 256;
-constexpr int SCAN_ITEMS = 4;
-constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
-
-// exclusive scan of one tile inside a block; returns the tile total through *total
-__device__ int block_exclusive_scan(int thread_sum, int* lds, int* total) {
-  const int t = threadIdx.x;
-  lds[t] = thread_sum;
-  __syncthreads();
-#pragma unroll
-  for (int off = 1; off < SCAN_T; off <<= 1) {
-    int v = (t >= off) ? lds[t - off] : 0;
-    __syncthreads();
-    lds[t] += v;
-    __syncthreads();
-  }
-  const int incl = lds[t];
-  *total = lds[SCAN_T - 1];
-  __syncthreads();
-  return incl - thread_sum;
-}
-
-__global__ void scan_tile_sums_kernel(const int32_t* __restrict__ counts, int nv, int32_t* __restrict__ tile_sums) {
-  __shared__ int lds[SCAN_T];
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int s = 0;
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) s += (base + j < nv) ? counts[base + j] : 0;
-  int total;
-  block_exclusive_scan(s, lds, &total);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
-
-// single block: exclusive scan of the tile sums in place (ntiles is small: NV/1024)
-__global__ void scan_tile_offsets_kernel(int32_t* __restrict__ tile_sums, int ntiles) {
-  __shared__ int lds[SCAN_T];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += SCAN_T) {
-    const int i = base + threadIdx.x;
-    const int v = (i < ntiles) ? tile_sums[i] : 0;
-    int total;
-    const int ex = block_exclusive_scan(v, lds, &total);
-    if (i < ntiles) tile_sums[i] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
-  }
-}
-
-__global__ void scan_write_kernel(const int32_t* __restrict__ counts, int nv, const int32_t* __restrict__ tile_off,
-                                  int32_t* __restrict__ starts, int n_total_slot) {
-  __shared__ int lds[SCAN_T];
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int c[SCAN_ITEMS];
-  int s = 0;
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    c[j] = (base + j < nv) ? counts[base + j] : 0;
-    s += c[j];
-  }
-  int total;
-  int ex = block_exclusive_scan(s, lds, &total) + tile_off[blockIdx.x];
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    if (base + j < nv) starts[base + j] = ex;
-    ex += c[j];
-    if (base + j == nv - 1) starts[nv] = ex;  // grand total in the sentinel slot
-  }
-  (void)n_total_slot;
-}
-
-// Canonical CSR order by ONE stable radix sort: key = voxel id (dropped points get key nv and sort behind every voxel),
-// value = point id.  The ids enter in ascending order and an LSD radix sort is stable, so each voxel's run comes out in
-// ascending point id -- the sequential-sum order of the CPU oracle -- with no per-voxel work at all (the previous
-// atomic fill + per-voxel rank sort spent 0.77 ms on the long lists of the near-camera voxels; this is ~0.1 ms).
-__global__ void sort_keys_kernel(const int32_t* __restrict__ vox, int n, int nv, uint32_t* __restrict__ keys,
-                                 int32_t* __restrict__ ids) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int v = vox[i];
-  keys[i] = v < 0 ? (uint32_t)nv : (uint32_t)v;
-  ids[i] = i;
-}
-
-int key_bits(int nv) {
+int key_bits(long long maxkey) {
   int b = 1;
-  while ((1ll << b) <= (long long)nv) ++b;
+  while ((1ll << b) <= maxkey) ++b;
   return b;
+}
+
+struct CsrPlan {
+  int lo_bits, npass, shift[16], nbits[16];
+  int items, nblk, nbuckets;
+};
+
+// SSBEV_POOL_MAX_DIGIT_BITS (2..11, tests only) narrows the level-1 digit so that small inputs exercise the multi-pass path
+int csr_max_digit_bits() {
+  const char* e = getenv("SSBEV_POOL_MAX_DIGIT_BITS");
+  const int x = e ? atoi(e) : CSR_MAX_DIGIT_BITS;
+  return x < 2 ? 2 : (x > CSR_MAX_DIGIT_BITS ? CSR_MAX_DIGIT_BITS : x);
+}
+
+bool csr_plan(long long nv, long long n, CsrPlan* p) {
+  const int maxd = csr_max_digit_bits();
+  const int bits = key_bits(nv - 1);
+  int hi = bits - 9 > (bits + 1) / 2 ? bits - 9 : (bits + 1) / 2;
+  if (hi > maxd) hi = maxd;
+  int lo = bits - hi;
+  if (lo > maxd) lo = maxd;
+  const int hi_total = bits - lo;
+  p->lo_bits = lo;
+  p->npass = (hi_total + maxd - 1) / maxd;
+  if (p->npass > 16) return false;
+  int sh = lo, left = hi_total;
+  for (int j = 0; j < p->npass; ++j) {
+    const int nb = (left + (p->npass - j) - 1) / (p->npass - j);
+    p->shift[j] = sh; p->nbits[j] = nb;
+    sh += nb; left -= nb;
+  }
+  long long items = 8;
+  // (measured on the KITTI frustum, 1.47 M points: 8 rows per wave 35.5 us for the four kernels, 16 rows 43 us, 32 rows 60 us
+  // -- the placing phase is a chain of dependent 64-point steps, so small tiles / many workgroups win)
+  while ((n + CSR_T * items - 1) / (CSR_T * items) > 1024) items *= 2;
+  p->items = (int)items;
+  p->nblk = (int)((n + CSR_T * items - 1) / (CSR_T * items));
+  if (p->nblk < 1) p->nblk = 1;
+  p->nbuckets = (int)(((nv - 1) >> lo) + 1);
+  return true;
+}
+
+// lanes of this wave that hold the same digit (among the valid ones): one ballot per digit bit
+__device__ __forceinline__ unsigned long long match_digit(int digit, bool valid, int nbits) {
+  unsigned long long m = __ballot(valid);
+  for (int b = 0; b < nbits; ++b) {
+    const bool bit = (digit >> b) & 1;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// hist[d * nblk + tile] = points of the tile whose digit is d; totals[d] += the same (zeroed by the host)
+__global__ void __launch_bounds__(CSR_T)
+csr_hist_kernel(const int32_t* __restrict__ keys, int n, int nv, int shift, int nbits, int items, int nblk,
+                int32_t* __restrict__ hist, int32_t* __restrict__ totals) {
+  extern __shared__ int cnt[];
+  const int nd = 1 << nbits, tid = threadIdx.x;
+  for (int d = tid; d < nd; d += CSR_T) cnt[d] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * CSR_T * items;
+  for (int s0 = 0; s0 < items; s0 += 8) {         // items is a multiple of 8: eight loads in flight per thread
+    int k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long e = base + (long long)(s0 + j) * CSR_T + tid;
+      k[j] = e < n ? keys[e] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((unsigned)k[j] < (unsigned)nv) atomicAdd(&cnt[(k[j] >> shift) & (nd - 1)], 1);
+  }
+  __syncthreads();
+  for (int d = tid; d < nd; d += CSR_T) {
+    const int c = cnt[d];
+    hist[(size_t)d * nblk + blockIdx.x] = c;
+    if (c) atomicAdd(&totals[d], c);
+  }
+}
+
+// one workgroup per digit d: hist[d][*] -> exclusive offsets, starting at the number of points with a smaller digit
+__global__ void __launch_bounds__(256)
+csr_scan_kernel(int32_t* __restrict__ hist, const int32_t* __restrict__ totals, int nd, int nblk,
+                int32_t* __restrict__ bucket_base) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int part = 0;
+  for (int i = tid; i < d; i += 256) part += totals[i];
+  part = wave_incl_scan(part, lane);
+  if (lane == 63) wsum[wave] = part;
+  __syncthreads();
+  const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) {
+    carry_s = base;
+    bucket_base[d] = base;
+    if (d == nd - 1) bucket_base[nd] = base + totals[d];
+  }
+  __syncthreads();
+  int32_t* row = hist + (size_t)d * nblk;
+  for (int c0 = 0; c0 < nblk; c0 += 256) {
+    const int i = c0 + tid;
+    const int v = i < nblk ? row[i] : 0;
+    const int incl = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (i < nblk) row[i] = before + incl - v;
+    __syncthreads();
+    if (tid == 0) carry_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+
+// stable placement of a tile's points behind the offsets of csr_scan_kernel.  FIRST: keys = vox[], id = position.
+// KEEP: items == 8, the wave's eight key rows stay in registers between the counting and the placing phase.
+template <bool FIRST, bool KEEP>
+__global__ void __launch_bounds__(CSR_T)
+csr_partition_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ ids, int n, int nv, int shift, int nbits,
+                     int items, int nblk, const int32_t* __restrict__ offsets, int32_t* __restrict__ keys_out,
+                     int32_t* __restrict__ ids_out) {
+  extern __shared__ int cnt[];                   // [4 waves][nd]
+  const int nd = 1 << nbits, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int d = tid; d < CSR_WAVES * nd; d += CSR_T) cnt[d] = 0;
+  __syncthreads();
+  const long long sub = ((long long)blockIdx.x * CSR_WAVES + wave) * 64 * items;
+  int* mine = cnt + wave * nd;
+  int kk[8], ii[8];
+  unsigned long long mm[8];                     // KEEP: the match masks of the counting phase serve the placing phase too
+  for (int s0 = 0; s0 < items; s0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long e = sub + (s0 + j) * 64 + lane;
+      kk[j] = e < n ? keys[e] : -1;
+      if (KEEP && !FIRST) ii[j] = e < n ? ids[e] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool valid = (unsigned)kk[j] < (unsigned)nv;
+      const int digit = valid ? (kk[j] >> shift) & (nd - 1) : 0;
+      mm[j] = match_digit(digit, valid, nbits);
+      if (valid && lane == 63 - __clzll(mm[j])) atomicAdd(&mine[digit], __popcll(mm[j]));
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < nd; d += CSR_T) {
+    int run = offsets[(size_t)d * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < CSR_WAVES; ++w) {
+      const int c = cnt[w * nd + d];
+      cnt[w * nd + d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  volatile int* run = mine;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int s0 = 0; s0 < items; s0 += 8) {
+    if (!KEEP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long long e = sub + (s0 + j) * 64 + lane;
+        kk[j] = e < n ? keys[e] : -1;
+        if (!FIRST) ii[j] = e < n ? ids[e] : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kk[j];
+      const bool valid = (unsigned)k < (unsigned)nv;
+      const int digit = valid ? (k >> shift) & (nd - 1) : 0;
+      const unsigned long long m = KEEP ? mm[j] : match_digit(digit, valid, nbits);
+      int old = 0;
+      if (valid) {
+        old = run[digit];
+        const int pos = old + __popcll(m & below);
+        keys_out[pos] = k;
+        ids_out[pos] = FIRST ? (int)(sub + (s0 + j) * 64 + lane) : ii[j];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (valid && lane == 63 - __clzll(m)) run[digit] = old + __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// keys[n_valid ..] = -1 (between two level-1 passes: the compacted buffer's tail is stale)
+__global__ void csr_invalidate_tail_kernel(int32_t* __restrict__ keys, int n, const int32_t* __restrict__ n_valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && i >= *n_valid) keys[i] = -1;
+}
+
+// level 2: one workgroup of 16 waves per bucket (= value of key >> lo_bits); keys / ids are sorted by bucket, ascending id
+// inside a bucket.  Wave w owns the w-th contiguous 16th of the bucket (rounded up to whole 64-point rows): it counts its
+// points per low digit, the workgroup turns the [16][2^lo] counts into offsets (scan over digits = starts[], prefix over
+// waves inside a digit), and every wave places its points with the match-mask ranking of level 1.  A wave's share of up to
+// 256 points stays in registers between the two phases (the KITTI frustum's largest bucket holds 3936 points: one load
+// round per wave; a first version with one wave per bucket walked 62 dependent 64-point rows and took 72 us).
+constexpr int CSR_BW = 16;
+__global__ void __launch_bounds__(CSR_BW * 64)
+csr_bucket_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ ids, const int32_t* __restrict__ bucket_base,
+                  const int32_t* __restrict__ n_valid, int nv, int lo_bits, int32_t* __restrict__ starts,
+                  int32_t* __restrict__ order) {
+  extern __shared__ int cnt[];                   // [16 waves][1 << lo_bits] | wave sums [16]
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = 1 << lo_bits;
+  int* wsum = cnt + CSR_BW * nl;
+  int b0, b1;
+  if (bucket_base) {
+    b0 = bucket_base[h]; b1 = bucket_base[h + 1];
+  } else {                                        // several level-1 passes: bounds of the bucket by binary search
+    const int nval = *n_valid;
+    int lo = 0, hi = nval;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((keys[mid] >> lo_bits) < h) lo = mid + 1; else hi = mid; }
+    b0 = lo; hi = nval;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((keys[mid] >> lo_bits) <= h) lo = mid + 1; else hi = mid; }
+    b1 = lo;
+  }
+  for (int l = tid; l < CSR_BW * nl; l += CSR_BW * 64) cnt[l] = 0;
+  __syncthreads();
+  const int share = (((b1 - b0 + CSR_BW - 1) / CSR_BW) + 63) & ~63;      // points per wave, whole rows
+  const int w0 = b0 + wave * share, w1 = min(b1, w0 + share);
+  const bool keep = share <= 256;
+  int* mine = cnt + wave * nl;
+  int kk[4], ii[4];
+  unsigned long long mm[4];
+  for (int e0 = w0; e0 < w1; e0 += 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j * 64 + lane;
+      kk[j] = e < w1 ? keys[e] : -1;
+      ii[j] = e < w1 ? ids[e] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mm[j] = match_digit(kk[j] >= 0 ? kk[j] & (nl - 1) : 0, kk[j] >= 0, lo_bits);
+      if (kk[j] >= 0 && lane == 63 - __clzll(mm[j])) atomicAdd(&mine[kk[j] & (nl - 1)], __popcll(mm[j]));
+    }
+  }
+  __syncthreads();
+  // per digit: prefix over the waves; then the exclusive scan over the digits (each thread owns `per` consecutive digits)
+  const int per = (nl + CSR_BW * 64 - 1) / (CSR_BW * 64);
+  int tot[2] = {0, 0};                            // nl <= 2048 = 2 per thread
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int l = tid * per + j;
+    if (j < per && l < nl) {
+      int run = 0;
+#pragma unroll
+      for (int w = 0; w < CSR_BW; ++w) { const int c = cnt[w * nl + l]; cnt[w * nl + l] = run; run += c; }
+      tot[j] = run;
+    }
+  }
+  const int tsum = tot[0] + tot[1];
+  const int incl = wave_incl_scan(tsum, lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int dbase = b0 + incl - tsum;
+  for (int w = 0; w < wave; ++w) dbase += wsum[w];
+  const long long v0 = (long long)h << lo_bits;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int l = tid * per + j;
+    if (j < per && l < nl) {
+      if (v0 + l < nv) starts[v0 + l] = dbase;
+#pragma unroll
+      for (int w = 0; w < CSR_BW; ++w) cnt[w * nl + l] += dbase;
+      dbase += tot[j];
+    }
+  }
+  if (h == (int)gridDim.x - 1 && tid == 0) starts[nv] = b1;
+  __syncthreads();
+  volatile int* run = mine;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int e0 = w0; e0 < w1; e0 += 256) {
+    if (!keep) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 64 + lane;
+        kk[j] = e < w1 ? keys[e] : -1;
+        ii[j] = e < w1 ? ids[e] : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool valid = kk[j] >= 0;
+      const int digit = valid ? kk[j] & (nl - 1) : 0;
+      const unsigned long long m = keep ? mm[j] : match_digit(digit, valid, lo_bits);
+      int old = 0;
+      if (valid) {
+        old = run[digit];
+        order[old + __popcll(m & below)] = ii[j];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (valid && lane == 63 - __clzll(m)) run[digit] = old + __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // ---------------------------------------------------------------- gather-sum kernels
@@ -899,51 +1127,80 @@ int ssbev_coords_to_vox(const int32_t* coords, int n, int32_t* vox, const ssbev_
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-// upper bound of hipcub::DeviceRadixSort::SortPairs' temporary storage for n (uint32, int32) pairs (alternate key / value
-// buffers + digit histograms / look-back state); the exact size is queried at run time and checked against it
-static size_t sort_scratch_bound(size_t n) { return align256(n * 8) + ((size_t)8 << 20); }
+
+// workspace of ssbev_pool_prepare: totals[npass][2048] | bucket_base[2049] | hist[2^digit bits][tiles] | (keys, ids) x 1 or 2
+struct CsrWs { size_t totals, base, hist, pairs, total; };
+static CsrWs csr_ws(const CsrPlan& p, size_t n) {
+  CsrWs w;
+  int nd_max = 1;
+  for (int j = 0; j < p.npass; ++j) nd_max = nd_max > (1 << p.nbits[j]) ? nd_max : (1 << p.nbits[j]);
+  w.totals = 0;
+  w.base = w.totals + align256((size_t)p.npass * 2048 * 4);
+  w.hist = w.base + align256(2049 * 4);
+  w.pairs = w.hist + align256((size_t)nd_max * p.nblk * 4);
+  w.total = w.pairs + (p.npass > 1 ? 4 : 2) * align256(n * 4 + 4);
+  return w;
+}
 
 size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d) {
   if (!pool_dims_ok(d) || n_points < 0) return 0;
-  const size_t nv = (size_t)d->B * d->nx * d->ny * d->nz;
-  const size_t ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
-  // counts[nv] | tile_sums[ntiles] | keys_in[n] | keys_out[n] | ids_in[n] | radix-sort scratch
-  return align256(nv * 4) + align256(ntiles * 4) + 3 * align256((size_t)n_points * 4 + 4) + sort_scratch_bound(n_points);
+  CsrPlan p;
+  if (!csr_plan((long long)d->B * d->nx * d->ny * d->nz, n_points, &p)) return 0;
+  return csr_ws(p, (size_t)n_points).total;
 }
 
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!pool_dims_ok(d) || n_points < 0 || !starts || !ws || (n_points && (!vox || !order))) return SSBEV_EINVAL;
-  if (ws_bytes < ssbev_pool_prepare_workspace(n_points, d)) return SSBEV_EWORKSPACE;
+  const long long nvl = (long long)d->B * d->nx * d->ny * d->nz;
+  CsrPlan p;
+  if (nvl >= (1ll << 31) || !csr_plan(nvl, n_points, &p)) return SSBEV_EINVAL;
+  const CsrWs w = csr_ws(p, (size_t)n_points);
+  if (ws_bytes < w.total) return SSBEV_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const int nv = d->B * d->nx * d->ny * d->nz;
-  const int ntiles = (nv + SCAN_TILE - 1) / SCAN_TILE;
-  char* base = static_cast<char*>(ws);
-  int32_t* counts = reinterpret_cast<int32_t*>(base);
-  int32_t* tiles = reinterpret_cast<int32_t*>(base + align256((size_t)nv * 4));
-  char* p = base + align256((size_t)nv * 4) + align256((size_t)ntiles * 4);
-  const size_t nb = align256((size_t)n_points * 4 + 4);
-  uint32_t* keys_in = reinterpret_cast<uint32_t*>(p);
-  uint32_t* keys_out = reinterpret_cast<uint32_t*>(p + nb);
-  int32_t* ids_in = reinterpret_cast<int32_t*>(p + 2 * nb);
-  void* scratch = p + 3 * nb;
-  const size_t scratch_avail = ws_bytes - (size_t)(p + 3 * nb - base);
-  if (hipMemsetAsync(base, 0, align256((size_t)nv * 4), st) != hipSuccess) return SSBEV_ELAUNCH;
-  if (n_points)
-    hipLaunchKernelGGL(histogram_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, counts);
-  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles);
-  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_T), 0, st, tiles, ntiles);
-  hipLaunchKernelGGL(scan_write_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, counts, nv, tiles, starts, nv);
-  if (n_points) {
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, st, vox, n_points, nv, keys_in, ids_in);
-    size_t need = 0;
-    const int bits = key_bits(nv);
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_in, keys_out, ids_in, order, n_points, 0, bits, st) != hipSuccess)
-      return SSBEV_ELAUNCH;
-    if (need > scratch_avail) return SSBEV_EWORKSPACE;
-    if (hipcub::DeviceRadixSort::SortPairs(scratch, need, keys_in, keys_out, ids_in, order, n_points, 0, bits, st) != hipSuccess)
-      return SSBEV_ELAUNCH;
+  const int nv = (int)nvl;
+  if (n_points == 0) {
+    if (hipMemsetAsync(starts, 0, ((size_t)nv + 1) * 4, st) != hipSuccess) return SSBEV_ELAUNCH;
+    return SSBEV_OK;
   }
+  char* base = static_cast<char*>(ws);
+  int32_t* totals = reinterpret_cast<int32_t*>(base + w.totals);
+  int32_t* bucket_base = reinterpret_cast<int32_t*>(base + w.base);
+  int32_t* hist = reinterpret_cast<int32_t*>(base + w.hist);
+  const size_t nb = align256((size_t)n_points * 4 + 4);
+  int32_t* kbuf[2] = {reinterpret_cast<int32_t*>(base + w.pairs), reinterpret_cast<int32_t*>(base + w.pairs + 2 * nb)};
+  int32_t* ibuf[2] = {reinterpret_cast<int32_t*>(base + w.pairs + nb), reinterpret_cast<int32_t*>(base + w.pairs + 3 * nb)};
+  if (hipMemsetAsync(totals, 0, (size_t)p.npass * 2048 * 4, st) != hipSuccess) return SSBEV_ELAUNCH;
+  const int32_t* kin = vox;
+  const int32_t* iin = nullptr;
+  for (int j = 0; j < p.npass; ++j) {
+    const int nd = 1 << p.nbits[j];
+    int32_t* tot = totals + (size_t)j * 2048;
+    hipLaunchKernelGGL(csr_hist_kernel, dim3(p.nblk), dim3(CSR_T), (size_t)nd * 4, st, kin, n_points, nv, p.shift[j],
+                       p.nbits[j], p.items, p.nblk, hist, tot);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(nd), dim3(256), 0, st, hist, tot, nd, p.nblk, bucket_base);
+    const size_t lds = (size_t)CSR_WAVES * nd * 4;
+    auto part = j == 0 ? (p.items == 8 ? csr_partition_kernel<true, true> : csr_partition_kernel<true, false>)
+                       : (p.items == 8 ? csr_partition_kernel<false, true> : csr_partition_kernel<false, false>);
+    hipLaunchKernelGGL(part, dim3(p.nblk), dim3(CSR_T), lds, st, kin, iin, n_points, nv, p.shift[j], p.nbits[j], p.items,
+                       p.nblk, hist, kbuf[j & 1], ibuf[j & 1]);
+    kin = kbuf[j & 1]; iin = ibuf[j & 1];
+    // the passes behind the first see only the valid points, packed at the front; the tail of the buffers is stale
+    // (keys_out of pass j has bucket_base[nd] entries) -- the kernels bound their reads by n_points and by the key range,
+    // so the stale tail must not look valid:
+    if (j + 1 < p.npass) {
+      // n_valid is on the device; mark the tail invalid instead of reading it back
+      hipLaunchKernelGGL(csr_invalidate_tail_kernel, dim3(cdiv((size_t)n_points, 256)), dim3(256), 0, st,
+                         kbuf[j & 1], n_points, bucket_base + nd);
+    }
+  }
+  const int nd_last = 1 << p.nbits[p.npass - 1];
+  const size_t blds = ((size_t)CSR_BW * (1 << p.lo_bits) + CSR_BW) * 4;
+  if (blds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(csr_bucket_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(csr_bucket_kernel, dim3(p.nbuckets), dim3(CSR_BW * 64), blds, st, kin, iin,
+                     p.npass == 1 ? bucket_base : nullptr, bucket_base + nd_last, nv, p.lo_bits, starts, order);
   return ssbev_launch_status();
 }
 

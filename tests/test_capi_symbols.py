@@ -46,7 +46,7 @@ def test_workspace_queries_and_einval_on_host():
     lib = capi.load()
     d = capi.PoolDims()
     d.B, d.P, d.C, d.nx, d.ny, d.nz = 1, 1000, 128, 32, 32, 8
-    assert lib.ssbev_pool_prepare_workspace(1000, C.byref(d)) >= 2 * 32 * 32 * 8 * 4 + 4000
+    assert lib.ssbev_pool_prepare_workspace(1000, C.byref(d)) >= 2 * 1000 * 4 + 2049 * 4     # (key, id) pairs + digit bases
     d.nx = 0
     assert lib.ssbev_pool_prepare_workspace(1000, C.byref(d)) == 0
     assert lib.ssbev_voxel_index(None, None, None, C.byref(d), None) == capi.EINVAL

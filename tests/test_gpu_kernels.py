@@ -98,6 +98,44 @@ def test_bev_pool_dropin_matches_oracle_and_golden_coords():
     assert e.shape == (1, 16, 2, 4, 4) and float(e.abs().sum()) == 0.0
 
 
+def _csr_check(vox, B, nx, ny, nz):
+    starts, order = F.pool_prepare(vox.to(DEV), B, nx, ny, nz)
+    nv = B * nx * ny * nz
+    v = vox.numpy().astype(np.int64)
+    keep = (v >= 0) & (v < nv)
+    counts = np.bincount(v[keep], minlength=nv)
+    want_starts = np.concatenate([[0], np.cumsum(counts)])
+    assert np.array_equal(starts.cpu().numpy().astype(np.int64), want_starts)
+    ids = np.nonzero(keep)[0]
+    want_order = ids[np.argsort(v[keep], kind="stable")]
+    assert np.array_equal(order.cpu().numpy()[:len(ids)].astype(np.int64), want_order)
+
+
+@pytest.mark.parametrize("digit_bits", [None, "3", "2"])
+def test_pool_prepare_csr_is_a_stable_sort(digit_bits, monkeypatch):
+    """starts / order of ssbev_pool_prepare == exclusive scan of the voxel histogram / stable argsort by voxel id (the ascending
+    point order the sequential sums of the oracle need).  Ragged cases: dropped points, one voxel taking everything, a grid
+    that is not a power of two, fewer points than one wave, more tiles than one; SSBEV_POOL_MAX_DIGIT_BITS forces the
+    several-pass level 1 (bucket bounds by binary search) that full-size grids above 2^22 cells would take."""
+    if digit_bits is not None:
+        monkeypatch.setenv("SSBEV_POOL_MAX_DIGIT_BITS", digit_bits)
+    g = torch.Generator().manual_seed(7)
+    for (n, B, nx, ny, nz) in [(100000, 2, 32, 32, 8), (5000, 1, 7, 5, 3), (37, 1, 4, 4, 2), (70000, 1, 128, 128, 16), (1, 1, 1, 1, 1)]:
+        nv = B * nx * ny * nz
+        vox = torch.randint(-nv // 4 - 1, nv, (n,), generator=g, dtype=torch.int64).clamp_(min=-1).to(torch.int32)
+        _csr_check(vox, B, nx, ny, nz)
+    # clustered like a frustum: long lists on few voxels, everything else empty
+    hot = torch.randint(0, 64, (200000,), generator=g) * 517 + 11
+    _csr_check(hot.to(torch.int32), 1, 128, 128, 16)
+    _csr_check(torch.full((3000,), 4242, dtype=torch.int32), 1, 32, 32, 8)          # one voxel takes every point
+    _csr_check(torch.full((3000,), -1, dtype=torch.int32), 1, 32, 32, 8)            # every point dropped
+    if digit_bits is None:                                                              # the KITTI frustum itself
+        geom, dx, bx, nx_ = _geometry(S.CONFIGS["kitti_d112"], 1)
+        vox = F.voxel_index(geom.to(DEV), bx, dx, nx_).cpu()
+        n3 = [int(v) for v in nx_.tolist()]
+        _csr_check(vox, 1, n3[0], n3[1], n3[2])
+
+
 def test_pool_is_deterministic_run_to_run():
     cfg = S.CONFIGS["small_d48"]
     geom, dx, bx, nx = _geometry(cfg, 2)
