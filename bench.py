@@ -42,6 +42,7 @@ CPU_BASELINE_THREADS = 16
 # the step by summed duration).  value = (kernel name, bound)
 EXECUTED_NOTE = {
     "conv_tap_h": "in-kernel Winograd F(2,3) along h: 2/3 of the direct convolution's",
+    "conv_tap_dh": "in-kernel Winograd F(2,3) along d and h: 4/9 of the direct convolution's",
     "conv_wino_fused": "F(4,3)^2 over (h, w) in memory and F(2,3) along d in registers: 1/6 of the direct convolution's; "
                        "bytes = the kernel's own operands P / Mo (2.25x the activations) and packed weights",
     "conv_tap16": "direct convolution on v_mfma_f32_32x32x16_bf16, bf16 tensors: all of the direct convolution's",
@@ -53,6 +54,7 @@ EXECUTED_NOTE = {
 }
 SINGLE_KERNEL_FAMILIES = {
     "conv_tap_h": ("conv_taph_kernel", "mfma"),
+    "conv_tap_dh": ("conv_tapdh_kernel", "mfma"),
     "conv_wino_fused": ("wino_df_kernel", "mfma"),
     # bf16 storage mode (--precision bf16, BASELINE configs[3]): priced against the dense bf16 MFMA peak
     "conv_tap16": ("conv_tap16_kernel", "mfma"),

@@ -43,3 +43,37 @@ __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cas
 __device__ __forceinline__ void st4(bf16_t* p, const float4 v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
 }
+
+// One 1 KiB LDS-DMA (global_load_lds_dwordx4: lane l copies 16 bytes from gsrc to lds_dst + 16 l) issued behind the compiler's
+// back.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows a __builtin_amdgcn_global_load_lds
+// it cannot prove disjoint -- in the LDS-ring kernels that is the first operand read of every walk, so the rows "in flight
+// during the walk" were waited for before it (round 4: the .s of conv_taph_kernel).  An asm statement is outside its
+// bookkeeping: the kernel waits (`s_waitcnt vmcnt(0)` + barrier) exactly where the ring protocol needs it.  lds_dst must be
+// wave-uniform; M0 is saved and restored (the compiler keeps its own values there).
+__device__ __forceinline__ void glds16(const float* gsrc, const float* lds_dst) {
+  unsigned keep;
+  const unsigned ldsaddr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(ldsaddr)
+               : "memory");
+}
+
+// `s_waitcnt vmcnt(0)` as an INSTRUCTION hipcc sees (the builtin; simm16 = vmcnt 0, expcnt 7, lgkmcnt 15 on gfx9): it retires
+// the compiler's own pending loads in its bookkeeping -- behind an asm wait it keeps believing they are in flight and waits
+// for them (and for every glds16 issued since) at their next register hazard -- and it is a hard wait, so it also covers
+// the glds16 copies the compiler knows nothing about.
+__device__ __forceinline__ void wait_vm0() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
+}
+
+// Workgroup barrier that retires this wave's LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() is a fence:
+// it also waits vmcnt(0) for the wave's pending global STORES -- the write acknowledgement of an epilogue store issued just
+// before it (1.8 k clocks per block in conv_tapdh_kernel).  Use where the barrier orders LDS accesses only.
+__device__ __forceinline__ void barrier_lds() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}

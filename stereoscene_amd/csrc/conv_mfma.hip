@@ -29,6 +29,8 @@
 #include "conv_thin_mfma.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <array>
 #include <map>
 #include <mutex>
@@ -1644,6 +1646,7 @@ struct ConvTapGeom {
   int relu, has_bias;
   int accumulate = 0;             // y += result (second consumer of a multi-consumer activation's gradient, see functional.fork)
   int Ds = 0, Hs = 0, Ws = 0;     // conv_tap2_kernel: source grid of the stride-2 gather (D / H / W are the destination grid)
+  unsigned long long* dbg = nullptr;   // conv_tapdh_kernel phase clocks (tuning hook, SSBEV_TAPDH_TIMES=1)
   int slab = 0, cut = 0;          // conv_taph_kernel, plane-aligned chunk order (0 = off): planes per XCD; row pairs of a plane's
                                   // first chunk (the rest of the plane is a second, shorter chunk dispatched behind all first ones)
 };
@@ -2117,6 +2120,268 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       if (++d == g.D) { d = 0; ++b; }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_tapdh_kernel (round 4): the same <= 32-channel layers with Winograd F(2,3) along d AND h (fp32, even D and H).
+// conv_taph_kernel sits at 0.61 of the fp32 matrix pipe whatever is done to its schedule (round 3); what is left is fewer
+// multiply-adds.  A block of 2 x 2 output (plane, row) pairs needs the 4 x 4 input (plane, row)s d0-1 .. d0+2, h0-1 .. h0+2:
+//     V[fd][fh] = B^T x B            (B^T of F(2,3): V0 = x0 - x2, V1 = x1 + x2, V2 = x2 - x1, V3 = x1 - x3, on both axes)
+//     M[fd][fh] = sum over (kw, k) U[fd][fh][n][k][kw] * V[fd][fh]            U = G w G^T over (kd, kh)  (pack_tapdh_kernel)
+//     y = A^T M A                    (y0 = M0 + M1 + M2, y1 = M1 - M2 - M3, on both axes)
+// 16 x 3 weight matrices per 2 x 2 outputs instead of 4 x 27: 2.25x fewer MFMAs than the direct kernel (taph: 1.5x), +-1
+// transforms only (no F(4,3) constants: the rounding behaviour of taph).  Sixteen waves (1024 threads, four per SIMD at
+// <= 128 VGPRs, so a wave's LDS reads and its three add/subs per operand hide behind the other waves' MFMAs): wave =
+// frequency (fd, fh) keeps its three 32 x 32 U slices (kw) in 48 VGPRs, reads FOUR ring rows per operand quad (2 planes x 2
+// rows) and owns one 32 x 32 accumulator.  The ring holds 5 row slots x 4 planes (rows h0 .. h0+3 in use, h0+4 in flight
+// during the walk, h0+5 requested behind the walk into the slot of h0 and landing during the fold); the sixteen partial
+// tiles meet in LDS (64 KB), where the output transform is a signed sum of nine tiles per output.  A workgroup stages 4
+// planes for 2 output planes: every input plane is fetched twice instead of taph's three times.
+constexpr int kDhSlots = 5, kDhPlaneF = kDhSlots * kTapRowF, kDhRingF = 4 * kDhPlaneF;
+constexpr int kDhRedF = 16 * 16 * 64;
+constexpr size_t kDhLdsBytes = (size_t)(kDhRingF + kDhRedF) * sizeof(float);
+constexpr int kDhPackedElems = 16 * 3 * 16 * 64;
+static_assert(kDhLdsBytes <= 160 * 1024, "conv_tapdh_kernel: ring + fold buffer must fit the CU's LDS");
+
+// F(2,3) weight transform G along one axis: (t0, t1, t2) -> frequency f
+__device__ __forceinline__ float wino_g23(float t0, float t1, float t2, int f) {
+  return f == 0 ? t0 : f == 1 ? 0.5f * ((t0 + t2) + t1) : f == 2 ? 0.5f * ((t0 + t2) - t1) : t2;
+}
+
+// w_packed[((wave * 3 + kw) * 16 + r) * 64 + lane] = U[fd = wave >> 2][fh = wave & 3][n = lane & 31][k][kw],
+// k = 8 (r >> 2) + 4 (lane >> 5) + (r & 3); Weff as in pack_tap_kernel (mode 1: roles swapped, taps mirrored)
+__global__ void __launch_bounds__(256)
+pack_tapdh_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kDhPackedElems) return;
+  const int lane = i & 63, r = (i >> 6) & 15, wk = i >> 10;
+  const int kw = wk % 3, wave = wk / 3, fd = wave >> 2, fh = wave & 3;
+  const int n = lane & 31, k = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (n < N && k < K) {
+    float th[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      float t[3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int tap = kd * 9 + kh * 3 + kw;
+        t[kh] = mode == 0 ? w[((size_t)n * Cin + k) * 27 + tap] : w[((size_t)k * Cin + n) * 27 + (26 - tap)];
+      }
+      th[kd] = wino_g23(t[0], t[1], t[2], fh);
+    }
+    v = wino_g23(th[0], th[1], th[2], fd);
+  }
+  wp[i] = v;
+}
+
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                  float* __restrict__ Y, ConvTapGeom g) {     // g.NG / g.gpc count 2 x 2 (plane, row) blocks
+  extern __shared__ __align__(16) float tl[];
+  float* ring = tl;                          // [4 planes][5 slots][34 voxels][32 channels], 16-byte swizzled
+  float* red = tl + kDhRingF;                // [16 waves][16 rows][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int fd = wave >> 2, fh = wave & 3;
+
+  float wr[3][16];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[c][r] = wp[((wave * 3 + c) * 16 + r) * 64 + lane];
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int H2 = g.H >> 1, D2 = g.D >> 1;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  const int w0 = seg * kTapWseg;
+
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 staging entries per (plane, row), see conv_tap_kernel
+  int xoff[2], xmeta[2];                                        // 4 planes x 5 entries = 20 per row: waves 0-3 take two
+  const int plane_g = g.H * g.W * g.K;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int q = wave + n * 16;
+    int off = -2, meta = -1;
+    if (q < 4 * nxc) {
+      const int pl = q / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (((j & 7) ^ ((u >> 1) & 7)) << 2), wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
+      }
+      meta = pl | ((pl * kDhPlaneF + ch * 256) << 4);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  // padded row hp (= input row hp - 1) of the planes 2 d2 - 1 .. 2 d2 + 2 -> slot hp % 5
+  auto stage_row = [&](int b, int d2, int hp) {
+    const float* base = X + ((long)(b * g.D + 2 * d2 - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
+    const int h = hp - 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int pl = meta & 3, dp = 2 * d2 - 1 + pl;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = ring + (meta >> 4) + (hp % kDhSlots) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) glds16(src, dst);
+    }
+  };
+
+  // B^T of F(2,3): frequency f combines inputs (a, b) with sign s:  0: x0 - x2   1: x1 + x2   2: x2 - x1   3: x1 - x3
+  const int ra = fh == 0 ? 0 : (fh == 2 ? 2 : 1), rb = fh == 3 ? 3 : (fh == 2 ? 1 : 2);
+  const float sh = fh == 1 ? 1.0f : -1.0f;
+  const int pa = fd == 0 ? 0 : (fd == 2 ? 2 : 1), pb = fd == 3 ? 3 : (fd == 2 ? 1 : 2);
+  const float sd = fd == 1 ? 1.0f : -1.0f;
+  const int offPA = pa * kDhPlaneF, offPB = pb * kDhPlaneF;
+  // store phase: wave = (output plane jd, output row jh, channel group rg)
+  const int jd = wave >> 3, jh = (wave >> 2) & 1, rg = wave & 3;
+  const int nb = 8 * rg + 4 * lk;            // first of the 4 output channels this lane stores
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
+  }
+  // A^T of F(2,3): output j sums the frequencies j, j + 1, j + 2 with signs (+, +, +) for j = 0 and (+, -, -) for j = 1
+  const float s1 = 1.0f - 2.0f * jh, t1 = 1.0f - 2.0f * jd;     // sign of the 2nd and 3rd term along h / d
+
+  wait_vm0();                                 // weights and bias are in: nothing of the prologue is pending inside the loop
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  const unsigned long long t_start = t_prev;
+#ifdef SSBEV_TAPDH_CLOCKS       // build-time tuning hook (-DSSBEV_TAPDH_CLOCKS + SSBEV_TAPDH_TIMES=1): per-phase shader clocks
+#define TAPDH_TICK(i) if (g.dbg) { const unsigned long long t_now = __builtin_readcyclecounter(); tk[i] += t_now - t_prev; t_prev = t_now; }
+#else
+#define TAPDH_TICK(i)
+#endif
+  bool fresh = true;
+  int h2 = g_begin % H2, d2, b;
+  {
+    const int bd = g_begin / H2;
+    b = bd / D2; d2 = bd % D2;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = 2 * h2;
+    if (fresh) {
+      stage_row(b, d2, h0); stage_row(b, d2, h0 + 1); stage_row(b, d2, h0 + 2); stage_row(b, d2, h0 + 3);
+      wait_vm0();
+      __syncthreads();
+    }
+    TAPDH_TICK(0)
+    const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
+    if (same_plane) stage_row(b, d2, h0 + 4);                   // slot of h0 - 1: free since the previous walk
+
+    const int offA = ((h0 + ra) % kDhSlots) * kTapRowF, offB = ((h0 + rb) % kDhSlots) * kTapRowF;
+    const bool okst = w0 + li < g.W && nb < g.N;
+    float* dst = Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0 + li) * g.N + nb;
+    float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.accumulate && (g.N & 3) == 0 && okst) told = *reinterpret_cast<const float4*>(dst);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    auto fetch = [&](int c, int q, float4& v) {
+      const int u = li + c;
+      const float* colp = ring + u * 32 + ((((2 * q + lk) ^ ((u >> 1) & 7))) << 2);
+      const float4 aa = *reinterpret_cast<const float4*>(colp + offPA + offA);
+      const float4 ab = *reinterpret_cast<const float4*>(colp + offPA + offB);
+      const float4 ba = *reinterpret_cast<const float4*>(colp + offPB + offA);
+      const float4 bb = *reinterpret_cast<const float4*>(colp + offPB + offB);
+      const float4 pa4 = make_float4(fmaf(sh, ab.x, aa.x), fmaf(sh, ab.y, aa.y), fmaf(sh, ab.z, aa.z), fmaf(sh, ab.w, aa.w));
+      const float4 pb4 = make_float4(fmaf(sh, bb.x, ba.x), fmaf(sh, bb.y, ba.y), fmaf(sh, bb.z, ba.z), fmaf(sh, bb.w, ba.w));
+      v = make_float4(fmaf(sd, pb4.x, pa4.x), fmaf(sd, pb4.y, pa4.y), fmaf(sd, pb4.z, pa4.z), fmaf(sd, pb4.w, pa4.w));
+    };
+    float4 va, vb;
+    fetch(0, 0, va);
+#pragma unroll
+    for (int s = 0; s < 12; s += 2) {          // step s = (kw = s / 4, channel quad = s % 4): 4 MFMAs each
+      fetch((s + 1) >> 2, (s + 1) & 3, vb);
+      {
+        const int c = s >> 2, q = s & 3;
+        acc = mfma32(wr[c][4 * q + 0], va.x, acc);
+        acc = mfma32(wr[c][4 * q + 1], va.y, acc);
+        acc = mfma32(wr[c][4 * q + 2], va.z, acc);
+        acc = mfma32(wr[c][4 * q + 3], va.w, acc);
+      }
+      if (s + 2 < 12) fetch((s + 2) >> 2, (s + 2) & 3, va);
+      {
+        const int c = (s + 1) >> 2, q = (s + 1) & 3;
+        acc = mfma32(wr[c][4 * q + 0], vb.x, acc);
+        acc = mfma32(wr[c][4 * q + 1], vb.y, acc);
+        acc = mfma32(wr[c][4 * q + 2], vb.z, acc);
+        acc = mfma32(wr[c][4 * q + 3], vb.w, acc);
+      }
+    }
+    TAPDH_TICK(1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    wait_vm0();            // row h0 + 4 has landed (and the previous block's stores)
+    __syncthreads();                                            // every wave is done with rows h0, h0 + 1 and has published
+    TAPDH_TICK(2)
+    if (same_plane) stage_row(b, d2, h0 + 5);                   // slot of h0; lands during the fold
+    {
+      // all 36 partial values of this lane's output quad are requested before the first add (a wait per tile made this
+      // phase 3.4 k clocks of LDS latency)
+      const float* rp = red + ((jd * 4 + jh) * 16 + 4 * rg) * 64 + lane;         // tile (fd = jd, fh = jh), row 4 rg
+      float m[3][3][4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) m[a][c][i] = rp[(a * 4 + c) * 1024 + i * 64];
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a] = (m[a][0][i] + s1 * m[a][1][i]) + s1 * m[a][2][i];
+        o[i] = ((t[0] + t1 * t[1]) + t1 * t[2]) + bv[i];
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      TAPDH_TICK(3)
+      // row h0 + 5 must have landed before the next walk; waited for BEFORE this block's stores are issued (vmcnt counts
+      // stores too: behind them the wait would sit out the write acknowledgement, 1.8 k clocks per block)
+      wait_vm0();
+      if (w0 + li < g.W) {
+        if ((g.N & 3) == 0) {
+          if (nb < g.N)
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0] + told.x, o[1] + told.y, o[2] + told.z, o[3] + told.w);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < g.N) dst[i] = g.accumulate ? dst[i] + o[i] : o[i];
+        }
+      }
+    }
+    barrier_lds();                                              // the fold buffer is rewritten by the next block; stores stay in flight
+    TAPDH_TICK(4)
+    fresh = !same_plane;
+    if (++h2 == H2) {
+      h2 = 0;
+      if (++d2 == D2) { d2 = 0; ++b; }
+    }
+  }
+  if (g.dbg && lane == 0) {
+    unsigned long long* o = g.dbg + ((size_t)blockIdx.x * 16 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[i] = tk[i];
+    o[5] = t_start; o[6] = __builtin_readcyclecounter(); o[7] = g_end - g_begin;
+  }
+#undef TAPDH_TICK
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2987,6 +3252,69 @@ bool conv_taph_applicable(const ssbev_conv_dims* d, int mode) {
   return conv_tap_applicable(d, mode) && d->Ho % 2 == 0 && d->precision == 0 && d->tile_hint != 6;
 }
 
+// F(2,3) along d and h: even D as well.  tile_hint 4 keeps the h-only kernel (A/B timing, tests)
+bool conv_tapdh_applicable(const ssbev_conv_dims* d, int mode) {
+  static const int off = getenv("SSBEV_TAPDH") ? atoi(getenv("SSBEV_TAPDH")) == 0 : 0;
+  return !off && conv_taph_applicable(d, mode) && d->Do % 2 == 0 && d->tile_hint != 4;
+}
+
+int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                      hipStream_t st) {
+  ConvTapGeom g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.nseg = (g.W + kTapWseg - 1) / kTapWseg;
+  g.NG = g.B * (g.D / 2) * (g.H / 2);        // 2 x 2 (plane, row) blocks
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
+  // one 1024-thread workgroup per CU (149 KB of LDS); chunk length as in launch_conv_taph: whole rounds of 256 workgroups,
+  // then the start-up of a chunk (weights + first four rows of four planes) and the restage at every plane-pair crossing
+  const int H2 = g.H / 2;
+  double best = 1e30;
+  g.gpc = 1;
+  for (int c = 1; c <= g.NG && c <= 96; ++c) {
+    const long blocks = (long)((g.NG + c - 1) / c) * g.nseg;
+    const long rounds = (blocks + 255) / 256;
+    const double crossings = H2 % c == 0 ? 0.0 : (c % H2 == 0 ? c / H2 - 1 : (double)c / H2);
+    const double cost = rounds * (c + 0.5 + 0.3 * crossings);
+    if (cost < best) { best = cost; g.gpc = c; }
+  }
+  if (const char* e = getenv("SSBEV_TAPDH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  const long nranges = (g.NG + g.gpc - 1) / g.gpc;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tapdh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kDhLdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  static const int times = getenv("SSBEV_TAPDH_TIMES") ? atoi(getenv("SSBEV_TAPDH_TIMES")) : 0;
+  if (times) {      // tuning hook: per-phase shader clocks of every wave (fresh stage / walk / publish + barrier / fold / tail barrier)
+    const size_t nwg = (size_t)(nranges * g.nseg), n = nwg * 16 * 8;
+    unsigned long long* dev = nullptr;
+    if (hipMalloc(&dev, n * 8) != hipSuccess) return SSBEV_ELAUNCH;
+    g.dbg = dev;
+    hipLaunchKernelGGL(conv_tapdh_kernel, dim3((unsigned)nwg), dim3(1024), kDhLdsBytes, st, x, wp, bias, y, g);
+    std::vector<unsigned long long> h(n);
+    hipStreamSynchronize(st);
+    hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost);
+    hipFree(dev);
+    double ph[5] = {0, 0, 0, 0, 0}, life = 0, blocks = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < nwg * 16; ++w) {
+      for (int i = 0; i < 5; ++i) ph[i] += (double)h[w * 8 + i];
+      life += (double)(h[w * 8 + 6] - h[w * 8 + 5]);
+      blocks += (double)h[w * 8 + 7];
+      t0 = std::min(t0, h[w * 8 + 5]); t1 = std::max(t1, h[w * 8 + 6]);
+    }
+    fprintf(stderr, "tapdh clocks per 2x2 block and wave (s_memtime ticks): stage %.0f walk %.0f publish+barrier %.0f fold %.0f tail barrier %.0f"
+            " | per chunk: life %.0f for %.1f blocks | kernel span %.0f ticks, %zu workgroups\n",
+            ph[0] / blocks, ph[1] / blocks, ph[2] / blocks, ph[3] / blocks, ph[4] / blocks, life / (nwg * 16), blocks / (nwg * 16),
+            (double)(t1 - t0), nwg);
+    return ssbev_launch_status();
+  }
+  hipLaunchKernelGGL(conv_tapdh_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(1024), kDhLdsBytes, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
 int launch_conv_taph(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
                      hipStream_t st) {
   ConvTapGeom g;
@@ -3194,6 +3522,7 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (conv_thin_applicable(d, mode)) return 3;
   if (conv_tap2_applicable(d, mode)) return 7;                // stride-2 "down" gather on conv_tap2_kernel
   if (conv_tap2up_applicable(d, mode)) return 8;              // stride-2 "up" gather on conv_tap2up_kernel
+  if (conv_tapdh_applicable(d, mode)) return 9;               // F(2,3) along d and h inside the tap walk
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
   return 0;
@@ -3206,7 +3535,7 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d) {
   const size_t taps = (size_t)d->kd * d->kh * d->kw;
   const size_t a = (size_t)pad8(d->Cin) * pad32(d->Cout), b = (size_t)pad8(d->Cout) * pad32(d->Cin);
   const size_t generic = taps * (a > b ? a : b);
-  const size_t special = (size_t)std::max(kTwPackedElems, std::max(kT2PackedElems, kUpPackedElems));
+  const size_t special = (size_t)std::max(std::max(kTwPackedElems, kDhPackedElems), std::max(kT2PackedElems, kUpPackedElems));
   return generic > special ? generic : special;
 }
 
@@ -3228,6 +3557,11 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   if (conv_tap2up_applicable(d, mode)) {     // stride-2 "up" gather: [K][N][27] in both roles, see pack_tap2up_kernel
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     hipLaunchKernelGGL(pack_tap2up_kernel, dim3(cdiv(kUpPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, N, K);
+    return ssbev_launch_status();
+  }
+  if (conv_tapdh_applicable(d, mode)) {      // Winograd along d and h: U = G w G^T per kw
+    hipLaunchKernelGGL(pack_tapdh_kernel, dim3(cdiv(kDhPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed,
+                       d->Cout, d->Cin, mode);
     return ssbev_launch_status();
   }
   if (conv_taph_applicable(d, mode)) {       // Winograd-along-h variant of the tap kernel: U = G w per (kd, kw)
@@ -3263,6 +3597,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap2_applicable(d, 0)) return launch_conv_tap2(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap2up_applicable(d, 0)) return launch_conv_tap2up(x, w_packed, bias, y, d, 0, as_stream(stream));
+  if (conv_tapdh_applicable(d, 0)) return launch_conv_tapdh(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
   ConvGeom g;
@@ -3284,6 +3619,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2up_applicable(d, 1)) return launch_conv_tap2up(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
+  if (conv_tapdh_applicable(d, 1)) return launch_conv_tapdh(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   ConvGeom g;   // roles swapped: source grid = forward output grid, K = Cout, N = Cin

@@ -105,14 +105,16 @@ def _conv_tag(d, role):
 
 def _conv_family(lib, d, mode):
     """Span family of a direct conv launch: the <= 32-channel layers on conv_taph_kernel execute 2/3 of the operator's
-    multiply-adds (F(2,3) along h), which bench.py's executed-FLOP figure accounts for."""
+    multiply-adds (F(2,3) along h), on conv_tapdh_kernel 4/9 (F(2,3) along d and h), which bench.py's executed-FLOP figure
+    accounts for."""
     if KERNEL_TIMER is None:
         return "conv_gather"
-    return "conv_tap_h" if lib.ssbev_conv_kernel_class(C.byref(d), mode) == 2 else "conv_gather"
+    return {2: "conv_tap_h", 9: "conv_tap_dh"}.get(lib.ssbev_conv_kernel_class(C.byref(d), mode), "conv_gather")
 
 
-# conv_taph_kernel runs F(2,3) along h inside the direct kernel: 2/3 of the operator's multiply-adds are executed
-_EXEC_DIV = {"conv_gather": 1.0, "conv_tap_h": 1.5}
+# conv_taph_kernel runs F(2,3) along h inside the direct kernel: 2/3 of the operator's multiply-adds are executed;
+# conv_tapdh_kernel (round 4) F(2,3) along d and h: 4/9
+_EXEC_DIV = {"conv_gather": 1.0, "conv_tap_h": 1.5, "conv_tap_dh": 2.25}
 
 
 def conv_bytes(d):
