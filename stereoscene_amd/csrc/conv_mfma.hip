@@ -1754,7 +1754,7 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
       float* dst = ring + (meta >> 4) + (hp & 3) * kTapRowF;
       const int off = xoff[n];
       const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
-      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      if (off != -2) glds16(src, dst);
     }
   };
 
@@ -1772,6 +1772,7 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
     for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
   }
 
+  wait_vm0();                                 // weights and bias are in: nothing of the prologue is pending inside the loop
   bool fresh = true;
   int h = g_begin % g.H, d, b;
   {
@@ -1781,7 +1782,7 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
   for (int G = g_begin; G < g_end; ++G) {
     if (fresh) {
       stage_row(b, d, h); stage_row(b, d, h + 1); stage_row(b, d, h + 2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm0();
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h + 1 < g.H;
@@ -1846,7 +1847,7 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
     // fold the four tap groups: every wave publishes its partial tile, then sums rows 4*wave .. 4*wave+3
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __syncthreads();
     {
       float o[4];
@@ -1872,7 +1873,7 @@ conv_tap_kernel(const float* __restrict__ X, const float* __restrict__ wp, const
         }
       }
     }
-    __syncthreads();                       // the partial buffer is reused by the next row
+    barrier_lds();                         // the partial buffer is reused by the next row; the stores stay in flight
     fresh = !same_plane;
     if (++h == g.H) {
       h = 0;
@@ -1998,7 +1999,7 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       float* dst = ring + (meta >> 4) + (hp % kTwSlots) * kTapRowF;
       const int off = xoff[n];
       const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
-      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      if (off != -2) glds16(src, dst);
     }
   };
 
@@ -2013,6 +2014,7 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
   }
 
+  wait_vm0();                                 // weights and bias are in: nothing of the prologue is pending inside the loop
   bool fresh = true;
   int h2 = g_begin % H2, d, b;
   {
@@ -2023,7 +2025,7 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     const int h0 = 2 * h2;
     if (fresh) {
       stage_row(b, d, h0); stage_row(b, d, h0 + 1); stage_row(b, d, h0 + 2); stage_row(b, d, h0 + 3);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm0();
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
@@ -2088,7 +2090,7 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __syncthreads();
     {
       float o[4];
@@ -2477,7 +2479,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       float* dst = ring + (meta >> 4) + (hp % kT2Slots) * kTapRowF;
       const int off = xoff[n];
       const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
-      if (off != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      if (off != -2) glds16(src, dst);
     }
   };
 
@@ -2494,6 +2496,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
   }
 
+  wait_vm0();                                 // weights and bias are in: nothing of the prologue is pending inside the loop
   bool fresh = true;
   int h2 = g_begin % H2, d, b;
   {
@@ -2505,7 +2508,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     if (fresh) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) stage_row(b, d, 2 * h0 + r);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm0();
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
@@ -2532,7 +2535,8 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     float4 xa[4], xb4[4];
     auto fetch = [&](int tt, float4 (&xv)[4]) {
       const int u = 2 * vx + tp_kw[tt];
-      const float* rowp = ring + tp_plane[tt] + srow[tp_kh[tt]] + u * 32;
+      const int sr = tp_kh[tt] == 0 ? srow[0] : (tp_kh[tt] == 1 ? srow[1] : srow[2]);   // (a select: srow[tp_kh[tt]] is a scratch array)
+      const float* rowp = ring + tp_plane[tt] + sr + u * 32;
       const int sw = (u >> 1) & 7;
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
@@ -2571,7 +2575,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     // fold the four tap groups of each channel half: every wave publishes its partial tile, then sums rows 4 tg .. 4 tg + 3
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __syncthreads();
     {
       float o[4];
@@ -2592,7 +2596,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
         }
       }
     }
-    __syncthreads();                       // the partial buffer is reused by the next row pair
+    barrier_lds();                         // the partial buffer is reused by the next row pair; the stores stay in flight
     fresh = !same_plane;
     if (++h2 == H2) {
       h2 = 0;
@@ -2699,13 +2703,14 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
     const bool rowok = hr < g.Hs && d + pl < g.Ds;
     float* dst = ring + (xmeta >> 4) + (hr % kUpSlots) * kUpRowF;
     const float* src = (rowok && xoff >= 0) ? base + xoff : kWgZeros;
-    if (xoff != -2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    if (xoff != -2) glds16(src, dst);
   };
 
   const int sc = wave >> 1, jp = wave & 1;   // store phase: class slot and channel-group pair of this wave
   const int scls = kUpStoreClass[sc], stile = kUpStoreTile[sc], sntile = kUpStoreNTiles[sc];
   const int spd = scls >> 2, sph = (scls >> 1) & 1, spw = scls & 1;
 
+  wait_vm0();                                 // weights and bias are in: nothing of the prologue is pending inside the loop
   bool fresh = true;
   int h2 = g_begin % H2, d, b;
   {
@@ -2716,7 +2721,7 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
     const int h0 = 2 * h2;
     if (fresh) {
       stage_row(b, d, h0); stage_row(b, d, h0 + 1); stage_row(b, d, h0 + 2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm0();
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
@@ -2753,7 +2758,7 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm0();
     __syncthreads();
     {
       // waves 2 c, 2 c + 1 store class kUpStoreClass[c]: lane (cell li, lk) holds channels 8 j + 4 lk .. + 3; this wave j = 2 jp, 2 jp + 1
@@ -2786,7 +2791,7 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
         }
       }
     }
-    __syncthreads();                       // the fold buffer is reused by the next row pair
+    barrier_lds();                         // the fold buffer is reused by the next row pair; the stores stay in flight
     fresh = !same_plane;
     if (++h2 == H2) {
       h2 = 0;
