@@ -2742,15 +2742,16 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
         const int u = vx + t_dw[tt];
         const float* rowp = ring + t_pl[tt] + (t_dh[tt] ? srow1 : srow0) + u * 64;
         const int sw = u & 15;
-        float4 xv[4];
+        float4 xc = *reinterpret_cast<const float4*>(rowp + (((2 * (4 * hq) + lk) ^ sw) << 2));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * (4 * hq + q) + lk) ^ sw) << 2));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc = mfma32(wr[tt][16 * hq + 4 * q + 0], xv[q].x, acc);
-          acc = mfma32(wr[tt][16 * hq + 4 * q + 1], xv[q].y, acc);
-          acc = mfma32(wr[tt][16 * hq + 4 * q + 2], xv[q].z, acc);
-          acc = mfma32(wr[tt][16 * hq + 4 * q + 3], xv[q].w, acc);
+        for (int q = 0; q < 4; ++q) {          // one quad ahead (four in flight left no room for 13 of the weight registers)
+          float4 xn = xc;
+          if (q + 1 < 4) xn = *reinterpret_cast<const float4*>(rowp + (((2 * (4 * hq + q + 1) + lk) ^ sw) << 2));
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 0], xc.x, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 1], xc.y, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 2], xc.z, acc);
+          acc = mfma32(wr[tt][16 * hq + 4 * q + 3], xc.w, acc);
+          xc = xn;
         }
       }
     }
@@ -2761,34 +2762,45 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
     wait_vm0();
     __syncthreads();
     {
-      // waves 2 c, 2 c + 1 store class kUpStoreClass[c]: lane (cell li, lk) holds channels 8 j + 4 lk .. + 3; this wave j = 2 jp, 2 jp + 1
+      // waves 2 c, 2 c + 1 store class kUpStoreClass[c]: lane (cell li, lk) holds channels 8 j + 4 lk .. + 3; this wave j = 2 jp, 2 jp + 1.
+      // Round 4: every global load of the phase (old values, bias) is issued first, then ALL partial values of the lane's
+      // eight outputs (one uniform branch per tile, reads batched inside), then the sums in the fixed tile order -- the r3
+      // form (a run-time loop per output with a wait per tile, a bias load per element) serialised ~40 LDS / L2 latencies.
       const int cw = c0 + vx, chr = h0 + rw;
       const bool ok = cw < g.Ws && chr < g.Hs;
       float* dst = Y + (((long)(b * g.D + 2 * d + spd) * g.H + 2 * chr + sph) * g.W + 2 * cw + spw) * g.N + 4 * lk;
-      float4 oldv[2];
-      if (g.accumulate && ok) {
+      const int n0 = 16 * jp + 4 * lk;           // first channel of jj = 0; jj = 1 is 8 further
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = 2 * jp + jj;
-          oldv[jj] = (8 * j + 4 * lk < g.N) ? *reinterpret_cast<const float4*>(dst + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int jj = 0; jj < 2; ++jj) {           // (one output quad at a time: both at once spilled 19 registers)
+        const bool chok = n0 + 8 * jj < g.N;
+        float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.accumulate && ok && chok) ov = *reinterpret_cast<const float4*>(dst + 16 * jp + 8 * jj);
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.has_bias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bb[i] = n0 + 8 * jj + i < g.N ? bias[n0 + 8 * jj + i] : 0.0f;
         }
-      }
+        float pv[4][4];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * jp + jj;
+        for (int t = 0; t < 4; ++t) {
+          if (t < sntile) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[t][i] = red[((stile + t) * 16 + 8 * jp + 4 * jj + i) * 64 + lane];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[t][i] = 0.0f;
+          }
+        }
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = 4 * j + i;
-          float v = red[(stile * 16 + r) * 64 + lane];
-          for (int t = 1; t < sntile; ++t) v += red[((stile + t) * 16 + r) * 64 + lane];
-          if (g.has_bias && 8 * j + 4 * lk + i < g.N) v += bias[8 * j + 4 * lk + i];      // (L2-resident; not kept in registers)
+          float v = pv[0][i];
+          if (sntile > 1) v += pv[1][i];
+          if (sntile > 2) { v += pv[2][i]; v += pv[3][i]; }
+          v += bb[i];
           o[i] = g.relu ? fmaxf(v, 0.0f) : v;
         }
-        if (ok && 8 * j + 4 * lk < g.N) {
-          if (g.accumulate) { o[0] += oldv[jj].x; o[1] += oldv[jj].y; o[2] += oldv[jj].z; o[3] += oldv[jj].w; }
-          *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        if (ok && chok) *reinterpret_cast<float4*>(dst + 16 * jp + 8 * jj) = make_float4(o[0] + ov.x, o[1] + ov.y, o[2] + ov.z, o[3] + ov.w);
       }
     }
     barrier_lds();                         // the fold buffer is reused by the next row pair; the stores stay in flight
