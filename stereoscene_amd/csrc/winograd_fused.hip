@@ -27,6 +27,9 @@
 // v from P (saved by the forward) and z0 = g0, z1 = g0 + g1, z2 = g0 - g1, z3 = -g1 from the (h, w)-adjoint planes of gy.
 #include "common.h"
 
+#include <cstdio>
+#include <vector>
+
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -45,6 +48,7 @@ struct DfGeom {
   int ncolgrp;    // column groups of NW * 32
   int NU;         // row tasks per frequency (B * ND * nrowgrp)
   int nxi;        // (h, w) frequencies (36)
+  unsigned long long* dbg = nullptr;   // phase clocks (build with -DSSBEV_DF_CLOCKS, run with SSBEV_DF_TIMES=1)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -173,30 +177,60 @@ wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float*
     df_wait_b<0>(bb[0]);                                    // next stage's first fragments (and this wave's LDS-DMA) landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of `buf` are complete before it moves on
   };
+#ifdef SSBEV_DF_CLOCKS
+  const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
   load_b(0, bb[0]);
   issue(0, 0);
   df_wait_b<0>(bb[0]);
+#ifdef SSBEV_DF_CLOCKS
+  const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
   for (int st = 0; st + 1 < nst; ++st) stage(st, st & 1, std::true_type{});
   stage(nst - 1, (nst - 1) & 1, std::false_type{});
-  // ---- epilogue: depth output transform; accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li
+#ifdef SSBEV_DF_CLOCKS
+  const unsigned long long c2 = __builtin_readcyclecounter();
+  struct ClockOut { unsigned long long* p; unsigned long long a, b, c; int w; ~ClockOut() {} };
+#endif
+  // ---- epilogue: depth output transform; accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li.
+  // Round 4: the two output tiles of a wave (BM rows x 32 columns each) go through the wave's share of the (now idle) stage
+  // buffers and leave as 16-byte stores, 8 rows x 128 bytes per wave instruction -- the r2 form issued 32 MT four-byte stores
+  // per lane behind per-row bound branches and cost 13 k clocks per workgroup (phase clocks, -DSSBEV_DF_CLOCKS), as much as
+  // 0.8 of a k-stage, with the matrix pipe idle for this wave.
+  __builtin_amdgcn_s_barrier();                             // every wave has finished reading the stage buffers
   if (!col_active) return;
-  const int co = n0 + li;
-  if (co >= g.N) return;
-  float* Mx = Mo + (long)xhw * R * g.N;
+  if (n0 >= g.N) return;
+  float* wb = lds + wave * (2 * BM * 32);                   // [2 outputs][BM rows][32 columns]
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    float* o0 = Mx + (((long)b * g.D + 2 * i) * g.Thw + t0 + mt * 32) * g.N + co;
-    float* o1 = o0 + (long)g.Thw * g.N;
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
-      const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lk;
-      if (t0 + mt * 32 + row < g.Thw) {
-        const float m0 = acc[0][mt][rr], m1 = acc[1][mt][rr], m2 = acc[2][mt][rr], m3 = acc[3][mt][rr];
-        o0[(long)row * g.N] = m0 + m1 + m2;
-        o1[(long)row * g.N] = m1 - m2 - m3;
-      }
+      const int row = mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lk;
+      const float m0 = acc[0][mt][rr], m1 = acc[1][mt][rr], m2 = acc[2][mt][rr], m3 = acc[3][mt][rr];
+      wb[row * 32 + li] = m0 + m1 + m2;
+      wb[(BM + row) * 32 + li] = m1 - m2 - m3;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave reads back only what it wrote itself
+  float* Mx = Mo + (long)xhw * R * g.N;
+  const int cq = lane & 7, r8 = lane >> 3;
+  const bool cok = n0 + 4 * cq < g.N;                       // N % 4 == 0 (ssbev_wino43_df_supported)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float* oj = Mx + (((long)b * g.D + 2 * i + j) * g.Thw + t0) * g.N + n0 + 4 * cq;
+#pragma unroll
+    for (int it = 0; it < BM / 8; ++it) {
+      const int row = it * 8 + r8;
+      const v4f v = *reinterpret_cast<const v4f*>(wb + (j * BM + row) * 32 + 4 * cq);
+      if (cok && t0 + row < g.Thw) *reinterpret_cast<v4f*>(oj + (long)row * g.N) = v;
     }
   }
+#ifdef SSBEV_DF_CLOCKS
+  if (g.dbg && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = g.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+    o[0] = c1 - c0; o[1] = c2 - c1; o[2] = __builtin_readcyclecounter() - c2; o[3] = c0;
+  }
+#endif
 }
 
 // ---- packed weights ----------------------------------------------------------------------------------------------------
@@ -479,7 +513,7 @@ wino_dfw_reduce_kernel(const float* __restrict__ gU, float* __restrict__ gw, int
 
 bool df_dims_ok(const ssbev_wino_dims* d, int N) {
   return d && d->B > 0 && d->C > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->H % 4 == 0 && d->W % 4 == 0 && d->D % 2 == 0 &&
-         d->C % DF_BK == 0 && N > 0;
+         d->C % DF_BK == 0 && N > 0 && N % 4 == 0;       // (N % 4: 16-byte stores of the output rows)
 }
 
 int env_int(const char* name, int dflt) {
@@ -539,7 +573,7 @@ int ssbev_wino43_df_instance(const ssbev_wino_dims* d, int N) {
 }
 
 // P [36][B*D*Thw][K] = ssbev_wino43_2d_input_transform(x), Wp = ssbev_wino43_df_pack(...), Mo [36][B*D*Thw][N];
-// d = (B, D, H, W, C = K).  Requires H % 4 == W % 4 == 0, even D, K % 32 == 0 (ssbev_wino43_df_supported).
+// d = (B, D, H, W, C = K).  Requires H % 4 == W % 4 == 0, even D, K % 32 == 0, N % 4 == 0 (ssbev_wino43_df_supported).
 int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev_wino_dims* d, int N, ssbev_stream_t stream) {
   if (!df_dims_ok(d, N) || !P || !Wp || !Mo) return SSBEV_EINVAL;
   DfGeom g;
@@ -555,6 +589,26 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
   const size_t lds = (size_t)2 * 4 * 32 * mt * DF_BK * sizeof(float);        // 64 KiB (MT = 2) / 32 KiB
   const long nwg = (long)g.nxi * g.NU * g.ncolgrp;
   hipStream_t st = as_stream(stream);
+#ifdef SSBEV_DF_CLOCKS
+#define DF_CLOCKS_BEGIN(NW_)                                                                                               \
+  unsigned long long* dbg_dev = nullptr;                                                                                   \
+  const bool dbg_on = getenv("SSBEV_DF_TIMES") != nullptr;                                                                \
+  if (dbg_on) { if (hipMalloc(&dbg_dev, (size_t)nwg * NW_ * 32) != hipSuccess) return SSBEV_ELAUNCH; g.dbg = dbg_dev; }
+#define DF_CLOCKS_END(NW_)                                                                                                 \
+  if (dbg_on) {                                                                                                            \
+    std::vector<unsigned long long> h((size_t)nwg * NW_ * 4);                                                              \
+    (void)hipStreamSynchronize(st); (void)hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost); (void)hipFree(dbg_dev); \
+    double ph[3] = {0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;                                                       \
+    for (size_t w = 0; w < (size_t)nwg * NW_; ++w) { for (int i = 0; i < 3; ++i) ph[i] += (double)h[w * 4 + i];            \
+      t0 = std::min(t0, h[w * 4 + 3]); t1 = std::max(t1, h[w * 4 + 3] + h[w * 4] + h[w * 4 + 1] + h[w * 4 + 2]); }         \
+    const double nw_ = (double)nwg * NW_;                                                                                  \
+    fprintf(stderr, "wino_df<mt %d, %d> K=%d N=%d: clocks per wave: prologue %.0f stages %.0f (%d stages) epilogue %.0f | span %.0f, %ld workgroups\n", \
+            mt, NW_, g.K, g.N, ph[0] / nw_, ph[1] / nw_, g.K / DF_BK, ph[2] / nw_, (double)(t1 - t0), nwg);                \
+  }
+#else
+#define DF_CLOCKS_BEGIN(NW_)
+#define DF_CLOCKS_END(NW_)
+#endif
 #define SSBEV_DF_LAUNCH(MT_, NW_)                                                                                          \
   do {                                                                                                                     \
     auto kern = wino_df_kernel<MT_, NW_>;                                                                                  \
@@ -562,7 +616,9 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess)                                                                                                    \
       return SSBEV_ELAUNCH;                                                                                                \
+    DF_CLOCKS_BEGIN(NW_)                                                                                                    \
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW_), lds, st, P, Wp, Mo, g);                                  \
+    DF_CLOCKS_END(NW_)                                                                                                      \
   } while (0)
   switch (mt * 10 + nw) {
     case 24: SSBEV_DF_LAUNCH(2, 4); break;
