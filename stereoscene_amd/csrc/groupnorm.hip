@@ -198,15 +198,23 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __
 
 constexpr int FT = 1024;     // threads of the (tiny, latency-bound) finalize kernels
 
-// block-wide sum of two doubles (fixed tree: deterministic)
+// block-wide sum of two doubles (fixed tree: deterministic).  Round 4: butterflies inside the waves, ONE barrier for the 16
+// wave totals (the r1 form walked a 1024-entry LDS tree with ten barriers: most of the ~10 us these latency-bound
+// kernels took, 104 launches per step).  s0 / s1 need FT / 64 entries.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ void block_sum2(double& a, double& q, double* s0, double* s1) {
-  s0[threadIdx.x] = a; s1[threadIdx.x] = q;
+  a = wave_sum_d(a); q = wave_sum_d(q);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s0[w] = a; s1[w] = q; }
   __syncthreads();
-  for (int off = FT / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
-    __syncthreads();
-  }
-  a = s0[0]; q = s1[0];
+  double ta = 0.0, tq = 0.0;
+#pragma unroll
+  for (int i = 0; i < FT / 64; ++i) { ta += s0[i]; tq += s1[i]; }
+  a = ta; q = tq;
 }
 
 // forward finalize: one thread block per (b, group): mean / rstd in double.  Only B*G workgroups exist (2 for GN(2) at
@@ -259,12 +267,6 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const T* __restrict__ 
 // Per-channel statistics (BatchNorm: one channel per group): one WAVE per (b, channel), lanes striding over the chunk
 // partials, butterfly sum.  The image branch runs ~170 BatchNorms per pass, most of them on maps of a few thousand
 // pixels where the workgroup-per-group kernels above (1024 threads, ten barriers) are pure latency.
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 template <typename T>
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const T* __restrict__ x, float* __restrict__ mean,
