@@ -2387,6 +2387,206 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad_tapdh_kernel (round 4): weight gradient of the same <= 32-channel stride-1 3x3x3 layers in the F(2,3) x F(2,3)
+// domain over (d, h) -- the transpose of conv_tapdh_kernel:
+//     gU[fd][fh][kw][k][n] = sum over 2 x 2 (plane, row) blocks and voxels v of  V[fd][fh](x)[v + kw][k] * Z[fd][fh](gy)[v][n]
+//     V = B^T x B (as in the forward kernel)        Z = A gy A^T  (Z0 = g0, Z1 = g0 + g1, Z2 = g0 - g1, Z3 = -g1 per axis)
+//     gw = G^T gU G over (kd, kh)                    (wgrad_dh_finish_kernel, after the fixed-order fold of the chunk partials)
+// 16 x 3 products per 2 x 2 outputs instead of 4 x 27 (wgrad_lds_kernel<.., WINO>: 4 x 9 per row pair = 1.5x; here 2.25x).
+// Sixteen waves = sixteen frequencies, three 32 x 32 accumulators (kw) each that live for the whole chunk: no fold, no
+// publish -- one barrier per block.  MFMA roles: rows = input channel k, columns = output channel n, reduction = voxels (two
+// per instruction, one per lane half); both operands are formed from four ds_read_b32 each (2 planes x 2 rows; conflict-free:
+// the 32 lanes of a half read the 32 channels of one voxel line) and the column V(v + 2) of a step is V(v) of the next.
+// LDS: x ring of 6 row slots x 4 planes (rows h0 .. h0+3 in use, h0+4 / h0+5 landing during the walk) + two buffers of the
+// block's four gy rows = 134 KB, filled by glds16; partial tiles [chunk][48][k][n] -> launch_wgrad_reduce -> finish kernel.
+constexpr int kWdSlots = 6, kWdPlaneF = kWdSlots * kTapRowF, kWdRingF = 4 * kWdPlaneF;
+constexpr int kWdGRowF = 32 * 32, kWdGBufF = 4 * kWdGRowF;
+constexpr size_t kWdLdsBytes = (size_t)(kWdRingF + 2 * kWdGBufF) * sizeof(float);
+static_assert(kWdLdsBytes <= 160 * 1024, "wgrad_tapdh_kernel: rings must fit the CU's LDS");
+
+struct WgradDhGeom {
+  int B, D, H, W, Cq, Cp;         // Cq = channels of x (rows of a tile), Cp = channels of gy (columns)
+  int nseg, NG, gpc;              // 32-voxel segments per row, 2 x 2 blocks in total, blocks per chunk
+};
+
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, float* __restrict__ ws, WgradDhGeom g) {
+  extern __shared__ __align__(16) float tl[];
+  float* xr = tl;                            // [4 planes][6 slots][34 voxels][32 channels], linear
+  float* gr = tl + kWdRingF;                 // [2 buffers][2 planes][2 rows][32 voxels][32 channels]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int fd = wave >> 2, fh = wave & 3;
+
+  unsigned chunk_id;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    chunk_id = base + (L >> 3);
+  }
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int H2 = g.H >> 1, D2 = g.D >> 1;
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
+  const int w0 = seg * kTapWseg;
+
+  // staging lists.  x: one call brings TWO padded rows of the four planes = 2 x 4 x 5 entries of 64 sixteen-byte items;
+  // gy: the block's 2 planes x 2 rows = 16 entries (one per wave)
+  constexpr int nxc = (kTapCols * 8 + 63) / 64;
+  int xoff[3], xmeta[3];
+  const int rowq = g.W * g.Cq, planeq = g.H * rowq;
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int q = wave + n * 16;
+    int off = -2, meta = -1;
+    if (q < 2 * 4 * nxc) {
+      const int rr = q / (4 * nxc), pl = (q % (4 * nxc)) / nxc, ch = q % nxc;
+      const int j = ch * 64 + lane;
+      if (j < kTapCols * 8) {
+        const int u = j >> 3, c = (j & 7) << 2, wsrc = w0 + u - 1;
+        off = (wsrc >= 0 && wsrc < g.W && c < g.Cq) ? pl * planeq + rr * rowq + wsrc * g.Cq + c : -1;
+      }
+      meta = rr | (pl << 2) | ((pl * kWdPlaneF + ch * 256) << 8);
+    }
+    xoff[n] = off;
+    xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
+  }
+  int goff, gmeta;
+  {
+    const int rowp = g.W * g.Cp, planep = g.H * rowp;
+    const int pl = wave >> 3, r = (wave >> 2) & 1, ch = wave & 3;
+    const int j = ch * 64 + lane, v = j >> 3, c = (j & 7) << 2, wv = w0 + v;
+    goff = (wv < g.W && c < g.Cp) ? pl * planep + r * rowp + wv * g.Cp + c : -1;
+    gmeta = (pl * 2 + r) * kWdGRowF + ch * 256;
+  }
+  // padded rows hp0, hp0 + 1 (= input rows hp0 - 1, hp0) of the planes 2 d2 - 1 .. 2 d2 + 2 -> slots hp % 6
+  auto stage_x = [&](int b, int d2, int hp0) {
+    const float* base = X + ((long)(b * g.D + 2 * d2 - 1) * g.H + (hp0 - 1)) * (long)rowq;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int meta = xmeta[n];
+      if (meta < 0) break;
+      const int rr = meta & 1, pl = (meta >> 2) & 3, dp = 2 * d2 - 1 + pl, h = hp0 - 1 + rr;
+      const bool rowok = h >= 0 && h < g.H && dp >= 0 && dp < g.D;
+      float* dst = xr + (meta >> 8) + ((hp0 + rr) % kWdSlots) * kTapRowF;
+      const int off = xoff[n];
+      const float* src = (rowok && off >= 0) ? base + off : kWgZeros;
+      if (off != -2) glds16(src, dst);
+    }
+  };
+  auto stage_g = [&](int b, int d2, int h2, int buf) {
+    const float* base = GY + ((long)(b * g.D + 2 * d2) * g.H + 2 * h2) * (long)(g.W * g.Cp);
+    glds16(goff >= 0 ? base + goff : kWgZeros, gr + buf * kWdGBufF + gmeta);
+  };
+
+  // B^T of F(2,3) on x (as conv_tapdh_kernel) and A of F(2,3) on gy: Z_f = z0[f] g0 + z1[f] g1
+  const int ra = fh == 0 ? 0 : (fh == 2 ? 2 : 1), rb = fh == 3 ? 3 : (fh == 2 ? 1 : 2);
+  const float sh = fh == 1 ? 1.0f : -1.0f;
+  const int pa = fd == 0 ? 0 : (fd == 2 ? 2 : 1), pb = fd == 3 ? 3 : (fd == 2 ? 1 : 2);
+  const float sd = fd == 1 ? 1.0f : -1.0f;
+  const float zh0 = fh == 3 ? 0.0f : 1.0f, zh1 = fh == 0 ? 0.0f : (fh == 1 ? 1.0f : -1.0f);
+  const float zd0 = fd == 3 ? 0.0f : 1.0f, zd1 = fd == 0 ? 0.0f : (fd == 1 ? 1.0f : -1.0f);
+  const float c00 = zd0 * zh0, c01 = zd0 * zh1, c10 = zd1 * zh0, c11 = zd1 * zh1;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+  bool fresh = true;
+  int cur = 0;
+  int h2 = g_begin % H2, d2, b;
+  {
+    const int bd = g_begin / H2;
+    b = bd / D2; d2 = bd % D2;
+  }
+  for (int G = g_begin; G < g_end; ++G) {
+    const int h0 = 2 * h2;
+    if (fresh) {                              // first block of the chunk or of a plane pair: the ring is restaged
+      if (G != g_begin) __syncthreads();      // ... once every wave has left the previous pair's last walk
+      stage_x(b, d2, h0); stage_x(b, d2, h0 + 2);
+      if (G == g_begin) stage_g(b, d2, h2, cur);
+    }
+    wait_vm0();                               // this block's rows (issued during the previous block, or just above)
+    __syncthreads();                          // ... of every wave; and every wave has left the previous walk
+    const bool has_next = G + 1 < g_end, same_plane = has_next && h2 + 1 < H2;
+    if (same_plane) stage_x(b, d2, h0 + 4);   // the next block's two new rows -> the slots of h0 - 2, h0 - 1 (free since the barrier)
+    if (has_next) {
+      int nh2 = h2 + 1, nd2 = d2, nb = b;
+      if (nh2 == H2) { nh2 = 0; if (++nd2 == D2) { nd2 = 0; ++nb; } }
+      stage_g(nb, nd2, nh2, cur ^ 1);
+    }
+
+    const float* xA = xr + pa * kWdPlaneF + ((h0 + ra) % kWdSlots) * kTapRowF + lk * 32 + li;
+    const float* xB = xr + pa * kWdPlaneF + ((h0 + rb) % kWdSlots) * kTapRowF + lk * 32 + li;
+    const float* xC = xr + pb * kWdPlaneF + ((h0 + ra) % kWdSlots) * kTapRowF + lk * 32 + li;
+    const float* xD = xr + pb * kWdPlaneF + ((h0 + rb) % kWdSlots) * kTapRowF + lk * 32 + li;
+    const float* gA = gr + cur * kWdGBufF + lk * 32 + li;
+    auto vcol = [&](int u) {                  // V at voxel column u + lk of the staged row (column 0 = voxel w0 - 1)
+      const float a = fmaf(sh, xB[u * 32], xA[u * 32]);
+      const float c = fmaf(sh, xD[u * 32], xC[u * 32]);
+      return fmaf(sd, c, a);
+    };
+    auto zcol = [&](int v) {
+      float z = c00 * gA[v * 32];
+      z = fmaf(c01, gA[kWdGRowF + v * 32], z);
+      z = fmaf(c10, gA[2 * kWdGRowF + v * 32], z);
+      return fmaf(c11, gA[3 * kWdGRowF + v * 32], z);
+    };
+    float vc = vcol(0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {            // voxels 2 s + lk of the segment
+      const float v1 = vcol(2 * s + 1), v2 = vcol(2 * s + 2), z = zcol(2 * s);
+      acc[0] = mfma32(vc, z, acc[0]);
+      acc[1] = mfma32(v1, z, acc[1]);
+      acc[2] = mfma32(v2, z, acc[2]);
+      vc = v2;
+    }
+    cur ^= 1;
+    fresh = !same_plane;
+    if (++h2 == H2) {
+      h2 = 0;
+      if (++d2 == D2) { d2 = 0; ++b; }
+    }
+  }
+  // partial tiles of this chunk: ws[chunk][T = wave * 3 + kw][k][n]; accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li
+  float* wo = ws + ((size_t)chunk_id * 48 + wave * 3) * g.Cq * g.Cp;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (k < g.Cq && li < g.Cp) wo[((size_t)c * g.Cq + k) * g.Cp + li] = acc[c][r];
+    }
+}
+
+// gw[p][q][kd][kh][kw] = sum over (fd, fh) of G[fd][kd] G[fh][kh] gU[p][q][(fd * 4 + fh) * 3 + kw]   (G^T gU G, G of F(2,3))
+__global__ void __launch_bounds__(256)
+wgrad_dh_finish_kernel(const float* __restrict__ gU, float* __restrict__ gw, int npq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npq * 3) return;
+  const int kw = i % 3, pq = i / 3;
+  float t[4][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float u[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[c] = gU[(size_t)pq * 48 + (a * 4 + c) * 3 + kw];
+    t[a][0] = u[0] + 0.5f * (u[1] + u[2]);
+    t[a][1] = 0.5f * (u[1] - u[2]);
+    t[a][2] = 0.5f * (u[1] + u[2]) + u[3];
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    gw[(size_t)pq * 27 + 0 * 9 + kh * 3 + kw] = t[0][kh] + 0.5f * (t[1][kh] + t[2][kh]);
+    gw[(size_t)pq * 27 + 1 * 9 + kh * 3 + kw] = 0.5f * (t[1][kh] - t[2][kh]);
+    gw[(size_t)pq * 27 + 2 * 9 + kh * 3 + kw] = 0.5f * (t[1][kh] + t[2][kh]) + t[3][kh];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_tap2_kernel (round 3): the stride-2 3x3x3 "down" gather with <= 32 input and 33..64 output channels on the LDS-ring /
 // register-weights design of conv_tap_kernel -- the first convolution of every hourglass (VT:73-76, 32 -> 64 on the
 // 192 x 48 x 160 cost volume) and the data gradient of its last transposed convolution (VT:86-88, 64 -> 32), 8 launches per
@@ -3332,6 +3532,63 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
   return ssbev_launch_status();
 }
 
+// weight gradient of the conv_tapdh layers in the F(2,3) x F(2,3) domain (wgrad_tapdh_kernel).  tile_hint 9 forces it on
+// small problems (tests); 4 / 5 / 6 / 7 keep the older kernels (A/B timing)
+size_t align256b(size_t x);
+struct WgradDhPlan { bool ok; WgradDhGeom g; int nchunks; };
+WgradDhPlan plan_wgrad_dh(const ssbev_conv_dims* d) {
+  static const int off = getenv("SSBEV_WGRAD_DH") ? atoi(getenv("SSBEV_WGRAD_DH")) == 0 : 0;
+  WgradDhPlan p;
+  p.ok = false; p.nchunks = 0;
+  if (off || d->transposed || d->precision != 0) return p;
+  if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return p;
+  if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return p;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo || d->Do % 2 || d->Ho % 2) return p;
+  if (d->Cin > 32 || d->Cout > 32 || d->Cin % 4 || d->Cout % 4 || d->Cin < 16 || d->Cout < 8) return p;
+  if (d->tile_hint == 4 || d->tile_hint == 5 || d->tile_hint == 6 || d->tile_hint == 7 || d->tile_hint == 8) return p;
+  const int nseg = (d->Wo + kTapWseg - 1) / kTapWseg;
+  if (d->tile_hint != 9 && (long)d->B * d->Do * d->Ho * nseg < 1024L * 16) return p;
+  if ((long)d->Ho * d->Wo * 32 >= (1L << 30)) return p;
+  WgradDhGeom& g = p.g;
+  g.B = d->B; g.D = d->Do; g.H = d->Ho; g.W = d->Wo; g.Cq = d->Cin; g.Cp = d->Cout;
+  g.nseg = nseg;
+  g.NG = g.B * (g.D / 2) * (g.H / 2);
+  // one 1024-thread workgroup per CU; the chunk partials (48 tiles per chunk) are folded afterwards, so ONE round of long
+  // chunks: whole rounds of 256 workgroups, start-up + plane-pair crossings as in launch_conv_tapdh
+  const int H2 = g.H / 2;
+  double best = 1e30;
+  g.gpc = 1;
+  for (int c = 1; c <= g.NG && c <= 192; ++c) {
+    const long blocks = (long)((g.NG + c - 1) / c) * g.nseg;
+    const long rounds = (blocks + 255) / 256;
+    const double crossings = H2 % c == 0 ? 0.0 : (c % H2 == 0 ? c / H2 - 1 : (double)c / H2);
+    const double cost = rounds * (c + 1.0 + 0.3 * crossings);
+    if (cost < best) { best = cost; g.gpc = c; }
+  }
+  if (const char* e = getenv("SSBEV_WGRAD_DH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  p.nchunks = ((g.NG + g.gpc - 1) / g.gpc) * g.nseg;
+  p.ok = true;
+  return p;
+}
+
+size_t wgrad_dh_workspace(const WgradDhPlan& p) {
+  const size_t tile = (size_t)48 * p.g.Cq * p.g.Cp * sizeof(float);
+  return align256b((size_t)p.nchunks * tile) + align256b(tile);
+}
+
+int run_wgrad_dh(const float* x, const float* gy, float* gw, const WgradDhPlan& p, void* ws, hipStream_t st) {
+  float* partial = static_cast<float*>(ws);
+  float* gU = reinterpret_cast<float*>(static_cast<char*>(ws) + align256b((size_t)p.nchunks * 48 * p.g.Cq * p.g.Cp * sizeof(float)));
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tapdh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kWdLdsBytes) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(wgrad_tapdh_kernel, dim3((unsigned)p.nchunks), dim3(1024), kWdLdsBytes, st, x, gy, partial, p.g);
+  launch_wgrad_reduce(partial, gU, p.nchunks, 48, p.g.Cq, p.g.Cp, st);          // -> gU[n][k][48]
+  const int npq = p.g.Cq * p.g.Cp;
+  hipLaunchKernelGGL(wgrad_dh_finish_kernel, dim3(cdiv((size_t)npq * 3, 256)), dim3(256), 0, st, gU, gw, npq);
+  return ssbev_launch_status();
+}
+
 int launch_conv_taph(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
                      hipStream_t st) {
   ConvTapGeom g;
@@ -3664,6 +3921,10 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
     if (p1.ok && d->tile_hint != 7) return align256b((size_t)p1.nchunks * p1.Cq * p1.Cp * sizeof(float));
   }
   {
+    const WgradDhPlan hp = plan_wgrad_dh(d);
+    if (hp.ok) return wgrad_dh_workspace(hp);
+  }
+  {
     const WgradLdsPlan lp = plan_wgrad_lds(d);
     if (lp.ok && d->tile_hint != 7)
       return align256b((size_t)lp.nchunks * lp.ksplit * d->kd * 9 * d->Cout * d->Cin * sizeof(float));
@@ -3716,6 +3977,10 @@ int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbe
       launch_wgrad_reduce(partial, gw, p1.nchunks, 1, p1.Cq, p1.Cp, st);
       return ssbev_launch_status();
     }
+  }
+  {
+    const WgradDhPlan hp = plan_wgrad_dh(d);   // <= 32 x 32 channels, even D and H: F(2,3) along d and h (round 4)
+    if (hp.ok) return run_wgrad_dh(x, gy, gw, hp, ws, as_stream(stream));
   }
   {
     const WgradLdsPlan lp = plan_wgrad_lds(d);
