@@ -550,9 +550,9 @@ static void df_instance(const ssbev_wino_dims* d, int N, int& mt, int& nw) {
   nw = ntile % 4 == 0 ? 4 : (ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 4));
   if (forced_nw >= 2 && forced_nw <= 4) nw = forced_nw;
   const int ncolgrp = (ntile + nw - 1) / nw;
-  // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than twice covered
+  // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than four times covered
   mt = 2;
-  if ((long)36 * d->B * ND * ((Thw + 63) / 64) * ncolgrp < 1024) mt = 1;
+  if ((long)36 * d->B * ND * ((Thw + 63) / 64) * ncolgrp < 2048) mt = 1;      // (r4: 256 -> 256 at 64 x 64 x 8, 1152 workgroups of 64 rows: 0.249 -> 0.235 ms with 32-row tiles)
   // three-wave workgroups: two 64 KiB workgroups per CU put 6 waves on 4 SIMDs (2, 2, 1, 1); four 32 KiB ones are balanced
   // (384 -> 192 head conv: 1.98 -> 1.72 ms)
   if (nw == 3) mt = 1;

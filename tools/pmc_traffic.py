@@ -18,7 +18,7 @@ FAMILIES = [("conv_wide16_kernel", ("conv_wide16_kernel",)), ("conv_tap16_kernel
             ("conv_fwd_dgrad", ("conv_gather_kernel", "conv_tap_kernel", "conv_taph_kernel", "conv_tapdh_kernel", "conv_thin_kernel")),
             ("conv_gather_kernel", ("conv_gather_kernel",)),
             ("conv_tap_kernel", ("conv_tap_kernel",)), ("conv_taph_kernel", ("conv_taph_kernel",)), ("conv_tapdh_kernel", ("conv_tapdh_kernel",)),
-            ("conv_tap2_kernel", ("conv_tap2_kernel",)), ("conv_tap2up_kernel", ("conv_tap2up_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
+            ("wgrad_tapdh_kernel", ("wgrad_tapdh_kernel",)), ("conv_tap2_kernel", ("conv_tap2_kernel",)), ("conv_tap2up_kernel", ("conv_tap2up_kernel",)), ("wgrad_lds_kernel", ("wgrad_lds_kernel",)),
             ("gwc_warp_fwd", ("gwc_warp_fwd_kernel", "gwc_warp_fwd4_kernel", "gwc_warp_fwd5_kernel")), ("pool_gather", ("pool_gather_kernel", "pool_gather2_kernel", "pool_gather3_kernel", "pool_gather5_kernel")),
             ("gn_apply_fwd", ("gn_apply_fwd_kernel",)), ("gn_apply_bwd", ("gn_apply_bwd_kernel",)),
             ("gn2_apply_fwd", ("gn2_apply_fwd_kernel",)), ("gn2_partial_bwd", ("gn2_partial_bwd_kernel",)), ("gn2_apply_bwd", ("gn2_apply_bwd_kernel",)),
