@@ -39,6 +39,9 @@ python tools/pmc_traffic.py /tmp/pmc_${tag}_FETCH_SIZE.csv /tmp/pmc_${tag}_WRITE
 SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcm_$tag -o p -- python bench.py --steps 2 --warmup 1 --cpu-sample none --skip-forward-extra --skip-serial-replay > /dev/null 2>&1
 python tools/pmc_mfma.py $(find /tmp/pmcm_$tag -name "*counter_collection.csv" | head -1) > $out/pmc_mfma.txt 2>&1
 timeout 600 python tools/stream_probe.py > $out/stream_probe.txt 2>&1
+timeout 300 python tools/tapdh_probe.py 2>&1 | grep -v amdgpu > $out/tapdh_probe.txt
+timeout 300 python tools/wgrad_dh_probe.py 2>&1 | grep -v amdgpu > $out/wgrad_dh_probe.txt
+timeout 300 python tools/pool_prepare_probe.py 2>&1 | grep -v amdgpu > $out/pool_prepare_probe.txt
 SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 600 python tools/layer_table.py kitti_d192 3 2>&1 | grep -v amdgpu > $out/layer_table.txt
 timeout 600 python tools/bucket_timeline.py 64 300 2>&1 | grep -v amdgpu > $out/bucket_timeline.txt
 # configs[4]: one whole-step roofline object per ablation mode
