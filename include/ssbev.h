@@ -181,7 +181,9 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d);
  * kernels; 7 / 8 = the stride-2 "down" / "up" gathers on conv_tap2_kernel / conv_tap2up_kernel; 9 = conv_tapdh_kernel
  * (round 4: Winograd F(2,3) along d AND h inside the kernel, even D and H: executes 4/9 of the operator's multiply-adds;
  * SSBEV_TAPDH=0 or tile_hint 4 keeps class 2); < 0 = error.  The weight gradient of a class-9 problem runs on
- * wgrad_tapdh_kernel (same transform domain; SSBEV_WGRAD_DH=0 or tile_hint 4 / 5 / 6 / 7 keep wgrad_lds_kernel). */
+ * wgrad_tapdh_kernel (same transform domain; SSBEV_WGRAD_DH=0 or tile_hint 4 / 5 / 6 / 7 keep wgrad_lds_kernel);
+ * 10 = conv_pw32_kernel (1x1x1 stride-1 layers with <= 32 channels on both sides: an HBM stream through per-wave LDS tiles;
+ * SSBEV_PW32=0 or tile_hint 8 keep the generic gather kernel). */
 int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode);
 
 /* 32 -> 1 / 2 / 4 channel 3x3x3 stride-1 "same" layers (the 32 -> 1 classifiers of the cost-volume stack,

@@ -2587,6 +2587,124 @@ wgrad_dh_finish_kernel(const float* __restrict__ gU, float* __restrict__ gw, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_pw32_kernel (round 4): 1x1x1 stride-1 convolution (forward and data gradient) with <= 32 channels on both sides -- the
+// redirect convolutions of the hourglasses on the 189 MB cost-volume tensors (VT:83-96).  2 kFLOP per 256 bytes moved: a pure
+// HBM stream, which conv_gather_kernel runs at 3.2 TB/s because every lane fetches 16-byte pieces of 128-byte voxel lines
+// (eight L1 accesses per line).  Here a wave owns a run of 32-voxel tiles; a tile travels global -> LDS as four whole
+// kilobytes (glds16, two tiles in flight per wave, no workgroup barrier: the LDS tiles are private to the wave), is read back
+// with the conflict-free swizzled ds_read_b128 of the tap kernels, multiplied by the 32 x 32 weights held in 16 VGPRs and
+// leaves as four 16-byte stores per lane.
+constexpr int kPwPackedElems = 16 * 64;
+
+// w_packed[r * 64 + lane] = Weff[n = lane & 31][k = 8 (r >> 2) + 4 (lane >> 5) + (r & 3)];  mode 0: Weff[n][k] = w[n][k]
+// (torch [Cout][Cin]), mode 1 (data gradient): Weff[n][k] = w[k][n]
+__global__ void __launch_bounds__(256)
+pack_pw32_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kPwPackedElems) return;
+  const int lane = i & 63, r = i >> 6;
+  const int n = lane & 31, k = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+  const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+  float v = 0.0f;
+  if (n < N && k < K) v = mode == 0 ? w[(size_t)n * Cin + k] : w[(size_t)k * Cin + n];
+  wp[i] = v;
+}
+
+struct PwGeom {
+  long M;                         // voxels
+  int K, N;                       // input / output channels of this pass (multiples of 4, <= 32)
+  int relu, has_bias, accumulate;
+  long tpw;                       // tiles per wave
+};
+
+__global__ void __launch_bounds__(256)
+conv_pw32_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
+                 float* __restrict__ Y, PwGeom g) {
+  __shared__ __align__(16) float tl[4 * 2 * 1024];          // [4 waves][2 tiles][32 voxels][32 channels], 16-byte swizzled
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  float* mine = tl + wave * 2048;
+  float wr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) wr[r] = wp[r * 64 + lane];
+  float bv[4][4];
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = 8 * rq + 4 * lk + i;
+      bv[rq][i] = (g.has_bias && n < g.N) ? bias[n] : 0.0f;
+    }
+  const long ntiles = (g.M + 31) >> 5;
+  const long t0 = ((long)blockIdx.x * 4 + wave) * g.tpw, t1 = min(ntiles, t0 + g.tpw);
+  // staging: instruction e copies the voxels 8 e .. 8 e + 7 of the tile; lane = (voxel u, physical quad p), source quad p ^ key(u)
+  int soff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = e * 64 + lane, u = j >> 3, c = ((j & 7) ^ ((u >> 1) & 7)) << 2;
+    soff[e] = c < g.K ? u * g.K + c : -1;
+  }
+  auto stage = [&](long t, int buf) {
+    const float* base = X + t * 32 * (long)g.K;
+    const long left = g.M - t * 32;                        // voxels of this tile that exist
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int u = (e * 64 + lane) >> 3;
+      const float* src = (soff[e] >= 0 && u < left) ? base + soff[e] : kWgZeros;
+      glds16(src, mine + buf * 1024 + e * 256);
+    }
+  };
+  wait_vm0();                                               // weights and bias are in
+  if (t0 < t1) stage(t0, 0);
+  for (long t = t0; t < t1; ++t) {
+    const int buf = (int)(t - t0) & 1;
+    if (t + 1 < t1) {
+      stage(t + 1, buf ^ 1);
+      __builtin_amdgcn_s_waitcnt(0x0F74);                   // vmcnt(4): everything but the four copies just issued has landed
+    } else {
+      wait_vm0();
+    }
+    asm volatile("" ::: "memory");
+    const float* tp = mine + buf * 1024 + li * 32;
+    const int sw = (li >> 1) & 7;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 xv = *reinterpret_cast<const float4*>(tp + (((2 * q + lk) ^ sw) << 2));
+      acc = mfma32(wr[4 * q + 0], xv.x, acc);
+      acc = mfma32(wr[4 * q + 1], xv.y, acc);
+      acc = mfma32(wr[4 * q + 2], xv.z, acc);
+      acc = mfma32(wr[4 * q + 3], xv.w, acc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile has been read: its buffer is restaged next iteration
+    const long v = t * 32 + li;
+    float* dst = Y + v * g.N + 4 * lk;
+    if (v < g.M) {
+      float4 ov[4];
+      if (g.accumulate) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          ov[rq] = (8 * rq + 4 * lk < g.N) ? *reinterpret_cast<const float4*>(dst + 8 * rq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = acc[4 * rq + i] + bv[rq][i];
+          if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+        }
+        if (g.accumulate) { o[0] += ov[rq].x; o[1] += ov[rq].y; o[2] += ov[rq].z; o[3] += ov[rq].w; }
+        if (8 * rq + 4 * lk < g.N) *reinterpret_cast<float4*>(dst + 8 * rq) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_tap2_kernel (round 3): the stride-2 3x3x3 "down" gather with <= 32 input and 33..64 output channels on the LDS-ring /
 // register-weights design of conv_tap_kernel -- the first convolution of every hourglass (VT:73-76, 32 -> 64 on the
 // 192 x 48 x 160 cost volume) and the data gradient of its last transposed convolution (VT:86-88, 64 -> 32), 8 launches per
@@ -3469,6 +3587,37 @@ bool conv_taph_applicable(const ssbev_conv_dims* d, int mode) {
   return conv_tap_applicable(d, mode) && d->Ho % 2 == 0 && d->precision == 0 && d->tile_hint != 6;
 }
 
+// 1x1x1 stride-1 layers with <= 32 channels on both sides on conv_pw32_kernel (tile_hint 8 keeps the generic gather kernel)
+bool conv_pw32_applicable(const ssbev_conv_dims* d, int mode) {
+  static const int off = getenv("SSBEV_PW32") ? atoi(getenv("SSBEV_PW32")) == 0 : 0;
+  if (off || d->transposed || d->precision != 0 || d->tile_hint == 8) return false;
+  if (d->kd != 1 || d->kh != 1 || d->kw != 1 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pd != 0 || d->ph != 0 || d->pw != 0) return false;
+  if (d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
+  if (d->Cin > 32 || d->Cout > 32 || d->Cin % 4 || d->Cout % 4 || d->Cin < 8 || d->Cout < 8) return false;
+  (void)mode;
+  return (long)d->B * d->Do * d->Ho * d->Wo >= 32768;
+}
+
+int launch_conv_pw32(const float* x, const float* wp, const float* bias, float* y, const ssbev_conv_dims* d, int mode,
+                     hipStream_t st) {
+  PwGeom g;
+  g.M = (long)d->B * d->Do * d->Ho * d->Wo;
+  g.K = mode == 0 ? d->Cin : d->Cout;
+  g.N = mode == 0 ? d->Cout : d->Cin;
+  g.relu = mode == 0 ? d->relu : 0;
+  g.has_bias = (mode == 0 && bias) ? 1 : 0;
+  g.accumulate = d->accumulate;
+  const long ntiles = (g.M + 31) / 32;
+  // ~16 waves per CU, each with a run of at least 4 tiles
+  long waves = 256L * 16;
+  if (waves * 4 > ntiles) waves = (ntiles + 3) / 4;
+  g.tpw = (ntiles + waves - 1) / waves;
+  const long nblocks = ((ntiles + g.tpw - 1) / g.tpw + 3) / 4;
+  hipLaunchKernelGGL(conv_pw32_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, x, wp, bias, y, g);
+  return ssbev_launch_status();
+}
+
 // F(2,3) along d and h: even D as well.  tile_hint 4 keeps the h-only kernel (A/B timing, tests)
 bool conv_tapdh_applicable(const ssbev_conv_dims* d, int mode) {
   static const int off = getenv("SSBEV_TAPDH") ? atoi(getenv("SSBEV_TAPDH")) == 0 : 0;
@@ -3796,6 +3945,7 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (conv_thin_applicable(d, mode)) return 3;
   if (conv_tap2_applicable(d, mode)) return 7;                // stride-2 "down" gather on conv_tap2_kernel
   if (conv_tap2up_applicable(d, mode)) return 8;              // stride-2 "up" gather on conv_tap2up_kernel
+  if (conv_pw32_applicable(d, mode)) return 10;               // 1x1x1, <= 32 channels: streaming kernel
   if (conv_tapdh_applicable(d, mode)) return 9;               // F(2,3) along d and h inside the tap walk
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
@@ -3831,6 +3981,11 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   if (conv_tap2up_applicable(d, mode)) {     // stride-2 "up" gather: [K][N][27] in both roles, see pack_tap2up_kernel
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     hipLaunchKernelGGL(pack_tap2up_kernel, dim3(cdiv(kUpPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed, N, K);
+    return ssbev_launch_status();
+  }
+  if (conv_pw32_applicable(d, mode)) {
+    hipLaunchKernelGGL(pack_pw32_kernel, dim3(cdiv(kPwPackedElems, 256)), dim3(256), 0, as_stream(stream), w_src, w_packed,
+                       d->Cout, d->Cin, mode);
     return ssbev_launch_status();
   }
   if (conv_tapdh_applicable(d, mode)) {      // Winograd along d and h: U = G w G^T per kw
@@ -3871,6 +4026,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap2_applicable(d, 0)) return launch_conv_tap2(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap2up_applicable(d, 0)) return launch_conv_tap2up(x, w_packed, bias, y, d, 0, as_stream(stream));
+  if (conv_pw32_applicable(d, 0)) return launch_conv_pw32(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tapdh_applicable(d, 0)) return launch_conv_tapdh(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_taph_applicable(d, 0)) return launch_conv_taph(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (conv_tap_applicable(d, 0)) return launch_conv_tap(x, w_packed, bias, y, d, 0, as_stream(stream));
@@ -3893,6 +4049,7 @@ int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2up_applicable(d, 1)) return launch_conv_tap2up(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
+  if (conv_pw32_applicable(d, 1)) return launch_conv_pw32(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tapdh_applicable(d, 1)) return launch_conv_tapdh(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_taph_applicable(d, 1)) return launch_conv_taph(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap_applicable(d, 1)) return launch_conv_tap(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
