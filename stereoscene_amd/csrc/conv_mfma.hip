@@ -2776,7 +2776,10 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       const int pl = q / nxc, ch = q % nxc;
       const int j = ch * 64 + lane;
       if (j < kTapCols * 8) {
-        const int u = j >> 3, c = (((j & 7) ^ ((u >> 1) & 7)) << 2), wsrc = 2 * w0 - 1 + u;
+        // LDS slot j >> 3 holds voxel column u = slot ^ ((slot >> 4) & 1): the walk reads columns of ONE parity (2 v + kw), whose
+        // 128-byte lines all start in the same half of the 64 banks -- with the columns 16..31 swapped in pairs the sixteen
+        // lanes of a ds_read_b128 group use both halves (r4 SQ counters: 38.6 % of this kernel's LDS cycles were conflicts)
+        const int sl = j >> 3, u = sl ^ ((sl >> 4) & 1), c = (((j & 7) ^ ((u >> 1) & 7)) << 2), wsrc = 2 * w0 - 1 + u;
         off = (wsrc >= 0 && wsrc < g.Ws && c < g.K) ? pl * plane_g + wsrc * g.K + c : -1;
       }
       meta = pl | ((pl * kT2PlaneF + ch * 256) << 4);
@@ -2854,7 +2857,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     auto fetch = [&](int tt, float4 (&xv)[4]) {
       const int u = 2 * vx + tp_kw[tt];
       const int sr = tp_kh[tt] == 0 ? srow[0] : (tp_kh[tt] == 1 ? srow[1] : srow[2]);   // (a select: srow[tp_kh[tt]] is a scratch array)
-      const float* rowp = ring + tp_plane[tt] + sr + u * 32;
+      const float* rowp = ring + tp_plane[tt] + sr + (u ^ ((u >> 4) & 1)) * 32;
       const int sw = (u >> 1) & 7;
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const float4*>(rowp + (((2 * q + lk) ^ sw) << 2));
