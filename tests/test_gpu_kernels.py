@@ -223,6 +223,7 @@ CONV_CASES = [
     (2, 32, 32, 9, 11, 13, 1, 1, 0, 1, False, 0, False),
     (1, 64, 96, 8, 8, 8, 1, 1, 0, 1, False, 0, True),
     (1, 32, 32, 32, 48, 160, 1, 1, 0, 1, False, 0, False),
+    (1, 24, 16, 33, 37, 29, 1, 1, 0, 1, False, 0, True),       # conv_pw32_kernel: ragged last tile, 24 -> 16 channels, bias
     # large-M problems: exercise the big register tiles <4,1>, <2,2>, <2,4> of the gather kernel
     (1, 32, 32, 32, 64, 136, 3, 1, 1, 1, False, 0, False),
     (1, 32, 64, 64, 64, 72, 3, 2, 1, 1, False, 0, False),
@@ -323,6 +324,30 @@ def test_conv_stride2_down_tap_kernel(case, monkeypatch):
         xr = x.clone().requires_grad_(True)
         (TF.conv_transpose3d(xr, w, None, 2, 1, 1) + TF.conv_transpose3d(xr, w2, None, 2, 1, 1)).backward(go)
         assert maxdiff(xa.grad, xr.grad) < 3e-5 * max(1.0, xr.grad.abs().max().item())
+
+
+def test_conv_pointwise32_streaming_kernel_accumulate_and_relu():
+    """conv_pw32_kernel (round 4; kernel class 10): the 1x1x1 <= 32-channel layers as an HBM stream.  Forward with bias + fused
+    ReLU, and the data gradient ACCUMULATING into a gradient slot shared with a second consumer (the way the hourglass redirects
+    meet the 3x3x3 branch), on a voxel count that is not a multiple of the 32-voxel tile."""
+    B, K, N, D, H, W = 1, 32, 32, 31, 35, 33
+    x = S.hash_normal("pw/x", (B, K, D, H, W))
+    w = S.hash_uniform("pw/w", (N, K, 1, 1, 1), -1, 1) * 0.2
+    b = S.hash_uniform("pw/b", (N,), -0.5, 0.5)
+    d = F._conv_dims((B, D, H, W, K), (N, K, 1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), False, (0, 0, 0))
+    lib = F.capi.load()
+    assert lib.ssbev_conv_kernel_class(F.C.byref(d), 0) == 10 and lib.ssbev_conv_kernel_class(F.C.byref(d), 1) == 10
+    got = F.conv3d(x.to(DEV), w.to(DEV), b.to(DEV), 1, 0, relu=True)
+    want = TF.relu(TF.conv3d(x, w, b, 1, 0))
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    w3 = S.hash_uniform("pw/w3", (N, K, 3, 3, 3), -1, 1) * 0.05
+    go, g3 = S.hash_normal("pw/go", (B, N, D, H, W)), S.hash_normal("pw/g3", (B, N, D, H, W))
+    xa = x.to(DEV).requires_grad_(True)
+    a, c = F.fork(xa)
+    torch.autograd.backward([F.conv3d(a, w3.to(DEV), None, 1, 1), F.conv3d(c, w.to(DEV), None, 1, 0)], [g3.to(DEV), go.to(DEV)])
+    xr = x.clone().requires_grad_(True)
+    torch.autograd.backward([TF.conv3d(xr, w3, None, 1, 1), TF.conv3d(xr, w, None, 1, 0)], [g3, go])
+    assert maxdiff(xa.grad, xr.grad) < 3e-5 * max(1.0, xr.grad.abs().max().item())
 
 
 WGRAD_LDS_CASES = [
