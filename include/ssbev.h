@@ -84,6 +84,11 @@ int ssbev_frustum_geometry(const float* frustum, const float* m1, const float* t
  * high digit of the voxel id, then one wavefront per 2^lo-voxel bucket that counts, scans (= starts) and places; five
  * launches for NV <= 2^22, no device-wide library sort.  SSBEV_POOL_MAX_DIGIT_BITS (2..11) narrows the digit (tests). */
 size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d);
+/* ... 2: additionally long_list[ssbev_pool_long_list_elems(n)] (nullable): long_list[0] = number of voxels with more than 32
+ * points, long_list[1 ..] their ids in no particular order -- the work list of ssbev_lift_splat_fwd2's long-list waves. */
+size_t ssbev_pool_long_list_elems(int n_points);
+int ssbev_pool_prepare2(const int32_t* vox, int n_points, int32_t* starts, int32_t* order, int32_t* long_list,
+                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
@@ -104,6 +109,11 @@ typedef struct { int N, D, HW; } ssbev_lift_dims;
 int ssbev_lift_splat_fwd(const float* depth, const float* feat, const int32_t* starts,
                          const int32_t* order, float* out, const ssbev_pool_dims* d,
                          const ssbev_lift_dims* l, ssbev_stream_t stream);
+/* ... 2: with the long-voxel list of ssbev_pool_prepare2 (nullable = ssbev_lift_splat_fwd): the lists of more than 32 points are
+ * summed by dedicated whole-wave workgroups, the short ones four voxels per wave; same sums in the same order. */
+int ssbev_lift_splat_fwd2(const float* depth, const float* feat, const int32_t* starts, const int32_t* order,
+                          const int32_t* long_list, float* out, const ssbev_pool_dims* d, const ssbev_lift_dims* l,
+                          ssbev_stream_t stream);
 int ssbev_lift_splat_bwd(const float* grad_out, const float* depth, const float* feat,
                          const int32_t* vox, float* grad_depth, float* grad_feat,
                          const ssbev_pool_dims* d, const ssbev_lift_dims* l, ssbev_stream_t stream);

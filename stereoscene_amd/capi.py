@@ -99,9 +99,12 @@ SIGNATURES = {
     "ssbev_coords_to_vox": (C.c_int, [_P, C.c_int, _P, C.POINTER(PoolDims), _P]),
     "ssbev_pool_prepare_workspace": (C.c_size_t, [C.c_int, C.POINTER(PoolDims)]),
     "ssbev_pool_prepare": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(PoolDims), _P, C.c_size_t, _P]),
+    "ssbev_pool_long_list_elems": (C.c_size_t, [C.c_int]),
+    "ssbev_pool_prepare2": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(PoolDims), _P, C.c_size_t, _P]),
     "ssbev_bev_pool_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(PoolDims), _P]),
     "ssbev_bev_pool_bwd": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(PoolDims), _P]),
     "ssbev_lift_splat_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
+    "ssbev_lift_splat_fwd2": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
     "ssbev_lift_splat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(PoolDims), C.POINTER(LiftDims), _P]),
     "ssbev_gwc_warp_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(GwcDims), _P]),
     "ssbev_gwc_warp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(GwcDims), _P]),

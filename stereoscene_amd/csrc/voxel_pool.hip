@@ -112,6 +112,7 @@ __global__ void coords_to_vox_kernel(const int32_t* __restrict__ coords, int n, 
 //            LOW digit in LDS, scans them -- that IS starts[] for its voxels, written as coalesced lines, so the 262 144-bin
 //            histogram of the old path is gone -- and places the point ids with the same match-mask ranking.
 // Voxel grids above 2^22 cells take more than one level-1 pass (LSD over the high part; bucket bounds by binary search).
+constexpr int POOL_LONG = 32;              // lists longer than this are "long": whole-wave path of the gather kernels
 constexpr int CSR_T = 256;                 // threads of a level-1 workgroup
 constexpr int CSR_WAVES = CSR_T / 64;
 constexpr int CSR_MAX_DIGIT_BITS = 11;
@@ -185,9 +186,10 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // hist[d * nblk + tile] = points of the tile whose digit is d; totals[d] += the same (zeroed by the host)
 __global__ void __launch_bounds__(CSR_T)
 csr_hist_kernel(const int32_t* __restrict__ keys, int n, int nv, int shift, int nbits, int items, int nblk,
-                int32_t* __restrict__ hist, int32_t* __restrict__ totals) {
+                int32_t* __restrict__ hist, int32_t* __restrict__ totals, int32_t* __restrict__ long_list) {
   extern __shared__ int cnt[];
   const int nd = 1 << nbits, tid = threadIdx.x;
+  if (long_list && blockIdx.x == 0 && tid == 0) long_list[0] = 0;      // (the level-2 kernel of this call appends behind it)
   for (int d = tid; d < nd; d += CSR_T) cnt[d] = 0;
   __syncthreads();
   const long long base = (long long)blockIdx.x * CSR_T * items;
@@ -333,7 +335,7 @@ constexpr int CSR_BW = 16;
 __global__ void __launch_bounds__(CSR_BW * 64)
 csr_bucket_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ ids, const int32_t* __restrict__ bucket_base,
                   const int32_t* __restrict__ n_valid, int nv, int lo_bits, int32_t* __restrict__ starts,
-                  int32_t* __restrict__ order) {
+                  int32_t* __restrict__ order, int32_t* __restrict__ long_list) {
   extern __shared__ int cnt[];                   // [16 waves][1 << lo_bits] | wave sums [16]
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = 1 << lo_bits;
   int* wsum = cnt + CSR_BW * nl;
@@ -395,6 +397,9 @@ csr_bucket_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ 
     const int l = tid * per + j;
     if (j < per && l < nl) {
       if (v0 + l < nv) starts[v0 + l] = dbase;
+      // compacted list of the voxels with more than POOL_LONG points (long_list[0] = count, any order): the gather sums them
+      // on dedicated waves (ssbev_lift_splat_fwd2)
+      if (long_list && tot[j] > POOL_LONG && v0 + l < nv) long_list[1 + atomicAdd(&long_list[0], 1)] = (int32_t)(v0 + l);
 #pragma unroll
       for (int w = 0; w < CSR_BW; ++w) cnt[w * nl + l] += dbase;
       dbase += tot[j];
@@ -649,7 +654,6 @@ pool_gather3_kernel(const float* __restrict__ depth, const float* __restrict__ f
 // and walks them one after the other; with lists cut to <= 64 points the kernel takes 58 us, to <= 1 point 51 us, and the bare
 // 134 MB zero store 28 us.  A 79-register variant (4 rows per batch, 6 waves per SIMD) brings the short lists to 34-40 us but
 // then spends 72 us on the real CSR: the long lists want registers, the short ones want occupancy, one kernel has one budget.)
-constexpr int POOL_LONG = 32;
 
 template <bool FUSED, int NV4>
 __global__ void __launch_bounds__(256)
@@ -769,6 +773,276 @@ pool_gather5_kernel(const float* __restrict__ depth, const float* __restrict__ f
     float* dst = out + (size_t)vv * C + lane * NV4;
 #pragma unroll
     for (int k = 0; k < NV4; ++k) dst[k] = a[k];
+  }
+}
+
+// Sixth layout (round 4) = the fifth one split by ROLE over a compacted list of the long voxels (ssbev_pool_prepare2).  The
+// r3 experiment (profiles/r3y_gather_role_split_refuted.txt) showed the short lists alone can be written in 32.5 us at 48 VGPRs /
+// 8 waves per SIMD, and that the long ones need a work list: found by scanning starts[], the ~1100 long voxels of the KITTI
+// frustum are neighbours and pile up on a few workgroups.  pool_gather_long_kernel: wave i of a fixed pool takes entries i,
+// i + nwaves, ... of the list -- one long voxel on all 64 lanes, 32 feature rows in flight (the whole-wave path of gather5);
+// pool_gather_short_kernel: gather3's four voxels per wave, long voxels skipped.  Same sums in the same order: bit-exact.
+template <bool FUSED, int NV4>
+__global__ void __launch_bounds__(256)
+pool_gather_long_kernel(const float* __restrict__ depth, const float* __restrict__ feat, const int32_t* __restrict__ starts,
+                        const int32_t* __restrict__ order, const int32_t* __restrict__ long_list, float* __restrict__ out,
+                        int P, int vox_per_batch, int N, int D, int HW) {
+  constexpr int C = 64 * NV4, UW = 32;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = (int)((size_t)gridDim.x * blockDim.x >> 6);
+  const int nlong = long_list[0];
+  for (int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < nlong; i += nwaves) {
+    const int vv = long_list[1 + i];
+    const int vs = starts[vv], ve = starts[vv + 1], vb = vv / vox_per_batch;
+    float a[NV4];
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) a[k] = 0.0f;
+    for (int base = vs; base < ve; base += 64) {
+      const int cnt = min(64, ve - base);
+      const int p = lane < cnt ? order[base + lane] : 0;
+      int row = p;
+      float wgt = 1.0f;
+      if (FUSED) {
+        const int q = p - vb * P;
+        const int n = q / (D * HW);
+        row = (vb * N + n) * HW + (q % HW);
+        wgt = lane < cnt ? depth[p] : 0.0f;
+      }
+      for (int j0 = 0; j0 < cnt; j0 += UW) {
+        float f[UW][NV4], ww[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int jj = min(j0 + u, cnt - 1);
+          const int r = __shfl(row, jj, 64);
+          ww[u] = __shfl(wgt, jj, 64);
+          const float* src = feat + (size_t)r * C + lane * NV4;
+          if (NV4 == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            f[u][0] = t.x; f[u][1 % NV4] = t.y; f[u][2 % NV4] = t.z; f[u][3 % NV4] = t.w;
+          } else if (NV4 == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(src);
+            f[u][0] = t.x; f[u][1 % NV4] = t.y;
+          } else {
+            f[u][0] = src[0];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          if (j0 + u < cnt) {
+#pragma unroll
+            for (int k = 0; k < NV4; ++k) a[k] = __fadd_rn(a[k], FUSED ? __fmul_rn(ww[u], f[u][k]) : f[u][k]);
+          }
+        }
+      }
+    }
+    float* dst = out + (size_t)vv * C + lane * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = a[k];
+  }
+}
+
+template <bool FUSED, int NV4>
+__global__ void __launch_bounds__(256)
+pool_gather_short_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                         const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                         float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
+  constexpr int C = 64 * NV4, U = 4;
+  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
+  const int v = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+  const bool vok = v < nv;
+  const int s = vok ? starts[v] : 0, e0 = vok ? starts[v + 1] : 0;
+  const bool is_long = e0 - s > POOL_LONG;
+  const int e = is_long ? s : e0;                          // long lists belong to pool_gather_long_kernel
+  const int b = vok ? v / vox_per_batch : 0;
+  float4 acc[NV4];
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int p_next = (s + gl < e) ? order[s + gl] : 0;
+  for (int base = s; base < e; base += 16) {
+    const int cnt = min(16, e - base);
+    const int p = p_next;
+    p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
+    int row = p;
+    float wgt = 1.0f;
+    if (FUSED) {
+      const int q = p - b * P;
+      const int n = q / (D * HW);
+      row = (b * N + n) * HW + (q % HW);
+      wgt = gl < cnt ? depth[p] : 0.0f;
+    }
+    for (int j0 = 0; j0 < cnt; j0 += U) {
+      float4 f[U][NV4];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = gbase + min(j0 + u, cnt - 1);
+        const int r = __shfl(row, jj, 64);
+        ww[u] = __shfl(wgt, jj, 64);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u < cnt) {
+#pragma unroll
+          for (int k = 0; k < NV4; ++k) {
+            if (FUSED) {
+              acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
+              acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
+              acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
+              acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
+            } else {
+              acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
+              acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
+              acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
+              acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (vok && !is_long) {
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
+  }
+}
+
+// Seventh layout (round 4, C = 128): both roles in ONE launch.  Two launches (long 26 us: the longest list's chain of dependent
+// 32-row batches; short 35 us) only tie gather5's 59 us, and a kernel holding gather5's 32-rows-in-registers long path cannot keep
+// the short path at 8 waves per SIMD.  Here the first POOL7_LONG_WGS workgroups walk the long-voxel list with the rows of a
+// 16-point chunk travelling global -> LDS by LDS-DMA (glds16: 2 x 1 KB per wave, no registers, 2 x 8 KB of LDS per
+// workgroup so that the short role keeps 7 waves per SIMD -- with 64- / 32-point chunks it ran at 2 / 5 and the kernel took 47 us; the next chunk is requested
+// before this one is summed), two of their waves then add the chunk's products in ascending point order out of LDS (lane =
+// channel; product rounded, then added: the oracle's arithmetic); all other workgroups are gather3's four short voxels per
+// wave.  The long workgroups are dispatched first and hide under the short ones' store stream: 58.5 -> 39.1 us on the KITTI
+// frustum (144 MB of algorithmic traffic: 3.7 TB/s), bit-identical output.
+constexpr int POOL7_LONG_WGS = 1024;       // (KITTI frustum: 1004 long voxels -> one each; measured 512: 44.1 us, 1024: 39.1 us, 2048: 38.4 us)
+
+template <bool FUSED>
+__global__ void __launch_bounds__(256)
+pool_gather7_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
+                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                    const int32_t* __restrict__ long_list, float* __restrict__ out, int nv, int P, int vox_per_batch, int N,
+                    int D, int HW, int nlw) {
+  constexpr int C = 128, NV4 = 2, U = 4;
+  constexpr int CH = 16;                                   // list entries per chunk (2 x 8 KB of LDS: the short role keeps 7 waves per SIMD)
+  __shared__ __align__(16) float rows[2][CH * C];
+  __shared__ float wl[2][CH];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if ((int)blockIdx.x < nlw) {
+    const int nlong = long_list[0];
+    for (int i = blockIdx.x; i < nlong; i += nlw) {
+      const int vv = long_list[1 + i];
+      const int vs = starts[vv], ve = starts[vv + 1], vb = vv / vox_per_batch;
+      // a chunk = CH consecutive list entries; wave w stages the rows 8 w .. 8 w + 7 (two rows per LDS-DMA instruction)
+      auto stage = [&](int base, int buf) {
+        const int cnt = min(CH, ve - base);
+        const int p = lane < cnt ? order[base + lane] : 0;
+        int row = p;
+        float wgt = 1.0f;
+        if (FUSED) {
+          const int q = p - vb * P;
+          const int n = q / (D * HW);
+          row = (vb * N + n) * HW + (q % HW);
+          wgt = lane < cnt ? depth[p] : 0.0f;
+        }
+        if (wave == 0 && lane < CH) wl[buf][lane] = wgt;
+#pragma unroll
+        for (int e = 0; e < CH / 8; ++e) {
+          const int j = (CH / 4) * wave + 2 * e + (lane >> 5);
+          const int r = __shfl(row, min(j, cnt - 1), 64);
+          if ((CH / 4) * wave + 2 * e < cnt) glds16(feat + (size_t)r * C + (lane & 31) * 4, rows[buf] + ((CH / 4) * wave + 2 * e) * C);
+        }
+      };
+      float a = 0.0f;
+      int buf = 0;
+      stage(vs, 0);
+      for (int base = vs; base < ve; base += CH, buf ^= 1) {
+        wait_vm0();
+        __syncthreads();                                    // chunk `base` is in rows[buf] for every wave; rows[buf ^ 1] is free
+        if (base + CH < ve) stage(base + CH, buf ^ 1);
+        if (wave < 2) {
+          const int cnt = min(CH, ve - base);
+          const float* rp = rows[buf] + 64 * wave + lane;
+          for (int j0 = 0; j0 < cnt; j0 += 8) {
+            float f[8], w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { f[u] = rp[min(j0 + u, cnt - 1) * C]; w8[u] = wl[buf][min(j0 + u, cnt - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (j0 + u < cnt) a = __fadd_rn(a, FUSED ? __fmul_rn(w8[u], f[u]) : f[u]);
+          }
+        }
+      }
+      if (wave < 2) out[(size_t)vv * C + 64 * wave + lane] = a;
+      __syncthreads();                                      // the buffers are restaged for the next voxel
+    }
+    return;
+  }
+  const int gl = lane & 15, gbase = lane & 48;
+  const int v = (int)(((size_t)(blockIdx.x - nlw) * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+  const bool vok = v < nv;
+  const int s = vok ? starts[v] : 0, e0 = vok ? starts[v + 1] : 0;
+  const bool is_long = e0 - s > POOL_LONG;
+  const int e = is_long ? s : e0;
+  const int b = vok ? v / vox_per_batch : 0;
+  float4 acc[NV4];
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int p_next = (s + gl < e) ? order[s + gl] : 0;
+  for (int base = s; base < e; base += 16) {
+    const int cnt = min(16, e - base);
+    const int p = p_next;
+    p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
+    int row = p;
+    float wgt = 1.0f;
+    if (FUSED) {
+      const int q = p - b * P;
+      const int n = q / (D * HW);
+      row = (b * N + n) * HW + (q % HW);
+      wgt = gl < cnt ? depth[p] : 0.0f;
+    }
+    for (int j0 = 0; j0 < cnt; j0 += U) {
+      float4 f[U][NV4];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = gbase + min(j0 + u, cnt - 1);
+        const int r = __shfl(row, jj, 64);
+        ww[u] = __shfl(wgt, jj, 64);
+        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u < cnt) {
+#pragma unroll
+          for (int k = 0; k < NV4; ++k) {
+            if (FUSED) {
+              acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
+              acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
+              acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
+              acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
+            } else {
+              acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
+              acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
+              acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
+              acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (vok && !is_long) {
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
   }
 }
 
@@ -1019,9 +1293,28 @@ bool pool_dims_ok(const ssbev_pool_dims* d) {
 
 template <bool FUSED>
 int launch_gather(const float* depth, const float* feat, const int32_t* starts, const int32_t* order, float* out,
-                  const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st) {
+                  const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st, const int32_t* long_list = nullptr) {
   const int nv = d->B * d->nx * d->ny * d->nz;
   const int vpb = d->nx * d->ny * d->nz;
+  static const int split_variant = getenv("SSBEV_POOL_SPLIT") ? atoi(getenv("SSBEV_POOL_SPLIT")) : 7;   // 7 = one launch (C = 128), 6 = two launches
+  if (long_list && d->C == 128 && split_variant == 7) {
+    static const int nlw = getenv("SSBEV_POOL7_LONG_WGS") ? std::max(1, atoi(getenv("SSBEV_POOL7_LONG_WGS"))) : POOL7_LONG_WGS;   // (tuning hook)
+    dim3 g7(nlw + cdiv((size_t)cdiv(nv, 4) * 64, 256));
+    hipLaunchKernelGGL((pool_gather7_kernel<FUSED>), g7, dim3(256), 0, st, depth, feat, starts, order, long_list, out, nv, d->P, vpb,
+                       N, D, HW, nlw);
+    return ssbev_launch_status();
+  }
+  if (long_list && (d->C == 64 || d->C == 128 || d->C == 256)) {      // role split over the compacted long-voxel list (round 4)
+    dim3 gl_(512), gs_(cdiv((size_t)cdiv(nv, 4) * 64, 256)), blk(256);
+#define SSBEV_GATHER_SPLIT(NV4_)                                                                                            \
+    hipLaunchKernelGGL((pool_gather_long_kernel<FUSED, NV4_>), gl_, blk, 0, st, depth, feat, starts, order, long_list, out, d->P, \
+                       vpb, N, D, HW);                                                                                       \
+    hipLaunchKernelGGL((pool_gather_short_kernel<FUSED, NV4_>), gs_, blk, 0, st, depth, feat, starts, order, out, nv, d->P,  \
+                       vpb, N, D, HW)
+    if (d->C == 64) { SSBEV_GATHER_SPLIT(1); } else if (d->C == 128) { SSBEV_GATHER_SPLIT(2); } else { SSBEV_GATHER_SPLIT(4); }
+#undef SSBEV_GATHER_SPLIT
+    return ssbev_launch_status();
+  }
   static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 5;   // 1 = r1 kernel, 2 = one voxel per wave at a time, 3 = four side by side, 4 = 3 persistent + pipelined (not faster), 5 = 3 + whole-wave path for long lists
   if (variant == 5 && (d->C == 64 || d->C == 128 || d->C == 256)) {
     dim3 grid5(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block5(256);
@@ -1149,8 +1442,18 @@ size_t ssbev_pool_prepare_workspace(int n_points, const ssbev_pool_dims* d) {
   return csr_ws(p, (size_t)n_points).total;
 }
 
+int ssbev_pool_prepare2(const int32_t* vox, int n_points, int32_t* starts, int32_t* order, int32_t* long_list,
+                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
+
 int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_t* order,
                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return ssbev_pool_prepare2(vox, n_points, starts, order, nullptr, d, ws, ws_bytes, stream);
+}
+
+size_t ssbev_pool_long_list_elems(int n_points) { return n_points < 0 ? 0 : (size_t)n_points / (POOL_LONG + 1) + 2; }
+
+int ssbev_pool_prepare2(const int32_t* vox, int n_points, int32_t* starts, int32_t* order, int32_t* long_list,
+                        const ssbev_pool_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!pool_dims_ok(d) || n_points < 0 || !starts || !ws || (n_points && (!vox || !order))) return SSBEV_EINVAL;
   const long long nvl = (long long)d->B * d->nx * d->ny * d->nz;
   CsrPlan p;
@@ -1161,6 +1464,7 @@ int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_
   const int nv = (int)nvl;
   if (n_points == 0) {
     if (hipMemsetAsync(starts, 0, ((size_t)nv + 1) * 4, st) != hipSuccess) return SSBEV_ELAUNCH;
+    if (long_list && hipMemsetAsync(long_list, 0, 4, st) != hipSuccess) return SSBEV_ELAUNCH;
     return SSBEV_OK;
   }
   char* base = static_cast<char*>(ws);
@@ -1177,7 +1481,7 @@ int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_
     const int nd = 1 << p.nbits[j];
     int32_t* tot = totals + (size_t)j * 2048;
     hipLaunchKernelGGL(csr_hist_kernel, dim3(p.nblk), dim3(CSR_T), (size_t)nd * 4, st, kin, n_points, nv, p.shift[j],
-                       p.nbits[j], p.items, p.nblk, hist, tot);
+                       p.nbits[j], p.items, p.nblk, hist, tot, j == 0 ? long_list : nullptr);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(nd), dim3(256), 0, st, hist, tot, nd, p.nblk, bucket_base);
     const size_t lds = (size_t)CSR_WAVES * nd * 4;
     auto part = j == 0 ? (p.items == 8 ? csr_partition_kernel<true, true> : csr_partition_kernel<true, false>)
@@ -1200,7 +1504,7 @@ int ssbev_pool_prepare(const int32_t* vox, int n_points, int32_t* starts, int32_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds) != hipSuccess)
     return SSBEV_ELAUNCH;
   hipLaunchKernelGGL(csr_bucket_kernel, dim3(p.nbuckets), dim3(CSR_BW * 64), blds, st, kin, iin,
-                     p.npass == 1 ? bucket_base : nullptr, bucket_base + nd_last, nv, p.lo_bits, starts, order);
+                     p.npass == 1 ? bucket_base : nullptr, bucket_base + nd_last, nv, p.lo_bits, starts, order, long_list);
   return ssbev_launch_status();
 }
 
@@ -1227,6 +1531,14 @@ int ssbev_lift_splat_fwd(const float* depth, const float* feat, const int32_t* s
   if (!pool_dims_ok(d) || !l || !depth || !feat || !starts || !out) return SSBEV_EINVAL;
   if (l->N <= 0 || l->D <= 0 || l->HW <= 0 || (long)l->N * l->D * l->HW != d->P) return SSBEV_EINVAL;
   return launch_gather<true>(depth, feat, starts, order, out, d, l->N, l->D, l->HW, as_stream(stream));
+}
+
+int ssbev_lift_splat_fwd2(const float* depth, const float* feat, const int32_t* starts, const int32_t* order,
+                          const int32_t* long_list, float* out, const ssbev_pool_dims* d, const ssbev_lift_dims* l,
+                          ssbev_stream_t stream) {
+  if (!pool_dims_ok(d) || !l || !depth || !feat || !starts || !out) return SSBEV_EINVAL;
+  if (l->N <= 0 || l->D <= 0 || l->HW <= 0 || (long)l->N * l->D * l->HW != d->P) return SSBEV_EINVAL;
+  return launch_gather<true>(depth, feat, starts, order, out, d, l->N, l->D, l->HW, as_stream(stream), long_list);
 }
 
 int ssbev_lift_splat_bwd(const float* grad_out, const float* depth, const float* feat,

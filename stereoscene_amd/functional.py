@@ -229,17 +229,25 @@ def voxel_index(geom, bx, dx, nx, return_idx=False, grid_host=None):
     return (vox, idx3) if return_idx else vox
 
 
+class _Order(torch.Tensor):
+    """The `order` tensor of a CSR table carrying the compacted long-voxel list of ssbev_pool_prepare2 (`.long_list`), so that the
+    (starts, order) pairs handed around by callers keep their shape."""
+    long_list = None
+
+
 def pool_prepare(vox, B, nx, ny, nz):
-    """CSR table (starts int32 [NV+1], order int32 [n]) of the voxel -> ascending point lists."""
+    """CSR table (starts int32 [NV+1], order int32 [n]) of the voxel -> ascending point lists; `order.long_list` (int32: count,
+    then the ids of the voxels with more than 32 points) is the work list of the fused gather's long-list waves."""
     lib = capi.load()
     n = vox.numel()
     d = _pool_dims(B, max(n // max(B, 1), 0), 1, nx, ny, nz)
     nv = B * nx * ny * nz
     starts = torch.empty(nv + 1, dtype=torch.int32, device=vox.device)
-    order = torch.empty(max(n, 1), dtype=torch.int32, device=vox.device)
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=vox.device).as_subclass(_Order)
+    order.long_list = torch.empty(lib.ssbev_pool_long_list_elems(n), dtype=torch.int32, device=vox.device)
     ws = _ws(lib.ssbev_pool_prepare_workspace(n, C.byref(d)), vox.device)
-    capi.check(lib.ssbev_pool_prepare(capi.ptr(vox), n, capi.ptr(starts), capi.ptr(order), C.byref(d),
-                                      capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_pool_prepare")
+    capi.check(lib.ssbev_pool_prepare2(capi.ptr(vox), n, capi.ptr(starts), capi.ptr(order), capi.ptr(order.long_list), C.byref(d),
+                                       capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_pool_prepare2")
     return starts, order
 
 
@@ -285,6 +293,10 @@ def bev_pool(feats, coords, B, D, H, W):
     return _BevPool.apply(feats, coords, int(B), int(D), int(H), int(W))
 
 
+# role-split gather over the compacted long-voxel list (round 4); SSBEV_GATHER_SPLIT=0: the one-kernel gather5
+GATHER_SPLIT = os.environ.get("SSBEV_GATHER_SPLIT", "1") != "0"
+
+
 class _LiftSplat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, feat, vox, starts, order, B, N, grid):
@@ -300,9 +312,10 @@ class _LiftSplat(torch.autograd.Function):
         # algorithmic bytes: depth + features + the int32 voxel table in, the BEV volume out
         nby = 4.0 * (depth.numel() + feat_cl.numel() + order.numel() + starts.numel() + out.numel())
         with _span("lift_splat", 2.0 * depth.numel() * Cch, nby, f"fwd   lift_splat D={D} HW={H * W} C={Cch} grid={nx}x{ny}x{nz}"):
-            capi.check(lib.ssbev_lift_splat_fwd(capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(starts), capi.ptr(order),
-                                                capi.ptr(out), C.byref(d), C.byref(l), capi.stream()),
-                       "ssbev_lift_splat_fwd")
+            capi.check(lib.ssbev_lift_splat_fwd2(capi.ptr(depth), capi.ptr(feat_cl), capi.ptr(starts), capi.ptr(order),
+                                                 capi.ptr(getattr(order, "long_list", None) if GATHER_SPLIT else None),
+                                                 capi.ptr(out), C.byref(d), C.byref(l), capi.stream()),
+                       "ssbev_lift_splat_fwd2")
         ctx.save_for_backward(depth, feat_cl, vox)
         ctx.meta = (B, N, grid)
         return from_cl(out)                                       # logical [B, C, X, Y, Z]
