@@ -42,6 +42,9 @@ timeout 600 python tools/stream_probe.py > $out/stream_probe.txt 2>&1
 timeout 300 python tools/tapdh_probe.py 2>&1 | grep -v amdgpu > $out/tapdh_probe.txt
 timeout 300 python tools/wgrad_dh_probe.py 2>&1 | grep -v amdgpu > $out/wgrad_dh_probe.txt
 timeout 300 python tools/pool_prepare_probe.py 2>&1 | grep -v amdgpu > $out/pool_prepare_probe.txt
+timeout 300 python tools/gather_split_probe.py 2>&1 | grep -v amdgpu > $out/gather_split_probe.txt
+timeout 300 python tools/pw32_probe.py 2>&1 | grep -v amdgpu > $out/pw32_probe.txt
+bash tools/sq_counters.sh $tag > /dev/null 2>&1
 SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 600 python tools/layer_table.py kitti_d192 3 2>&1 | grep -v amdgpu > $out/layer_table.txt
 timeout 600 python tools/bucket_timeline.py 64 300 2>&1 | grep -v amdgpu > $out/bucket_timeline.txt
 # configs[4]: one whole-step roofline object per ablation mode
