@@ -98,15 +98,15 @@ class FlatGradAllReduce:
         self._handles = []
         self.no_grad_ranges = []          # [(start, end)] element ranges of the flat buffer without a gradient this step
         self.bytes_exchanged = 0
-        self._home = None
+        # the stream the flat buffer belongs to: the caller's stream NOW (a lazily resolved home could become the side
+        # stream when the first bucket completes inside DepthNet's side-stream backward); zero_grad() re-captures it
+        self._home = torch.cuda.current_stream(dev) if self.flat.is_cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _home_stream(self):
         """The stream the flat buffer belongs to: the caller's stream at ``zero_grad()`` (or at construction).  Packing and
         the exchange always run THERE, whatever stream the autograd hook happens to fire on (DepthNet's backward -- and with
         it the AccumulateGrad nodes of its parameters and this hook -- runs on the side stream, streams.py)."""
-        if self._home is None:
-            self._home = torch.cuda.current_stream(self.flat.device)
         return self._home
 
     def _pack(self, b):
@@ -122,9 +122,9 @@ class FlatGradAllReduce:
         # AND gradients computed there in place (DepthNet's), which never mark it dirty
         streams.wait_side(home)
         with torch.cuda.stream(home):
-            self._pack_on_current(b, foreign=here if here != home else None)
+            self._pack_on_current(b)
 
-    def _pack_on_current(self, b, foreign=None):
+    def _pack_on_current(self, b):
         dst, src = [], []
         for p in self._members[b]:
             view = self._views[p]

@@ -493,7 +493,7 @@ class _SpatialMean(torch.autograd.Function):
 def spatial_mean(x):
     """[B, C, *spatial] -> [B, C] mean; slot-aware (see _SpatialMean)."""
     if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
-        return x.mean(dim=tuple(range(2, x.dim())), dtype=torch.float32 if x.is_floating_point() else None)
+        return x.mean(dim=tuple(range(2, x.dim())), dtype=torch.float32 if x.dtype in (torch.bfloat16, torch.float16) else None)
     return _SpatialMean.apply(x, _slot_of(x))
 
 

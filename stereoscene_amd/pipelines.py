@@ -299,7 +299,12 @@ class LoadMultiViewImageFromFiles_SemanticKitti:
     def pixel_map(self, post_rot, post_tran, resize, crop, flip):
         """The pixel map raw image -> network input composed onto (post_rot, post_tran): scale, shift by the crop corner,
         mirror about the crop width (what the reference accumulates at loading_semkitti.py:109-125; a rotation about the crop
-        centre would be the fourth step)."""
+        centre would be the fourth step).  This is a true composition of affine maps; the reference's in-place update leaves an
+        incoming translation unscaled (loading_semkitti.py:113-114), and the two agree exactly when the incoming translation is
+        zero -- which is the only way the loader calls it (``_view`` passes eye(2) / zeros(2)).  Anything else is refused."""
+        if bool((torch.as_tensor(post_tran) != 0).any()):
+            raise ValueError("pixel_map: a non-zero incoming post_tran is not what the reference loader composes onto "
+                             "(loading_semkitti.py:113-114 would leave it unscaled)")
         eye = torch.eye(2)
         steps = [(eye * resize, torch.zeros(2)),
                  (eye, -torch.Tensor([crop[0], crop[1]]))]

@@ -96,12 +96,25 @@ def new_step():
     never run backward leave their weight-use counts."""
     global _EPOCH
     _CB_QUEUED.clear()
+    _EPOCH_CB[0] = False
     _EPOCH += 1
 
 
 def _end_of_backward():
     _CB_QUEUED.clear()
     join()
+
+
+_EPOCH_CB = [False]
+
+
+def _epoch_end_of_backward():
+    """End of ANY backward run that asked ``wgrad_on_side``: the weight-use counts of this graph are spent, and counts left by
+    forward passes that were never run backward (validation without no_grad, an exception between forward and backward) must
+    not make every later step look like a shared-weight graph."""
+    global _EPOCH
+    _EPOCH_CB[0] = False
+    _EPOCH += 1
 
 
 class on_side:
@@ -148,7 +161,8 @@ class on_side:
 # calls of one graph gets its two gradients summed in the engine's input buffer on the caller's stream, unordered against the
 # side stream.  The convolution wrappers therefore count the uses of a weight in forward (``note_use``) and backward asks
 # ``wgrad_on_side``: more than one use since the weight's counter was last at rest -> every one of them stays on the caller's
-# stream.  The counter rests again when all counted uses have run backward, or at the next ``new_step()``.
+# stream.  The counter rests again when all counted uses have run backward, at the end of every backward run that consulted it, or at the
+# next ``new_step()``.
 _EPOCH = 0
 
 
@@ -169,6 +183,12 @@ def wgrad_on_side(weight):
     # a LEAF parameter: its gradient goes to AccumulateGrad, which keeps the tensor when .grad is None; the gradient of a
     # computed weight (CA3D folds its channel gate into the weights) is read by the next backward node at once
     shared = False
+    if WGRAD_STREAM and not _EPOCH_CB[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_epoch_end_of_backward)
+            _EPOCH_CB[0] = True
+        except RuntimeError:              # a backward() called by hand, outside an engine run: nothing to hang the reset on
+            pass
     st = getattr(weight, "_ssbev_uses", None)
     if st is not None:
         shared = st[2]

@@ -64,8 +64,10 @@ class FlatAdamW:
     def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
                  reducer=None, loss_scaler=None):
         # Mixed-precision policy (BASELINE configs[3]; the reference's Fp16OptimizerHook): parameters, moments and the flat
-        # gradient buffer are fp32 -- they ARE the master weights, the bf16 mode only narrows what the conv kernels compute
-        # on -- so the hook reduces to its loss scaler: scaled loss, unscale before the clip, skip + rescale on overflow.
+        # gradient buffer are fp32 -- they ARE the master weights; SSBEV_PRECISION=bf16 stores activations and activation
+        # gradients as bf16 between layers and ALSO switches the data-parallel wire format to bf16 (dp.py; override with
+        # SSBEV_DP_COMM_DTYPE / comm_dtype) -- so the hook reduces to its loss scaler: scaled loss, unscale before the
+        # clip, skip + rescale on overflow.
         self.loss_scaler = loss_scaler
         self.reducer = reducer or FlatGradAllReduce(module)
         params = self.reducer.params                       # same order as the flat gradient buffer

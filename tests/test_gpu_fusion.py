@@ -316,6 +316,15 @@ def test_weight_used_twice_keeps_its_gradients_off_the_side_stream():
     w.grad = None
     y = F.conv3d(x, w, None, 1, 1)
     assert w._ssbev_uses[1] == 1 and not w._ssbev_uses[2] and streams.WGRAD_STREAM
+    # forward passes whose graph is never run backward (the one above, one more here) leave their counts behind;
+    # the next step is treated as a shared-weight graph (safe), and the end of ITS backward puts the counter to rest again
+    F.conv3d(x, w, None, 1, 1)
+    y = F.conv3d(x, w, None, 1, 1)
+    assert w._ssbev_uses[1] == 3 and w._ssbev_uses[2]
+    y.square().mean().backward()
+    w.grad = None
+    y = F.conv3d(x, w, None, 1, 1)
+    assert w._ssbev_uses[1] == 1 and not w._ssbev_uses[2]
 
 
 @pytest.mark.parametrize("case", [((64, 32, 128), (8, 4, 32), (3, 4, 5), False, True), ((32, 32), (32, 32), (6, 10), True, True),

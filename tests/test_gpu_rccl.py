@@ -1,0 +1,131 @@
+"""First RCCL calls: the data-parallel gradient exchange of dp.FlatGradAllReduce under a REAL
+``torch.distributed`` process group on the ``nccl`` backend (= RCCL on ROCm), world size 1 on the one GPU a test box has.
+
+With one rank the reduce-scatter(AVG) + all-gather pair is the identity on the bucket, so the packed flat gradient buffer of a
+KITTI-size step must be bit-identical to the run without any process group -- what this pins is everything around the
+arithmetic that the gloo emulation (tests/test_dp_gloo.py) cannot: the in-place ``reduce_scatter_tensor(mine < buf, AVG)``
+and ``all_gather_into_tensor(buf, mine)`` calls RCCL actually accepts, asynchronous work handles issued from autograd hooks
+on the home stream while backward is still running on two streams, the bf16 wire format, and the wait in ``finish()``.
+The reference exchange: MMDistributedDataParallel, mmdet_train.py:70-79 (launched by tools/dist_train.sh:9-19).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from stereoscene_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture
+def rccl_world1():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        yield
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def _setup(tag):
+    from stereoscene_amd import model_zoo
+    cfg = S.CFG_K112
+    model = model_zoo.build_detector(cfg).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    smp = S.synthetic_sample(cfg, B=1, tag=tag)
+    inputs = model_zoo.img_inputs_from_sample(smp)
+    gt = smp["gt_occ"].to(DEV)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model, inputs, gt, sd0
+
+
+def _step(model, red, inputs, gt, sd0):
+    model.load_state_dict(sd0)
+    red.zero_grad()
+    losses = model.forward_train(img_inputs=inputs, gt_occ=gt)
+    sum(v for k, v in losses.items() if k.startswith("loss")).backward()
+    nbytes = red.finish()
+    torch.cuda.synchronize()
+    return red.flat.detach().clone(), nbytes
+
+
+def _loose_mask(model, red):
+    """Gradients behind DepthNet's atomics-based DCN backward are reproducible to rounding only (tests/test_gpu_fusion.py)."""
+    names = {p: n for n, p in model.named_parameters()}
+    strict = torch.ones_like(red.flat, dtype=torch.bool)
+    for p in red.params:
+        if "depth_net" in names[p]:
+            strict[red._offsets[p]:red._offsets[p] + p.numel()] = False
+    return strict
+
+
+def test_rccl_world1_exchange_is_the_identity_on_the_flat_buffer(rccl_world1):
+    from stereoscene_amd import dp
+    model, inputs, gt, sd0 = _setup("rccl")
+    # --- no exchange at all (a reducer that believes there is no process group)
+    red0 = dp.FlatGradAllReduce(model, bucket_mb=4)
+    red0.active = False
+    want, n0 = _step(model, red0, inputs, gt, sd0)
+    strict = _loose_mask(model, red0)
+    red0.remove()
+    assert n0 == 0
+    for exchange in ("rs_ag", "all_reduce"):
+        red = dp.FlatGradAllReduce(model, bucket_mb=4, exchange=exchange)
+        assert red.active and red.world == 1 and red.native_avg and red.exchange == exchange and len(red.buckets) > 20
+        for _ in range(2):
+            got, nbytes = _step(model, red, inputs, gt, sd0)
+            assert nbytes == red.flat.numel() * 4                       # every bucket went through RCCL
+            assert torch.equal(got[strict], want[strict]), exchange
+            d = (got.double() - want.double())[~strict]
+            assert d.norm().item() < 1e-5 * want.double()[~strict].norm().item()
+        red.remove()
+
+
+def test_rccl_world1_bf16_wire_rounds_once(rccl_world1):
+    """bf16 wire format (dp.py, default in the bf16 storage mode): with one rank the exchanged gradient is the fp32 gradient
+    rounded to bf16 exactly once (AVG over one rank adds no arithmetic)."""
+    from stereoscene_amd import dp
+    model, inputs, gt, sd0 = _setup("rccl16")
+    red0 = dp.FlatGradAllReduce(model, bucket_mb=16)
+    red0.active = False
+    want, _ = _step(model, red0, inputs, gt, sd0)
+    strict = _loose_mask(model, red0)
+    red0.remove()
+    red = dp.FlatGradAllReduce(model, bucket_mb=16, comm_dtype="bf16")
+    got, nbytes = _step(model, red, inputs, gt, sd0)
+    assert nbytes == red.flat.numel() * 2
+    assert torch.equal(got[strict], want.to(torch.bfloat16).float()[strict])
+    red.remove()
+
+
+def test_rccl_world1_collectives_on_a_bucket_sized_buffer(rccl_world1):
+    """The two raw calls of the "rs_ag" exchange on a 64 MB bucket, in place, with AVG: what dp._exchange issues per bucket."""
+    buf = torch.randn(16 << 20, device=DEV)
+    ref = buf.clone()
+    mine = buf[0:buf.numel()]
+    h1 = dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.AVG, async_op=True)
+    h2 = dist.all_gather_into_tensor(buf, mine, async_op=True)
+    h1.wait()
+    h2.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, ref)
+    t = torch.tensor([3.0], device=DEV)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    assert float(t) == 3.0

@@ -164,6 +164,8 @@ def test_image_augmentation_draw_and_pixel_map_match_reference_loader():
         for name in ("left", "right"):                                       # one draw per sample, shared by both views
             assert np.abs(rot2.numpy() - g[f"load_{mode}_{name}_post_rot"][0][:2, :2]).max() < 1e-6
             assert np.abs(tran2.numpy() - g[f"load_{mode}_{name}_post_tran"][0][:2]).max() < 1e-5
+        with pytest.raises(ValueError):               # the reference never composes onto a non-zero translation
+            step.pixel_map(torch.eye(2), torch.ones(2), resize, crop, flip)
     # flips off in the config: the RNG stream is not consumed for them (the crop after it would move otherwise)
     cfg = dict(DATA_CONFIG, flip=False)
     step = P.PIPELINES.build(dict(type="LoadMultiViewImageFromFiles_SemanticKitti", data_config=cfg, is_train=True, device="cpu"))
