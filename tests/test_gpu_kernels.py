@@ -51,8 +51,10 @@ def test_voxel_index_bit_exact(cfgname, B):
     assert bool(kept[3]) and not bool(kept[4]) and not bool(kept[5])
 
 
-@pytest.mark.parametrize("cfgname,B,C", [("small_d48", 2, 128), ("tiny_d16", 1, 12), ("kitti_d112", 1, 128)])
+@pytest.mark.parametrize("cfgname,B,C", [("small_d48", 2, 128), ("tiny_d16", 1, 12), ("kitti_d112", 1, 128), ("kitti_d192", 1, 128)])
 def test_lift_splat_bit_exact_and_grads(cfgname, B, C):
+    """kitti_d192 = the BASELINE frustum (1.47 M points): its long-voxel population (pool_gather7's long-list role) differs
+    from the D = 112 one, so the bit-for-bit comparison with the oracle is made there too."""
     cfg = S.CONFIGS[cfgname]
     geom, dx, bx, nx = _geometry(cfg, B)
     _, N, D, H, W, _ = geom.shape
