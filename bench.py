@@ -25,6 +25,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step runs on two streams (streams.py); a RCCL
+# process group adds its own, and with four queues the step's two streams end up sharing one: measured on MI355X, the mere
+# presence of a one-rank process group cost +4.5 ms per step (76.5 vs 72.4 ms; serial schedule unaffected) and 8 queues give
+# it back (72.45 ms, profiles/r5_rccl_hw_queues.txt).  Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -115,6 +120,7 @@ def respawn_under_launcher(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this driver)
     env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
     return subprocess.call(cmd, env=env)
 
 
@@ -395,17 +401,20 @@ def main():
             F.KERNEL_TIMER = None
 
     exch = None
-    if distributed and reducer is not None and reducer.active:
+    if distributed and reducer is not None and (reducer.active or world == 1):
         exch = exchange_microbench(reducer, dist)
-        exch["mode_in_step"] = reducer.exchange
+        exch["mode_in_step"] = reducer.exchange if reducer.active else "none (one rank)"
         exch["bytes_per_step_per_rank"] = reducer.flat.numel() * 4
         exch["buckets"] = len(reducer.buckets)
         exch["world"] = world
         exch["backend"] = dist.get_backend()
         exch["wire_dtype"] = reducer.comm_dtype
         if world == 1:
-            exch["note"] = ("one-rank RCCL process group: every exchange call of the N > 1 step executes inside the timed region "
-                            "(in place, identity); bus bandwidth is undefined at N = 1 (no peer), `ms` is the call overhead")
+            exch["note"] = ("one-rank RCCL process group: the timing protocol's barrier is RCCL's and the exchange calls of the "
+                            "N > 1 step (reduce_scatter_tensor AVG + all_gather_into_tensor per bucket, in place) are executed and "
+                            "timed HERE, after the timed region -- inside it a one-rank group exchanges nothing (dp.py: the identity "
+                            "copies of the 353 MB buffer on RCCL's stream cost +6 ms per step next to backward); bus bandwidth is "
+                            "undefined at N = 1 (no peer), `ms` is the cost of the calls alone")
     elif rccl_world1 and rccl_world1 != "ok":
         exch = {"world": 1, "rccl_process_group": rccl_world1}
 
@@ -543,7 +552,8 @@ def main():
                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": f"dp{world}", "train_mode": True},
                "roofline": roof, "roofline_other_timed_kernels": roof_other, "roofline_serial_replay": roof_replay,
-               "streams": {"side_stream_weight_gradients": bool(_streams.WGRAD_STREAM), "side_stream_depthnet": bool(_vtm.VT_STREAMS)},
+               "streams": {"side_stream_weight_gradients": bool(_streams.WGRAD_STREAM), "side_stream_depthnet": bool(_vtm.VT_STREAMS),
+                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                "step_roofline": step_roof,
                "losses": {k: float(v.detach()) for k, v in losses.items()}}
         if fo_ms is not None:

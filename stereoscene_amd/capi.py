@@ -56,6 +56,19 @@ class Norm2Dims(C.Structure):
                 ("eps_b", C.c_float), ("relu", C.c_int), ("a_batch", C.c_int), ("b_batch", C.c_int), ("io_dtype", C.c_int)]
 
 
+class NormExt(C.Structure):
+    _fields_ = [("sync", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
+                ("n", C.c_int64)]
+
+
+class Norm2Ext(C.Structure):
+    _fields_ = [("sync", C.c_void_p), ("running_mean_a", C.c_void_p), ("running_var_a", C.c_void_p), ("momentum_a", C.c_float),
+                ("running_mean_b", C.c_void_p), ("running_var_b", C.c_void_p), ("momentum_b", C.c_float)]
+
+
+NORM_SYNC_WORDS = 16
+
+
 class DcnDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "G", "k", "pad", "dil")]
 
@@ -128,6 +141,10 @@ SIGNATURES = {
     "ssbev_groupnorm_mask_words": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd_mask": (C.c_int, [_P] * 8 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd_mask": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_fwd_ext": (C.c_int, [_P] * 8 + [C.POINTER(NormDims), C.POINTER(NormExt), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm_bwd_ext": (C.c_int, [_P] * 11 + [C.POINTER(NormDims), C.POINTER(NormExt), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm2_fwd_ext": (C.c_int, [_P] * 12 + [C.POINTER(Norm2Dims), C.POINTER(Norm2Ext), _P, C.c_size_t, _P]),
+    "ssbev_groupnorm2_bwd_ext": (C.c_int, [_P] * 16 + [C.POINTER(Norm2Dims), C.POINTER(Norm2Ext), _P, C.c_size_t, _P]),
     "ssbev_groupnorm2_workspace": (C.c_size_t, [C.POINTER(Norm2Dims)]),
     "ssbev_groupnorm2_fwd": (C.c_int, [_P] * 12 + [C.POINTER(Norm2Dims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm2_bwd": (C.c_int, [_P] * 16 + [C.POINTER(Norm2Dims), _P, C.c_size_t, _P]),

@@ -16,6 +16,14 @@
 namespace {
 
 constexpr int NT = 256;
+// The statistics kernels: PNT threads per workgroup, ~kStatBlocks workgroups (three per CU).  Round 5: a workgroup covers a
+// chunk of voxels x a SLAB of kSlabLanes lanes (32 fp32 / 64 bf16 channels), so that every problem, whatever its channel count,
+// leaves the same ~24.6 k (sum, sum-of-squares) records -- what one workgroup can reduce in two round trips (GnTail below).
+// (One workgroup per CU with 768 threads and 256 chunks was measured and dropped: the streaming passes lost 40-70 %, and a
+// 12-wave workgroup waits for a whole free CU next to the side stream's kernels.)
+constexpr int PNT = 256;
+constexpr int kStatBlocks = 768;
+constexpr int kSlabLanes = 8;
 
 struct GnGeom {
   int B, C, G;
@@ -24,6 +32,7 @@ struct GnGeom {
   long chunk_len;    // voxels per chunk
   float eps;
   int relu;
+  int slab_q;        // lanes (of VW channels) per channel slab of the statistics kernels (blockIdx.z)
   int pre;           // 1: u = gelu(x) (exact, erf) is what gets normalised; x is still the tensor in memory
   long ldy, ldg;     // row strides (floats) of y (forward) and gy (backward): C when dense, the width of the concatenation
                      // when the operator writes / reads a channel slice of a wider channels-last tensor (ssbev_norm_dims.ld_*)
@@ -76,20 +85,214 @@ __device__ __forceinline__ void stn(T* p, const float (&v)[VW]) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Finalize in the tail of the statistics kernel (round 5).  The statistics of a normalisation used to be three launches:
+// chunk partials -> one latency-bound finalize kernel (B * G workgroups; 104 launches of ~7-10 us per step) -> apply.  With a
+// caller-provided, zeroed 32-bit word (ssbev_norm_ext.sync; the C ABI keeps no state) every workgroup of the statistics
+// kernel takes a ticket after publishing its partial record, and the one that draws the last ticket reduces the records of
+// the whole problem -- in double, in a fixed order: run-to-run identical -- writes mean / rstd (forward; plus the BatchNorm
+// running-statistics update that was a launch of its own) or the per-group coefficients and dgamma / dbeta (backward), and
+// puts the word back to zero.  Hand-off = MI355X_MICROARCH "Workgroup dispatch ...", the write-through form: every record is
+// ONE 8-byte agent-scope (sc1) store -> every wave vmcnt(0) -> barrier -> lane 0 takes a relaxed agent-scope ticket; the last
+// arriver reads the records with 8-byte agent-scope (sc1) loads.  Results do not depend on which workgroup is last.
+struct GnTail {
+  unsigned* sync;            // nullptr: no tail (the finalize kernels run as separate launches)
+  unsigned total;            // tickets = workgroups of the launch
+  // forward
+  float* mean; float* rstd;
+  float* rm; float* rv;      // BatchNorm running statistics (G == C), nullptr = none
+  float mom, unbias;
+  // backward
+  const float* gamma; float* coef; float* dgamma; float* dbeta;
+};
+
+constexpr int kTailMaxC = 1024;       // channels the tail handles: everything on the voxel path and DepthNet
+constexpr int kTailRounds = (kTailMaxC + PNT - 1) / PNT;
+
+__host__ __device__ inline size_t gn_tail_lds_bytes(int C) { return (size_t)(2 * PNT + 2 * C) * sizeof(double); }
+
+// A chunk record = (sum, sum of squares) of one channel = ONE aligned 8-byte agent-scope (sc1, write-through) store, read back
+// by 8-byte agent-scope loads: the "8-byte agent atomics on both sides" form of the guide -- no release fence (a buffer_wbl2
+// per workgroup), no acquire.
+__device__ __forceinline__ void st_record(float* p, float a, float q) {
+  const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(q) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true in exactly one workgroup of the launch: the last one to arrive (all threads of the workgroup get the same answer).
+// Two levels of tickets: 768 arrivals on ONE word are a serial chain of ~12 ns each (MI355X_MICROARCH "fanin": 9 us behind the
+// last streaming read), so a workgroup first arrives on one of kTailShards words (workgroup index modulo 8 = its XCD on
+// today's dispatcher; any placement is correct) and only the last arriver of a shard goes on to the top word.
+constexpr unsigned kTailShards = 8;
+__device__ __forceinline__ bool gn_last_arriver(const GnTail& t, int* flag_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its (write-through) record stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned shard = lin % kTailShards;
+    const unsigned members = (t.total - shard + kTailShards - 1) / kTailShards;       // workgroups with this residue
+    int last = 0;
+    if (members > 0 && __hip_atomic_fetch_add(t.sync + 1 + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+      __hip_atomic_store(t.sync + 1 + shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next call
+      const unsigned shards = t.total < kTailShards ? t.total : kTailShards;
+      last = __hip_atomic_fetch_add(t.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u;
+    }
+    *flag_lds = last;
+  }
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+// per-(sample, channel) sums of the chunk records of one sample into dtot[C][2] (double).  PNT threads = CW channels x L
+// lanes; lane j of a channel takes chunks j, j + L, ..., lane 0 adds the L lane sums in lane order.  The records of a lane
+// are requested kTailBatch at a time (64 - 96 registers) before the first add: the tail is a chain of round trips to another CU's data
+// (~1.5 us each), not a bandwidth problem.
+template <bool SHIFT_BACK, typename T>
+__device__ __forceinline__ void gn_tail_channel_sums(const float* partial, const T* x, const GnGeom& g, int b, double* dred,
+                                                     double* dtot) {
+  constexpr int kTailBatch = 48;
+  const int tid = threadIdx.x, C = g.C, CW = C < PNT ? C : PNT, L = PNT / CW;
+  const int ci = tid % CW, j = tid / CW;
+  for (int c0 = 0; c0 < C; c0 += CW) {
+    const int c = c0 + ci;
+    const bool on = j < L && c < C;
+    double a = 0.0, q = 0.0;
+    if (on) {
+      float pf = 0.0f;
+      if (SHIFT_BACK) pf = ld1(x + (size_t)b * g.S * g.C + c);        // the pivot: requested with the first batch of records
+      const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(partial) + ((size_t)b * g.chunks * g.C + c);
+      for (int chunk0 = j; chunk0 < g.chunks; chunk0 += L * kTailBatch) {
+        unsigned long long raw[kTailBatch];
+#pragma unroll
+        for (int u = 0; u < kTailBatch; ++u) {
+          const int chunk = chunk0 + u * L;
+          raw[u] = chunk < g.chunks ? __hip_atomic_load(pp + (size_t)chunk * g.C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kTailBatch; ++u) {       // (records beyond the last chunk were requested as zeros)
+          a += (double)__uint_as_float((unsigned)raw[u]);
+          q += (double)__uint_as_float((unsigned)(raw[u] >> 32));
+        }
+      }
+      if (SHIFT_BACK) {
+        // shifted partials (pivot p = the channel's value at voxel 0, see gn_partial_kernel): over the n voxels of this lane's
+        // chunks  sum u = sum d + n p,  sum u^2 = sum d^2 + 2 p sum d + n p^2
+        if (g.pre) pf = gelu_f(pf);
+        const double pd = pf;
+        const long k = j < g.chunks ? (g.chunks - 1 - j) / L + 1 : 0;                       // chunks of this lane
+        long nv = k * g.chunk_len;
+        if (k > 0 && (g.chunks - 1 - j) % L == 0) nv -= (long)g.chunks * g.chunk_len - g.S;   // it owns the (shorter) last chunk
+        const double n = (double)nv;
+        q += 2.0 * pd * a + n * pd * pd;
+        a += n * pd;
+      }
+      dred[(j * CW + ci) * 2 + 0] = a;
+      dred[(j * CW + ci) * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (j == 0 && c < C) {
+      double sa = 0.0, sq = 0.0;
+      for (int jj = 0; jj < L; ++jj) { sa += dred[(jj * CW + ci) * 2]; sq += dred[(jj * CW + ci) * 2 + 1]; }
+      dtot[c * 2] = sa; dtot[c * 2 + 1] = sq;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__device__ void gn_tail_fwd(const float* partial, const T* x, const GnGeom& g, const GnTail& t, double* dl) {
+  double* dred = dl;
+  double* dtot = dl + 2 * PNT;
+  const int cpg = g.C / g.G;
+  for (int b = 0; b < g.B; ++b) {
+    if (g.G == g.C) {
+      // one channel per group (BatchNorm): the statistics of the SHIFTED values d = u - p directly (mean = p + E[d])
+      gn_tail_channel_sums<false>(partial, x, g, b, dred, dtot);
+      for (int c = threadIdx.x; c < g.C; c += PNT) {
+        float pf = ld1(x + (size_t)b * g.S * g.C + c);
+        if (g.pre) pf = gelu_f(pf);
+        const double n = (double)g.S, md = dtot[c * 2] / n;
+        double var = dtot[c * 2 + 1] / n - md * md;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)((double)pf + md), rs = (float)(1.0 / sqrt(var + (double)g.eps));
+        t.mean[b * g.C + c] = mf;
+        t.rstd[b * g.C + c] = rs;
+        if (t.rm && b == 0) {                           // (running statistics: B is folded into S for a BatchNorm)
+          const float vf = 1.0f / (rs * rs) - g.eps;    // as bn_update_running_kernel computes it from the stored rstd
+          t.rm[c] = (1.0f - t.mom) * t.rm[c] + t.mom * mf;
+          t.rv[c] = (1.0f - t.mom) * t.rv[c] + t.mom * (vf * t.unbias);
+        }
+      }
+    } else {
+      gn_tail_channel_sums<true>(partial, x, g, b, dred, dtot);
+      for (int grp = threadIdx.x; grp < g.G; grp += PNT) {
+        double sa = 0.0, sq = 0.0;
+        for (int k = 0; k < cpg; ++k) { sa += dtot[(grp * cpg + k) * 2]; sq += dtot[(grp * cpg + k) * 2 + 1]; }
+        const double n = (double)g.S * cpg, m = sa / n;
+        double var = sq / n - m * m;
+        if (var < 0.0) var = 0.0;
+        t.mean[b * g.G + grp] = (float)m;
+        t.rstd[b * g.G + grp] = (float)(1.0 / sqrt(var + (double)g.eps));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// backward: coef[(b, group)] = (sum_c gamma_c sum(g xhat), sum_c gamma_c sum(g)) / n ; dbeta / dgamma = sums over samples
+__device__ void gn_tail_bwd(const float* partial, const GnGeom& g, const GnTail& t, double* dl) {
+  double* dred = dl;
+  double* dtot = dl + 2 * PNT;
+  const int cpg = g.C / g.G;
+  const int CW = g.C < PNT ? g.C : PNT;
+  const bool owner = (int)threadIdx.x < CW;                  // lane 0 of a channel column
+  double accb[kTailRounds] = {0, 0}, accs[kTailRounds] = {0, 0};
+  for (int b = 0; b < g.B; ++b) {
+    gn_tail_channel_sums<false>(partial, (const float*)nullptr, g, b, dred, dtot);
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < kTailRounds; ++r) {
+        const int c = r * CW + threadIdx.x;
+        if (c < g.C) { accb[r] += dtot[c * 2]; accs[r] += dtot[c * 2 + 1]; }
+      }
+    }
+    for (int grp = threadIdx.x; grp < g.G; grp += PNT) {
+      double s = 0.0, u = 0.0;
+      for (int k = 0; k < cpg; ++k) {
+        const int c = grp * cpg + k;
+        const double gm = t.gamma[c];
+        u += gm * dtot[c * 2];
+        s += gm * dtot[c * 2 + 1];
+      }
+      const double n = (double)g.S * cpg;
+      t.coef[(b * g.G + grp) * 2 + 0] = (float)(s / n);
+      t.coef[(b * g.G + grp) * 2 + 1] = (float)(u / n);
+    }
+    __syncthreads();
+  }
+  if (owner) {
+#pragma unroll
+    for (int r = 0; r < kTailRounds; ++r) {
+      const int c = r * CW + threadIdx.x;
+      if (c < g.C) { t.dbeta[c] = (float)accb[r]; t.dgamma[c] = (float)accs[r]; }
+    }
+  }
+}
+
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): (sum g, sum g * xhat) with g = gy * [y > 0] when relu is fused.
 template <int MODE, bool PRE, int RM = 0, typename T = float, int VW = 4>   // RM: source of the fused ReLU's sign (0 none, 1 bit mask, 2 y)
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(PNT, 3)
 gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ y,
                   const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
-                  const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g) {
-  extern __shared__ float lds[];                       // [rows][Cs][2]
-  // channel slab of this block (blockIdx.z): up to NT lanes of VW channels (the image branch's BatchNorms
-  // reach 3840 channels; everything on the voxel path fits one slab)
-  const int q0 = blockIdx.z * NT;                      // first lane of the slab
-  const int q = min(g.C / VW - q0, NT);                // lanes per voxel in this slab
+                  const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g, GnTail tail) {
+  extern __shared__ __align__(16) float lds[];         // [rows][Cs][2]; the finalize tail re-uses it as doubles
+  // channel slab of this block (blockIdx.z): g.slab_q lanes of VW channels
+  const int q0 = blockIdx.z * g.slab_q;                // first lane of the slab
+  const int q = min(g.C / VW - q0, g.slab_q);          // lanes per voxel in this slab
   const int Cs = q * VW;
-  const int rows = NT / q > 0 ? NT / q : 1;            // voxels handled per block iteration
+  const int rows = PNT / q > 0 ? PNT / q : 1;          // voxels handled per block iteration
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const long s0 = (long)chunk * g.chunk_len;
@@ -188,11 +391,19 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __
     }
   }
   __syncthreads();
-  // fold the `rows` voxel lanes: thread t < 2*Cs sums column t of the slab
-  for (int t = tid; t < 2 * Cs; t += NT) {
-    float s = 0.0f;
-    for (int rr = 0; rr < rows; ++rr) s += lds[(size_t)rr * Cs * 2 + t];
-    partial[((size_t)(b * g.chunks + chunk) * g.C + q0 * VW) * 2 + t] = s;
+  // fold the `rows` voxel lanes: thread t < Cs sums the two columns of channel t of the slab and publishes the pair as one
+  // 8-byte write-through record (st_record)
+  for (int t = tid; t < Cs; t += PNT) {
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int rr = 0; rr < rows; ++rr) { s0 += lds[((size_t)rr * Cs + t) * 2]; s1 += lds[((size_t)rr * Cs + t) * 2 + 1]; }
+    st_record(partial + ((size_t)(b * g.chunks + chunk) * g.C + q0 * VW + t) * 2, s0, s1);
+  }
+  if (tail.sync) {
+    if (!gn_last_arriver(tail, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    if (MODE == 0) gn_tail_fwd<T>(partial, x, g, tail, reinterpret_cast<double*>(lds));
+    else gn_tail_bwd(partial, g, tail, reinterpret_cast<double*>(lds));
+    if (tid == 0) __hip_atomic_store(tail.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
   }
 }
 
@@ -228,27 +439,42 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const T* __restrict__ 
   const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
   const int cpg = g.C / g.G, n_el = g.chunks * cpg;
   const bool lds_piv = cpg <= FT;
-  if (lds_piv && (int)threadIdx.x < cpg) {
-    float pf = ld1(x + (size_t)b * g.S * g.C + grp * cpg + threadIdx.x);
-    piv[threadIdx.x] = g.pre ? gelu_f(pf) : pf;
-  }
-  __syncthreads();
+  // Round 5: the kernel is a chain of round trips (pivot, then records four at a time: ~10 us for 100 KB).  Now the pivot
+  // loads and the first kFinBatch records of every thread are requested together, and combined after one barrier.
+  constexpr int kFinBatch = 16;
+  float pf_own = 0.0f;
+  if (lds_piv && (int)threadIdx.x < cpg) pf_own = ld1(x + (size_t)b * g.S * g.C + grp * cpg + threadIdx.x);
   double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
+  bool first = true;
+  for (int i0 = threadIdx.x; i0 < n_el || first; i0 += kFinBatch * FT) {
+    float2 rec[kFinBatch];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kFinBatch; ++k) {
+      const int i = i0 + k * FT;
+      rec[k] = make_float2(0.f, 0.f);
+      if (i < n_el) {
+        const int chunk = i / cpg, c = grp * cpg + i % cpg;
+        rec[k] = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+      }
+    }
+    if (first) {
+      if (lds_piv && (int)threadIdx.x < cpg) piv[threadIdx.x] = g.pre ? gelu_f(pf_own) : pf_own;
+      __syncthreads();
+      first = false;
+    }
+#pragma unroll
+    for (int k = 0; k < kFinBatch; ++k) {
       const int i = i0 + k * FT;
       if (i < n_el) {
         const int chunk = i / cpg, c = grp * cpg + i % cpg;
-        const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
         // shifted partials (pivot = the channel's value at voxel 0, see gn_partial_kernel): sum u = sum d + n p,
         // sum u^2 = sum d^2 + 2 p sum d + n p^2, with n = voxels of this chunk
         float pf = lds_piv ? piv[i % cpg] : ld1(x + (size_t)b * g.S * g.C + c);
         if (!lds_piv && g.pre) pf = gelu_f(pf);
         const double pd = pf;
         const double n = (double)(min(g.S, (long)(chunk + 1) * g.chunk_len) - (long)chunk * g.chunk_len);
-        a[k] += (double)p.x + n * pd;
-        q[k] += (double)p.y + 2.0 * pd * (double)p.x + n * pd * pd;
+        a[k & 3] += (double)rec[k].x + n * pd;
+        q[k & 3] += (double)rec[k].y + 2.0 * pd * (double)rec[k].x + n * pd * pd;
       }
     }
   }
@@ -270,26 +496,41 @@ gn_finalize_fwd_kernel(const float* __restrict__ partial, const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_flat_kernel(const float* __restrict__ partial, const T* __restrict__ x, float* __restrict__ mean,
-                            float* __restrict__ rstd, GnGeom g) {
+                            float* __restrict__ rstd, GnGeom g, float* __restrict__ rm, float* __restrict__ rv, float mom,
+                            float unbias) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= g.B * g.C) return;
   const int b = i / g.C, c = i % g.C;
   double a = 0.0, q = 0.0;
-  for (int chunk = lane; chunk < g.chunks; chunk += 64) {
-    const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
-    a += p.x; q += p.y;
+  float pf = ld1(x + (size_t)b * g.S * g.C + c);          // the pivot travels with the first batch of records
+  constexpr int kFlatBatch = 12;                           // 768 chunks / 64 lanes: one batch
+  for (int chunk0 = lane; chunk0 < g.chunks; chunk0 += 64 * kFlatBatch) {
+    float2 rec[kFlatBatch];
+#pragma unroll
+    for (int k = 0; k < kFlatBatch; ++k) {
+      const int chunk = chunk0 + 64 * k;
+      rec[k] = chunk < g.chunks ? *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2)
+                                : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < kFlatBatch; ++k) { a += rec[k].x; q += rec[k].y; }
   }
   a = wave_sum_d(a); q = wave_sum_d(q);
   if (lane == 0) {
     // one channel per group: the statistics of the SHIFTED values d = u - p directly (mean = p + E[d], var = var(d))
-    float pf = ld1(x + (size_t)b * g.S * g.C + c);
     if (g.pre) pf = gelu_f(pf);
     const double n = (double)g.S, md = a / n;
     double var = q / n - md * md;
     if (var < 0.0) var = 0.0;
     const double m = (double)pf + md;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)g.eps));
+    const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)g.eps));
+    mean[i] = mf;
+    rstd[i] = rs;
+    if (rm && b == 0) {                                 // BatchNorm running statistics (round 5: was a launch of its own)
+      const float vf = 1.0f / (rs * rs) - g.eps;        // as bn_update_running_kernel computes it from the stored rstd
+      rm[c] = (1.0f - mom) * rm[c] + mom * mf;
+      rv[c] = (1.0f - mom) * rv[c] + mom * (vf * unbias);
+    }
   }
 }
 
@@ -302,9 +543,17 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
   const double gm = gamma[c], n = (double)g.S;
   for (int b = 0; b < g.B; ++b) {
     double sb = 0.0, ss = 0.0;
-    for (int chunk = lane; chunk < g.chunks; chunk += 64) {
-      const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
-      sb += p.x; ss += p.y;
+    constexpr int kFlatBatch = 12;
+    for (int chunk0 = lane; chunk0 < g.chunks; chunk0 += 64 * kFlatBatch) {
+      float2 rec[kFlatBatch];
+#pragma unroll
+      for (int k = 0; k < kFlatBatch; ++k) {
+        const int chunk = chunk0 + 64 * k;
+        rec[k] = chunk < g.chunks ? *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2)
+                                  : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < kFlatBatch; ++k) { sb += rec[k].x; ss += rec[k].y; }
     }
     sb = wave_sum_d(sb); ss = wave_sum_d(ss);
     if (lane == 0) {
@@ -386,17 +635,26 @@ gn_finalize_bwd_kernel(const float* __restrict__ partial, const float* __restric
     const int b = blockIdx.x / g.G, grp = blockIdx.x % g.G;
     const int cpg = g.C / g.G, n_el = g.chunks * cpg;
     double ds[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-    for (int i0 = threadIdx.x; i0 < n_el; i0 += 4 * FT) {
+    constexpr int kFinBatch = 16;                     // all records of a thread in flight together (see gn_finalize_fwd_kernel)
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += kFinBatch * FT) {
+      float2 rec[kFinBatch];
+      float gmf[kFinBatch];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < kFinBatch; ++k) {
         const int i = i0 + k * FT;
+        rec[k] = make_float2(0.f, 0.f);
+        gmf[k] = 0.0f;
         if (i < n_el) {
           const int chunk = i / cpg, c = grp * cpg + i % cpg;
-          const float2 p = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
-          const double gm = gamma[c];
-          db[k] += gm * p.x;
-          ds[k] += gm * p.y;
+          rec[k] = *reinterpret_cast<const float2*>(partial + ((size_t)(b * g.chunks + chunk) * g.C + c) * 2);
+          gmf[k] = gamma[c];
         }
+      }
+#pragma unroll
+      for (int k = 0; k < kFinBatch; ++k) {
+        const double gm = gmf[k];
+        db[k & 3] += gm * rec[k].x;
+        ds[k & 3] += gm * rec[k].y;
       }
     }
     double s = (ds[0] + ds[1]) + (ds[2] + ds[3]), t = (db[0] + db[1]) + (db[2] + db[3]);
@@ -502,14 +760,22 @@ bool gn_ok(const ssbev_norm_dims* d) {
          (d->io_dtype == 0 || d->io_dtype == 1);
 }
 
+// channels per lane of the STATISTICS passes: 8 for bf16 tensors whose channel count allows 16-byte lanes, else 4 (round 4,
+// measured per launch on the two-sample step: statistics passes 47 -> 32 us and 18.6 -> 19.6 us with 8; the apply passes got
+// SLOWER with 8 -- 41 -> 56 us forward, 60 -> 74 us backward: twice the registers for the per-channel constants, half the
+// waves in flight -- and stay at 4.  The ReLU bit mask has ONE layout, per channel quad, read by both widths.)
+int gn_vw(int io_dtype, int C) { return (io_dtype == 1 && C % 8 == 0) ? 8 : 4; }
+
 GnGeom make_geom(const ssbev_norm_dims* d) {
   GnGeom g;
   g.B = d->B; g.C = d->C; g.G = d->G; g.S = d->S; g.eps = d->eps; g.relu = d->relu; g.pre = d->pre_act;
   g.ldy = d->ld_y > 0 ? d->ld_y : d->C;
   g.ldg = d->ld_gy > 0 ? d->ld_gy : d->C;
-  // ~768 blocks over the chip (3 per CU), each at least 64 voxels: enough to saturate HBM, few enough that
-  // the single-workgroup-per-group finalize pass stays in the 10-us range
-  long chunks = 768 / d->B;
+  // ~768 workgroups over the chip (3 per CU) = samples x chunks x channel slabs, each chunk at least 64 voxels
+  const int vw = gn_vw(d->io_dtype, d->C);
+  g.slab_q = std::min(d->C / vw, kSlabLanes);
+  const long slabs = (d->C / vw + g.slab_q - 1) / g.slab_q;
+  long chunks = kStatBlocks / ((long)d->B * slabs);
   if (chunks < 1) chunks = 1;
   long len = (d->S + chunks - 1) / chunks;
   if (len < 64) len = 64;
@@ -519,18 +785,13 @@ GnGeom make_geom(const ssbev_norm_dims* d) {
 }
 
 size_t lds_bytes(const GnGeom& g, int vw = 4) {
-  const int q = std::min(g.C / vw, NT);               // widest slab; narrower ones need rows * q <= NT entries too
-  const int rows = NT / q > 0 ? NT / q : 1;
-  return (size_t)std::max(rows * q, NT) * vw * 2 * sizeof(float);
+  const int q = std::min(g.C / vw, g.slab_q);         // widest slab; narrower ones need rows * q <= PNT entries too
+  const int rows = PNT / q > 0 ? PNT / q : 1;
+  return (size_t)std::max(rows * q, PNT) * vw * 2 * sizeof(float);
 }
 
-unsigned gn_slabs(const GnGeom& g, int vw = 4) { return cdiv((size_t)(g.C / vw), NT); }
+unsigned gn_slabs(const GnGeom& g, int vw = 4) { return cdiv((size_t)(g.C / vw), g.slab_q); }
 
-// channels per lane of the STATISTICS passes: 8 for bf16 tensors whose channel count allows 16-byte lanes, else 4 (round 4,
-// measured per launch on the two-sample step: statistics passes 47 -> 32 us and 18.6 -> 19.6 us with 8; the apply passes got
-// SLOWER with 8 -- 41 -> 56 us forward, 60 -> 74 us backward: twice the registers for the per-channel constants, half the
-// waves in flight -- and stay at 4.  The ReLU bit mask has ONE layout, per channel quad, read by both widths.)
-int gn_vw(int io_dtype, int C) { return (io_dtype == 1 && C % 8 == 0) ? 8 : 4; }
 
 // running statistics of a training-mode BatchNorm (nn.BatchNorm semantics: unbiased variance in the running buffer)
 __global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -623,13 +884,13 @@ gn2_apply_fwd_kernel(const T* __restrict__ xa, const float* __restrict__ gamma_a
 // per-chunk (sum g, sum g xhat_a) -> pa, (sum g, sum g xhat_b) -> pb, both in gn_partial_kernel<1>'s layout (so the
 // finalize kernels of the single-norm operator serve unchanged); g = gy masked by the fused ReLU
 template <typename T, int VW>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(PNT, 3)
 gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
                        const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                        const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float* __restrict__ pa,
-                       float* __restrict__ pb, Gn2Geom g) {
-  extern __shared__ float lds[];                       // [rows][C][3]
-  const int q = g.C / VW, rows = NT / q > 0 ? NT / q : 1;
+                       float* __restrict__ pb, Gn2Geom g, GnGeom side_a, GnGeom side_b, GnTail tail_a, GnTail tail_b) {
+  extern __shared__ __align__(16) float lds[];         // [rows][C][3]; the finalize tail re-uses it as doubles
+  const int q = g.C / VW, rows = PNT / q > 0 ? PNT / q : 1;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
   const long s0 = (long)chunk * g.chunk_len, s1 = min(g.S, s0 + g.chunk_len);
   const int c4 = tid % q, r = tid / q;
@@ -668,15 +929,23 @@ gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __res
     }
   }
   __syncthreads();
-  for (int t = tid; t < g.C; t += NT) {
+  for (int t = tid; t < g.C; t += PNT) {
     float s0v = 0.0f, s1v = 0.0f, s2v = 0.0f;
     for (int rr = 0; rr < rows; ++rr) {
       const float* l = lds + ((size_t)rr * g.C + t) * 3;
       s0v += l[0]; s1v += l[1]; s2v += l[2];
     }
     const size_t o = ((size_t)(b * g.chunks + chunk) * g.C + t) * 2;
-    pa[o] = s0v; pa[o + 1] = s1v;
-    pb[o] = s0v; pb[o + 1] = s2v;
+    st_record(pa + o, s0v, s1v);
+    st_record(pb + o, s0v, s2v);
+  }
+  if (tail_a.sync) {                                   // both backward finalizes in the last workgroup's tail (see GnTail)
+    if (!gn_last_arriver(tail_a, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();
+    gn_tail_bwd(pa, side_a, tail_a, reinterpret_cast<double*>(lds));
+    __syncthreads();
+    gn_tail_bwd(pb, side_b, tail_b, reinterpret_cast<double*>(lds));
+    if (tid == 0) __hip_atomic_store(tail_a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -745,7 +1014,7 @@ ssbev_norm_dims gn2_side(const ssbev_norm2_dims* d, int side) {
 Gn2Geom make_geom2(const ssbev_norm2_dims* d) {
   Gn2Geom g;
   g.B = d->B; g.C = d->C; g.Ga = d->Ga; g.Gb = d->Gb; g.S = d->S; g.relu = d->relu; g.a_batch = d->a_batch; g.b_batch = d->b_batch;
-  long chunks = 768 / d->B;
+  long chunks = kStatBlocks / d->B;
   if (chunks < 1) chunks = 1;
   long len = (d->S + chunks - 1) / chunks;
   if (len < 64) len = 64;
@@ -755,12 +1024,18 @@ Gn2Geom make_geom2(const ssbev_norm2_dims* d) {
 }
 
 // backward finalize of one side on the [B * chunks] partial records: a batch norm folds the sample axis into the chunk axis
-void gn2_finalize_bwd(const Gn2Geom& g2, const ssbev_norm2_dims* d, int side, const float* partial, const float* gamma, float* coef,
-                      float* dgamma, float* dbeta, hipStream_t st) {
+GnGeom gn2_bwd_side_geom(const Gn2Geom& g2, const ssbev_norm2_dims* d, int side) {
   const bool batch = side ? d->b_batch : d->a_batch;
   GnGeom g;
   g.B = batch ? 1 : g2.B; g.C = g2.C; g.G = side ? g2.Gb : g2.Ga; g.S = batch ? g2.S * g2.B : g2.S;
   g.chunks = batch ? g2.chunks * g2.B : g2.chunks; g.chunk_len = g2.chunk_len; g.eps = 0.f; g.relu = g2.relu; g.pre = 0;
+  g.ldy = g.ldg = g.C; g.slab_q = 0;
+  return g;
+}
+
+void gn2_finalize_bwd(const Gn2Geom& g2, const ssbev_norm2_dims* d, int side, const float* partial, const float* gamma, float* coef,
+                      float* dgamma, float* dbeta, hipStream_t st) {
+  const GnGeom g = gn2_bwd_side_geom(g2, d, side);
   if (g.G == g.C)
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, dgamma, dbeta, g);
   else
@@ -784,26 +1059,54 @@ size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d) {
 }
 
 extern "C++" {
+// statistics of one normalisation: chunk partials + finalize, as ONE launch (finalize in the last workgroup's tail) when the
+// caller provides the zeroed sync word, else as two
+template <typename T, int VW>
+static int gn_stats_fwd(const T* x, float* mean, float* rstd, const GnGeom& g, float* partial, const ssbev_norm_ext* ext,
+                        hipStream_t st) {
+  size_t lds = lds_bytes(g, VW);
+  if (lds > 96 * 1024) return SSBEV_EINVAL;
+  const dim3 grid(g.chunks, g.B, gn_slabs(g, VW));
+  GnTail tail = {};
+  const bool fused = ext && ext->sync && g.C <= kTailMaxC;
+  if (fused) {
+    tail.sync = ext->sync; tail.total = grid.x * grid.y * grid.z;
+    tail.mean = mean; tail.rstd = rstd;
+    if (g.G == g.C && ext->running_mean && ext->running_var) {
+      tail.rm = ext->running_mean; tail.rv = ext->running_var; tail.mom = ext->momentum;
+      tail.unbias = (float)((double)ext->n / (double)(ext->n > 1 ? ext->n - 1 : 1));
+    }
+    lds = std::max(lds, gn_tail_lds_bytes(g.C));
+  }
+  if (g.pre)
+    hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T, VW>), grid, dim3(PNT), lds, st, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g, tail);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), grid, dim3(PNT), lds, st, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g, tail);
+  if (!fused) {
+    if (g.G == g.C) {
+      const bool run = ext && ext->running_mean && ext->running_var;       // running statistics: updated by the finalize kernel
+      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g,
+                         run ? ext->running_mean : nullptr, run ? ext->running_var : nullptr, run ? ext->momentum : 0.0f,
+                         run ? (float)((double)ext->n / (double)(ext->n > 1 ? ext->n - 1 : 1)) : 0.0f);
+    } else {
+      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
+    }
+  }
+  return SSBEV_OK;
+}
+
 template <typename T, int VW>
 static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y,
                            float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
-                           ssbev_stream_t stream) {
+                           ssbev_stream_t stream, const ssbev_norm_ext* ext = nullptr) {
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
-  const size_t lds = lds_bytes(g, VW);
-  if (lds > 64 * 1024) return SSBEV_EINVAL;
   if (!d->stats_given) {
-    if (g.pre)
-      hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, x, (const T*)nullptr,
-                         (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
-    else
-      hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, x, (const T*)nullptr,
-                         (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
-    if (g.G == g.C)
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g);
-    else
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
+    const int rc = gn_stats_fwd<T, VW>(x, mean, rstd, g, partial, ext, st);
+    if (rc != SSBEV_OK) return rc;
   }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
@@ -827,7 +1130,7 @@ static bool gn_rows16(const ssbev_norm_dims* d, const void* const* ptrs, int n) 
 
 static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                               float* mean, float* rstd, unsigned long long* mask, const ssbev_norm_dims* d, void* ws,
-                              size_t ws_bytes, ssbev_stream_t stream) {
+                              size_t ws_bytes, ssbev_stream_t stream, const ssbev_norm_ext* ext = nullptr) {
   if (!gn_ok(d) || !x || !gamma || !beta || !y || !mean || !rstd || !ws) return SSBEV_EINVAL;
   // a strided output (ld_y) is a slice of a concatenation: the residual operand has no stride of its own -> refused together
   if (residual && d->ld_y != 0 && d->ld_y != d->C) return SSBEV_EINVAL;
@@ -838,12 +1141,19 @@ static int groupnorm_fwd_impl(const float* x, const float* gamma, const float* b
     bf16_t* y16 = reinterpret_cast<bf16_t*>(y);
     if (gn_vw(1, d->C) == 8) {
       const void* ps[1] = {x};
-      if (!gn_rows16(d, ps, 1)) return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
-      return groupnorm_fwd_t<bf16_t, 8>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
+      if (!gn_rows16(d, ps, 1)) return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream, ext);
+      return groupnorm_fwd_t<bf16_t, 8>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream, ext);
     }
-    return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream);
+    return groupnorm_fwd_t<bf16_t, 4>(x16, gamma, beta, r16, y16, mean, rstd, mask, d, ws, stream, ext);
   }
-  return groupnorm_fwd_t<float, 4>(x, gamma, beta, residual, y, mean, rstd, mask, d, ws, stream);
+  return groupnorm_fwd_t<float, 4>(x, gamma, beta, residual, y, mean, rstd, mask, d, ws, stream, ext);
+}
+
+int ssbev_groupnorm_fwd_ext(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                            float* mean, float* rstd, uint64_t* relu_mask, const ssbev_norm_dims* d,
+                            const ssbev_norm_ext* ext, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return groupnorm_fwd_impl(x, gamma, beta, residual, y, mean, rstd, reinterpret_cast<unsigned long long*>(relu_mask), d, ws,
+                            ws_bytes, stream, ext);
 }
 
 int ssbev_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
@@ -872,23 +1182,32 @@ extern "C++" {
 template <typename T, int VW>
 static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned long long* mask,
                            const float* gamma, const float* mean, const float* rstd, T* gx, T* gresidual,
-                           float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, ssbev_stream_t stream) {
+                           float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, ssbev_stream_t stream,
+                           const ssbev_norm_ext* ext = nullptr) {
   const GnGeom g = make_geom(d);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
-  const size_t lds = lds_bytes(g, VW);
-  if (lds > 64 * 1024) return SSBEV_EINVAL;
+  size_t lds = lds_bytes(g, VW);
+  if (lds > 96 * 1024) return SSBEV_EINVAL;
+  GnTail tail = {};
   {
     const dim3 grid(g.chunks, g.B, gn_slabs(g, VW));
+    if (ext && ext->sync && g.C <= kTailMaxC) {
+      tail.sync = ext->sync; tail.total = grid.x * grid.y * grid.z;
+      tail.gamma = gamma; tail.coef = coef; tail.dgamma = ggamma; tail.dbeta = gbeta;
+      lds = std::max(lds, gn_tail_lds_bytes(g.C));
+    }
     const int rm = !g.relu ? 0 : (mask ? 1 : 2);
 #define SSBEV_GNP(PRE_, RM_) \
-    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T, VW>), grid, dim3(NT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
+    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T, VW>), grid, dim3(PNT), lds, st, x, gy, y, mask, mean, rstd, partial, g, tail)
     if (g.pre) { if (rm == 0) SSBEV_GNP(true, 0); else if (rm == 1) SSBEV_GNP(true, 1); else SSBEV_GNP(true, 2); }
     else { if (rm == 0) SSBEV_GNP(false, 0); else if (rm == 1) SSBEV_GNP(false, 1); else SSBEV_GNP(false, 2); }
 #undef SSBEV_GNP
   }
-  if (g.G == g.C)
+  if (tail.sync) {
+    // finalize ran in the statistics kernel's tail
+  } else if (g.G == g.C)
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
@@ -907,7 +1226,7 @@ static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned l
 static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, const unsigned long long* mask,
                               const float* gamma, const float* mean, const float* rstd, float* gx, float* gresidual,
                               float* ggamma, float* gbeta, const ssbev_norm_dims* d, void* ws, size_t ws_bytes,
-                              ssbev_stream_t stream) {
+                              ssbev_stream_t stream, const ssbev_norm_ext* ext = nullptr) {
   if (!gn_ok(d) || !gy || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !ws) return SSBEV_EINVAL;
   if (d->relu && !y && !mask) return SSBEV_EINVAL;
   // row strides are honoured for gy (ld_gy) on the paths that exist for them: the saved y of the non-mask ReLU path and the
@@ -922,12 +1241,20 @@ static int groupnorm_bwd_impl(const float* gy, const float* x, const float* y, c
       if (gn_rows16(d, ps, 3))
         return groupnorm_bwd_t<bf16_t, 8>(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean,
                                         rstd, reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws,
-                                        stream);
+                                        stream, ext);
     }
     return groupnorm_bwd_t<bf16_t, 4>(reinterpret_cast<cb>(gy), reinterpret_cast<cb>(x), reinterpret_cast<cb>(y), mask, gamma, mean, rstd,
-                                      reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws, stream);
+                                      reinterpret_cast<bf16_t*>(gx), reinterpret_cast<bf16_t*>(gresidual), ggamma, gbeta, d, ws, stream, ext);
   }
-  return groupnorm_bwd_t<float, 4>(gy, x, y, mask, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, stream);
+  return groupnorm_bwd_t<float, 4>(gy, x, y, mask, gamma, mean, rstd, gx, gresidual, ggamma, gbeta, d, ws, stream, ext);
+}
+
+int ssbev_groupnorm_bwd_ext(const float* gy, const float* x, const float* y, const uint64_t* relu_mask, const float* gamma,
+                            const float* mean, const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
+                            const ssbev_norm_dims* d, const ssbev_norm_ext* ext, void* ws, size_t ws_bytes,
+                            ssbev_stream_t stream) {
+  return groupnorm_bwd_impl(gy, x, y, reinterpret_cast<const unsigned long long*>(relu_mask), gamma, mean, rstd, gx, gresidual,
+                            ggamma, gbeta, d, ws, ws_bytes, stream, ext);
 }
 
 int ssbev_groupnorm_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* mean,
@@ -959,7 +1286,8 @@ extern "C++" {
 template <typename T, int VW>
 static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
                             const T* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, T* y,
-                            uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream) {
+                            uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream,
+                            const ssbev_norm2_ext* ext = nullptr) {
   hipStream_t st = as_stream(stream);
   const T* xs[2] = {xa, xb};
   float* means[2] = {mean_a, mean_b};
@@ -968,16 +1296,17 @@ static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta
   for (int side = 0; side < 2; ++side) {
     const ssbev_norm_dims n = gn2_side(d, side);
     const GnGeom g = make_geom(&n);
-    const size_t lds = lds_bytes(g, VW);
-    if (lds > 64 * 1024) return SSBEV_EINVAL;
     float* partial = reinterpret_cast<float*>(wsp);
-    hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), dim3(g.chunks, g.B, gn_slabs(g, VW)), dim3(NT), lds, st, xs[side],
-                       (const T*)nullptr, (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
-    if (g.G == g.C)
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, xs[side], means[side],
-                         rstds[side], g);
-    else
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, xs[side], means[side], rstds[side], g);
+    ssbev_norm_ext e1 = {};
+    if (ext) {
+      e1.sync = ext->sync;
+      e1.running_mean = side ? ext->running_mean_b : ext->running_mean_a;
+      e1.running_var = side ? ext->running_var_b : ext->running_var_a;
+      e1.momentum = side ? ext->momentum_b : ext->momentum_a;
+      e1.n = (int64_t)d->B * d->S;
+    }
+    const int rc = gn_stats_fwd<T, VW>(xs[side], means[side], rstds[side], g, partial, ext ? &e1 : nullptr, st);
+    if (rc != SSBEV_OK) return rc;
     wsp += ssbev_groupnorm_workspace(&n);
   }
   const Gn2Geom g2 = make_geom2(d);
@@ -989,9 +1318,10 @@ static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta
 }
 }  // extern "C++"
 
-int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
-                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
-                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+static int groupnorm2_fwd_impl(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                               const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                               uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream,
+                               const ssbev_norm2_ext* ext) {
   if (!gn2_ok(d) || !xa || !gamma_a || !beta_a || !mean_a || !rstd_a || !xb || !gamma_b || !beta_b || !mean_b || !rstd_b || !y || !ws)
     return SSBEV_EINVAL;
   if (d->relu && !relu_mask) return SSBEV_EINVAL;
@@ -1002,12 +1332,27 @@ int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* bet
                     reinterpret_cast<uintptr_t>(y) % 16 == 0;
     if (gn_vw(1, d->C) == 8 && al) {
       return groupnorm2_fwd_t<bf16_t, 8>(reinterpret_cast<cb>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<cb>(xb), gamma_b,
-                                         beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
+                                         beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream, ext);
     }
     return groupnorm2_fwd_t<bf16_t, 4>(reinterpret_cast<cb>(xa), gamma_a, beta_a, mean_a, rstd_a, reinterpret_cast<cb>(xb), gamma_b,
-                                       beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream);
+                                       beta_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(y), relu_mask, d, ws, stream, ext);
   }
-  return groupnorm2_fwd_t<float, 4>(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, stream);
+  return groupnorm2_fwd_t<float, 4>(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, stream, ext);
+}
+
+int ssbev_groupnorm2_fwd(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                         const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                         uint64_t* relu_mask, const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return groupnorm2_fwd_impl(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, ws_bytes,
+                             stream, nullptr);
+}
+
+int ssbev_groupnorm2_fwd_ext(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
+                             const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,
+                             uint64_t* relu_mask, const ssbev_norm2_dims* d, const ssbev_norm2_ext* ext, void* ws, size_t ws_bytes,
+                             ssbev_stream_t stream) {
+  return groupnorm2_fwd_impl(xa, gamma_a, beta_a, mean_a, rstd_a, xb, gamma_b, beta_b, mean_b, rstd_b, y, relu_mask, d, ws, ws_bytes,
+                             stream, ext);
 }
 
 extern "C++" {
@@ -1015,7 +1360,7 @@ template <typename T, int VW>
 static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa, const float* gamma_a, const float* mean_a,
                             const float* rstd_a, const T* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
                             T* gxa, T* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
-                            const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream) {
+                            const ssbev_norm2_dims* d, void* ws, ssbev_stream_t stream, const ssbev_norm2_ext* ext = nullptr) {
   hipStream_t st = as_stream(stream);
   const Gn2Geom g = make_geom2(d);
   const size_t part = (size_t)g.B * g.chunks * g.C * 2;
@@ -1023,13 +1368,32 @@ static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa,
   float* pb = pa + part;
   float* coef_a = pb + part;
   float* coef_b = coef_a + (size_t)g.B * g.C * 2 + 64;
-  const int q = g.C / VW, rows = NT / q > 0 ? NT / q : 1;
-  const size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
+  const int q = g.C / VW, rows = PNT / q > 0 ? PNT / q : 1;
+  size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(relu_mask);
-  hipLaunchKernelGGL((gn2_partial_bwd_kernel<T, VW>), dim3(g.chunks, g.B), dim3(NT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b,
-                     rstd_b, pa, pb, g);
-  gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
-  gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
+  const GnGeom side_a = gn2_bwd_side_geom(g, d, 0), side_b = gn2_bwd_side_geom(g, d, 1);
+  GnTail ta = {}, tb = {};
+  if (ext && ext->sync && g.C <= kTailMaxC) {
+    ta.sync = tb.sync = ext->sync; ta.total = tb.total = (unsigned)(g.chunks * g.B);
+    ta.gamma = gamma_a; ta.coef = coef_a; ta.dgamma = ggamma_a; ta.dbeta = gbeta_a;
+    tb.gamma = gamma_b; tb.coef = coef_b; tb.dgamma = ggamma_b; tb.dbeta = gbeta_b;
+    lds = std::max(lds, gn_tail_lds_bytes(g.C));
+  }
+  if (lds > 48 * 1024) {                    // above the default dynamic-LDS limit of a launch: raise it for this instance (once)
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gn2_partial_bwd_kernel<T, VW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024) != hipSuccess)
+        return SSBEV_ELAUNCH;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((gn2_partial_bwd_kernel<T, VW>), dim3(g.chunks, g.B), dim3(PNT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b,
+                     rstd_b, pa, pb, g, side_a, side_b, ta, tb);
+  if (!ta.sync) {
+    gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
+    gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
+  }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   hipLaunchKernelGGL((gn2_apply_bwd_kernel<T, 4>), dim3(apply_blocks(totalv, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a,
                      rstd_a, coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, totalv);
@@ -1037,10 +1401,11 @@ static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa,
 }
 }  // extern "C++"
 
-int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
-                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
-                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
-                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+static int groupnorm2_bwd_impl(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                               const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                               float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                               const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream,
+                               const ssbev_norm2_ext* ext) {
   if (!gn2_ok(d) || !gy || !xa || !gamma_a || !mean_a || !rstd_a || !xb || !gamma_b || !mean_b || !rstd_b || !gxa || !gxb ||
       !ggamma_a || !gbeta_a || !ggamma_b || !gbeta_b || !ws)
     return SSBEV_EINVAL;
@@ -1054,14 +1419,31 @@ int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float
     if (gn_vw(1, d->C) == 8 && al) {
       return groupnorm2_bwd_t<bf16_t, 8>(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
                                          reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
-                                         reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+                                         reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream, ext);
     }
     return groupnorm2_bwd_t<bf16_t, 4>(reinterpret_cast<cb>(gy), relu_mask, reinterpret_cast<cb>(xa), gamma_a, mean_a, rstd_a,
                                        reinterpret_cast<cb>(xb), gamma_b, mean_b, rstd_b, reinterpret_cast<bf16_t*>(gxa),
-                                       reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+                                       reinterpret_cast<bf16_t*>(gxb), ggamma_a, gbeta_a, ggamma_b, gbeta_b, d, ws, stream, ext);
   }
   return groupnorm2_bwd_t<float, 4>(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a,
-                                    gbeta_a, ggamma_b, gbeta_b, d, ws, stream);
+                                    gbeta_a, ggamma_b, gbeta_b, d, ws, stream, ext);
+}
+
+int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                         const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                         float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                         const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  return groupnorm2_bwd_impl(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a, gbeta_a,
+                             ggamma_b, gbeta_b, d, ws, ws_bytes, stream, nullptr);
+}
+
+int ssbev_groupnorm2_bwd_ext(const float* gy, const uint64_t* relu_mask, const float* xa, const float* gamma_a, const float* mean_a,
+                             const float* rstd_a, const float* xb, const float* gamma_b, const float* mean_b, const float* rstd_b,
+                             float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
+                             const ssbev_norm2_dims* d, const ssbev_norm2_ext* ext, void* ws, size_t ws_bytes,
+                             ssbev_stream_t stream) {
+  return groupnorm2_bwd_impl(gy, relu_mask, xa, gamma_a, mean_a, rstd_a, xb, gamma_b, mean_b, rstd_b, gxa, gxb, ggamma_a, gbeta_a,
+                             ggamma_b, gbeta_b, d, ws, ws_bytes, stream, ext);
 }
 
 }  // extern "C"

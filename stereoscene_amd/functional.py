@@ -1637,11 +1637,41 @@ def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
 GN_RELU_MASK = os.environ.get("SSBEV_GN_RELU_MASK", "1") != "0"
 
 
+# Finalize of the statistics in the tail of the statistics kernel (csrc/groupnorm.hip, GnTail): needs SSBEV_NORM_SYNC_WORDS zeroed
+# words that the kernels leave zeroed -- one small buffer per (device, stream), zeroed once when it is created.  OFF by default:
+# measured on MI355X (profiles/r5_gn_tail.txt) the last-arriver tail is a chain of 4-5 dependent round trips to other CUs' data
+# (tickets, two batches of records, write-out: 8-10 us behind the last streaming read) where the separate finalize kernel
+# spreads one batch over many workgroups (~5 us + a 1.7 us kernel boundary): 160 fewer launches, but +0.7 ms per step.
+GN_TAIL = os.environ.get("SSBEV_GN_TAIL", "0") != "0"
+_NORM_SYNC = {}
+
+
+def _norm_sync(device):
+    if not GN_TAIL:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    t = _NORM_SYNC.get(key)
+    if t is None:
+        t = _NORM_SYNC[key] = torch.zeros(capi.NORM_SYNC_WORDS, dtype=torch.int32, device=device)
+    return t
+
+
+def _norm_ext(device, running=None, n=0):
+    """ssbev_norm_ext: the sync words of this stream + (running_mean, running_var, momentum) of a training-mode BatchNorm."""
+    sync = _norm_sync(device)
+    e = capi.NormExt(sync.data_ptr() if sync is not None else None, None, None, 0.0, int(n))
+    if running is not None:
+        e.running_mean, e.running_var, e.momentum = running[0].data_ptr(), running[1].data_ptr(), float(running[2])
+    return e
+
+
 class _GroupNorm(torch.autograd.Function):
     """GroupNorm on a channels-last volume with optional fused residual add and ReLU."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd, pre_act=0, res_slot=None):
+    def forward(ctx, x, weight, bias, residual, groups, eps, relu, as_batch, given_mean, given_rstd, pre_act=0, res_slot=None,
+                running=None):
         lib = capi.load()
         ctx.res_slot = res_slot
         ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) statistics outputs
@@ -1660,15 +1690,12 @@ class _GroupNorm(torch.autograd.Function):
         nb = float(xcl.element_size()) * xcl.numel() * (3 + (residual is not None) - 2 * given)      # stats read + apply read/write
         use_mask = bool(relu) and GN_RELU_MASK and not given and any(ctx.needs_input_grad[:4])
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if use_mask else None
+        ext = _norm_ext(x.device, running, B * S)
         with _span("groupnorm", 0.0, nb, f"fwd   N C={Cch} G={groups} S={S} res={int(residual is not None)}"):
-            if use_mask:
-                capi.check(lib.ssbev_groupnorm_fwd_mask(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
-                                                        capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask), C.byref(d), capi.ptr(ws),
-                                                        ws.numel(), capi.stream()), "ssbev_groupnorm_fwd_mask")
-            else:
-                capi.check(lib.ssbev_groupnorm_fwd(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
-                                                   capi.ptr(mean), capi.ptr(rstd), C.byref(d), capi.ptr(ws), ws.numel(),
-                                                   capi.stream()), "ssbev_groupnorm_fwd")
+            capi.check(lib.ssbev_groupnorm_fwd_ext(capi.ptr(xcl), capi.ptr(w), capi.ptr(b), capi.ptr(rcl), capi.ptr(y),
+                                                   capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask) if use_mask else None,
+                                                   C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm_fwd_ext")
         ctx.save_for_backward(xcl, (mask if use_mask else y) if relu else None, w, mean, rstd)
         ctx.use_mask = use_mask
         ctx.meta = (B, S, Cch, groups, float(eps), int(relu), residual is not None, given, int(pre_act), io)
@@ -1691,14 +1718,16 @@ class _GroupNorm(torch.autograd.Function):
         ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
         # stats: x, gy (, y); apply: x, gy (, y) -> gx (, gres); the ReLU bit mask replaces both y reads
         nb = float(xcl.element_size()) * xcl.numel() * (5 + (relu and not ctx.use_mask) + has_res)
+        ext = _norm_ext(gy.device)
         with _span("groupnorm", 0.0, nb, f"bwd   N C={Cch} G={groups} S={S} res={int(has_res)}"):
-            fn = lib.ssbev_groupnorm_bwd_mask if ctx.use_mask else lib.ssbev_groupnorm_bwd
-            capi.check(fn(capi.ptr(gcl), capi.ptr(xcl), capi.ptr(y), capi.ptr(w), capi.ptr(mean),
-                          capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
-                          C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()), "ssbev_groupnorm_bwd")
+            capi.check(lib.ssbev_groupnorm_bwd_ext(capi.ptr(gcl), capi.ptr(xcl), None if ctx.use_mask else capi.ptr(y),
+                                                   capi.ptr(y) if ctx.use_mask else None, capi.ptr(w), capi.ptr(mean),
+                                                   capi.ptr(rstd), capi.ptr(gx), capi.ptr(gres), capi.ptr(gg), capi.ptr(gb),
+                                                   C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm_bwd_ext")
         if has_res and ctx.res_slot is not None and ctx.res_slot.buf is None:
             ctx.res_slot.buf = gres        # first gradient of a forked activation: later consumers accumulate into it
-        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None, None
+        return from_cl(gx), gg, gb, (from_cl(gres) if has_res else None), None, None, None, None, None, None, None, None, None
 
 
 NORM_CAT = os.environ.get("SSBEV_NORM_CAT", "1") != "0"     # concatenations of normalised branches without torch.cat (0 = cat)
@@ -1711,7 +1740,7 @@ class _NormCat(torch.autograd.Function):
     and re-read per step; ASPP, BD:404-410).  ``parts``: (groups, eps, as_batch) per branch; tensors: x_i, weight_i, bias_i."""
 
     @staticmethod
-    def forward(ctx, parts, relu, *tensors):
+    def forward(ctx, parts, relu, running, *tensors):
         lib = capi.load()
         ctx.set_materialize_grads(False)
         n = len(parts)
@@ -1740,11 +1769,13 @@ class _NormCat(torch.autograd.Function):
             rstd = torch.empty(B * groups, dtype=torch.float32, device=x.device)
             ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), x.device)
             mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(d)), dtype=torch.int64, device=x.device) if relu else None
+            run = running[i] if running is not None else None
+            ext = _norm_ext(x.device, run, B * S)
             with _span("groupnorm", 0.0, 3.0 * esz * x.numel(), f"fwd   N C={Cs[i]} G={groups} S={S} cat@{c0}/{Ctot}"):
-                capi.check(lib.ssbev_groupnorm_fwd_mask(capi.ptr(x), capi.ptr(ws_[i]), capi.ptr(bs_[i]), None,
-                                                        C.c_void_p(out.data_ptr() + esz * c0), capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask),
-                                                        C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                           "ssbev_groupnorm_fwd_mask")
+                capi.check(lib.ssbev_groupnorm_fwd_ext(capi.ptr(x), capi.ptr(ws_[i]), capi.ptr(bs_[i]), None,
+                                                       C.c_void_p(out.data_ptr() + esz * c0), capi.ptr(mean), capi.ptr(rstd), capi.ptr(mask),
+                                                       C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(), capi.stream()),
+                           "ssbev_groupnorm_fwd_ext")
             saved += [x, mask, ws_[i], mean, rstd]
             stats += [mean, rstd]
             metas.append((B, S, Cs[i], groups, float(eps), c0))
@@ -1774,27 +1805,29 @@ class _NormCat(torch.autograd.Function):
             gg = torch.empty(Cch, dtype=torch.float32, device=gy.device)
             gb = torch.empty(Cch, dtype=torch.float32, device=gy.device)
             ws = _ws(lib.ssbev_groupnorm_workspace(C.byref(d)), gy.device)
+            ext = _norm_ext(gy.device)
             with _span("groupnorm", 0.0, 5.0 * esz * x.numel(), f"bwd   N C={Cch} G={groups} S={S} cat@{c0}/{ctx.Ctot}"):
-                capi.check(lib.ssbev_groupnorm_bwd_mask(C.c_void_p(gcl.data_ptr() + esz * c0), capi.ptr(x), capi.ptr(mask), capi.ptr(w),
-                                                        capi.ptr(mean), capi.ptr(rstd), capi.ptr(gx), None, capi.ptr(gg),
-                                                        capi.ptr(gb), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                           "ssbev_groupnorm_bwd_mask")
+                capi.check(lib.ssbev_groupnorm_bwd_ext(C.c_void_p(gcl.data_ptr() + esz * c0), capi.ptr(x), None, capi.ptr(mask),
+                                                       capi.ptr(w), capi.ptr(mean), capi.ptr(rstd), capi.ptr(gx), None, capi.ptr(gg),
+                                                       capi.ptr(gb), C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(), capi.stream()),
+                           "ssbev_groupnorm_bwd_ext")
             grads += [from_cl(gx), gg, gb]
         if ctx.extra_at is not None:
             grads.append(gcl[..., ctx.extra_at:].movedim(-1, 1))
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
-def norm_cat(xs, norms, relu=True, extra=None):
+def norm_cat(xs, norms, relu=True, extra=None, running=None):
     """Concatenation along the channel axis of relu?(norm_i(x_i)) (+ ``extra`` as it is, behind them): ``norms`` = (weight, bias,
-    groups, eps, as_batch) per branch.  Returns (y, [(mean_i, rstd_i)])."""
+    groups, eps, as_batch) per branch; ``running``: per branch None or (running_mean, running_var, momentum) of a training-mode
+    BatchNorm, updated inside the operator.  Returns (y, [(mean_i, rstd_i)])."""
     parts = tuple((int(g), float(e), bool(ab)) for (_, _, g, e, ab) in norms)
     flat = []
     for x, (w, b, _, _, _) in zip(xs, norms):
         flat += [x, w, b]
     if extra is not None:
         flat.append(extra)
-    out = _NormCat.apply(parts, bool(relu), *flat)
+    out = _NormCat.apply(parts, bool(relu), running, *flat)
     return out[0], [(out[1 + 2 * i], out[2 + 2 * i]) for i in range(len(xs))]
 
 
@@ -1812,9 +1845,11 @@ def group_norm(x, groups, weight, bias, eps=1e-5, residual=None, relu=False, pre
                             _slot_of(residual))[0]
 
 
-def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False):
-    """Training-mode BatchNorm (batch statistics): returns (y, mean[C], rstd[C])."""
-    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None, 0, _slot_of(residual))
+def batch_norm_train(x, weight, bias, eps=1e-5, residual=None, relu=False, running=None):
+    """Training-mode BatchNorm (batch statistics): returns (y, mean[C], rstd[C]).  ``running`` = (running_mean, running_var,
+    momentum): nn.BatchNorm's momentum update of the running statistics, done inside the operator (in the finalize tail of
+    the statistics kernel; no launch of its own)."""
+    return _GroupNorm.apply(x, weight, bias, residual, x.shape[1], eps, relu, True, None, None, 0, _slot_of(residual), running)
 
 
 def bn_update_running_(running_mean, running_var, mean, rstd, momentum, eps, n):
@@ -1836,7 +1871,7 @@ class _DualNorm(torch.autograd.Function):
     batch normalisation; returns (y, mean_a, rstd_a, mean_b, rstd_b)."""
 
     @staticmethod
-    def forward(ctx, xa, wa, ba, xb, wb, bb, ga, gb, eps_a, eps_b, relu, a_batch, b_batch):
+    def forward(ctx, xa, wa, ba, xb, wb, bb, ga, gb, eps_a, eps_b, relu, a_batch, b_batch, run_a=None, run_b=None):
         lib = capi.load()
         ctx.set_materialize_grads(False)
         acl, io = _act(to_cl(xa), "dual_norm")
@@ -1859,11 +1894,18 @@ class _DualNorm(torch.autograd.Function):
         nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0, 0, 0, io)
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(nd)), dtype=torch.int64, device=dev) if relu else None
         wa_, ba_, wb_, bb_ = (t.detach().contiguous() for t in (wa, ba, wb, bb))
+        sync = _norm_sync(dev)
+        ext = capi.Norm2Ext(sync.data_ptr() if sync is not None else None, None, None, 0.0, None, None, 0.0)
+        if run_a is not None and a_batch:
+            ext.running_mean_a, ext.running_var_a, ext.momentum_a = run_a[0].data_ptr(), run_a[1].data_ptr(), float(run_a[2])
+        if run_b is not None and b_batch:
+            ext.running_mean_b, ext.running_var_b, ext.momentum_b = run_b[0].data_ptr(), run_b[1].data_ptr(), float(run_b[2])
         with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 5, f"fwd   N2 C={Cch} Ga={ga} Gb={gb} S={S}"):
-            capi.check(lib.ssbev_groupnorm2_fwd(capi.ptr(acl), capi.ptr(wa_), capi.ptr(ba_), capi.ptr(mean_a), capi.ptr(rstd_a),
-                                                capi.ptr(bcl), capi.ptr(wb_), capi.ptr(bb_), capi.ptr(mean_b), capi.ptr(rstd_b),
-                                                capi.ptr(y), capi.ptr(mask), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                       "ssbev_groupnorm2_fwd")
+            capi.check(lib.ssbev_groupnorm2_fwd_ext(capi.ptr(acl), capi.ptr(wa_), capi.ptr(ba_), capi.ptr(mean_a), capi.ptr(rstd_a),
+                                                    capi.ptr(bcl), capi.ptr(wb_), capi.ptr(bb_), capi.ptr(mean_b), capi.ptr(rstd_b),
+                                                    capi.ptr(y), capi.ptr(mask), C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(),
+                                                    capi.stream()),
+                       "ssbev_groupnorm2_fwd_ext")
         ctx.save_for_backward(acl, bcl, mask, wa_, wb_, mean_a, rstd_a, mean_b, rstd_b)
         ctx.meta = (B, Cch, int(ga), int(gb), S, float(eps_a), float(eps_b), int(relu), int(a_batch), int(b_batch), io)
         ctx.mark_non_differentiable(mean_a, rstd_a, mean_b, rstd_b)
@@ -1880,12 +1922,14 @@ class _DualNorm(torch.autograd.Function):
         gga, gba, ggb, gbb = (torch.empty(Cch, dtype=torch.float32, device=dev) for _ in range(4))
         ws = _ws(lib.ssbev_groupnorm2_workspace(C.byref(d)), dev)
         with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 8, f"bwd   N2 C={Cch} Ga={ctx.meta[2]} Gb={ctx.meta[3]} S={ctx.meta[4]}"):
-            capi.check(lib.ssbev_groupnorm2_bwd(capi.ptr(gcl), capi.ptr(mask), capi.ptr(acl), capi.ptr(wa_), capi.ptr(mean_a),
-                                                capi.ptr(rstd_a), capi.ptr(bcl), capi.ptr(wb_), capi.ptr(mean_b), capi.ptr(rstd_b),
-                                                capi.ptr(gxa), capi.ptr(gxb), capi.ptr(gga), capi.ptr(gba), capi.ptr(ggb),
-                                                capi.ptr(gbb), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                       "ssbev_groupnorm2_bwd")
-        return from_cl(gxa), gga, gba, from_cl(gxb), ggb, gbb, None, None, None, None, None, None, None
+            sync = _norm_sync(dev)
+            ext = capi.Norm2Ext(sync.data_ptr() if sync is not None else None, None, None, 0.0, None, None, 0.0)
+            capi.check(lib.ssbev_groupnorm2_bwd_ext(capi.ptr(gcl), capi.ptr(mask), capi.ptr(acl), capi.ptr(wa_), capi.ptr(mean_a),
+                                                    capi.ptr(rstd_a), capi.ptr(bcl), capi.ptr(wb_), capi.ptr(mean_b), capi.ptr(rstd_b),
+                                                    capi.ptr(gxa), capi.ptr(gxb), capi.ptr(gga), capi.ptr(gba), capi.ptr(ggb),
+                                                    capi.ptr(gbb), C.byref(d), C.byref(ext), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_groupnorm2_bwd_ext")
+        return from_cl(gxa), gga, gba, from_cl(gxb), ggb, gbb, None, None, None, None, None, None, None, None, None
 
 
 DUAL_NORM = os.environ.get("SSBEV_DUAL_NORM", "1") != "0"      # 0: the two-operator residual form (A/B timing)
@@ -1895,11 +1939,13 @@ def dual_norm_supported(xa, xb):
     return xa.is_cuda and xa.shape == xb.shape and xa.dim() >= 3 and xa.shape[1] % 4 == 0 and xa.shape[1] <= 1024
 
 
-def dual_norm(xa, wa, ba, groups_a, eps_a, xb, wb, bb, groups_b, eps_b, relu=False, a_batch=False, b_batch=False):
-    """relu?(N_a(xa) + N_b(xb)); ``x_batch`` = statistics over the batch axis too (BatchNorm when groups == channels).
+def dual_norm(xa, wa, ba, groups_a, eps_a, xb, wb, bb, groups_b, eps_b, relu=False, a_batch=False, b_batch=False,
+              running_a=None, running_b=None):
+    """relu?(N_a(xa) + N_b(xb)); ``x_batch`` = statistics over the batch axis too (BatchNorm when groups == channels);
+    ``running_x`` = (running_mean, running_var, momentum) of a training-mode BatchNorm side, updated inside the operator.
     Returns (y, (mean_a, rstd_a), (mean_b, rstd_b))."""
     y, ma, ra, mb, rb = _DualNorm.apply(xa, wa, ba, xb, wb, bb, int(groups_a), int(groups_b), eps_a, eps_b, relu,
-                                        bool(a_batch), bool(b_batch))
+                                        bool(a_batch), bool(b_batch), running_a, running_b)
     return y, (ma, ra), (mb, rb)
 
 

@@ -140,16 +140,20 @@ class _HipBatchNorm:
     residual add and ReLU: relu?(BN(x) + residual?) in one streaming pass."""
     fused_relu = False
 
+    def _running(self):
+        """(running_mean, running_var, momentum) for the operator to update in place (the momentum update of nn.BatchNorm in
+        training mode happens in the finalize tail of the statistics kernel), or None; counts the batch."""
+        if not self.track_running_stats:
+            return None
+        with torch.no_grad():
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
+            self.num_batches_tracked += 1
+        return (self.running_mean, self.running_var, m)
+
     def forward(self, x, residual=None, relu=None):
         relu = self.fused_relu if relu is None else relu
         if self.training:
-            y, mean, rstd = F.batch_norm_train(x, self.weight, self.bias, self.eps, residual, relu)
-            if self.track_running_stats:
-                with torch.no_grad():
-                    m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
-                    F.bn_update_running_(self.running_mean, self.running_var, mean, rstd, m, self.eps,
-                                         x.numel() // x.shape[1])
-                    self.num_batches_tracked += 1
+            y, mean, rstd = F.batch_norm_train(x, self.weight, self.bias, self.eps, residual, relu, running=self._running())
             return y
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             # eval-mode BN is a per-channel affine map; keep it differentiable with plain device ops
@@ -184,14 +188,9 @@ def norm_pair(norm_a, xa, norm_b, xb, relu=True):
             return n.num_groups, False
         return n.num_features, True
     (ga, a_batch), (gb, b_batch) = side(norm_a), side(norm_b)
+    run = [n._running() if isinstance(n, _HipBatchNorm) else None for n in (norm_a, norm_b)]
     y, sa, sb = F.dual_norm(xa, norm_a.weight, norm_a.bias, ga, norm_a.eps, xb, norm_b.weight, norm_b.bias, gb, norm_b.eps,
-                            relu=relu, a_batch=a_batch, b_batch=b_batch)
-    for n, (mean, rstd), x in ((norm_a, sa, xa), (norm_b, sb, xb)):
-        if isinstance(n, _HipBatchNorm) and n.track_running_stats:
-            with torch.no_grad():
-                m = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked + 1)
-                F.bn_update_running_(n.running_mean, n.running_var, mean, rstd, m, n.eps, x.numel() // x.shape[1])
-                n.num_batches_tracked += 1
+                            relu=relu, a_batch=a_batch, b_batch=b_batch, running_a=run[0], running_b=run[1])
     return y
 
 
@@ -207,13 +206,8 @@ def norm_cat(norms, xs, relu=True, extra=None):
         return torch.cat(ys + ([extra] if extra is not None else []), dim=1)
     spec = [(n.weight, n.bias, n.num_groups, n.eps, False) if isinstance(n, GroupNorm)
             else (n.weight, n.bias, n.num_features, n.eps, True) for n in norms]
-    y, stats = F.norm_cat(list(xs), spec, relu=relu, extra=extra)
-    for n, (mean, rstd), x in zip(norms, stats, xs):
-        if isinstance(n, _HipBatchNorm) and n.track_running_stats:
-            with torch.no_grad():
-                m = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked + 1)
-                F.bn_update_running_(n.running_mean, n.running_var, mean, rstd, m, n.eps, x.numel() // x.shape[1])
-                n.num_batches_tracked += 1
+    run = tuple(n._running() if isinstance(n, _HipBatchNorm) else None for n in norms)
+    y, stats = F.norm_cat(list(xs), spec, relu=relu, extra=extra, running=run)
     return y
 
 

@@ -550,6 +550,79 @@ def test_group_norm_large_mean_offset(G):
     assert maxdiff(got, want) < tol * max(1.0, want.abs().max().item())
 
 
+def _norm_step(kind, x, w, b, G, r, go, running=None):
+    xs = [t.detach().clone().requires_grad_(True) for t in (x, w, b)]
+    if kind == "gn":
+        y = F.group_norm(xs[0], G, xs[1], xs[2], 1e-5, residual=r, relu=True)
+    else:
+        y = F.batch_norm_train(xs[0], xs[1], xs[2], 1e-5, residual=r, relu=True, running=running)[0]
+    y.backward(go)
+    return [y.detach()] + [t.grad for t in xs]
+
+
+@pytest.mark.parametrize("kind,B,C,G,sp", [("gn", 1, 32, 2, (48, 24, 80)), ("gn", 2, 128, 32, (8, 16, 16)), ("gn", 1, 192, 32, (4, 16, 16)),
+                                            ("gn", 3, 640, 2, (1, 12, 40)), ("bn", 2, 64, 64, (6, 12, 20)), ("bn", 1, 640, 640, (1, 48, 160)),
+                                            ("gn", 1, 48, 1, (3, 5, 7)), ("bn", 2, 1024, 1024, (1, 4, 8))])
+def test_norm_finalize_in_the_statistics_tail_equals_the_separate_finalize(kind, B, C, G, sp, monkeypatch):
+    """Round 5: mean / rstd (forward) and the group coefficients + dgamma / dbeta (backward) are reduced by the last-arriving
+    workgroup of the statistics kernel (csrc/groupnorm.hip GnTail) instead of by a finalize launch.  Both reductions run in
+    double in a fixed order, so the two paths agree to the last rounding of the fp32 results; the tail path is run-to-run
+    identical; the BatchNorm running statistics it updates in passing match the stand-alone update; and the sync words it
+    borrows are zero again afterwards."""
+    x = (S.hash_normal(f"tail/x{C}", (B, C) + sp) * 1.5 + 0.7).to(DEV)
+    w = (1 + S.hash_uniform(f"tail/w{C}", (C,), -0.3, 0.3)).to(DEV)
+    b = S.hash_uniform(f"tail/b{C}", (C,), -0.2, 0.2).to(DEV)
+    r = S.hash_normal(f"tail/r{C}", (B, C) + sp).to(DEV)
+    go = S.hash_normal(f"tail/go{C}", (B, C) + sp).to(DEV)
+    n = x.numel() // C
+
+    def run(tail):
+        monkeypatch.setattr(F, "GN_TAIL", tail)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        outs = _norm_step(kind, x, w, b, G, r, go, running=(rm, rv, 0.1) if kind == "bn" else None)
+        return outs + ([rm, rv] if kind == "bn" else [])
+
+    sep, t1, t2 = run(False), run(True), run(True)
+    for a, c in zip(t1, t2):
+        assert torch.equal(a, c)                                     # deterministic whichever workgroup arrives last
+    for a, c in zip(t1, sep):
+        assert maxdiff(a, c) <= 2e-6 * max(1.0, c.abs().max().item())
+    if kind == "bn":                                                 # running statistics against nn.functional.batch_norm's update
+        rm, rv = torch.zeros(C), torch.ones(C)
+        TF.batch_norm(x.cpu(), rm, rv, w.cpu(), b.cpu(), True, 0.1, 1e-5)
+        assert maxdiff(t1[-2], rm) < 1e-5 and maxdiff(t1[-1], rv) < 1e-5 * max(1.0, rv.abs().max().item())
+    assert all(int(v.abs().sum()) == 0 for v in F._NORM_SYNC.values())
+
+
+def test_norm_tail_on_two_streams_back_to_back(monkeypatch):
+    """The sync words are per (device, stream): normalisations of different shapes issued back to back on two streams at once
+    (the stereo branch and DepthNet's side stream do exactly that) must neither disturb each other nor leave a word non-zero."""
+    monkeypatch.setattr(F, "GN_TAIL", True)
+    side = torch.cuda.Stream()
+    shapes = [(1, 32, 2, (24, 12, 40)), (2, 64, 2, (6, 12, 20)), (1, 128, 32, (8, 8, 8)), (1, 640, 640, (1, 12, 40))]
+    data = []
+    for i, (B, C, G, sp) in enumerate(shapes):
+        x = (S.hash_normal(f"ts/x{i}", (B, C) + sp) + 0.25 * i).to(DEV)
+        w = (1 + S.hash_uniform(f"ts/w{i}", (C,), -0.3, 0.3)).to(DEV)
+        b = S.hash_uniform(f"ts/b{i}", (C,), -0.2, 0.2).to(DEV)
+        want = TF.group_norm(x.double(), G, w.double(), b.double(), 1e-5).float()
+        data.append((x, w, b, G, want))
+    torch.cuda.synchronize()
+    got_main, got_side = [], []
+    for rep in range(20):
+        for x, w, b, G, _ in data:
+            got_main.append(F.group_norm(x, G, w, b, 1e-5))
+        with torch.cuda.stream(side):
+            for x, w, b, G, _ in reversed(data):
+                got_side.append(F.group_norm(x, G, w, b, 1e-5))
+    torch.cuda.synchronize()
+    for k, y in enumerate(got_main):
+        assert maxdiff(y, data[k % 4][4]) < 3e-5
+    for k, y in enumerate(got_side):
+        assert maxdiff(y, data[3 - k % 4][4]) < 3e-5
+    assert len(F._NORM_SYNC) >= 2 and all(int(v.abs().sum()) == 0 for v in F._NORM_SYNC.values())
+
+
 # ------------------------------------------------------------------------------------ trilinear x2
 @pytest.mark.parametrize("B,C,sp", [(1, 20, (8, 8, 4)), (2, 4, (3, 5, 2)), (1, 20, (16, 12, 8))])
 def test_trilinear2x_fwd_bwd(B, C, sp):

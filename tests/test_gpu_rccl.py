@@ -80,13 +80,13 @@ def test_rccl_world1_exchange_is_the_identity_on_the_flat_buffer(rccl_world1):
     model, inputs, gt, sd0 = _setup("rccl")
     # --- no exchange at all (a reducer that believes there is no process group)
     red0 = dp.FlatGradAllReduce(model, bucket_mb=4)
-    red0.active = False
+    assert not red0.active                          # default: a process group of one rank exchanges nothing
     want, n0 = _step(model, red0, inputs, gt, sd0)
     strict = _loose_mask(model, red0)
     red0.remove()
     assert n0 == 0
     for exchange in ("rs_ag", "all_reduce"):
-        red = dp.FlatGradAllReduce(model, bucket_mb=4, exchange=exchange)
+        red = dp.FlatGradAllReduce(model, bucket_mb=4, exchange=exchange, exchange_at_world1=True)
         assert red.active and red.world == 1 and red.native_avg and red.exchange == exchange and len(red.buckets) > 20
         for _ in range(2):
             got, nbytes = _step(model, red, inputs, gt, sd0)
@@ -103,11 +103,10 @@ def test_rccl_world1_bf16_wire_rounds_once(rccl_world1):
     from stereoscene_amd import dp
     model, inputs, gt, sd0 = _setup("rccl16")
     red0 = dp.FlatGradAllReduce(model, bucket_mb=16)
-    red0.active = False
     want, _ = _step(model, red0, inputs, gt, sd0)
     strict = _loose_mask(model, red0)
     red0.remove()
-    red = dp.FlatGradAllReduce(model, bucket_mb=16, comm_dtype="bf16")
+    red = dp.FlatGradAllReduce(model, bucket_mb=16, comm_dtype="bf16", exchange_at_world1=True)
     got, nbytes = _step(model, red, inputs, gt, sd0)
     assert nbytes == red.flat.numel() * 2
     assert torch.equal(got[strict], want.to(torch.bfloat16).float()[strict])
