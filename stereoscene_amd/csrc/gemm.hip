@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -77,18 +78,29 @@ __device__ __forceinline__ int xcd_logical(int bid, int nwg) {
 // BT = false: B is [K][N] (NN);  BT = true: B is [N][K] (NT).  D2S: 0 = plain, 1 = NN scatters its C rows, 2 = NT gathers its A rows.
 // MW = 32-row tiles per wave along M: 2 (workgroup tile 128 rows) or 3 (192 rows: the BRI products have M = D = 192 rows, on
 // which 128-row tiles spend a quarter of their MFMAs on padding)
-template <int WN, bool BT, int D2S, int MW = 2>
-__global__ void __launch_bounds__(256, 2)
+// WGN = waves along N (2: the 2 x 2 wave grid; 1: four waves stacked along M, each owning the full tile width -- round 5: the
+// 128 x 160 tile (MW = 1, WN = 5, WGN = 1) cuts the 16 x [1920 x 640 x 640] frequency products of DepthNet's Winograd layers into
+// 960 tiles = 1.9 rounds of the 512 workgroup slots instead of 1200 = 2.3 -> three rounds).
+// BKT = k depth of a stage (32, or 16: half the LDS per workgroup, so OCC = 3 workgroups per CU fit -- three waves per SIMD
+// to hide a stage's barrier and operand reads behind, at twice the barriers).
+template <int WN, bool BT, int D2S, int MW = 2, int WGN = 2, int BKT = 32, int OCC = 2>
+__global__ void __launch_bounds__(256, OCC)
 gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias, float* __restrict__ Cm,
                GemmGeom g) {
-  constexpr int BM = 64 * MW, BN = 64 * WN, BK = 32;
+  constexpr int WGM = 4 / WGN;
+  constexpr int BM = 32 * MW * WGM, BN = 32 * WN * WGN, BK = BKT;
+  constexpr int SPR = BK / 4;                                     // 16-byte slots per operand row of a [rows][BK] slab
   constexpr int AF = BM * BK, BF = BK * BN, SF = AF + BF;         // floats per stage
   constexpr int AI = AF / 256, BI = BF / 256;                     // 1 KiB LDS-DMA instructions per stage
-  constexpr int AE = AI / 4, BE = BI / 4;                         // ... per wave
+  constexpr int AE = (AI + 3) / 4, BE = (BI + 3) / 4;             // ... per wave (the last one may be partial: guarded)
+  static_assert(AF % 256 == 0 && BF % 256 == 0, "slabs are whole 1 KiB LDS-DMA pieces");
+  // XOR key of a row's 16-byte slots: conflict-free ds_read_b128 over the 16-lane groups (128-byte rows: (row >> 1) & 7, see
+  // conv_mfma.hip; 64-byte rows: four rows span the 64 banks, so rows equal modulo 4 must differ in their slot: (row >> 2) & 3)
+  auto swz = [](int row) { return BKT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   extern __shared__ __align__(16) float lds[];                    // [2][A slab | B slab]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   int id = xcd_logical(blockIdx.x, gridDim.x);
   const int nb = id % g.nblocks; id /= g.nblocks;
   const int mb = id % g.mblocks; id /= g.mblocks;
@@ -105,24 +117,24 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
   // tail (K % 32 != 0) is one compare per copy.  Straight-line selects: no branch inside the stage loop.
   const float* ap[AE]; int ak[AE];
 #pragma unroll
-  for (int e = 0; e < AE; ++e) {                  // A: BM rows x 8 slots of 16 B, slots XOR-swizzled by ((row >> 1) & 7)
-    const int item = (wave + 4 * e) * 64 + lane, row = item >> 3, slot = item & 7;
+  for (int e = 0; e < AE; ++e) {                  // A: BM rows x SPR slots of 16 B, slots XOR-swizzled
+    const int item = (wave + 4 * e) * 64 + lane, row = item / SPR, slot = item % SPR;
     const int m = m0 + row;
-    ak[e] = (slot ^ ((row >> 1) & 7)) << 2;
-    ap[e] = m < g.M ? (D2S == 2 ? Ab + g.rowoff[m] : Ab + (long)m * g.lda) + ak[e] : nullptr;
+    ak[e] = (slot ^ swz(row)) << 2;
+    ap[e] = (wave + 4 * e < AI && m < g.M) ? (D2S == 2 ? Ab + g.rowoff[m] : Ab + (long)m * g.lda) + ak[e] : nullptr;
   }
   const float* bp[BE]; int bk[BE];
 #pragma unroll
   for (int e = 0; e < BE; ++e) {
     const int item = (wave + 4 * e) * 64 + lane;
-    if (BT) {                                     // W: BN rows x 8 slots, same swizzle
-      const int row = item >> 3, slot = item & 7, n = n0 + row;
-      bk[e] = (slot ^ ((row >> 1) & 7)) << 2;
-      bp[e] = n < g.N ? Bb + (long)n * g.ldb + bk[e] : nullptr;
-    } else {                                      // B: 32 k-rows x BN/4 slots of 16 B, linear
+    if (BT) {                                     // W: BN rows x SPR slots, same swizzle
+      const int row = item / SPR, slot = item % SPR, n = n0 + row;
+      bk[e] = (slot ^ swz(row)) << 2;
+      bp[e] = (wave + 4 * e < BI && n < g.N) ? Bb + (long)n * g.ldb + bk[e] : nullptr;
+    } else {                                      // B: BK k-rows x BN/4 slots of 16 B, linear
       const int kr = item / (BN / 4), slot = item % (BN / 4), n = n0 + slot * 4;
       bk[e] = kr;
-      bp[e] = n < g.N ? Bb + (long)kr * g.ldb + n : nullptr;
+      bp[e] = (wave + 4 * e < BI && n < g.N) ? Bb + (long)kr * g.ldb + n : nullptr;
     }
   }
 
@@ -133,11 +145,13 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     const long boff = BT ? (long)k0 : (long)k0 * g.ldb;
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
+      if (AI % 4 != 0 && wave + 4 * e >= AI) break;
       const float* src = (ap[e] != nullptr && k0 + ak[e] < g.K) ? ap[e] + aoff : kGemmZeros;
       __builtin_amdgcn_global_load_lds(src, lds + buf * SF + (wave + 4 * e) * 256, 16, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
+      if (BI % 4 != 0 && wave + 4 * e >= BI) break;
       const float* src = (bp[e] != nullptr && k0 + bk[e] < g.K) ? bp[e] + boff : kGemmZeros;
       __builtin_amdgcn_global_load_lds(src, lds + buf * SF + AF + (wave + 4 * e) * 256, 16, 0, 0);
     }
@@ -165,13 +179,13 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
 #pragma unroll
       for (int mt = 0; mt < MW; ++mt) {
         const int row = (wm * MW + mt) * 32 + li;
-        a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ ((row >> 1) & 7)) << 2));
+        a[mt] = *reinterpret_cast<const gv4f*>(as + row * BK + (((2 * q + lk) ^ swz(row)) << 2));
       }
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) {
         if (BT) {
           const int row = (wn * WN + nt) * 32 + li;
-          bf[nt] = *reinterpret_cast<const gv4f*>(bs + row * BK + (((2 * q + lk) ^ ((row >> 1) & 7)) << 2));
+          bf[nt] = *reinterpret_cast<const gv4f*>(bs + row * BK + (((2 * q + lk) ^ swz(row)) << 2));
         } else {
 #pragma unroll
           for (int t = 0; t < 4; ++t) bf[nt][t] = bs[(8 * q + 4 * lk + t) * BN + (wn * WN + nt) * 32 + li];
@@ -535,9 +549,22 @@ int pick_wn(int N, int tap_width = 0) {
 
 int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
   // TN: M = reduction rows.  Enough workgroups for ~2 rounds of the 512 slots, at least 256 rows per chunk.
-  int nchunk = std::max(1, 1024 / std::max(1, tiles * d->batch));
-  nchunk = std::min(nchunk, std::max(1, d->M / 256));
-  return nchunk;
+  // (Round 5 tried the chunk count that minimises the rows the busiest CU walks -- 3 chunks instead of 2 on 16 x [1920 rows ->
+  // 640 x 640], 4 instead of 8 on the BRI energy product: +2 ... +9 % alone on the device, but +1.3 ms per step next to the side
+  // stream's kernels, where many small workgroups fill the gaps better (profiles/r5_gemm_cfg_probe.txt).  SSBEV_GEMM_TN_CHUNKS=model
+  // selects it.)
+  static const bool model = getenv("SSBEV_GEMM_TN_CHUNKS") && std::string(getenv("SSBEV_GEMM_TN_CHUNKS")) == "model";
+  if (!model) return std::min(std::max(1, 1024 / std::max(1, tiles * d->batch)), std::max(1, d->M / 256));
+  const int cmax = std::min(16, std::max(1, d->M / 256));
+  int best = 1;
+  double best_cost = 1e300;
+  for (int c = 1; c <= cmax; ++c) {
+    const long per_cu = std::max(2L, ((long)tiles * d->batch * c + 255) / 256);      // (a CU needs two workgroups to run at full rate)
+    const double rows = (double)((d->M + c - 1) / c) + 64.0;
+    const double cost = per_cu * rows + (c > 1 ? 12.0 * (c + 1) : 0.0);        // (the sum pass reads c and writes 1 result-sized buffers)
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+  }
+  return best;
 }
 
 // split-K: when the output tiles alone leave the 512 workgroup slots under-filled and K is deep (BRI's 192 x 7680 products,
@@ -559,12 +586,73 @@ int pick_bm(const ssbev_gemm_dims* d, int wn) {
   return p192 * 8 <= p128 * 7 ? 192 : 128;              // at least 1/8 fewer MFMA rows
 }
 
+// ---- tile configurations of gemm_nn_kernel (plain, non-d2s problems choose among all of them; d2s keeps the 2 x 2 wave grid)
+struct NnCfg { int bm, bn, bk, occ; };
+constexpr NnCfg kNnCfgs[] = {
+    {128, 128, 32, 2},     // 0: 2 x 2 waves of 64 x 64 (rounds 2-4)
+    {128, 64, 32, 2},      // 1
+    {192, 128, 32, 2},     // 2: 96-row wave tiles (M = 192)
+    {128, 160, 32, 2},     // 3: 4 x 1 waves of 32 x 160
+    {128, 128, 16, 3},     // 4: three workgroups per CU (probing only: +9 % on 16 x [1920 x 640 x 640], -3 % elsewhere)
+};
+constexpr int kNnCfgCount = sizeof(kNnCfgs) / sizeof(kNnCfgs[0]);
+
+int nn_forced_cfg() {          // SSBEV_GEMM_CFG=<n>: probing hook (tools/gemm_probe.py)
+  const char* e = getenv("SSBEV_GEMM_CFG");
+  if (!e || !*e) return -1;
+  const int c = atoi(e);
+  return c >= 0 && c < kNnCfgCount ? c : -1;
+}
+
+// Model of a configuration's run time on the 256 CUs: padded MFMA work of the busiest CU (the tiles of one launch are equal:
+// whole tiles per CU), a per-tile constant (prologue fill + epilogue) worth ~2 k-stages, and the measured efficiency of the
+// 4 x 1 wave grid relative to 2 x 2 (profiles/r5_gemm_cfg_probe.txt: the model picks the measured-best configuration on the
+// nine shapes of the path)
+double nn_cfg_cost(const ssbev_gemm_dims* d, const NnCfg& c, int nchunk) {
+  const long tiles = (long)((d->M + c.bm - 1) / c.bm) * ((d->N + c.bn - 1) / c.bn) * d->batch * nchunk;
+  const long per_cu = (tiles + 255) / 256;
+  const double stages = (double)((d->K + 31) / 32) / nchunk + 2.0;
+  return (double)per_cu * c.bm * c.bn * stages * (c.bn == 160 ? 0.93 : 1.0);
+}
+
+template <bool BT>
+int nn_pick_cfg(const ssbev_gemm_dims* d, int* nchunk_out) {
+  int cfg;
+  if (d->d2s_kd > 0) {
+    cfg = pick_wn(d->N, BT ? 0 : d->d2s_Co) == 2 ? 0 : 1;
+  } else {
+    const int forced = nn_forced_cfg();
+    if (forced >= 0) {
+      cfg = forced;
+    } else {
+      // rounds 2-4 choice (tiles that pad least), unless the model says another shape is >= 5 % cheaper
+      const int wn = pick_wn(d->N, 0);
+      cfg = wn == 2 ? (pick_bm(d, wn) == 192 ? 2 : 0) : 1;
+      static const bool wide = !(getenv("SSBEV_GEMM_WIDE_TILES") && atoi(getenv("SSBEV_GEMM_WIDE_TILES")) == 0);     // A/B hook
+      if (wide) {
+        const NnCfg& c0 = kNnCfgs[cfg];
+        const int t0 = ((d->M + c0.bm - 1) / c0.bm) * ((d->N + c0.bn - 1) / c0.bn);
+        double best = nn_cfg_cost(d, c0, nn_chunks(d, t0));
+        const double base = best;
+        for (int k : {1, 3}) {
+          const NnCfg& c = kNnCfgs[k];
+          const int t = ((d->M + c.bm - 1) / c.bm) * ((d->N + c.bn - 1) / c.bn);
+          const double cost = nn_cfg_cost(d, c, nn_chunks(d, t));
+          if (cost < 0.95 * base && cost < best) { best = cost; cfg = k; }
+        }
+      }
+    }
+  }
+  const NnCfg& c = kNnCfgs[cfg];
+  const int tiles = ((d->M + c.bm - 1) / c.bm) * ((d->N + c.bn - 1) / c.bn);
+  *nchunk_out = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, tiles);
+  return cfg;
+}
+
 template <bool BT>
 size_t nn_workspace(const ssbev_gemm_dims* d) {
-  const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
-  const int bm = pick_bm(d, wn);
-  const int tiles = ((d->M + bm - 1) / bm) * ((d->N + 64 * wn - 1) / (64 * wn));
-  const int nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, tiles);
+  int nchunk;
+  nn_pick_cfg<BT>(d, &nchunk);
   return nchunk > 1 ? (size_t)nchunk * d->batch * d->M * d->N * sizeof(float) : 0;
 }
 
@@ -573,13 +661,13 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
               hipStream_t st) {
   GemmGeom g;
   fill_geom(g, d);
-  const int wn = pick_wn(d->N, (!BT && d->d2s_kd > 0) ? d->d2s_Co : 0);
-  const int BN = 64 * wn;
-  const int bm = pick_bm(d, wn);
-  g.mblocks = (d->M + bm - 1) / bm;
-  g.nblocks = (d->N + BN - 1) / BN;
-  g.nchunk = (!BT && d->d2s_kd > 0) ? 1 : nn_chunks(d, g.mblocks * g.nblocks);
-  const int nst = (d->K + 31) / 32;
+  int nchunk;
+  const int cfg = nn_pick_cfg<BT>(d, &nchunk);
+  const NnCfg& c = kNnCfgs[cfg];
+  g.mblocks = (d->M + c.bm - 1) / c.bm;
+  g.nblocks = (d->N + c.bn - 1) / c.bn;
+  g.nchunk = nchunk;
+  const int nst = (d->K + c.bk - 1) / c.bk;
   g.rows_per_chunk = (nst + g.nchunk - 1) / g.nchunk;         // k stages per chunk
   float* dst = Cm;
   const float* kbias = bias;
@@ -590,24 +678,28 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
     kbias = nullptr;
   }
   const long nwg = (long)g.batch * g.nchunk * g.mblocks * g.nblocks;
-  const size_t lds = (size_t)2 * (bm * 32 + 32 * BN) * sizeof(float);        // 64 / 48 KiB (80 KiB for 192-row tiles)
+  const size_t lds = (size_t)2 * (c.bm * c.bk + c.bk * c.bn) * sizeof(float);
   constexpr int DM = BT ? 2 : 1;          // what d2s means for this form
-#define SSBEV_GEMM_LAUNCH(WN_, D2S_)                                                                                       \
+#define SSBEV_GEMM_LAUNCH(...)                                                                                             \
   do {                                                                                                                     \
-    auto kern = gemm_nn_kernel<WN_, BT, D2S_>;                                                                             \
+    auto kern = gemm_nn_kernel<__VA_ARGS__>;                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
         hipSuccess)                                                                                                        \
       return SSBEV_ELAUNCH;                                                                                                \
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, kbias, dst, g);                                \
   } while (0)
-  if (d->d2s_kd > 0) { if (wn == 2) SSBEV_GEMM_LAUNCH(2, DM); else SSBEV_GEMM_LAUNCH(1, DM); }
-  else if (bm == 192) {
-    auto kern = gemm_nn_kernel<2, BT, 0, 3>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SSBEV_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, A, B, kbias, dst, g);
+  if (d->d2s_kd > 0) {
+    if (cfg == 0) SSBEV_GEMM_LAUNCH(2, BT, DM); else SSBEV_GEMM_LAUNCH(1, BT, DM);
+  } else {
+    switch (cfg) {
+      case 0: SSBEV_GEMM_LAUNCH(2, BT, 0); break;
+      case 1: SSBEV_GEMM_LAUNCH(1, BT, 0); break;
+      case 2: SSBEV_GEMM_LAUNCH(2, BT, 0, 3); break;
+      case 3: SSBEV_GEMM_LAUNCH(5, BT, 0, 1, 1); break;
+      case 4: SSBEV_GEMM_LAUNCH(2, BT, 0, 2, 2, 16, 3); break;
+      default: return SSBEV_EINVAL;
+    }
   }
-  else { if (wn == 2) SSBEV_GEMM_LAUNCH(2, 0); else SSBEV_GEMM_LAUNCH(1, 0); }
 #undef SSBEV_GEMM_LAUNCH
   if (g.nchunk > 1) {
     if (d->ldc != d->N || (d->batch > 1 && d->sc != (long)d->M * d->N)) return SSBEV_EINVAL;     // split-K needs a dense C

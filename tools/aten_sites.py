@@ -4,12 +4,13 @@ import os, sys, traceback, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
-from stereoscene_amd import model_zoo, synthetic as S
+from stereoscene_amd import functional as F, model_zoo, synthetic as S
+F.set_precision(os.environ.get("PREC", "fp32"))
 
 MIN = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 cfg = S.CONFIGS["kitti_d192"]
 model = model_zoo.build_detector(cfg).train()
-smp = S.synthetic_sample(cfg, B=1, tag="bench0")
+smp = S.synthetic_sample(cfg, B=int(os.environ.get("BATCH", "1")), tag="bench0")
 inputs = model_zoo.img_inputs_from_sample(smp)
 gt = smp["gt_occ"].cuda()
 log = collections.Counter()
