@@ -167,10 +167,13 @@ typedef struct {
                         *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[3]); tensors in memory
                         *     stay fp32, the weight gradient kernels stay on the fp32 MFMA;
                         * 2 = bf16 STORAGE (round 4; the configs[3] path proper, csrc/conv_bf16.hip): the source tensor (x in
-                        *     ssbev_conv_fwd, gy in ssbev_conv_bwd_data; both in ssbev_conv_bwd_weight) AND the result (y / gx)
-                        *     are bf16 channels-last tensors (raw 16-bit patterns behind the float pointers), the packed
+                        *     ssbev_conv_fwd_bf16, gy in ssbev_conv_bwd_data_bf16; both in ssbev_conv_bwd_weight_bf16) AND the
+                        *     result (y / gx) are bf16 channels-last tensors (uint16_t bit patterns), the packed
                         *     weights hold bf16 operands, accumulation is fp32, gw is fp32.  Needs Cin % 8 == 0 (and
-                        *     Cout % 8 == 0 wherever the Cout-channel tensor is a source); bias stays fp32;
+                        *     Cout % 8 == 0 wherever the Cout-channel tensor is a source); bias stays fp32.  Round 5: modes 2 / 3
+                        *     are served by the typed *_bf16 entry points ONLY; ssbev_conv_fwd / _bwd_data / _bwd_weight
+                        *     answer SSBEV_EINVAL for them (and the *_bf16 ones for precision 0 / 1): a precision value that
+                        *     does not match the tensors cannot be passed silently any more;
                         * 3 = as 2 with an fp32 RESULT (the layer in front of an fp32 island, e.g. the logits conv)
                         *     ssbev_conv_kernel_class answers, for these modes: 16 generic gather (conv_gather16_kernel), 17
                         *     LDS-ring tap kernel (<= 32 channels, conv_tap16_kernel), 19 LDS-ring implicit GEMM for the wide
@@ -210,6 +213,15 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
                            ssbev_stream_t stream);
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                    const ssbev_conv_dims* d, ssbev_stream_t stream);
+/* bf16 storage (precision 2: y / gx are uint16_t bf16 tensors; 3: fp32 results, forward / data gradient only); pack the
+ * weights with ssbev_conv_pack_weight under the same dims; workspace of the weight gradient from
+ * ssbev_conv_bwd_weight_workspace under the same dims */
+int ssbev_conv_fwd_bf16(const uint16_t* x, const float* w_packed, const float* bias, void* y,
+                        const ssbev_conv_dims* d, ssbev_stream_t stream);
+int ssbev_conv_bwd_data_bf16(const uint16_t* gy, const float* w_packed_t, void* gx,
+                             const ssbev_conv_dims* d, ssbev_stream_t stream);
+int ssbev_conv_bwd_weight_bf16(const uint16_t* x, const uint16_t* gy, float* gw, const ssbev_conv_dims* d,
+                               void* ws, size_t ws_bytes, ssbev_stream_t stream);
 /* data gradient: gx from gy with weights packed in mode 1 (d describes the FORWARD problem) */
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream);

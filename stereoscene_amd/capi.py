@@ -133,6 +133,9 @@ SIGNATURES = {
     "ssbev_conv_thin_run": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), C.c_int, _P, C.c_size_t, _P]),
     "ssbev_conv_fwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), _P]),
     "ssbev_conv_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),
+    "ssbev_conv_fwd_bf16": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDims), _P]),
+    "ssbev_conv_bwd_data_bf16": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P]),
+    "ssbev_conv_bwd_weight_bf16": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
     "ssbev_conv_bwd_weight_workspace": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_bwd_weight": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),

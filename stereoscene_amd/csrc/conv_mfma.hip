@@ -4020,10 +4020,31 @@ int ssbev_conv_pack_weight(const float* w_src, float* w_packed, const ssbev_conv
   return ssbev_launch_status();
 }
 
+// bf16-STORAGE twins (ssbev_conv_dims.precision = 2 / 3, csrc/conv_bf16.hip): the activation tensors are bf16 bit patterns and the
+// signatures say so; a call whose `precision` does not match its entry point is SSBEV_EINVAL on either side (round 4 passed the
+// bf16 tensors through the float* entry points: a wrong `precision` value was silent garbage).
+int ssbev_conv_fwd_bf16(const uint16_t* x, const float* w_packed, const float* bias, void* y, const ssbev_conv_dims* d,
+                        ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !ssbev_bf16::storage_mode(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
+  return ssbev_bf16::forward(x, w_packed, bias, y, d, as_stream(stream));
+}
+
+int ssbev_conv_bwd_data_bf16(const uint16_t* gy, const float* w_packed_t, void* gx, const ssbev_conv_dims* d,
+                             ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || !ssbev_bf16::storage_mode(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
+  return ssbev_bf16::backward_data(gy, w_packed_t, gx, d, as_stream(stream));
+}
+
+int ssbev_conv_bwd_weight_bf16(const uint16_t* x, const uint16_t* gy, float* gw, const ssbev_conv_dims* d, void* ws,
+                               size_t ws_bytes, ssbev_stream_t stream) {
+  if (!conv_dims_ok(d) || d->precision != 2 || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
+  return ssbev_bf16::backward_weight(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
+}
+
 int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                    const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !w_packed || !y) return SSBEV_EINVAL;
-  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::forward(x, w_packed, bias, y, d, as_stream(stream));
+  if (ssbev_bf16::storage_mode(d)) return SSBEV_EINVAL;      // bf16 tensors go through ssbev_conv_fwd_bf16 (typed pointers)
   if (ssbev_thin::thinin_applicable(d, 0)) return ssbev_thin::thinin_launch(x, w_packed, bias, y, d, 0, as_stream(stream));
   if (d->Cin % 4 != 0) return SSBEV_EINVAL;   // float4 channel loads: caller pads K channels to 4
   if (conv_thin_applicable(d, 0)) return launch_conv_thin(x, w_packed, bias, y, d, 0, as_stream(stream));
@@ -4047,7 +4068,7 @@ int ssbev_conv_fwd(const float* x, const float* w_packed, const float* bias, flo
 int ssbev_conv_bwd_data(const float* gy, const float* w_packed_t, float* gx,
                         const ssbev_conv_dims* d, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !gy || !w_packed_t || !gx) return SSBEV_EINVAL;
-  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::backward_data(gy, w_packed_t, gx, d, as_stream(stream));
+  if (ssbev_bf16::storage_mode(d)) return SSBEV_EINVAL;      // -> ssbev_conv_bwd_data_bf16
   if (ssbev_thin::thinin_applicable(d, 1)) return ssbev_thin::thinin_launch(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_thin_applicable(d, 1)) return launch_conv_thin(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
   if (conv_tap2_applicable(d, 1)) return launch_conv_tap2(gy, w_packed_t, nullptr, gx, d, 1, as_stream(stream));
@@ -4104,7 +4125,7 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d) {
 int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_conv_dims* d,
                           void* ws, size_t ws_bytes, ssbev_stream_t stream) {
   if (!conv_dims_ok(d) || !x || !gy || !gw || !ws) return SSBEV_EINVAL;
-  if (ssbev_bf16::storage_mode(d)) return ssbev_bf16::backward_weight(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
+  if (ssbev_bf16::storage_mode(d)) return SSBEV_EINVAL;      // -> ssbev_conv_bwd_weight_bf16
   if (ws_bytes < ssbev_conv_bwd_weight_workspace(d)) return SSBEV_EWORKSPACE;
   if (ssbev_thin::wgrad_applicable(d)) return ssbev_thin::wgrad_launch(x, gy, gw, d, ws, ws_bytes, as_stream(stream));
   {

@@ -727,8 +727,8 @@ class _ConvNd16(torch.autograd.Function):
         fam = {17: "conv_tap16", 19: "conv_wide16"}.get(lib.ssbev_conv_kernel_class(C.byref(d), 0), "conv_gather16") if KERNEL_TIMER is not None else "conv_gather16"
         with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "fwd")):
             wp = _packed(weight.detach(), d, 0)
-            capi.check(lib.ssbev_conv_fwd(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d), capi.stream()),
-                       "ssbev_conv_fwd[bf16]")
+            capi.check(lib.ssbev_conv_fwd_bf16(capi.ptr(xcl), capi.ptr(wp), capi.ptr(b), capi.ptr(y), C.byref(d), capi.stream()),
+                       "ssbev_conv_fwd_bf16")
         ctx.relu = bool(relu)
         ctx.save_for_backward(xcl, weight, *((y,) if relu else ()))
         ctx.cfg = (stride, padding, dilation, transposed, output_padding, bias is not None)
@@ -760,8 +760,8 @@ class _ConvNd16(torch.autograd.Function):
             ws = _ws(lib.ssbev_conv_bwd_weight_workspace(C.byref(d)), gy.device)
             fam = "wgrad_ring16" if (KERNEL_TIMER is not None and lib.ssbev_conv_kernel_class(C.byref(d), 2) == 20) else "wgrad16"
             with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "wgrad")):
-                capi.check(lib.ssbev_conv_bwd_weight(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d), capi.ptr(ws),
-                                                     ws.numel(), capi.stream()), "ssbev_conv_bwd_weight[bf16]")
+                capi.check(lib.ssbev_conv_bwd_weight_bf16(capi.ptr(xcl), capi.ptr(gcl), capi.ptr(gwp), C.byref(d), capi.ptr(ws),
+                                                          ws.numel(), capi.stream()), "ssbev_conv_bwd_weight_bf16")
             return gwp
 
         gw_side = want_gw and streams.wgrad_on_side(weight)
@@ -781,8 +781,8 @@ class _ConvNd16(torch.autograd.Function):
             fam = {17: "conv_tap16", 19: "conv_wide16"}.get(lib.ssbev_conv_kernel_class(C.byref(d), 1), "conv_gather16") if KERNEL_TIMER is not None else "conv_gather16"
             with _span(fam, conv_flops(d), conv_bytes(d) / 2.0, _conv_tag(d, "dgrad")):
                 wpt = _packed(weight.detach(), d, 1)
-                capi.check(lib.ssbev_conv_bwd_data(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d), capi.stream()),
-                           "ssbev_conv_bwd_data[bf16]")
+                capi.check(lib.ssbev_conv_bwd_data_bf16(capi.ptr(gcl), capi.ptr(wpt), capi.ptr(gxcl), C.byref(d), capi.stream()),
+                           "ssbev_conv_bwd_data_bf16")
             d.accumulate = 0
             if ctx.slot is not None:
                 ctx.slot.buf = gxcl

@@ -85,3 +85,28 @@ def test_round3_entry_points_validate_their_arguments_on_host():
         assert lib.ssbev_groupnorm_workspace(C.byref(nd)) == 0
     g = capi.GwcDims(1, 64, 32, 192, 48, 160, 1.0, 1)
     assert lib.ssbev_gwc_warp_bwd_workspace(C.byref(g)) >= 2 * 2 * 48 * 160 * 64 * 4   # >= two chunks of both partial gradients
+
+
+def test_bf16_storage_entry_points_refuse_a_mismatched_precision_on_host():
+    """Round 5 ("a wrong precision value is silent garbage"): bf16-storage problems (ssbev_conv_dims.precision 2 / 3) are
+    served by the typed ``*_bf16`` entry points only, fp32 / bf16-operand problems (0 / 1) by the ``float*`` ones; either family
+    answers SSBEV_EINVAL for the other's modes before touching a pointer."""
+    import ctypes as C
+    lib = capi.load()
+    fake = C.c_void_p(256)                # never dereferenced: the calls are refused on their arguments
+    for prec in (0, 1, 2, 3):
+        c = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, prec)
+        storage = prec in (2, 3)
+        if storage:
+            assert lib.ssbev_conv_fwd(fake, fake, None, fake, C.byref(c), None) == capi.EINVAL
+            assert lib.ssbev_conv_bwd_data(fake, fake, fake, C.byref(c), None) == capi.EINVAL
+            assert lib.ssbev_conv_bwd_weight(fake, fake, fake, C.byref(c), fake, 1 << 30, None) == capi.EINVAL
+        else:
+            assert lib.ssbev_conv_fwd_bf16(fake, fake, None, fake, C.byref(c), None) == capi.EINVAL
+            assert lib.ssbev_conv_bwd_data_bf16(fake, fake, fake, C.byref(c), None) == capi.EINVAL
+            assert lib.ssbev_conv_bwd_weight_bf16(fake, fake, fake, C.byref(c), fake, 1 << 30, None) == capi.EINVAL
+    c3 = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 3)
+    assert lib.ssbev_conv_bwd_weight_bf16(fake, fake, fake, C.byref(c3), fake, 1 << 30, None) == capi.EINVAL   # fp32-result mode has no wgrad
+    # normalisation: sync words and running statistics ride in ssbev_norm_ext; NULL ext is allowed, bad dims are not
+    n = capi.NormDims(1, 30, 2, 100, 1e-5, 0, 0, 0, 0, 0, 0)          # C % 4 != 0
+    assert lib.ssbev_groupnorm_fwd_ext(fake, fake, fake, None, fake, fake, fake, None, C.byref(n), None, fake, 1 << 20, None) == capi.EINVAL
