@@ -793,8 +793,311 @@ long gather_blocks(const ConvGeom& g, int MT, int NT) {
 //   * MT: 2 unless that leaves fewer than ~160 workgroups;
 //   * QU (k-steps whose operand loads are issued together): deep prefetch (4) for wide tiles and for
 //     small grids (latency-bound), 1-2 when many waves per SIMD already hide the latency.
+__device__ const float kGatherZeros[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_kernel (round 5): LDS-staged implicit GEMM for the layers conv_gather_kernel still served at 59-97 TF/s -- the
+// stride-2 3x3x3 convolutions and transposed convolutions between the hourglass levels 64 <-> 128 (VT:75-88), the encoder's
+// downsamplers 128 -> 256 -> 512 (resnet3d.py) and their data gradients, any layer with Cin % 32 == 0 of the gather's source.
+//     y[m][n] = sum over (tap, k) of  x[src(m, tap)][k] * W[tap][k][n]            m = destination voxel, rows of a GEMM
+// conv_gather_kernel lets every lane fetch the float4s of its voxel from L1/L2 for every MFMA group (one wave per SIMD
+// waits for each of them); here a workgroup owns a BM x BN tile like gemm_nn_kernel (csrc/gemm.hip): per stage (= one tap x
+// 32 source channels) the BM gathered rows and the 32 x BN weight block travel global -> LDS by global_load_lds_dwordx4,
+// double buffered, and the fragments are ds_read_b128 on both sides -- the packed weight layout of pack_weight_kernel
+// ([tap][q][kh][n][4]) IS the B fragment layout, so one 16-byte read feeds four MFMAs.  Padding = the zero line (per row and
+// tap: a 24-bit per-axis validity mask, as in conv_gather_kernel); parity classes of the transposed forms = blockIdx.z.
+// Rows are decoded ONCE per workgroup into an LDS table (source offset, mask, destination offset).
+template <int WN, int MW, int WGN>
+__global__ void __launch_bounds__(256, 2)
+conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                  float* __restrict__ y, ConvGeom g, int mblocks, int nblocks) {
+  constexpr int WGM = 4 / WGN;
+  constexpr int BM = 32 * MW * WGM, BN = 32 * WN * WGN, BK = 32;
+  constexpr int AF = BM * BK, BF = BK * BN, SF = AF + BF;
+  constexpr int AI = AF / 256, BI = BF / 256;
+  constexpr int AE = (AI + 3) / 4, BE = (BI + 3) / 4;
+  extern __shared__ __align__(16) float lds[];                    // [2][A slab | B slab] | row table
+  long* t_src = reinterpret_cast<long*>(lds + 2 * SF);            // [BM] source offset (floats) of the row's base voxel
+  long* t_dst = t_src + BM;                                       // [BM] destination offset (floats), -1 = no such row
+  unsigned* t_msk = reinterpret_cast<unsigned*>(t_dst + BM);      // [BM] per-axis tap validity: d | h << 8 | w << 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- parity class (form 1), as conv_gather_kernel: heaviest class first
+  int par_d = 0, par_h = 0, par_w = 0;
+  int Dc = g.Do, Hc = g.Ho, Wc = g.Wo;
+  if (g.form == 1) {
+    int cls = (int)gridDim.z - 1 - (int)blockIdx.z;
+    par_w = cls % g.sw; cls /= g.sw;
+    par_h = cls % g.sh; cls /= g.sh;
+    par_d = cls;
+    Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
+  }
+  const long Mtot = (long)g.B * Dc * Hc * Wc;
+  int mb, nb;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    nb = (int)(Lp % (unsigned)nblocks);
+    mb = (int)(Lp / (unsigned)nblocks);
+  }
+  const long m0 = (long)mb * BM;
+  const int n0 = nb * BN;
+  if (m0 >= Mtot) return;                                         // (class extents differ: the grid is sized for the largest)
+
+  int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
+  if (g.form == 1) {
+    kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
+    kds = g.sd; khs = g.sh; kws = g.sw;
+  }
+  const int nkd = (g.kd - kd0 + kds - 1) / kds, nkh = (g.kh - kh0 + khs - 1) / khs, nkw = (g.kw - kw0 + kws - 1) / kws;
+  const int ntaps = (kd0 < g.kd && kh0 < g.kh && kw0 < g.kw) ? nkd * nkh * nkw : 0;
+  int step_d, step_h, step_w;
+  if (g.form == 0) { step_d = g.dd; step_h = g.dh; step_w = g.dw; }
+  else { step_d = -(kds * g.dd) / g.sd; step_h = -(khs * g.dh) / g.sh; step_w = -(kws * g.dw) / g.sw; }
+
+  // ---- row table: thread r decodes row r of the tile
+  if (tid < BM) {
+    long m = m0 + tid;
+    const bool ok = m < Mtot;
+    if (!ok) m = 0;
+    const int ow = (int)(m % Wc); m /= Wc;
+    const int oh = (int)(m % Hc); m /= Hc;
+    const int od = (int)(m % Dc);
+    const int ob = (int)(m / Dc);
+    int bd, bh, bw;
+    if (g.form == 0) {
+      bd = od * g.sd - g.pd; bh = oh * g.sh - g.ph; bw = ow * g.sw - g.pw;
+    } else {
+      bd = od + (par_d + g.pd - kd0 * g.dd) / g.sd;
+      bh = oh + (par_h + g.ph - kh0 * g.dh) / g.sh;
+      bw = ow + (par_w + g.pw - kw0 * g.dw) / g.sw;
+    }
+    unsigned msk = 0;
+    for (int i = 0; i < nkd && i < 8; ++i) { const int v = bd + i * step_d; msk |= (v >= 0 && v < g.Di) ? (1u << i) : 0u; }
+    for (int i = 0; i < nkh && i < 8; ++i) { const int v = bh + i * step_h; msk |= (v >= 0 && v < g.Hi) ? (1u << (8 + i)) : 0u; }
+    for (int i = 0; i < nkw && i < 8; ++i) { const int v = bw + i * step_w; msk |= (v >= 0 && v < g.Wi) ? (1u << (16 + i)) : 0u; }
+    t_msk[tid] = ok ? msk : 0u;
+    t_src[tid] = ((((long)ob * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin;      // may lie outside: only used under the mask
+    long dst;
+    if (g.form == 0) dst = (((long)ob * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+    else dst = (((long)ob * g.Do + (od * g.sd + par_d)) * g.Ho + (oh * g.sh + par_h)) * g.Wo + (ow * g.sw + par_w);
+    t_dst[tid] = ok ? dst * (long)g.Cout : -1;
+  }
+  __syncthreads();
+
+  // ---- per-lane copy sources of the A slab: BM rows x 8 slots of 16 B, slots XOR-swizzled by ((row >> 1) & 7)
+  const float* ap[AE]; unsigned am[AE];
+#pragma unroll
+  for (int e = 0; e < AE; ++e) {
+    const int item = (wave + 4 * e) * 64 + lane, row = item >> 3, slot = item & 7;
+    const bool on = wave + 4 * e < AI;
+    ap[e] = x + (on ? t_src[row] : 0) + ((slot ^ ((row >> 1) & 7)) << 2);
+    am[e] = on ? t_msk[row] : 0u;
+  }
+  // B slab: the 8 (q, kh) rows of this stage's 32 source channels x BN columns x 4 floats, contiguous per row in the packed
+  // weights; piece j = wave + 4 e covers slab floats [256 j, 256 j + 256)
+  const int Q = g.CinPad >> 3;
+  long boff[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    const int j = wave + 4 * e, f = j * 256 + 4 * lane;
+    const int r8 = f / (BN * 4), col = f % (BN * 4);
+    boff[e] = (long)r8 * g.CoutPad * 4 + (long)n0 * 4 + col;
+  }
+  const int cq_n = g.Cin >> 5;                                    // 32-channel stages per tap
+  const int nst = ntaps * cq_n;
+  // tap state of the stage being ISSUED (wave-uniform, advanced incrementally)
+  int i_ia = 0, i_ib = 0, i_ic = 0, i_cq = 0;
+  auto issue = [&](int buf) {
+    const int tap = ((kd0 + i_ia * kds) * g.kh + (kh0 + i_ib * khs)) * g.kw + (kw0 + i_ic * kws);
+    const long toff = (((long)i_ia * step_d * g.Hi + (long)i_ib * step_h) * g.Wi + (long)i_ic * step_w) * g.Cin + i_cq * 32;
+    const unsigned need = (1u << i_ia) | (1u << (8 + i_ib)) | (1u << (16 + i_ic));
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      if (AI % 4 != 0 && wave + 4 * e >= AI) break;
+      const float* src = ((am[e] & need) == need) ? ap[e] + toff : kGatherZeros;
+      __builtin_amdgcn_global_load_lds(src, lds + buf * SF + (wave + 4 * e) * 256, 16, 0, 0);
+    }
+    const float* wb = wp + ((size_t)tap * Q + 4 * i_cq) * 2 * g.CoutPad * 4;
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      if (BI % 4 != 0 && wave + 4 * e >= BI) break;
+      const float* bsrc = wb + boff[e];       // (a named pointer: with the sum as the builtin's argument hipcc 7.2 drops the HOST stub of the kernel)
+      __builtin_amdgcn_global_load_lds(bsrc, lds + buf * SF + AF + (wave + 4 * e) * 256, 16, 0, 0);
+    }
+    if (++i_cq == cq_n) {
+      i_cq = 0;
+      if (++i_ic == nkw) { i_ic = 0; if (++i_ib == nkh) { i_ib = 0; ++i_ia; } }
+    }
+  };
+
+  f32x16 acc[MW][WN];
+#pragma unroll
+  for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if (nst > 0) issue(0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < nst) issue(buf ^ 1);
+    const float* as = lds + buf * SF;
+    const float* bs = as + AF;
+    v4f ac[MW], bc[WN], an[MW], bn[WN];
+    auto fetch = [&](int q, v4f (&a)[MW], v4f (&bf)[WN]) {
+#pragma unroll
+      for (int mt = 0; mt < MW; ++mt) {
+        const int row = (wm * MW + mt) * 32 + li;
+        a[mt] = *reinterpret_cast<const v4f*>(as + row * BK + (((2 * q + lk) ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt)
+        bf[nt] = *reinterpret_cast<const v4f*>(bs + ((2 * q + lk) * BN + (wn * WN + nt) * 32 + li) * 4);
+    };
+    fetch(0, ac, bc);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      if (q + 1 < BK / 8) fetch(q + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt][t], bc[nt][t], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MW; ++mt) ac[mt] = an[mt];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- epilogue: accumulator row = (r & 3) + 8 (r >> 2) + 4 lk, column li; every load before the first store
+  float bv[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int co = min(n0 + (wn * WN + nt) * 32 + li, g.Cout - 1);
+    bv[nt] = bias ? bias[co] : 0.0f;
+  }
+  long rowbase[MW][16];
+#pragma unroll
+  for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowbase[mt][r] = t_dst[(wm * MW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+  if (g.accumulate) {
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float oldv[8][WN];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            const int co = n0 + (wn * WN + nt) * 32 + li;
+            oldv[r][nt] = (rowbase[mt][r0 + r] >= 0 && co < g.Cout) ? y[rowbase[mt][r0 + r] + co] : 0.0f;
+          }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt][r0 + r] += oldv[r][nt];
+      }
+  }
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) asm volatile("" : "+v"(bv[nt]));
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int co = n0 + (wn * WN + nt) * 32 + li;
+    if (co >= g.Cout) continue;
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rowbase[mt][r] >= 0) {
+          float v = acc[mt][nt][r] + bv[nt];
+          if (g.relu) v = fmaxf(v, 0.0f);
+          y[rowbase[mt][r] + co] = v;
+        }
+      }
+  }
+}
+
+// the layers conv_igemm_kernel takes (SSBEV_IGEMM=0 or tile_hint >= 10 keep conv_gather_kernel): fp32 gathers whose source
+// has a multiple of 32 channels, more than one tap or stride, <= 8 taps per axis, and enough rows to fill tiles
+bool conv_igemm_applicable(const ConvGeom& g) {
+  const char* env = getenv("SSBEV_IGEMM");                        // (read per call: the tests switch it inside one process)
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || g.bf16 || g.hint) return false;
+  if (g.Cin % 32 != 0 || g.Cout % 4 != 0 || g.Cout < 64) return false;
+  if (g.kd > 8 || g.kh > 8 || g.kw > 8) return false;
+  const int taps = g.kd * g.kh * g.kw;
+  if (taps == 1) return false;                                    // pointwise layers: the GEMM family / conv_pw32
+  if (g.form == 0 && g.sd * g.sh * g.sw == 1 && mode != 2)
+    return false;                                                 // stride-1 wide layers: Winograd / tap kernels (2 = probe them too)
+  const long M = (long)g.B * g.Do * g.Ho * g.Wo;
+  return M >= 2048;
+}
+
+template <int WN, int MW, int WGN>
+int launch_igemm_t(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+  constexpr int BM = 32 * MW * (4 / WGN), BN = 32 * WN * WGN;
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  int classes = 1;
+  if (g.form == 1) {
+    classes = g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  const int mblocks = (int)((Mtot + BM - 1) / BM), nblocks = (g.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM * 32 + 32 * BN) * sizeof(float) + (size_t)BM * (2 * sizeof(long) + sizeof(unsigned));
+  auto kern = conv_igemm_kernel<WN, MW, WGN>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * nblocks), 1, classes), dim3(256), lds, st, x, wp, bias, y, g, mblocks, nblocks);
+  return ssbev_launch_status();
+}
+
+int launch_igemm(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  long classes = 1;
+  if (g.form == 1) {
+    classes = (long)g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  // the largest tile that still leaves enough workgroups: 512 for the plain form, 1024 for the parity-class form (its classes walk
+  // 1 .. 8 taps: the heavy ones must fill the chip on their own).  Measured (tools/igemm_probe.py, profiles/r5_igemm_probe.txt):
+  // 64 -> 128 s2 at 23 040 output voxels: 128x128 = 180 workgroups 134 us, 64x64 = 720 workgroups 113 us.
+  const int force = getenv("SSBEV_IGEMM_TILE") ? atoi(getenv("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
+  const bool wide = g.CoutPad % 128 == 0;
+  const long need = g.form == 1 ? 1024 : 512;
+  const int cand[3][2] = {{128, wide ? 128 : 64}, {64, wide ? 128 : 64}, {64, 64}};
+  int bm = 64, bn = 64;
+  for (int i = 0; i < 3; ++i) {
+    const long blocks = ((Mtot + cand[i][0] - 1) / cand[i][0]) * ((g.Cout + cand[i][1] - 1) / cand[i][1]) * classes;
+    if (blocks >= need) { bm = cand[i][0]; bn = cand[i][1]; break; }
+  }
+  if (force) { bm = force / 1000; bn = force % 1000; }
+  if (g.CoutPad % bn != 0) return SSBEV_EINVAL;
+  if (bm == 128 && bn == 128) return launch_igemm_t<2, 2, 2>(x, wp, bias, y, g, st);
+  if (bm == 128 && bn == 64) return launch_igemm_t<1, 2, 2>(x, wp, bias, y, g, st);
+  if (bm == 64 && bn == 128) return launch_igemm_t<2, 1, 2>(x, wp, bias, y, g, st);
+  if (bm == 64 && bn == 64) return launch_igemm_t<1, 1, 2>(x, wp, bias, y, g, st);
+  return SSBEV_EINVAL;
+}
+
 int dispatch_gather(const float* x, const float* wp, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
   if (g.Cin % 4 != 0) return SSBEV_EINVAL;
+  if (conv_igemm_applicable(g)) return launch_igemm(x, wp, bias, y, g, st);
   if (g.hint) return launch_gather_cfg(g.hint / 100, (g.hint / 10) % 10, g.hint % 10, x, wp, bias, y, g, st);
   const long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
   // 48x160 feature maps (7680 pixels = 240 row tiles): <1,5> makes 240 x (Cout/160) waves -- 960 of the chip's 1024

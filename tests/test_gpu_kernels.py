@@ -271,6 +271,67 @@ TAP2_CASES = [
 ]
 
 
+IGEMM_CASES = [   # (B, Cin, Cout, D, H, W, transposed, stride, dilation): the 64 <-> 128 hourglass level, the encoder downsamplers
+    (1, 64, 128, 12, 8, 40, False, 2, 1), (2, 64, 128, 7, 9, 21, False, 2, 1), (1, 128, 64, 6, 4, 20, True, 2, 1),
+    (2, 128, 64, 5, 3, 11, True, 2, 1), (1, 128, 256, 16, 16, 8, False, 2, 1), (1, 256, 512, 8, 8, 4, False, 2, 1),
+    (1, 64, 64, 6, 10, 12, False, 1, 2), (1, 96, 160, 5, 6, 14, False, 2, 1), (1, 64, 72, 4, 6, 10, True, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_conv_igemm_kernel_strided_and_transposed(case, monkeypatch):
+    """conv_igemm_kernel (round 5: LDS-staged implicit GEMM for the stride-2 convolutions / transposed convolutions with >= 64
+    channels that conv_gather_kernel served): forward, data gradient (the opposite gather form), accumulating epilogue through a
+    gradient slot, fused ReLU + bias -- against ATen, and bit for bit against conv_gather_kernel where the two walk the taps in
+    the same order (SSBEV_IGEMM=0)."""
+    B, K, N, D, H, W, tr, st, dil = case
+    pad = dil
+    x = S.hash_normal(f"ig/x{case}", (B, K, D, H, W))
+    bias = S.hash_uniform(f"ig/b{case}", (N,), -0.5, 0.5)
+    go = None
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SSBEV_IGEMM", mode)
+        xg = x.to(DEV).requires_grad_(True)
+        if not tr:
+            w = S.hash_uniform(f"ig/w{case}", (N, K, 3, 3, 3), -1, 1) * (3.0 / (K * 27)) ** 0.5
+            wg = w.to(DEV).requires_grad_(True)
+            got = F.conv3d(xg, wg, bias.to(DEV), st, pad, dil, relu=True)
+        else:
+            w = S.hash_uniform(f"ig/w{case}", (K, N, 3, 3, 3), -1, 1) * (3.0 / (K * 27 / 8)) ** 0.5
+            wg = w.to(DEV).requires_grad_(True)
+            got = torch.relu(F.conv_transpose3d(xg, wg, bias.to(DEV), st, pad, st - 1))
+        if go is None:
+            go = S.hash_normal(f"ig/go{case}", tuple(got.shape))
+        got.backward(go.to(DEV))
+        outs[mode] = (got.detach(), xg.grad.detach(), wg.grad.detach())
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone()
+    want = torch.relu(TF.conv3d(xc, wc, bc, st, pad, dil) if not tr else TF.conv_transpose3d(xc, wc, bc, st, pad, st - 1))
+    want.backward(go)
+    got, gx, gw = outs["1"]
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+    assert maxdiff(gx, xc.grad) < 2e-5 * max(1.0, xc.grad.abs().max().item())
+    assert maxdiff(gw, wc.grad) < 5e-5 * max(1.0, wc.grad.abs().max().item())
+    # same products, same order over (tap, channel) per output element as the gather kernel: identical bits
+    assert torch.equal(got, outs["0"][0]) and torch.equal(gx, outs["0"][1])
+    # accumulating epilogue: the data gradient lands on top of another consumer's gradient (gradient slot)
+    monkeypatch.setenv("SSBEV_IGEMM", "1")
+    if not tr:
+        xa = x.to(DEV).requires_grad_(True)
+        a, b = F.fork(xa)
+        w1 = (S.hash_uniform(f"ig/w1{case}", (K, K, 1, 1, 1), -1, 1) * 0.2).to(DEV)
+        ya, yb = F.conv3d(a, wg.detach(), None, st, pad, dil), F.conv3d(b, w1, None, 1, 0)
+        g1 = S.hash_normal(f"ig/g1{case}", tuple(yb.shape)).to(DEV)
+        torch.autograd.backward([ya, yb], [go.to(DEV), g1])
+        xr = x.clone().requires_grad_(True)
+        (TF.conv3d(xr, w, None, st, pad, dil) * go).sum().backward()
+        r2 = x.clone().requires_grad_(True)
+        (TF.conv3d(r2, w1.cpu(), None, 1, 0) * g1.cpu()).sum().backward()
+        ref = xr.grad + r2.grad
+        assert maxdiff(xa.grad, ref) < 3e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("case", TAP2_CASES)
 def test_conv_stride2_down_tap_kernel(case, monkeypatch):
     """conv_tap2_kernel / conv_tap2up_kernel (round 3): the k3 s2 p1 conv with <= 32 input / 33..64 output channels and the
