@@ -1033,18 +1033,20 @@ conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
   }
 }
 
-// the layers conv_igemm_kernel takes (SSBEV_IGEMM=0 or tile_hint >= 10 keep conv_gather_kernel): fp32 gathers whose source
+// the layers conv_igemm_kernel takes (SSBEV_IGEMM=0 or tile_hint >= 10 keep conv_gather_kernel; the Winograd / tap / thin kernels are
+// chosen before dispatch_gather is reached): fp32 gathers whose source
 // has a multiple of 32 channels, more than one tap or stride, <= 8 taps per axis, and enough rows to fill tiles
 bool conv_igemm_applicable(const ConvGeom& g) {
   const char* env = getenv("SSBEV_IGEMM");                        // (read per call: the tests switch it inside one process)
-  const int mode = env ? atoi(env) : 1;
+  const int mode = env ? atoi(env) : 2;
   if (mode == 0 || g.bf16 || g.hint) return false;
   if (g.Cin % 32 != 0 || g.Cout % 4 != 0 || g.Cout < 64) return false;
   if (g.kd > 8 || g.kh > 8 || g.kw > 8) return false;
   const int taps = g.kd * g.kh * g.kw;
   if (taps == 1) return false;                                    // pointwise layers: the GEMM family / conv_pw32
   if (g.form == 0 && g.sd * g.sh * g.sw == 1 && mode != 2)
-    return false;                                                 // stride-1 wide layers: Winograd / tap kernels (2 = probe them too)
+    return false;                                                 // 1 = strided / transposed forms only; 2 (default) = also the stride-1
+                                                                  // layers no Winograd / tap kernel took (DepthNet's dilated 640 -> 640: -0.25 ms)
   const long M = (long)g.B * g.Do * g.Ho * g.Wo;
   return M >= 2048;
 }
