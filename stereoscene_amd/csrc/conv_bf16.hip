@@ -987,8 +987,296 @@ int launch_gather16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y,
   return ssbev_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged implicit GEMM
+// conv_igemm16_kernel (round 5): conv_igemm_kernel (conv_mfma.hip) for bf16 tensors -- the strided / transposed / dilated /
+// pointwise layers that conv_gather16_kernel served at 4-10 % of the bf16 matrix peak (95-250 TF/s: every lane fetching its
+// voxel's 16 bytes from L1/L2 for each MFMA, one MFMA of work per load).  A workgroup owns a BM x BN tile; a stage = one tap x
+// BKC source channels: the BM gathered rows (BKC bf16 = 128 or 64 bytes each) and the BKC x BN weight block go global -> LDS by
+// global_load_lds_dwordx4, double buffered; both fragments are ONE ds_read_b128 per v_mfma_f32_32x32x16_bf16 (pack16_kernel's
+// [tap][p][lk][n][8] layout is the B fragment layout).  Row table, tap masks, parity classes as in the fp32 kernel.
+template <int WN, int MW, int WGN, int BKC, typename YT>
+__global__ void __launch_bounds__(256, 2)
+conv_igemm16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+                    YT* __restrict__ y, Geom16 g, int mblocks, int nblocks) {
+  constexpr int WGM = 4 / WGN;
+  constexpr int BM = 32 * MW * WGM, BN = 32 * WN * WGN;
+  constexpr int SPR = BKC / 8;                                    // 16-byte units per gathered row
+  constexpr int KPS = BKC / 16;                                   // MFMA k-steps (16 channels) per stage
+  constexpr int AU = BM * SPR, BU = KPS * 2 * BN, SU = AU + BU;   // 16-byte units per stage
+  constexpr int AI = AU / 64, BI = BU / 64;                       // 1 KiB LDS-DMA instructions per stage
+  constexpr int AE = (AI + 3) / 4, BE = (BI + 3) / 4;
+  static_assert(AU % 64 == 0 && BU % 64 == 0, "slabs are whole 1 KiB pieces");
+  extern __shared__ __align__(16) uint4 lds16[];                  // [2][A slab | B slab] | row table
+  long* t_src = reinterpret_cast<long*>(lds16 + 2 * SU);
+  long* t_dst = t_src + BM;
+  unsigned* t_msk = reinterpret_cast<unsigned*>(t_dst + BM);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  auto swz = [](int row) { return SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+  int par_d = 0, par_h = 0, par_w = 0;
+  int Dc = g.Do, Hc = g.Ho, Wc = g.Wo;
+  if (g.form == 1) {
+    int cls = (int)gridDim.z - 1 - (int)blockIdx.z;
+    par_w = cls % g.sw; cls /= g.sw;
+    par_h = cls % g.sh; cls /= g.sh;
+    par_d = cls;
+    Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
+  }
+  const long Mtot = (long)g.B * Dc * Hc * Wc;
+  int mb, nb;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned Lp = base + (L >> 3);
+    nb = (int)(Lp % (unsigned)nblocks);
+    mb = (int)(Lp / (unsigned)nblocks);
+  }
+  const long m0 = (long)mb * BM;
+  const int n0 = nb * BN;
+  if (m0 >= Mtot) return;
+
+  int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
+  if (g.form == 1) {
+    kd0 = (par_d + g.pd) % g.sd; kh0 = (par_h + g.ph) % g.sh; kw0 = (par_w + g.pw) % g.sw;
+    kds = g.sd; khs = g.sh; kws = g.sw;
+  }
+  const int nkd = (g.kd - kd0 + kds - 1) / kds, nkh = (g.kh - kh0 + khs - 1) / khs, nkw = (g.kw - kw0 + kws - 1) / kws;
+  const int ntaps = (kd0 < g.kd && kh0 < g.kh && kw0 < g.kw) ? nkd * nkh * nkw : 0;
+  int step_d, step_h, step_w;
+  if (g.form == 0) { step_d = g.dd; step_h = g.dh; step_w = g.dw; }
+  else { step_d = -(kds * g.dd) / g.sd; step_h = -(khs * g.dh) / g.sh; step_w = -(kws * g.dw) / g.sw; }
+
+  if (tid < BM) {
+    long m = m0 + tid;
+    const bool ok = m < Mtot;
+    if (!ok) m = 0;
+    const int ow = (int)(m % Wc); m /= Wc;
+    const int oh = (int)(m % Hc); m /= Hc;
+    const int od = (int)(m % Dc);
+    const int ob = (int)(m / Dc);
+    int bd, bh, bw;
+    if (g.form == 0) {
+      bd = od * g.sd - g.pd; bh = oh * g.sh - g.ph; bw = ow * g.sw - g.pw;
+    } else {
+      bd = od + (par_d + g.pd - kd0 * g.dd) / g.sd;
+      bh = oh + (par_h + g.ph - kh0 * g.dh) / g.sh;
+      bw = ow + (par_w + g.pw - kw0 * g.dw) / g.sw;
+    }
+    unsigned msk = 0;
+    for (int i = 0; i < nkd && i < 8; ++i) { const int v = bd + i * step_d; msk |= (v >= 0 && v < g.Di) ? (1u << i) : 0u; }
+    for (int i = 0; i < nkh && i < 8; ++i) { const int v = bh + i * step_h; msk |= (v >= 0 && v < g.Hi) ? (1u << (8 + i)) : 0u; }
+    for (int i = 0; i < nkw && i < 8; ++i) { const int v = bw + i * step_w; msk |= (v >= 0 && v < g.Wi) ? (1u << (16 + i)) : 0u; }
+    t_msk[tid] = ok ? msk : 0u;
+    t_src[tid] = ((((long)ob * g.Di + bd) * g.Hi + bh) * g.Wi + bw) * (long)g.Cin;
+    long dst;
+    if (g.form == 0) dst = (((long)ob * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+    else dst = (((long)ob * g.Do + (od * g.sd + par_d)) * g.Ho + (oh * g.sh + par_h)) * g.Wo + (ow * g.sw + par_w);
+    t_dst[tid] = ok ? dst * (long)g.Cout : -1;
+  }
+  __syncthreads();
+
+  const bf16_t* ap[AE]; unsigned am[AE];
+#pragma unroll
+  for (int e = 0; e < AE; ++e) {
+    const int item = (wave + 4 * e) * 64 + lane, row = item / SPR, slot = item % SPR;
+    const bool on = wave + 4 * e < AI;
+    ap[e] = x + (on ? t_src[row] : 0) + ((slot ^ swz(row)) << 3);
+    am[e] = on ? t_msk[row] : 0u;
+  }
+  // B slab: KPS * 2 rows (p, lk) of BN columns x 8 bf16, contiguous per row in the packed weights; piece j covers units [64 j, 64 j + 64)
+  long boff[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    const int j = wave + 4 * e, u = j * 64 + lane;
+    const int r = u / BN, col = u % BN;
+    boff[e] = n0 + col < g.CoutPad ? ((long)r * g.CoutPad + n0 + col) * 8 : -1;      // columns past the padded weights: zeros
+  }
+  const int cq_n = g.Cin / BKC;
+  const int nst = ntaps * cq_n;
+  int i_ia = 0, i_ib = 0, i_ic = 0, i_cq = 0;
+  auto issue = [&](int buf) {
+    const int tap = ((kd0 + i_ia * kds) * g.kh + (kh0 + i_ib * khs)) * g.kw + (kw0 + i_ic * kws);
+    const long toff = (((long)i_ia * step_d * g.Hi + (long)i_ib * step_h) * g.Wi + (long)i_ic * step_w) * g.Cin + i_cq * BKC;
+    const unsigned need = (1u << i_ia) | (1u << (8 + i_ib)) | (1u << (16 + i_ic));
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      if (AI % 4 != 0 && wave + 4 * e >= AI) break;
+      const void* asrc = ((am[e] & need) == need) ? static_cast<const void*>(ap[e] + toff) : static_cast<const void*>(&kZero16);
+      __builtin_amdgcn_global_load_lds(asrc, lds16 + buf * SU + (wave + 4 * e) * 64, 16, 0, 0);
+    }
+    const bf16_t* wb = wp + ((size_t)tap * g.KP + (size_t)i_cq * KPS) * 2 * g.CoutPad * 8;
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      if (BI % 4 != 0 && wave + 4 * e >= BI) break;
+      const void* bsrc = boff[e] >= 0 ? static_cast<const void*>(wb + boff[e]) : static_cast<const void*>(&kZero16);
+      __builtin_amdgcn_global_load_lds(bsrc, lds16 + buf * SU + AU + (wave + 4 * e) * 64, 16, 0, 0);
+    }
+    if (++i_cq == cq_n) {
+      i_cq = 0;
+      if (++i_ic == nkw) { i_ic = 0; if (++i_ib == nkh) { i_ib = 0; ++i_ia; } }
+    }
+  };
+
+  f32x16 acc[MW][WN];
+#pragma unroll
+  for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  if (nst > 0) issue(0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < nst) issue(buf ^ 1);
+    const uint4* as = lds16 + buf * SU;
+    const uint4* bs = as + AU;
+    uint4 ac[MW], bc[WN], an[MW], bn[WN];
+    auto fetch = [&](int ks, uint4 (&a)[MW], uint4 (&bf)[WN]) {
+#pragma unroll
+      for (int mt = 0; mt < MW; ++mt) {
+        const int row = (wm * MW + mt) * 32 + li;
+        a[mt] = as[row * SPR + ((2 * ks + lk) ^ swz(row))];
+      }
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bf[nt] = bs[(2 * ks + lk) * BN + (wn * WN + nt) * 32 + li];
+    };
+    fetch(0, ac, bc);
+#pragma unroll
+    for (int ks = 0; ks < KPS; ++ks) {
+      if (ks + 1 < KPS) fetch(ks + 1, an, bn);
+#pragma unroll
+      for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma16(ac[mt], bc[nt], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < MW; ++mt) ac[mt] = an[mt];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  float bv[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int co = min(n0 + (wn * WN + nt) * 32 + li, g.Cout - 1);
+    bv[nt] = bias ? bias[co] : 0.0f;
+  }
+  long rowbase[MW][16];
+#pragma unroll
+  for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowbase[mt][r] = t_dst[(wm * MW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+  if (g.accumulate) {
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float oldv[8][WN];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            const int co = n0 + (wn * WN + nt) * 32 + li;
+            oldv[r][nt] = (rowbase[mt][r0 + r] >= 0 && co < g.Cout) ? ld1(y + rowbase[mt][r0 + r] + co) : 0.0f;
+          }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt][r0 + r] += oldv[r][nt];
+      }
+  }
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) asm volatile("" : "+v"(bv[nt]));
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int co = n0 + (wn * WN + nt) * 32 + li;
+    if (co >= g.Cout) continue;
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rowbase[mt][r] >= 0) {
+          float v = acc[mt][nt][r] + bv[nt];
+          if (g.relu) v = fmaxf(v, 0.0f);
+          st1(y + rowbase[mt][r] + co, v);
+        }
+      }
+  }
+}
+
+// SSBEV_IGEMM16=0 keeps conv_gather16_kernel everywhere.  Source channels a multiple of 32, >= 64 destination channels, enough rows.
+bool conv_igemm16_applicable(const Geom16& g, int hint) {
+  const char* env = getenv("SSBEV_IGEMM16");
+  if ((env && atoi(env) == 0) || hint) return false;
+  const char* mc = getenv("SSBEV_IGEMM16_MIN_COUT");             // A/B hook: 32 = also the layers with 32 destination channels
+  const int min_cout = mc ? atoi(mc) : 64;
+  if (g.Cin % 32 != 0 || g.Cout < min_cout || g.Cout % 8 != 0) return false;
+  if (g.kd > 8 || g.kh > 8 || g.kw > 8) return false;
+  return (long)g.B * g.Do * g.Ho * g.Wo >= 2048;
+}
+
+template <int WN, int MW, int WGN, int BKC, typename YT>
+int launch_igemm16_t(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st) {
+  constexpr int BM = 32 * MW * (4 / WGN), BN = 32 * WN * WGN;
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  int classes = 1;
+  if (g.form == 1) {
+    classes = g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  const int mblocks = (int)((Mtot + BM - 1) / BM), nblocks = (g.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM * (BKC / 8) + (BKC / 16) * 2 * BN) * 16 + (size_t)BM * (2 * sizeof(long) + sizeof(unsigned));
+  auto kern = conv_igemm16_kernel<WN, MW, WGN, BKC, YT>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSBEV_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * nblocks), 1, classes), dim3(256), lds, st, x, wp, bias, y, g, mblocks, nblocks);
+  return ssbev_launch_status();
+}
+
+template <typename YT>
+int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st) {
+  long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
+  long classes = 1;
+  if (g.form == 1) {
+    classes = (long)g.sd * g.sh * g.sw;
+    Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
+  }
+  const int force = getenv("SSBEV_IGEMM_TILE") ? atoi(getenv("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
+  const bool wide = g.CoutPad % 128 == 0;
+  const long need = g.form == 1 ? 1024 : 512;
+  const int cand[3][2] = {{128, wide ? 128 : 64}, {64, wide ? 128 : 64}, {64, 64}};
+  int bm = 64, bn = 64;
+  for (int i = 0; i < 3; ++i) {
+    const long blocks = ((Mtot + cand[i][0] - 1) / cand[i][0]) * ((g.Cout + cand[i][1] - 1) / cand[i][1]) * classes;
+    if (blocks >= need) { bm = cand[i][0]; bn = cand[i][1]; break; }
+  }
+  if (g.CoutPad == 32) { bm = 256; bn = 32; }          // 32 destination channels: four waves stacked along M, 64 rows each
+  if (force) { bm = force / 1000; bn = force % 1000; }
+  const bool k64 = g.Cin % 64 == 0;
+#define SSBEV_IG16(WN_, MW_) (k64 ? launch_igemm16_t<WN_, MW_, 2, 64, YT>(x, wp, bias, y, g, st) \
+                                  : launch_igemm16_t<WN_, MW_, 2, 32, YT>(x, wp, bias, y, g, st))
+  if (bm == 128 && bn == 128) return SSBEV_IG16(2, 2);
+  if (bm == 128 && bn == 64) return SSBEV_IG16(1, 2);
+  if (bm == 64 && bn == 128) return SSBEV_IG16(2, 1);
+  if (bm == 64 && bn == 64) return SSBEV_IG16(1, 1);
+  if (bm == 256 && bn == 32)
+    return k64 ? launch_igemm16_t<1, 2, 1, 64, YT>(x, wp, bias, y, g, st) : launch_igemm16_t<1, 2, 1, 32, YT>(x, wp, bias, y, g, st);
+  if (bm == 128 && bn == 32)
+    return k64 ? launch_igemm16_t<1, 1, 1, 64, YT>(x, wp, bias, y, g, st) : launch_igemm16_t<1, 1, 1, 32, YT>(x, wp, bias, y, g, st);
+#undef SSBEV_IG16
+  return SSBEV_EINVAL;
+}
+
 template <typename YT>
 int dispatch_gather16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, int hint, hipStream_t st) {
+  if (conv_igemm16_applicable(g, hint)) return launch_igemm16(x, wp, bias, y, g, st);
   int mt, nt;
   if (hint >= 10) { mt = hint / 10; nt = hint % 10; }
   else {

@@ -906,7 +906,7 @@ conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
   for (int e = 0; e < BE; ++e) {
     const int j = wave + 4 * e, f = j * 256 + 4 * lane;
     const int r8 = f / (BN * 4), col = f % (BN * 4);
-    boff[e] = (long)r8 * g.CoutPad * 4 + (long)n0 * 4 + col;
+    boff[e] = n0 + col / 4 < g.CoutPad ? (long)r8 * g.CoutPad * 4 + (long)n0 * 4 + col : -1;     // columns past the padded weights: zeros
   }
   const int cq_n = g.Cin >> 5;                                    // 32-channel stages per tap
   const int nst = ntaps * cq_n;
@@ -926,7 +926,8 @@ conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
       if (BI % 4 != 0 && wave + 4 * e >= BI) break;
-      const float* bsrc = wb + boff[e];       // (a named pointer: with the sum as the builtin's argument hipcc 7.2 drops the HOST stub of the kernel)
+      // (a named pointer: with the sum as the builtin's argument hipcc 7.2 drops the HOST stub of the kernel)
+      const float* bsrc = boff[e] >= 0 ? wb + boff[e] : kGatherZeros;
       __builtin_amdgcn_global_load_lds(bsrc, lds + buf * SF + AF + (wave + 4 * e) * 256, 16, 0, 0);
     }
     if (++i_cq == cq_n) {
@@ -1089,7 +1090,6 @@ int launch_igemm(const float* x, const float* wp, const float* bias, float* y, c
     if (blocks >= need) { bm = cand[i][0]; bn = cand[i][1]; break; }
   }
   if (force) { bm = force / 1000; bn = force % 1000; }
-  if (g.CoutPad % bn != 0) return SSBEV_EINVAL;
   if (bm == 128 && bn == 128) return launch_igemm_t<2, 2, 2>(x, wp, bias, y, g, st);
   if (bm == 128 && bn == 64) return launch_igemm_t<1, 2, 2>(x, wp, bias, y, g, st);
   if (bm == 64 && bn == 128) return launch_igemm_t<2, 1, 2>(x, wp, bias, y, g, st);

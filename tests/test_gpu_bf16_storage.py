@@ -40,6 +40,15 @@ CASES = [
     ("conv3d", 128, 128, (4, 20, 16), 3, 1, 1, 1, 7, False),     # LDS-ring wide kernel forced (four column tiles per wave, ragged rows)
     ("conv3d", 64, 64, (3, 16, 32), 3, 1, 1, 1, 7, False),       # ... two column tiles, two w-tiles
     ("conv3d", 96, 192, (2, 18, 16), 3, 1, 1, 1, 7, False),      # ... three column tiles x two workgroup columns, three channel chunks
+    # round 5: conv_igemm16_kernel (LDS-staged implicit GEMM: >= 2048 output voxels, Cin % 32 == 0, Cout >= 64)
+    ("conv3d", 64, 128, (16, 16, 32), 3, 2, 1, 1, 0, False),     # stride 2, 64-channel stages
+    ("conv3d", 32, 64, (16, 16, 34), 3, 2, 1, 1, 0, False),      # 32-channel stages, ragged rows
+    ("deconv", 128, 64, (8, 8, 16), 3, 2, 1, 1, 0, False),       # transposed: parity classes (grid.z = 8)
+    ("conv3d", 128, 160, (4, 20, 16), 1, 1, 0, 1, 0, False),     # pointwise through the same kernel, Cout = 160
+    ("conv2d", 640, 640, (1, 48, 32), 3, 1, 18, 18, 0, False),   # DepthNet's dilated layer
+    ("deconv", 512, 128, (4, 8, 8), 4, 4, 0, 1, 0, False),       # k == s == 4 (SECONDFPN3D)
+    ("deconv", 64, 32, (8, 8, 16), 3, 2, 1, 1, 0, False),        # 32 destination channels: 256 x 32 tiles (and 32 -> 64 as its data gradient)
+    ("conv3d", 64, 32, (8, 12, 24), 1, 1, 0, 1, 0, False),       # pointwise into 32 channels
 ]
 
 
@@ -191,3 +200,26 @@ def test_dual_norm_and_norm_cat_with_bf16_io():
     assert _err(y16, y32)[0] < 8e-3 and _err(c16, c32)[0] < 8e-3
     for a, b in list(zip(g16, g32)) + list(zip(cg16, cg32)):
         assert _err(a, b)[0] < (8e-3 if a.dtype == torch.bfloat16 else 1e-4)
+
+
+@pytest.mark.parametrize("case", [("conv3d", 64, 128, (16, 16, 32), 2), ("deconv", 128, 64, (8, 8, 16), 2), ("conv3d", 96, 64, (4, 16, 40), 1)])
+def test_conv_igemm16_is_bit_identical_to_the_gather_kernel(case, monkeypatch):
+    """conv_igemm16_kernel accumulates every output element over (tap, channel) in the order conv_gather16_kernel does, in fp32,
+    from the same bf16 products: forward results and data gradients are the same bits (SSBEV_IGEMM16=0 selects the gather)."""
+    kind, Cin, Cout, sp, st = case
+    x = _r16(S.hash_normal(f"ig16/x{case}", (2, Cin) + sp)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    ws = ((Cin, Cout) if kind == "deconv" else (Cout, Cin)) + (3, 3, 3)
+    w = _r16(S.hash_uniform(f"ig16/w{case}", ws, -1, 1) * 0.05).to(DEV)
+    F.set_precision("bf16")
+    try:
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SSBEV_IGEMM16", mode)
+            xg = x.detach().requires_grad_(True)
+            y = F.conv_transpose3d(xg, w, None, st, 1, st - 1) if kind == "deconv" else F.conv3d(xg, w, None, st, 1, 1)
+            go = _r16(S.hash_normal(f"ig16/go{case}", tuple(y.shape))).to(DEV).to(torch.bfloat16)
+            y.backward(go)
+            outs.append((y.detach(), xg.grad.detach()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        F.set_precision("fp32")
