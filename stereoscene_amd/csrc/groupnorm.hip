@@ -743,6 +743,128 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 apply passes with 16-byte lanes (round 5).  With 8-byte lanes (VW = 4) the bf16 passes move half the bytes per load
+// instruction of the fp32 ones and run at 60 / 42 us where fp32 takes 36 / 29 us for the same bytes; round 4's 8-channel lanes
+// were slower still because the per-channel constants doubled (gamma, beta, mean, rstd, two coefficients: 48 registers).  Here the
+// constants are FUSED per channel before the loop -- forward y = a x + b with a = rstd gamma, b = beta - mean a (16 registers);
+// backward gx = A g + B (x - mean) + C with A = gamma rstd, B = -rstd^2 c0, C = -c1 rstd (32) -- so an 8-channel lane carries
+// fewer registers than the 4-channel one did.  The ReLU bit mask keeps its per-quad layout: a lane's two quads are neighbouring
+// bits, so a mask word is the bit-interleave of two half ballots.
+// MEASURED (bf16, two samples, kitti_d192): 73.6 ms per step with these kernels against 72.5 ms with the 8-byte lanes -- half the
+// threads carry the same bytes in flight and three times the unpack / pack / ballot work each; OFF unless SSBEV_GN_APPLY16=1.
+__device__ __forceinline__ unsigned long long spread32(unsigned x) {
+  unsigned long long v = x;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
+
+__global__ void __launch_bounds__(NT)
+gn_apply_fwd16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const bf16_t* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
+                      bf16_t* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total8) {
+  constexpr int VW = 8;
+  const int q = g.C / VW, cpg = g.C / g.G;
+  const long stride = (long)gridDim.x * NT;
+  const bool fixed = stride % q == 0;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * VW, bcur = -1;
+  float sc[VW], sh[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) { sc[k] = 0.f; sh[k] = 0.f; }
+  const long total4 = 2 * total8;
+  for (; i < total8; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) c = (int)(i % q) * VW;
+    if (!fixed || b != bcur) {
+      bcur = b;
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        const int grp = b * g.G + (c + k) / cpg;
+        const float a = rstd[grp] * gamma[c + k];
+        sc[k] = a;
+        sh[k] = beta[c + k] - mean[grp] * a;
+      }
+    }
+    float v[VW], rr[VW];
+    ldn<VW>(x + (size_t)VW * i, v);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) rr[k] = 0.0f;
+    if (res) ldn<VW>(res + (size_t)VW * i, rr);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float o = fmaf(v[k], sc[k], sh[k]) + rr[k];
+      v[k] = g.relu ? fmaxf(o, 0.0f) : o;
+    }
+    if (mask) {
+      // quad Q = 2 i + h of lane-vector i; word (Q / 64) * 4 + k, bit Q % 64: the wave's 64 lanes cover 128 quads = two word sets
+      const long Q0 = 2 * (i - (threadIdx.x & 63));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long b0 = __ballot(v[k] > 0.0f), b1 = __ballot(v[4 + k] > 0.0f);
+        if ((threadIdx.x & 63) == 0) {
+          mask[(Q0 >> 6) * 4 + k] = spread32((unsigned)b0) | (spread32((unsigned)b1) << 1);
+          if (Q0 + 64 < total4) mask[((Q0 >> 6) + 1) * 4 + k] = spread32((unsigned)(b0 >> 32)) | (spread32((unsigned)(b1 >> 32)) << 1);
+        }
+      }
+    }
+    if (g.ldy == g.C) stn<VW>(y + (size_t)VW * i, v);
+    else stn<VW>(y + (i / q) * g.ldy + (i % q) * VW, v);
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+gn_apply_bwd16_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
+                      bf16_t* __restrict__ gx, bf16_t* __restrict__ gres, const unsigned long long* __restrict__ mask, GnGeom g,
+                      long total8) {
+  constexpr int VW = 8;
+  const int q = g.C / VW, cpg = g.C / g.G;
+  const long stride = (long)gridDim.x * NT;
+  const bool fixed = stride % q == 0;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  int c = (int)(i % q) * VW, bcur = -1;
+  float ka[VW], kb[VW], kc[VW], mu[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) { ka[k] = 0.f; kb[k] = 0.f; kc[k] = 0.f; mu[k] = 0.f; }
+  for (; i < total8; i += stride) {
+    const int b = (int)(i / ((long)q * g.S));
+    if (!fixed) c = (int)(i % q) * VW;
+    if (!fixed || b != bcur) {
+      bcur = b;
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        const int grp = b * g.G + (c + k) / cpg;
+        const float rs = rstd[grp];
+        mu[k] = mean[grp];
+        ka[k] = gamma[c + k] * rs;
+        kb[k] = -rs * rs * coef[grp * 2];
+        kc[k] = -coef[grp * 2 + 1] * rs;
+      }
+    }
+    float xs[VW], gs[VW];
+    ldn<VW>(x + (size_t)VW * i, xs);
+    if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, gs);
+    else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
+    if (mask) {
+      const long Q = 2 * i;
+      const unsigned long long* mw = mask + (Q >> 6) * 4;
+      const int sb = (int)(Q & 63);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k & 3] >> (sb + (k >> 2))) & 1ull) ? gs[k] : 0.0f;
+    }
+    float o[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) o[k] = fmaf(ka[k], gs[k], fmaf(kb[k], xs[k] - mu[k], kc[k]));
+    stn<VW>(gx + (size_t)VW * i, o);
+    if (gres) stn<VW>(gres + (size_t)VW * i, gs);
+  }
+}
+
 // grid of the streaming apply kernels: <= 16384 workgroups, and (workgroups * NT) a multiple of the float4 count per
 // voxel q so that every thread keeps its channels for the whole grid-stride loop
 unsigned apply_blocks(long total4, int q) {
@@ -1108,6 +1230,16 @@ static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, co
     const int rc = gn_stats_fwd<T, VW>(x, mean, rstd, g, partial, ext, st);
     if (rc != SSBEV_OK) return rc;
   }
+  if constexpr (VW == 8) {          // bf16 tensors with 16-byte rows: the fused-constant 8-channel apply pass
+    static const bool wide_apply = getenv("SSBEV_GN_APPLY16") && atoi(getenv("SSBEV_GN_APPLY16")) != 0;          // opt-in, see above
+    auto a16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (wide_apply && !g.pre && a16(x) && a16(y) && a16(residual) && g.ldy % 8 == 0) {
+      const long total8 = (long)g.B * g.S * (g.C / 8);
+      hipLaunchKernelGGL(gn_apply_fwd16_kernel, dim3(apply_blocks(total8, g.C / 8)), dim3(NT), 0, st, x, gamma, beta, residual, mean,
+                         rstd, y, d->relu ? mask : nullptr, g, total8);
+      return ssbev_launch_status();
+    }
+  }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
   if (g.pre)
@@ -1211,6 +1343,16 @@ static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned l
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
+  if constexpr (VW == 8) {
+    static const bool wide_apply = getenv("SSBEV_GN_APPLY16") && atoi(getenv("SSBEV_GN_APPLY16")) != 0;
+    auto a16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (wide_apply && !g.pre && (!g.relu || mask) && a16(gy) && a16(x) && a16(gx) && a16(gresidual) && g.ldg % 8 == 0) {
+      const long total8 = (long)g.B * g.S * (g.C / 8);
+      hipLaunchKernelGGL(gn_apply_bwd16_kernel, dim3(apply_blocks(total8, g.C / 8)), dim3(NT), 0, st, gy, x, gamma, mean, rstd, coef, gx,
+                         gresidual, g.relu ? mask : nullptr, g, total8);
+      return ssbev_launch_status();
+    }
+  }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
   if (g.pre)
