@@ -553,7 +553,8 @@ int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
   // 640 x 640], 4 instead of 8 on the BRI energy product: +2 ... +9 % alone on the device, but +1.3 ms per step next to the side
   // stream's kernels, where many small workgroups fill the gaps better (profiles/r5_gemm_cfg_probe.txt).  SSBEV_GEMM_TN_CHUNKS=model
   // selects it.)
-  static const bool model = getenv("SSBEV_GEMM_TN_CHUNKS") && std::string(getenv("SSBEV_GEMM_TN_CHUNKS")) == "model";
+  static const std::string sel = getenv("SSBEV_GEMM_TN_CHUNKS") ? getenv("SSBEV_GEMM_TN_CHUNKS") : "";
+  const bool model = sel == "model" || (sel == "batched" && d->batch >= 8);       // "batched": only the frequency products
   if (!model) return std::min(std::max(1, 1024 / std::max(1, tiles * d->batch)), std::max(1, d->M / 256));
   const int cmax = std::min(16, std::max(1, d->M / 256));
   int best = 1;

@@ -5,9 +5,9 @@ import re
 import sys
 
 FAMILIES = [
-    ("bf16-storage conv fwd+dgrad (conv_gather16_kernel, conv_tap16_kernel, conv_wide16_kernel, pack16 / pack_tap16)", r"conv_gather16|conv_tap16|conv_wide16|pack16_kernel|pack_tap16"),
+    ("bf16-storage conv fwd+dgrad (conv_gather16_kernel, conv_igemm16_kernel, conv_tap16_kernel, conv_wide16_kernel, pack16 / pack_tap16)", r"conv_gather16|conv_igemm16|conv_tap16|conv_wide16|pack16_kernel|pack_tap16"),
     ("bf16-storage weight gradient (wgrad16_kernel, wgrad_ring16_kernel)", r"wgrad16|wgrad_ring16"),
-    ("direct conv fwd+dgrad (conv_gather_kernel, conv_tap_kernel, conv_taph_kernel, conv_tapdh_kernel, conv_tap2_kernel, conv_tap2up_kernel, conv_pw32_kernel, conv_thin*_kernel)", r"conv_gather_kernel|conv_tap_kernel|conv_taph_kernel|conv_tapdh_kernel|conv_tap2_kernel|conv_tap2up_kernel|conv_pw32_kernel|conv_thin"),
+    ("direct conv fwd+dgrad (conv_gather_kernel, conv_igemm_kernel, conv_tap_kernel, conv_taph_kernel, conv_tapdh_kernel, conv_tap2_kernel, conv_tap2up_kernel, conv_pw32_kernel, conv_thin*_kernel)", r"conv_gather_kernel|conv_igemm_kernel|conv_tap_kernel|conv_taph_kernel|conv_tapdh_kernel|conv_tap2_kernel|conv_tap2up_kernel|conv_pw32_kernel|conv_thin"),
     ("own MFMA GEMM family (gemm_nn / gemm_tn / skinny / sum: BRI products, k == s deconvs, pointwise weight gradients)", r"gemm_"),
     ("depth-fused Winograd contraction, own MFMA kernels (wino_df_kernel fwd/dgrad, wino_dfw_kernel wgrad, + pack / sum / reduce)", r"wino_df"),
     ("Winograd transforms (wino*_input/output/output_adjoint/weight*)", r"wino"),
