@@ -901,7 +901,11 @@ OWN_GEMM = os.environ.get("SSBEV_OWN_GEMM", "1") != "0"
 # r3 (one side stream, DepthNet off the critical chain; profiles/r3m_own_gemm_sites.txt, ms/step): deconv,bri 78.85 |
 # + linear 78.92 (now free: default) | + wino 79.48 | all 79.85.  The batched frequency products of the 2-D / weight-streaming
 # Winograd layers stay on the library: 0.6 ms per step is what its tuned kernels are still worth there.
-OWN_GEMM_SITES = set(os.environ.get("SSBEV_OWN_GEMM_SITES", "deconv,bri,linear").split(","))
+# r5: "wino" joins the default -- no Cijk_* frequency product is left on a1-a16.  The price, measured with the
+# r5 tile configurations (128 x 160 tiles on the 640-column products, 128 x 64 on the 512-channel layer; profiles/
+# r5_gemm_cfg_probe.txt): 72.2-72.4 ms per step against 71.4-71.6 with rocBLAS on those 33 launches (own NN 113 vs 122 TF/s, own
+# TN 85 vs 99 TF/s on 16 x [1920 x 640 x 640]).  SSBEV_OWN_GEMM_SITES=deconv,bri,linear restores the library there.
+OWN_GEMM_SITES = set(os.environ.get("SSBEV_OWN_GEMM_SITES", "deconv,bri,linear,wino").split(","))
 
 
 def own_gemm_site(name):
