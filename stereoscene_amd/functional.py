@@ -2272,6 +2272,19 @@ def linear_cl(x, weight, bias=None):
     return from_cl(y.view(*shp[:-1], w2.shape[0]))
 
 
+def small_linear(x2, weight2, bias=None):
+    """nn.functional.linear for the few-row products of the path (camera MLPs, squeeze-excite gates, CA3D's channel MLP:
+    [B, K] x [N, K]^T): on the own GEMM kernels (N a multiple of 4; K is zero-padded to one), so that no rocBLAS kernel is launched
+    for them either."""
+    if (x2.is_cuda and x2.dim() == 2 and own_gemm_site("linear") and x2.dtype == torch.float32
+            and weight2.shape[0] % 4 == 0 and weight2.shape[1] == x2.shape[1]):
+        pad = -x2.shape[1] % 4
+        if pad:                      # (the 27-feature camera vector: zero columns on both operands, 16-byte rows)
+            x2, weight2 = torch.nn.functional.pad(x2, (0, pad)), torch.nn.functional.pad(weight2, (0, pad))
+        return _LinearCL.apply(x2.contiguous(), weight2.contiguous(), bias)
+    return torch.nn.functional.linear(x2, weight2, bias)
+
+
 class _DwConv2d(torch.autograd.Function):
     """Depthwise k x k conv (groups = channels), TF-"same" padding; x logical [B,C,H,W], weight [C,1,k,k]."""
 

@@ -40,7 +40,8 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
-        return self.fc2(torch.relu(self.fc1(x)))
+        h = torch.relu(F.small_linear(x, self.fc1.weight, self.fc1.bias) if x.dim() == 2 else self.fc1(x))
+        return F.small_linear(h, self.fc2.weight, self.fc2.bias) if h.dim() == 2 else self.fc2(h)
 
 
 class SELayer(nn.Module):
@@ -53,8 +54,8 @@ class SELayer(nn.Module):
 
     def forward(self, x, x_se):
         w, b = self.conv_reduce.weight.flatten(1), self.conv_reduce.bias
-        s = torch.relu(TF.linear(x_se.flatten(1), w, b))
-        s = TF.linear(s, self.conv_expand.weight.flatten(1), self.conv_expand.bias)
+        s = torch.relu(F.small_linear(x_se.flatten(1), w, b))
+        s = F.small_linear(s, self.conv_expand.weight.flatten(1), self.conv_expand.bias)
         gate = torch.sigmoid(s)[..., None, None]
         if x.is_cuda and x.dim() == 4 and x.shape[1] % 4 == 0:
             return F.chan_scale(x, gate)          # one streaming pass forward, gate gradient by a two-stage reduction
@@ -419,8 +420,8 @@ class CA3D(nn.Module):
             pool = F.spatial_mean(dpool)
         else:
             pool = data.mean(dim=(2, 3, 4))
-        s = TF.gelu(TF.linear(pool, self.conv2[0].weight.flatten(1), self.conv2[0].bias))
-        s = TF.gelu(TF.linear(s, self.conv2[2].weight.flatten(1), self.conv2[2].bias))
+        s = TF.gelu(F.small_linear(pool, self.conv2[0].weight.flatten(1), self.conv2[0].bias))
+        s = TF.gelu(F.small_linear(s, self.conv2[2].weight.flatten(1), self.conv2[2].bias))
         gate = torch.sigmoid(s)
         if not x.is_cuda:
             y = self.conv(gate[..., None, None, None] * data)
