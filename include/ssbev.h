@@ -196,7 +196,9 @@ size_t ssbev_conv_packed_weight_elems(const ssbev_conv_dims* d);
  * SSBEV_TAPDH=0 or tile_hint 4 keeps class 2); < 0 = error.  The weight gradient of a class-9 problem runs on
  * wgrad_tapdh_kernel (same transform domain; SSBEV_WGRAD_DH=0 or tile_hint 4 / 5 / 6 / 7 keep wgrad_lds_kernel);
  * 10 = conv_pw32_kernel (1x1x1 stride-1 layers with <= 32 channels on both sides: an HBM stream through per-wave LDS tiles;
- * SSBEV_PW32=0 or tile_hint 8 keep the generic gather kernel). */
+ * SSBEV_PW32=0 or tile_hint 8 keep the generic gather kernel); 11 = conv_igemm_kernel (round 5: LDS-staged implicit GEMM for the
+ * strided / transposed / dilated layers whose gather source has a multiple of 32 channels and whose destination has >= 64;
+ * SSBEV_IGEMM=0 or tile_hint >= 10 keep class 0); bf16 storage: 21 = conv_igemm16_kernel (SSBEV_IGEMM16=0 keeps 16). */
 int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode);
 
 /* 32 -> 1 / 2 / 4 channel 3x3x3 stride-1 "same" layers (the 32 -> 1 classifiers of the cost-volume stack,

@@ -1432,7 +1432,8 @@ bool dims_ok(const ssbev_conv_dims* d, int mode) {
 int kernel_class(const ssbev_conv_dims* d, int mode) {
   if (mode == 2) return wg_ring_applicable(d) ? 20 : 18;
   if (wide16_ntl(d, mode)) return 19;
-  return tap16_applicable(d, mode) ? 17 : 16;
+  if (tap16_applicable(d, mode)) return 17;
+  return conv_igemm16_applicable(make_geom(d, mode), d->tile_hint >= 10 ? d->tile_hint : 0) ? 21 : 16;
 }
 
 size_t packed_elems(const ssbev_conv_dims* d) {

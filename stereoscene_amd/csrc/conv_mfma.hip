@@ -4257,6 +4257,18 @@ int ssbev_conv_kernel_class(const ssbev_conv_dims* d, int mode) {
   if (conv_tapdh_applicable(d, mode)) return 9;               // F(2,3) along d and h inside the tap walk
   if (conv_taph_applicable(d, mode)) return 2;
   if (conv_tap_applicable(d, mode)) return 1;
+  {                                                           // the generic gather: conv_igemm_kernel (11) or conv_gather_kernel (0)
+    ConvGeom g;
+    const bool fwd = mode == 0;
+    g.B = d->B; g.Cin = fwd ? d->Cin : d->Cout; g.Cout = fwd ? d->Cout : d->Cin; g.CinPad = pad8(g.Cin); g.CoutPad = pad32(g.Cout);
+    g.Di = fwd ? d->Di : d->Do; g.Hi = fwd ? d->Hi : d->Ho; g.Wi = fwd ? d->Wi : d->Wo;
+    g.Do = fwd ? d->Do : d->Di; g.Ho = fwd ? d->Ho : d->Hi; g.Wo = fwd ? d->Wo : d->Wi;
+    g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+    g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dd; g.dh = d->dh; g.dw = d->dw;
+    g.form = (d->transposed != 0) == fwd ? 1 : 0; g.relu = 0; g.accumulate = 0;
+    g.hint = d->tile_hint >= 10 ? d->tile_hint : 0; g.chunk_taps = 0; g.bf16 = d->precision == 1;
+    if (g.Cin % 4 == 0 && conv_igemm_applicable(g)) return 11;
+  }
   return 0;
 }
 
