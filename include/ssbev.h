@@ -232,6 +232,15 @@ size_t ssbev_conv_bwd_weight_workspace(const ssbev_conv_dims* d);
 int ssbev_conv_bwd_weight(const float* x, const float* gy, float* gw, const ssbev_conv_dims* d,
                           void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
+/* Batched plain products of the bf16 storage mode (round 5): C[b][m][n] = sum_k A[b][m][k] B[b][k][n], A and (out_fp32 = 0) C
+ * bf16 bit patterns, fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- the Winograd frequency products (functional._WinoConv:
+ * torch.bmm / rocBLAS in round 4).  B is fp32 [batch][K][N] (the transformed weights) and is packed once per call by
+ * ssbev_gemm16_pack into ssbev_gemm16_packed_elems 16-bit elements (layout private to the library).  K % 32 == 0, N % 8 == 0. */
+typedef struct { int M, N, K, batch; int out_fp32; } ssbev_gemm16_dims;
+size_t ssbev_gemm16_packed_elems(const ssbev_gemm16_dims* d);
+int ssbev_gemm16_pack(const float* B, uint16_t* packed, const ssbev_gemm16_dims* d, ssbev_stream_t stream);
+int ssbev_gemm16_nn(const uint16_t* A, const uint16_t* packed, void* C, const ssbev_gemm16_dims* d, ssbev_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GroupNorm / BatchNorm(train) over channels-last volumes with fused residual add + ReLU.
  * Replaces the ATen group_norm / batch_norm calls behind build_norm_layer (VT:31,45,69,83,86;

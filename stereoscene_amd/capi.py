@@ -56,6 +56,10 @@ class Norm2Dims(C.Structure):
                 ("eps_b", C.c_float), ("relu", C.c_int), ("a_batch", C.c_int), ("b_batch", C.c_int), ("io_dtype", C.c_int)]
 
 
+class Gemm16Dims(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int), ("out_fp32", C.c_int)]
+
+
 class NormExt(C.Structure):
     _fields_ = [("sync", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
                 ("n", C.c_int64)]
@@ -138,6 +142,9 @@ SIGNATURES = {
     "ssbev_conv_bwd_weight_bf16": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
     "ssbev_conv_bwd_weight_workspace": (C.c_size_t, [C.POINTER(ConvDims)]),
     "ssbev_conv_bwd_weight": (C.c_int, [_P, _P, _P, C.POINTER(ConvDims), _P, C.c_size_t, _P]),
+    "ssbev_gemm16_packed_elems": (C.c_size_t, [C.POINTER(Gemm16Dims)]),
+    "ssbev_gemm16_pack": (C.c_int, [_P, _P, C.POINTER(Gemm16Dims), _P]),
+    "ssbev_gemm16_nn": (C.c_int, [_P, _P, _P, C.POINTER(Gemm16Dims), _P]),
     "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd": (C.c_int, [_P] * 7 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),

@@ -51,6 +51,7 @@ struct Geom16 {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int form;                            // 0 conv gather, 1 transposed gather (parity classes)
   int relu, accumulate;
+  long bsx = 0, bsy = 0, bsw = 0;      // conv_igemm16_kernel as a batched plain GEMM (ssbev_gemm16_nn): element strides of x / y / packed weights per blockIdx.z
 };
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -1037,6 +1038,9 @@ conv_igemm16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
   const long m0 = (long)mb * BM;
   const int n0 = nb * BN;
   if (m0 >= Mtot) return;
+  if (g.form == 0) {                   // batched plain products: blockIdx.z = batch element (strides 0 for a convolution)
+    x += (long)blockIdx.z * g.bsx; y += (long)blockIdx.z * g.bsy; wp += (long)blockIdx.z * g.bsw;
+  }
 
   int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
   if (g.form == 1) {
@@ -1223,10 +1227,10 @@ bool conv_igemm16_applicable(const Geom16& g, int hint) {
 }
 
 template <int WN, int MW, int WGN, int BKC, typename YT>
-int launch_igemm16_t(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st) {
+int launch_igemm16_t(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st, int nbatch = 1) {
   constexpr int BM = 32 * MW * (4 / WGN), BN = 32 * WN * WGN;
   long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
-  int classes = 1;
+  int classes = nbatch;
   if (g.form == 1) {
     classes = g.sd * g.sh * g.sw;
     Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
@@ -1241,9 +1245,9 @@ int launch_igemm16_t(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y
 }
 
 template <typename YT>
-int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st) {
+int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, const Geom16& g, hipStream_t st, int nbatch = 1) {
   long Mtot = (long)g.B * g.Do * g.Ho * g.Wo;
-  long classes = 1;
+  long classes = nbatch;
   if (g.form == 1) {
     classes = (long)g.sd * g.sh * g.sw;
     Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
@@ -1260,16 +1264,16 @@ int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, 
   if (g.CoutPad == 32) { bm = 256; bn = 32; }          // 32 destination channels: four waves stacked along M, 64 rows each
   if (force) { bm = force / 1000; bn = force % 1000; }
   const bool k64 = g.Cin % 64 == 0;
-#define SSBEV_IG16(WN_, MW_) (k64 ? launch_igemm16_t<WN_, MW_, 2, 64, YT>(x, wp, bias, y, g, st) \
-                                  : launch_igemm16_t<WN_, MW_, 2, 32, YT>(x, wp, bias, y, g, st))
+#define SSBEV_IG16(WN_, MW_) (k64 ? launch_igemm16_t<WN_, MW_, 2, 64, YT>(x, wp, bias, y, g, st, nbatch) \
+                                  : launch_igemm16_t<WN_, MW_, 2, 32, YT>(x, wp, bias, y, g, st, nbatch))
   if (bm == 128 && bn == 128) return SSBEV_IG16(2, 2);
   if (bm == 128 && bn == 64) return SSBEV_IG16(1, 2);
   if (bm == 64 && bn == 128) return SSBEV_IG16(2, 1);
   if (bm == 64 && bn == 64) return SSBEV_IG16(1, 1);
   if (bm == 256 && bn == 32)
-    return k64 ? launch_igemm16_t<1, 2, 1, 64, YT>(x, wp, bias, y, g, st) : launch_igemm16_t<1, 2, 1, 32, YT>(x, wp, bias, y, g, st);
+    return k64 ? launch_igemm16_t<1, 2, 1, 64, YT>(x, wp, bias, y, g, st, nbatch) : launch_igemm16_t<1, 2, 1, 32, YT>(x, wp, bias, y, g, st, nbatch);
   if (bm == 128 && bn == 32)
-    return k64 ? launch_igemm16_t<1, 1, 1, 64, YT>(x, wp, bias, y, g, st) : launch_igemm16_t<1, 1, 1, 32, YT>(x, wp, bias, y, g, st);
+    return k64 ? launch_igemm16_t<1, 1, 1, 64, YT>(x, wp, bias, y, g, st, nbatch) : launch_igemm16_t<1, 1, 1, 32, YT>(x, wp, bias, y, g, st, nbatch);
 #undef SSBEV_IG16
   return SSBEV_EINVAL;
 }
@@ -1526,4 +1530,64 @@ int backward_weight(const void* x, const void* gy, float* gw, const ssbev_conv_d
   return ssbev_launch_status();
 }
 
+// ---- batched plain products on conv_igemm16_kernel (the Winograd frequency products of the bf16 storage mode) ----
+__global__ void pack_gemm16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int N, int KP, int NPad, long total) {
+  // dst [batch][p][lk][n][t] = B[batch][k = 16 p + 8 lk + t][n]  (the [tap][p][lk][n][8] layout of pack16_kernel, batch for tap)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long r = i;
+  const int t = (int)(r & 7); r >>= 3;
+  const int n = (int)(r % NPad); r /= NPad;
+  const int lk = (int)(r & 1); r >>= 1;
+  const int p = (int)(r % KP);
+  const long bt = r / KP;
+  const int k = 16 * p + 8 * lk + t;
+  dst[i] = f2bf((k < K && n < N) ? src[(bt * K + k) * N + n] : 0.0f);
+}
+
+bool gemm16_ok(const ssbev_gemm16_dims* d) {
+  return d && d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->K % 32 == 0 && d->N % 8 == 0 && d->batch < 65536 &&
+         (long)d->M < (1L << 31);
+}
+
+size_t gemm16_packed_elems(const ssbev_gemm16_dims* d) {
+  return gemm16_ok(d) ? (size_t)d->batch * (pad16(d->K) / 16) * 2 * pad32(d->N) * 8 : 0;
+}
+
+int gemm16_pack(const float* B, bf16_t* packed, const ssbev_gemm16_dims* d, hipStream_t st) {
+  if (!gemm16_ok(d) || !B || !packed) return SSBEV_EINVAL;
+  const long total = (long)gemm16_packed_elems(d);
+  hipLaunchKernelGGL(pack_gemm16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, B, packed, d->K, d->N, pad16(d->K) / 16, pad32(d->N), total);
+  return ssbev_launch_status();
+}
+
+int gemm16_nn(const bf16_t* A, const bf16_t* packed, void* Cm, const ssbev_gemm16_dims* d, hipStream_t st) {
+  if (!gemm16_ok(d) || !A || !packed || !Cm) return SSBEV_EINVAL;
+  Geom16 g;
+  g.B = 1; g.Cin = d->K; g.Cout = d->N; g.KP = pad16(d->K) / 16; g.CoutPad = pad32(d->N);
+  g.Di = g.Hi = 1; g.Wi = d->M; g.Do = g.Ho = 1; g.Wo = d->M;
+  g.kd = g.kh = g.kw = 1; g.sd = g.sh = g.sw = 1; g.pd = g.ph = g.pw = 0; g.dd = g.dh = g.dw = 1;
+  g.form = 0; g.relu = 0; g.accumulate = 0;
+  g.bsx = (long)d->M * d->K; g.bsy = (long)d->M * d->N; g.bsw = (long)g.KP * 2 * g.CoutPad * 8;
+  return d->out_fp32 ? launch_igemm16(A, packed, nullptr, static_cast<float*>(Cm), g, st, d->batch)
+                     : launch_igemm16(A, packed, nullptr, static_cast<bf16_t*>(Cm), g, st, d->batch);
+}
+
 }  // namespace ssbev_bf16
+
+extern "C" {
+
+// Batched plain products C[b] = A[b] x B[b] with bf16 operands and fp32 accumulation on conv_igemm16_kernel: the Winograd
+// frequency products of the bf16 storage mode (functional._WinoConv: 16 x [1920 x 640 x 640], 64 x [4096 x 256 x 256], ...),
+// which round 4 sent to rocBLAS through torch.bmm.
+size_t ssbev_gemm16_packed_elems(const ssbev_gemm16_dims* d) { return ssbev_bf16::gemm16_packed_elems(d); }
+
+int ssbev_gemm16_pack(const float* B, uint16_t* packed, const ssbev_gemm16_dims* d, ssbev_stream_t stream) {
+  return ssbev_bf16::gemm16_pack(B, packed, d, as_stream(stream));
+}
+
+int ssbev_gemm16_nn(const uint16_t* A, const uint16_t* packed, void* C, const ssbev_gemm16_dims* d, ssbev_stream_t stream) {
+  return ssbev_bf16::gemm16_nn(A, packed, C, d, as_stream(stream));
+}
+
+}  // extern "C"

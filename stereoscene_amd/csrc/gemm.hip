@@ -261,16 +261,18 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
 
 // ---------------------------------------------------------------------------------------------------------------- TN
 // C[b][k][n] = sum_r A[b][r][k] B[b][r][n]; workgroup tile 128 k x (64 WN) n, 32 rows per stage.
-template <int WN>
+// KT = 32-row k tiles per wave, WGN = waves along n (2: 2 x 2 waves of 64 x 32 WN -- rounds 2-4; 1: four waves stacked along k, each
+// 32 KT x 32 WN: the 128 x 160 tile for the 640-column frequency products, see gemm_nn_kernel)
+template <int WN, int KT = 2, int WGN = 2>
 __global__ void __launch_bounds__(256, 2)
 gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, GemmGeom g) {
-  constexpr int BKK = 128, BN = 64 * WN, BR = 32;
+  constexpr int BKK = (4 / WGN) * 32 * KT, BN = WGN * 32 * WN, BR = 32;
   constexpr int AF = BR * BKK, BF = BR * BN, SF = AF + BF;
   constexpr int AI = AF / 256, BI = BF / 256;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
-  const int wk = wave >> 1, wn = wave & 1;
+  const int wk = wave / WGN, wn = wave % WGN;
   int id = xcd_logical(blockIdx.x, gridDim.x);
   const int nb = id % g.nblocks; id /= g.nblocks;
   const int kb = id % g.mblocks; id /= g.mblocks;
@@ -314,9 +316,9 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     }
   };
 
-  gf32x16 acc[2][WN];
+  gf32x16 acc[KT][WN];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
@@ -330,11 +332,11 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_rowoff(st + 2); }
     const float* as = lds + buf * SF;
     const float* bs = as + AF;
-    float ac[2], bc[WN], an[2], bn[WN];
-    auto fetch = [&](int rp, float (&av)[2], float (&bv)[WN]) {
+    float ac[KT], bc[WN], an[KT], bn[WN];
+    auto fetch = [&](int rp, float (&av)[KT], float (&bv)[WN]) {
       const int row = 2 * rp + lk;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) av[kt] = as[row * BKK + (wk * 2 + kt) * 32 + li];
+      for (int kt = 0; kt < KT; ++kt) av[kt] = as[row * BKK + (wk * KT + kt) * 32 + li];
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) bv[nt] = bs[row * BN + (wn * WN + nt) * 32 + li];
     };
@@ -344,12 +346,12 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
       if (rp + 1 < BR / 2) fetch(rp + 1, an, bn);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kt], bc[nt], acc[kt][nt], 0, 0, 0);
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) ac[kt] = an[kt];
+      for (int kt = 0; kt < KT; ++kt) ac[kt] = an[kt];
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) bc[nt] = bn[nt];
     }
@@ -361,11 +363,11 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     // a load inside the bound branches makes hipcc wait vmcnt(0) in front of every store, stores count in vmcnt on gfx9: 64
     // serialised load -> store round trips per lane, 0.46 ms for the BRI softmax-backward product against 0.21 ms plain)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {             // two rounds of 16 x (1 + WN) loads (all 32 rows at once do not fit the registers)
+    for (int kt = 0; kt < KT; ++kt) {             // two rounds of 16 x (1 + WN) loads (all 32 rows at once do not fit the registers)
       float rs[16], em[WN][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int k = min(k0 + (wk * 2 + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, g.K - 1);
+        const int k = min(k0 + (wk * KT + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, g.K - 1);
         rs[r] = g.ep_rowsub[(long)b * g.K + k];
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
@@ -390,10 +392,10 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     const int n = n0 + (wn * WN + nt) * 32 + li;
     if (n >= g.N) continue;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int k = k0 + (wk * 2 + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int k = k0 + (wk * KT + kt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (k < g.K) Cb[(long)k * g.ldc + n] = acc[kt][nt][r];
       }
   }
@@ -545,6 +547,28 @@ int pick_wn(int N, int tap_width = 0) {
   const int pad2 = (N + 127) / 128 * 128 - N, pad1 = (N + 63) / 64 * 64 - N;
   if (tap_width && tap_width % 128 != 0) return 1;          // d2s: a column block stays inside one tap
   return pad2 <= pad1 ? 2 : 1;
+}
+
+// the chunk count that minimises the rows the busiest CU walks plus the partial-sum pass (see tn_chunks)
+int tn_chunks_model(const ssbev_gemm_dims* d, int tiles) {
+  const int cmax = std::min(16, std::max(1, d->M / 256));
+  int best = 1;
+  double best_cost = 1e300;
+  for (int c = 1; c <= cmax; ++c) {
+    const long per_cu = std::max(2L, ((long)tiles * d->batch * c + 255) / 256);      // (a CU needs two workgroups to run at full rate)
+    const double rows = (double)((d->M + c - 1) / c) + 64.0;
+    const double cost = per_cu * rows + (c > 1 ? 12.0 * (c + 1) : 0.0);        // (the sum pass reads c and writes 1 result-sized buffers)
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+// round 5: 128 x 160 tiles (four waves stacked along k) + the chunk model for the batched frequency products whose column count is
+// a multiple of 160 (16 x [1920 rows -> 640 x 640]: 320 tiles x 4 chunks = 5.0 per CU instead of 400 x 2 = 3.1 -> 4 rounds of
+// twice the rows); SSBEV_GEMM_TN_WIDE=0 keeps the 128 x 128 tiles
+bool tn_wide(const ssbev_gemm_dims* d) {
+  static const bool enabled = !(getenv("SSBEV_GEMM_TN_WIDE") && atoi(getenv("SSBEV_GEMM_TN_WIDE")) == 0);
+  return enabled && d->batch >= 8 && d->N % 160 == 0 && d->d2s_kd == 0 && !d->ep_mul;
 }
 
 int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
@@ -762,8 +786,9 @@ size_t ssbev_gemm_tn_workspace(const ssbev_gemm_dims* d) {
   if (!gemm_ok(d)) return 0;
   if (tn_skinny(d)) return (size_t)tn_skinny_wgs(d) * d->batch * d->K * d->N * sizeof(float);
   const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
-  const int tiles = ((d->K + 127) / 128) * ((d->N + 64 * wn - 1) / (64 * wn));
-  const int nchunk = tn_chunks(d, tiles);
+  const bool wide = tn_wide(d);
+  const int tiles = ((d->K + 127) / 128) * (wide ? (d->N + 159) / 160 : (d->N + 64 * wn - 1) / (64 * wn));
+  const int nchunk = d->ep_mul ? 1 : (wide ? tn_chunks_model(d, tiles) : tn_chunks(d, tiles));
   return nchunk > 1 ? (size_t)nchunk * d->batch * d->K * d->N * sizeof(float) : 0;
 }
 
@@ -800,17 +825,24 @@ int ssbev_gemm_tn(const float* A, const float* B, float* Cm, const ssbev_gemm_di
     return ssbev_launch_status();
   }
   const int wn = pick_wn(d->N, d->d2s_kd > 0 ? d->d2s_Co : 0);
-  const int BN = 64 * wn;
+  const bool wide = tn_wide(d);
+  const int BN = wide ? 160 : 64 * wn;
   g.mblocks = (d->K + 127) / 128;
   g.nblocks = (d->N + BN - 1) / BN;
-  g.nchunk = d->ep_mul ? 1 : tn_chunks(d, g.mblocks * g.nblocks);      // the fused epilogue needs the complete row reduction
+  g.nchunk = d->ep_mul ? 1 : (wide ? tn_chunks_model(d, g.mblocks * g.nblocks) : tn_chunks(d, g.mblocks * g.nblocks));      // the fused epilogue needs the complete row reduction
   g.rows_per_chunk = ((d->M + g.nchunk - 1) / g.nchunk + 31) / 32 * 32;
   if (g.nchunk > 1 && (!ws || ws_bytes < ssbev_gemm_tn_workspace(d))) return SSBEV_EWORKSPACE;
   float* dst = g.nchunk > 1 ? static_cast<float*>(ws) : Cm;
   const long nwg = (long)g.batch * g.nchunk * g.mblocks * g.nblocks;
   const size_t lds = (size_t)2 * (32 * 128 + 32 * BN) * sizeof(float);       // 64 / 48 KiB
   hipStream_t st = as_stream(stream);
-  if (wn == 2) {
+  if (wide) {
+    auto kern = gemm_tn_kernel<5, 1, 1>;
+    const size_t ldsw = (size_t)2 * (32 * 128 + 32 * 160) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess)
+      return SSBEV_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), ldsw, st, A, B, dst, g);
+  } else if (wn == 2) {
     auto kern = gemm_tn_kernel<2>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SSBEV_ELAUNCH;

@@ -1269,6 +1269,38 @@ WINO_DEPTH_FUSED = os.environ.get("SSBEV_WINO_DEPTH_FUSED", "0") != "0"
 WINO_OWN_GEMM = os.environ.get("SSBEV_WINO_OWN_GEMM", "0") != "0"
 
 
+def gemm16_nn(a16, b32, out_fp32=False, tag=None):
+    """C[b] = A[b] @ B[b]: a16 [Bt, M, K] bf16, b32 [Bt, K, N] fp32 (rounded to bf16 while it is packed) -> [Bt, M, N] bf16 / fp32,
+    fp32 accumulation on conv_igemm16_kernel (csrc/conv_bf16.hip).  None when the shapes do not fit (K % 32, N % 8)."""
+    lib = capi.load()
+    Bt, M, K = a16.shape
+    N = b32.shape[2]
+    d = capi.Gemm16Dims(M, N, K, Bt, int(out_fp32))
+    n = lib.ssbev_gemm16_packed_elems(C.byref(d))
+    if n == 0 or a16.dtype != torch.bfloat16 or b32.dtype != torch.float32 or tuple(b32.shape[:2]) != (Bt, K):
+        return None
+    a16, b32 = a16.contiguous(), b32.contiguous()
+    packed = torch.empty(n, dtype=torch.int16, device=a16.device)
+    out = torch.empty(Bt, M, N, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=a16.device)
+    with _span("gemm16", 2.0 * Bt * M * K * N, 2.0 * (a16.numel() + out.numel()) + 4.0 * b32.numel(), tag or f"gemm16 {Bt}x[{M}x{K}x{N}]"):
+        capi.check(lib.ssbev_gemm16_pack(capi.ptr(b32), capi.ptr(packed), C.byref(d), capi.stream()), "ssbev_gemm16_pack")
+        capi.check(lib.ssbev_gemm16_nn(capi.ptr(a16), capi.ptr(packed), capi.ptr(out), C.byref(d), capi.stream()), "ssbev_gemm16_nn")
+    return out
+
+
+# bf16 storage mode: the Winograd frequency products on the own bf16 kernel instead of torch.bmm / rocBLAS (0 = library)
+GEMM16_OWN = os.environ.get("SSBEV_GEMM16_OWN", "1") != "0"
+
+
+def _bmm16(V, U):
+    """V [nf, T, K] bf16 x U [nf, K, N] fp32 -> bf16 [nf, T, N]"""
+    if GEMM16_OWN and V.is_cuda:
+        M = gemm16_nn(V, U, tag=f"wino16 gemm {V.shape[0]}x[{V.shape[1]}x{V.shape[2]}x{U.shape[2]}]")
+        if M is not None:
+            return M
+    return torch.bmm(V, U.to(torch.bfloat16))
+
+
 def _wino_bgemm(V, w, Cout, Cin, mode):
     """M[xi] = V[xi] @ U[xi] for the 64 frequencies on the LDS-streaming MFMA kernel (mode 0 forward, 1 data gradient)."""
     lib = capi.load()
@@ -1494,7 +1526,7 @@ class _WinoConv(torch.autograd.Function):
             elif bf:
                 sfx = "_bf16a" if a16 else "_bf16"
                 V = _wino_call(pre + "input_transform" + sfx, xcl, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin), torch.bfloat16)
-                M = torch.bmm(V, U.to(torch.bfloat16))
+                M = _bmm16(V, U)
                 y = _wino_call(pre + "output_transform" + sfx, M, capi.WinoDims(B, D, H, W, Cout), (B, D, H, W, Cout),
                                torch.bfloat16 if a16 else torch.float32)
             else:
@@ -1530,7 +1562,7 @@ class _WinoConv(torch.autograd.Function):
             with _span("conv_winograd", fl, nby, f"wino{vtag} dgrad {Cin}->{Cout} {D}x{H}x{W}", fl / red):
                 Vg = _wino_call(pre + "input_transform" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
                 Mx = _wino_bgemm(Vg, w, Cout, Cin, 1) if (three_d and WINO_OWN_GEMM and not bf and not f43) \
-                    else (torch.bmm(Vg, Ut.to(fdt)) if (bf or not own_gemm_site("wino")) else gemm_nn(Vg, Ut, tag="wino dgrad gemm"))
+                    else ((_bmm16(Vg, Ut) if fdt == torch.bfloat16 else torch.bmm(Vg, Ut.to(fdt))) if (bf or not own_gemm_site("wino")) else gemm_nn(Vg, Ut, tag="wino dgrad gemm"))
                 del Vg
                 acc_fn = {"ssbev_wino2d_": "ssbev_wino2d_output_transform_acc",
                           "ssbev_wino43_2d_": "ssbev_wino43_2d_output_transform_acc"}.get(pre) if not bf else None

@@ -223,3 +223,21 @@ def test_conv_igemm16_is_bit_identical_to_the_gather_kernel(case, monkeypatch):
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     finally:
         F.set_precision("fp32")
+
+
+@pytest.mark.parametrize("shape", [(16, 1920, 640, 640), (64, 360, 256, 256), (3, 100, 96, 40), (36, 130, 128, 192)])
+def test_gemm16_batched_products_vs_fp32_reference(shape):
+    """ssbev_gemm16_nn (conv_igemm16_kernel as a batched plain GEMM: the Winograd frequency products of the bf16 mode): bf16 x bf16
+    products accumulated in fp32 against torch.bmm in fp32 on the same rounded operands; bf16 and fp32 results; ragged M / N."""
+    Bt, M, K, N = shape
+    a = _r16(S.hash_normal(f"g16/a{shape}", (Bt, M, K)))
+    b = S.hash_normal(f"g16/b{shape}", (Bt, K, N)) * (1.0 / K) ** 0.5
+    want = torch.bmm(a, _r16(b))
+    a16 = a.to(DEV).to(torch.bfloat16)
+    got32 = F.gemm16_nn(a16, b.to(DEV), out_fp32=True)
+    got16 = F.gemm16_nn(a16, b.to(DEV))
+    assert got32 is not None and got32.dtype == torch.float32 and got16.dtype == torch.bfloat16
+    rel_max, rel_l2 = _err(got32, want)
+    assert rel_max < 2e-5 and rel_l2 < 1e-5, (rel_max, rel_l2)
+    rel_max, rel_l2 = _err(got16, want)
+    assert rel_max < 6e-3 and rel_l2 < 3e-3, (rel_max, rel_l2)       # one bf16 rounding of the result
