@@ -240,6 +240,12 @@ typedef struct { int M, N, K, batch; int out_fp32; } ssbev_gemm16_dims;
 size_t ssbev_gemm16_packed_elems(const ssbev_gemm16_dims* d);
 int ssbev_gemm16_pack(const float* B, uint16_t* packed, const ssbev_gemm16_dims* d, ssbev_stream_t stream);
 int ssbev_gemm16_nn(const uint16_t* A, const uint16_t* packed, void* C, const ssbev_gemm16_dims* d, ssbev_stream_t stream);
+/* C[b] = A[b]^T x B[b] over the row axis: A [batch][M][K], B [batch][M][N] (bf16, row-major) -> C [batch][K][N] fp32 -- the weight-
+ * gradient frequency products (reference: the F.conv2d / F.conv3d weight gradients of the same layers).  K % 8 == 0, N % 8 == 0.
+ * workspace: ssbev_gemm16_tn_workspace(d) floats, caller-owned (0 when the output tiles alone fill the chip; fixed-order sums). */
+size_t ssbev_gemm16_tn_workspace(const ssbev_gemm16_dims* d);
+int ssbev_gemm16_tn(const uint16_t* A, const uint16_t* B, float* C, const ssbev_gemm16_dims* d, float* workspace,
+                    size_t workspace_elems, ssbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm / BatchNorm(train) over channels-last volumes with fused residual add + ReLU.

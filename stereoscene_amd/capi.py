@@ -145,6 +145,8 @@ SIGNATURES = {
     "ssbev_gemm16_packed_elems": (C.c_size_t, [C.POINTER(Gemm16Dims)]),
     "ssbev_gemm16_pack": (C.c_int, [_P, _P, C.POINTER(Gemm16Dims), _P]),
     "ssbev_gemm16_nn": (C.c_int, [_P, _P, _P, C.POINTER(Gemm16Dims), _P]),
+    "ssbev_gemm16_tn_workspace": (C.c_size_t, [C.POINTER(Gemm16Dims)]),
+    "ssbev_gemm16_tn": (C.c_int, [_P, _P, _P, C.POINTER(Gemm16Dims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_workspace": (C.c_size_t, [C.POINTER(NormDims)]),
     "ssbev_groupnorm_fwd": (C.c_int, [_P] * 7 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),
     "ssbev_groupnorm_bwd": (C.c_int, [_P] * 10 + [C.POINTER(NormDims), _P, C.c_size_t, _P]),

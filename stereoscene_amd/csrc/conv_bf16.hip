@@ -1026,20 +1026,21 @@ conv_igemm16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
     Dc = (g.Do - par_d + g.sd - 1) / g.sd; Hc = (g.Ho - par_h + g.sh - 1) / g.sh; Wc = (g.Wo - par_w + g.sw - 1) / g.sw;
   }
   const long Mtot = (long)g.B * Dc * Hc * Wc;
-  int mb, nb;
+  int mb, nb, bt;
   {
     const unsigned n = gridDim.x, L = blockIdx.x;
     const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const unsigned Lp = base + (L >> 3);
-    nb = (int)(Lp % (unsigned)nblocks);
-    mb = (int)(Lp / (unsigned)nblocks);
+    unsigned Lp = base + (L >> 3);
+    nb = (int)(Lp % (unsigned)nblocks); Lp /= (unsigned)nblocks;
+    mb = (int)(Lp % (unsigned)mblocks);
+    bt = (int)(Lp / (unsigned)mblocks);
   }
   const long m0 = (long)mb * BM;
   const int n0 = nb * BN;
   if (m0 >= Mtot) return;
-  if (g.form == 0) {                   // batched plain products: blockIdx.z = batch element (strides 0 for a convolution)
-    x += (long)blockIdx.z * g.bsx; y += (long)blockIdx.z * g.bsy; wp += (long)blockIdx.z * g.bsw;
+  if (g.form == 0) {                   // batched plain products: the batch element is part of the 1-D XCD-aware order, so that the
+    x += (long)bt * g.bsx; y += (long)bt * g.bsy; wp += (long)bt * g.bsw;   // tiles of one element meet in one L2 (bt = 0 for a convolution)
   }
 
   int kd0 = 0, kh0 = 0, kw0 = 0, kds = 1, khs = 1, kws = 1;
@@ -1240,7 +1241,10 @@ int launch_igemm16_t(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y
   auto kern = conv_igemm16_kernel<WN, MW, WGN, BKC, YT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SSBEV_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * nblocks), 1, classes), dim3(256), lds, st, x, wp, bias, y, g, mblocks, nblocks);
+  if (g.form == 0)
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * nblocks * classes)), dim3(256), lds, st, x, wp, bias, y, g, mblocks, nblocks);
+  else
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * nblocks), 1, classes), dim3(256), lds, st, x, wp, bias, y, g, mblocks, nblocks);
   return ssbev_launch_status();
 }
 
@@ -1263,7 +1267,8 @@ int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, 
   }
   if (g.CoutPad == 32) { bm = 256; bn = 32; }          // 32 destination channels: four waves stacked along M, 64 rows each
   if (force) { bm = force / 1000; bn = force % 1000; }
-  const bool k64 = g.Cin % 64 == 0;
+  static const int bkc_force = getenv("SSBEV_IGEMM16_BKC") ? atoi(getenv("SSBEV_IGEMM16_BKC")) : 0;    // probing: 32 = 32-channel stages
+  const bool k64 = g.Cin % 64 == 0 && bkc_force != 32;
 #define SSBEV_IG16(WN_, MW_) (k64 ? launch_igemm16_t<WN_, MW_, 2, 64, YT>(x, wp, bias, y, g, st, nbatch) \
                                   : launch_igemm16_t<WN_, MW_, 2, 32, YT>(x, wp, bias, y, g, st, nbatch))
   if (bm == 128 && bn == 128) return SSBEV_IG16(2, 2);
@@ -1573,6 +1578,166 @@ int gemm16_nn(const bf16_t* A, const bf16_t* packed, void* Cm, const ssbev_gemm1
                      : launch_igemm16(A, packed, nullptr, static_cast<bf16_t*>(Cm), g, st, d->batch);
 }
 
+
+// ---- batched TN products C[b][k][n] = sum_m A[b][m][k] * B[b][m][n]: the Winograd WEIGHT-GRADIENT frequency products ----
+// Both operands are row-major over the reduced axis m (the tile axis of the transformed activations / output gradients), so the
+// MFMA operands (8 consecutive m of one channel per lane) are k-strided in memory: the stage goes global -> LDS as lane-linear
+// 1 KiB [16 m][32 channels] pieces (global_load_lds_dwordx4, the wgrad16_kernel tile) and every operand is one pair of
+// ds_read_b64_tr_b16 -- the hardware transposes.  Workgroup = 128 (k) x 128 (n) output tile, 2 x 2 waves of 64 x 64; stage = 32
+// rows of m (two MFMA k-steps), double buffered (2 x 16 KiB).  Waves 0/1 stage the two m-halves of A, waves 2/3 those of B.
+// blockIdx.y = slice of the m axis (fixed-order partial sums through the workspace when the output tiles alone do not fill the
+// chip), blockIdx.z = batch element.
+template <int NBUF>
+__global__ void __launch_bounds__(256, 2)
+gemm16_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ Cm, int M, int K, int N,
+                 int chunk, int ktiles, int ntiles, int nslices, long split_stride) {
+  extern __shared__ __align__(16) uint4 tl16[];                    // [2][A: 8 pieces | B: 8 pieces] of 64 uint4
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8, so XCD x takes the x-th CONTIGUOUS eighth of the logical order
+  // [batch][slice][tile] -- the tiles of one batch element (which share its A / B panels) meet in one L2.
+  int kt, nt, slice, bt;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    unsigned Lp = base + (L >> 3);
+    const unsigned tiles = (unsigned)(ktiles * ntiles);
+    const unsigned t = Lp % tiles; Lp /= tiles;
+    slice = (int)(Lp % (unsigned)nslices);
+    bt = (int)(Lp / (unsigned)nslices);
+    kt = (int)(t / (unsigned)ntiles); nt = (int)(t % (unsigned)ntiles);
+  }
+  const long m_begin = (long)slice * chunk;
+  const long m_end = min((long)M, m_begin + chunk);
+  A += (size_t)bt * M * K;
+  Bm += (size_t)bt * M * N;
+  // staging role
+  const int is_b = wave >> 1, mh = wave & 1;
+  const bf16_t* src = is_b ? Bm : A;
+  const int ld = is_b ? N : K;
+  const int c0 = (is_b ? nt : kt) * 128 + (lane & 3) * 8;
+  const int jrow = mh * 16 + (lane >> 2);
+  auto issue = [&](int buf, long m0) {
+    const long m = m0 + jrow;
+    const bool mok = m < m_end;
+    const bf16_t* rowp = src + (size_t)(mok ? m : 0) * ld;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = c0 + e * 32;
+      const void* s = (mok && ch < ld) ? static_cast<const void*>(rowp + ch) : static_cast<const void*>(&kZero16);
+      __builtin_amdgcn_global_load_lds(s, tl16 + buf * 1024 + is_b * 512 + (mh * 4 + e) * 64, 16, 0, 0);
+    }
+  };
+  const int wk = wave >> 1, wn = wave & 1;
+  const int trbase = (8 * lk + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nst = (int)((m_end - m_begin + 31) / 32);
+  // NBUF stages in LDS, NBUF - 1 in flight: a stage is 8 MFMAs per wave (256 cycles), far less than one L2 / HBM round trip
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p)
+    if (p < nst) issue(p, m_begin + (long)p * 32);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st % NBUF;
+    const int ahead = min(nst - 1 - st, NBUF - 2);                 // younger stages that may stay in flight (4 loads each)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + NBUF - 1 < nst) issue((st + NBUF - 1) % NBUF, m_begin + (long)(st + NBUF - 1) * 32);
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(tl16 + buf * 1024);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = tr_operand(base + (h * 4 + 2 * wk + i) * 1024, trbase);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = tr_operand(base + 8192 + (h * 4 + 2 * wn + j) * 1024, trbase);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  float* dst = Cm + (size_t)slice * split_stride + (size_t)bt * K * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = nt * 128 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = kt * 128 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < K && col < N) dst[(size_t)row * N + col] = acc[i][j][r];
+      }
+    }
+}
+
+typedef float g16_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+gemm16_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits, long total4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const g16_f4* p = reinterpret_cast<const g16_f4*>(ws) + i;
+  g16_f4 s = p[0];
+  for (int c = 1; c < splits; ++c) s += p[(size_t)c * total4];          // fixed order: deterministic
+  reinterpret_cast<g16_f4*>(out)[i] = s;
+}
+
+bool gemm16_tn_ok(const ssbev_gemm16_dims* d) {
+  return d && d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->K % 8 == 0 && d->N % 8 == 0 && d->batch < 65536 &&
+         (long)d->M < (1L << 31);
+}
+
+// slices of the m axis: enough workgroups for two per CU, never thinner than 256 rows
+static int gemm16_tn_splits(const ssbev_gemm16_dims* d) {
+  static const int forced = getenv("SSBEV_GEMM16_TN_SPLITS") ? atoi(getenv("SSBEV_GEMM16_TN_SPLITS")) : 0;
+  const long tiles = (long)cdiv(d->K, 128) * cdiv(d->N, 128) * d->batch;
+  long s = forced > 0 ? forced : cdiv(512, tiles);
+  s = std::min<long>(s, std::max<long>(1, d->M / 256));
+  return (int)std::max<long>(1, std::min<long>(s, 64));
+}
+
+size_t gemm16_tn_workspace(const ssbev_gemm16_dims* d) {
+  if (!gemm16_tn_ok(d)) return 0;
+  const int s = gemm16_tn_splits(d);
+  return s > 1 ? (size_t)s * d->batch * d->K * d->N : 0;
+}
+
+int gemm16_tn(const bf16_t* A, const bf16_t* Bm, float* Cm, const ssbev_gemm16_dims* d, float* ws, size_t ws_elems, hipStream_t st) {
+  if (!gemm16_tn_ok(d) || !A || !Bm || !Cm) return SSBEV_EINVAL;
+  const int splits = gemm16_tn_splits(d);
+  const size_t total = (size_t)d->batch * d->K * d->N;
+  if (splits > 1 && (!ws || ws_elems < (size_t)splits * total)) return SSBEV_EINVAL;
+  int chunk = cdiv(cdiv(d->M, splits), 32) * 32;
+  const int ntiles = cdiv(d->N, 128);
+  const int ktiles = cdiv(d->K, 128), nsl = cdiv(d->M, chunk);
+  const long blocks = (long)ktiles * ntiles * nsl * d->batch;
+  if (blocks >= (1L << 31)) return SSBEV_EINVAL;
+  dim3 grid((unsigned)blocks);
+  static const int nbuf = getenv("SSBEV_GEMM16_TN_NBUF") ? atoi(getenv("SSBEV_GEMM16_TN_NBUF")) : 2;
+  float* out = nsl > 1 ? ws : Cm;
+  if (nbuf == 4)
+    hipLaunchKernelGGL(gemm16_tn_kernel<4>, grid, dim3(256), 4 * 16384, st, A, Bm, out, d->M, d->K, d->N, chunk, ktiles, ntiles, nsl, (long)total);
+  else if (nbuf == 3)
+    hipLaunchKernelGGL(gemm16_tn_kernel<3>, grid, dim3(256), 3 * 16384, st, A, Bm, out, d->M, d->K, d->N, chunk, ktiles, ntiles, nsl, (long)total);
+  else
+    hipLaunchKernelGGL(gemm16_tn_kernel<2>, grid, dim3(256), 2 * 16384, st, A, Bm, out, d->M, d->K, d->N, chunk, ktiles, ntiles, nsl, (long)total);
+  int rc = ssbev_launch_status();
+  if (rc != SSBEV_OK || nsl == 1) return rc;
+  hipLaunchKernelGGL(gemm16_sum_kernel, dim3((unsigned)cdiv((long)(total / 4), 256)), dim3(256), 0, st, ws, Cm, nsl, (long)(total / 4));
+  return ssbev_launch_status();
+}
+
 }  // namespace ssbev_bf16
 
 extern "C" {
@@ -1588,6 +1753,15 @@ int ssbev_gemm16_pack(const float* B, uint16_t* packed, const ssbev_gemm16_dims*
 
 int ssbev_gemm16_nn(const uint16_t* A, const uint16_t* packed, void* C, const ssbev_gemm16_dims* d, ssbev_stream_t stream) {
   return ssbev_bf16::gemm16_nn(A, packed, C, d, as_stream(stream));
+}
+
+// C[b] = A[b]^T x B[b] over the row axis (A [batch][M][K], B [batch][M][N] bf16 -> C [batch][K][N] fp32): the Winograd weight-
+// gradient frequency products of the bf16 storage mode on gemm16_tn_kernel (round 4: torch.bmm(out_dtype=fp32) = rocBLAS).
+size_t ssbev_gemm16_tn_workspace(const ssbev_gemm16_dims* d) { return ssbev_bf16::gemm16_tn_workspace(d); }
+
+int ssbev_gemm16_tn(const uint16_t* A, const uint16_t* B, float* C, const ssbev_gemm16_dims* d, float* workspace,
+                    size_t workspace_elems, ssbev_stream_t stream) {
+  return ssbev_bf16::gemm16_tn(A, B, C, d, workspace, workspace_elems, as_stream(stream));
 }
 
 }  // extern "C"

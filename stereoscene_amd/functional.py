@@ -833,7 +833,7 @@ def _wino_wgrad_bf16(xcl, gcl, weight):
     T = B * (D // 2) * (H // 2) * (W // 2)
     V = _wino_call("ssbev_wino_input_transform_bf16a", xcl, capi.WinoDims(B, D, H, W, Cin), (64, T, Cin), torch.bfloat16)
     Z = _wino_call("ssbev_wino_output_adjoint_bf16a", gcl, capi.WinoDims(B, D, H, W, Cout), (64, T, Cout), torch.bfloat16)
-    gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32)
+    gU = _bmm16_tn(V, Z)
     gwt = torch.empty(tuple(weight.shape), dtype=torch.float32, device=xcl.device)
     capi.check(lib.ssbev_wino_weight_grad(capi.ptr(gU), capi.ptr(gwt), Cout, Cin, 3, capi.stream()), "ssbev_wino_weight_grad")
     return gwt
@@ -1301,6 +1301,34 @@ def _bmm16(V, U):
     return torch.bmm(V, U.to(torch.bfloat16))
 
 
+def gemm16_tn(a16, b16, tag=None):
+    """C[b] = A[b]^T @ B[b] over the row axis: a16 [Bt, M, K], b16 [Bt, M, N] bf16 -> [Bt, K, N] fp32 on gemm16_tn_kernel
+    (csrc/conv_bf16.hip: LDS-DMA staging + ds_read_b64_tr_b16 operands).  None when the shapes do not fit (K % 8, N % 8)."""
+    lib = capi.load()
+    Bt, M, K = a16.shape
+    N = b16.shape[2]
+    d = capi.Gemm16Dims(M, N, K, Bt, 1)
+    if (K % 8 or N % 8 or a16.dtype != torch.bfloat16 or b16.dtype != torch.bfloat16 or tuple(b16.shape[:2]) != (Bt, M)
+            or Bt >= 65536):
+        return None
+    a16, b16 = a16.contiguous(), b16.contiguous()
+    out = torch.empty(Bt, K, N, dtype=torch.float32, device=a16.device)
+    ws = torch.empty(max(int(lib.ssbev_gemm16_tn_workspace(C.byref(d))), 4), dtype=torch.float32, device=a16.device)
+    with _span("gemm16", 2.0 * Bt * M * K * N, 2.0 * (a16.numel() + b16.numel()) + 4.0 * out.numel(), tag or f"gemm16 tn {Bt}x[{K}x{M}x{N}]"):
+        capi.check(lib.ssbev_gemm16_tn(capi.ptr(a16), capi.ptr(b16), capi.ptr(out), C.byref(d), capi.ptr(ws), ws.numel(),
+                                       capi.stream()), "ssbev_gemm16_tn")
+    return out
+
+
+def _bmm16_tn(V, Z):
+    """V [nf, T, K]^T x Z [nf, T, N] (bf16) -> fp32 [nf, K, N]: the weight-gradient frequency products"""
+    if GEMM16_OWN and V.is_cuda:
+        g = gemm16_tn(V, Z, tag=f"wino16 wgrad gemm {V.shape[0]}x[{V.shape[2]}x{V.shape[1]}x{Z.shape[2]}]")
+        if g is not None:
+            return g
+    return torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32)
+
+
 def _wino_bgemm(V, w, Cout, Cin, mode):
     """M[xi] = V[xi] @ U[xi] for the 64 frequencies on the LDS-streaming MFMA kernel (mode 0 forward, 1 data gradient)."""
     lib = capi.load()
@@ -1582,7 +1610,7 @@ class _WinoConv(torch.autograd.Function):
                     if fused:
                         V = _wino_call(pre + "input_transform", V, capi.WinoDims(B, D, H, W, Cin), (nf, T, Cin))
                     Z = _wino_call(pre + "output_adjoint" + sfx, gcl, capi.WinoDims(B, D, H, W, Cout), (nf, T, Cout), fdt)
-                    gU = torch.bmm(V.transpose(1, 2), Z, out_dtype=torch.float32) if bf else (gemm_tn(V, Z, tag="wino wgrad gemm") if own_gemm_site("wino") else torch.bmm(V.transpose(1, 2), Z))
+                    gU = _bmm16_tn(V, Z) if bf else (gemm_tn(V, Z, tag="wino wgrad gemm") if own_gemm_site("wino") else torch.bmm(V.transpose(1, 2), Z))
                 gwt = torch.empty_like(w)
                 wg = lib.ssbev_wino43_weight_grad if f43 else lib.ssbev_wino_weight_grad
                 capi.check(wg(capi.ptr(gU), capi.ptr(gwt), Cout, Cin, nd, capi.stream()), "ssbev_wino_weight_grad")
@@ -2293,8 +2321,8 @@ def linear_cl(x, weight, bias=None):
     shp = xcl.shape
     w2 = weight.reshape(weight.shape[0], -1)
     x2 = xcl.reshape(-1, shp[-1])
-    if own_gemm_site("linear") and x2.shape[1] % 4 == 0 and w2.shape[0] % 4 == 0 and x2.shape[0] >= 64:
-        y = _LinearCL.apply(x2, w2, bias)
+    if own_gemm_site("linear") and x2.is_cuda and w2.shape[0] % 4 == 0:
+        y = small_linear(x2, w2, bias)                 # (any row count; Cin zero-padded to a multiple of 4 when it is not one)
         return from_cl(y.view(*shp[:-1], w2.shape[0]))
     fl = 2.0 * x2.shape[0] * x2.shape[1] * w2.shape[0]
     nby = 4.0 * (x2.numel() + w2.numel() + x2.shape[0] * w2.shape[0])

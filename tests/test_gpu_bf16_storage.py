@@ -241,3 +241,21 @@ def test_gemm16_batched_products_vs_fp32_reference(shape):
     assert rel_max < 2e-5 and rel_l2 < 1e-5, (rel_max, rel_l2)
     rel_max, rel_l2 = _err(got16, want)
     assert rel_max < 6e-3 and rel_l2 < 3e-3, (rel_max, rel_l2)       # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("shape", [(16, 1920, 640, 640), (64, 4096, 256, 256), (64, 360, 128, 128), (3, 100, 96, 40), (5, 1000, 136, 8),
+                                   (16, 3840, 640, 128)])
+def test_gemm16_tn_weight_gradient_products_vs_fp32_reference(shape, monkeypatch):
+    """ssbev_gemm16_tn (gemm16_tn_kernel: LDS-DMA staging + transposing LDS reads): C[b] = A[b]^T B[b] over the row axis, bf16
+    operands, fp32 accumulation and result, against torch.bmm in fp32 on the same operands; ragged M (not a multiple of the
+    32-row stage), K / N that are not multiples of the 128-wide tile, sliced and unsliced m axis (fixed-order partial sums)."""
+    Bt, M, K, N = shape
+    a = _r16(S.hash_normal(f"g16tn/a{shape}", (Bt, M, K)))
+    b = _r16(S.hash_normal(f"g16tn/b{shape}", (Bt, M, N)))
+    want = torch.bmm(a.transpose(1, 2), b)
+    a16, b16 = a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
+    got = F.gemm16_tn(a16, b16)
+    assert got is not None and got.dtype == torch.float32 and tuple(got.shape) == (Bt, K, N)
+    rel_max, rel_l2 = _err(got, want)
+    assert rel_max < 2e-5 and rel_l2 < 1e-5, (rel_max, rel_l2)
+    assert torch.equal(got, F.gemm16_tn(a16, b16))                       # deterministic

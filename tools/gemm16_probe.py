@@ -17,7 +17,7 @@ def timed(fn, iters=30):
 
 
 CASES = [(16, 1920, 640, 640), (16, 3840, 640, 128), (64, 4096, 256, 256), (64, 512, 512, 512), (64, 2880, 128, 128), (16, 2016, 640, 640)]
-tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "128128", "64128", "128064", "64064"]
+tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
 for Bt, M, K, N in CASES:
     a = torch.randn(Bt, M, K, device="cuda").to(torch.bfloat16)
     b = torch.randn(Bt, K, N, device="cuda")
@@ -30,4 +30,6 @@ for Bt, M, K, N in CASES:
         else:
             os.environ["SSBEV_IGEMM_TILE"] = t
         row.append(f"{t}: {gf / timed(lambda: F.gemm16_nn(a, b)):6.0f}")
+    z = torch.randn(Bt, M, N, device="cuda").to(torch.bfloat16)
+    row.append(f"| tn rocBLAS {gf / timed(lambda: torch.bmm(a.transpose(1, 2), z, out_dtype=torch.float32)):6.0f}  own {gf / timed(lambda: F.gemm16_tn(a, z)):6.0f}")
     print(f"{Bt:3d} x [{M} x {K} x {N}] TF/s  " + "  ".join(row), flush=True)
