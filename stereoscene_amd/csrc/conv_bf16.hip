@@ -618,6 +618,7 @@ struct Wg16Geom {
   int Dq, Hq, Wq;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int chunk, nchunks;
+  int xcd_order;                    // 1: [chunk group][channel tiles][tap groups] per XCD; 0: the plain x-fastest order (A/B)
 };
 
 __device__ __forceinline__ uint4 tr_operand(const unsigned char* tile, int trbase) {
@@ -639,13 +640,27 @@ wgrad16_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, float
   extern __shared__ __align__(16) unsigned char wl[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lk = lane >> 5;
-  const int chunk_id = blockIdx.x * 4 + wave;
+  // 1-D grid in the XCD-aware order [chunk group][channel tiles][tap groups]: the workgroups that read the SAME voxel chunk (one
+  // per channel tile and tap group) are neighbours on one XCD -- the chunk comes from HBM once and from that L2 afterwards
+  unsigned Lp;
+  {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    Lp = g.xcd_order ? base + (L >> 3) : L;
+  }
+  const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
+  const unsigned ztiles = (unsigned)(g.kd * kh_groups * kw_groups);
+  const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
+  const unsigned ytiles = (unsigned)(nqt * ((g.Cp + 32 * MP - 1) / (32 * MP)));
+  unsigned bx, by, bz;
+  if (g.xcd_order) { bz = Lp % ztiles; Lp /= ztiles; by = Lp % ytiles; bx = Lp / ytiles; }
+  else { const unsigned nx = gridDim.x / (ytiles * ztiles); bx = Lp % nx; Lp /= nx; by = Lp % ytiles; bz = Lp / ytiles; }
+  const int chunk_id = (int)bx * 4 + wave;
   if (chunk_id >= g.nchunks) return;
   unsigned char* my = wl + (size_t)wave * NTILE * 1024;
-  const int nqt = (g.Cq + 32 * MQ - 1) / (32 * MQ);
-  const int qt = blockIdx.y % nqt, pt = blockIdx.y / nqt;
-  const int kw_groups = (g.kw + TW - 1) / TW, kh_groups = (g.kh + TH - 1) / TH;
-  int tg = blockIdx.z;
+  const int qt = (int)by % nqt, pt = (int)by / nqt;
+  int tg = (int)bz;
   const int kwg = tg % kw_groups; tg /= kw_groups;
   const int khg = tg % kh_groups;
   const int kdi = tg / kh_groups;
@@ -775,6 +790,7 @@ struct WgRingGeom {
   int B, D, H, W, Cp, Cq;
   int nth, ntw, ntiles, tpc, nchunks;
   int ncqt;                        // wide: 32-channel Q tiles (blockIdx.y = cqt + ncqt * cp group)
+  int xcd_order;                   // wide: 1-D grid, XCD-aware [chunk][cp group][cqt][kd] order
 };
 
 constexpr int kWrRows = 8, kWrQR = kWrRows + 2, kWrQC = 18;
@@ -806,9 +822,22 @@ wgrad_ring16_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
-  const int chunk = blockIdx.x;
-  const int cqt = NARROW ? 0 : (int)blockIdx.y % g.ncqt, cpg = NARROW ? 0 : (int)blockIdx.y / g.ncqt;
-  const int kdz = NARROW ? 0 : (int)blockIdx.z;
+  // wide: 1-D grid in the XCD-aware order [chunk][channel tiles][kd] -- the workgroups that walk the SAME voxel chunk (every one
+  // re-reads its P lines, every third its Q plane) are neighbours on one XCD, so the chunk comes from HBM once and from that L2 after
+  int chunk = blockIdx.x, cqt = 0, cpg = 0, kdz = 0;
+  if (!NARROW && g.xcd_order) {
+    const unsigned n = gridDim.x, L = blockIdx.x;
+    const unsigned xcd = L & 7, q = n >> 3, r = n & 7;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    unsigned Lp = base + (L >> 3);
+    kdz = (int)(Lp % 3u); Lp /= 3u;
+    cqt = (int)(Lp % (unsigned)g.ncqt); Lp /= (unsigned)g.ncqt;
+    const unsigned ncpg = (unsigned)((g.Cp + 127) / 128);
+    cpg = (int)(Lp % ncpg);
+    chunk = (int)(Lp / ncpg);
+  } else if (!NARROW) {
+    cqt = (int)blockIdx.y % g.ncqt; cpg = (int)blockIdx.y / g.ncqt; kdz = (int)blockIdx.z;
+  }
   const int cq0 = cqt * 32, cp0 = cpg * 128;
   const int ntap = NARROW ? (wave < 3 ? 7 : 6) : 9;
 
@@ -1368,13 +1397,15 @@ Wg16Geom make_wg_geom(const ssbev_conv_dims* d) {
   chunk = (chunk + 15) & ~15L;
   g.chunk = (int)chunk;
   g.nchunks = (int)((Mtot + chunk - 1) / chunk);
+  static const int xcd_order = getenv("SSBEV_WGRAD16_XCD") ? atoi(getenv("SSBEV_WGRAD16_XCD")) : 1;
+  g.xcd_order = xcd_order;
   return g;
 }
 
 template <int MQ, int MP, int TH, int TW>
 int launch_wg16(const bf16_t* P, const bf16_t* Q, float* ws, const Wg16Geom& g, hipStream_t st) {
   const int ytiles = cdiv(g.Cq, 32 * MQ) * cdiv(g.Cp, 32 * MP);
-  dim3 grid(cdiv(g.nchunks, 4), ytiles, g.kd * cdiv(g.kh, TH) * cdiv(g.kw, TW));
+  dim3 grid((unsigned)((long)cdiv(g.nchunks, 4) * ytiles * (g.kd * cdiv(g.kh, TH) * cdiv(g.kw, TW))));
   const size_t lds = (size_t)4 * (MP + MQ * TH * TW) * 1024;
   hipLaunchKernelGGL((wgrad16_kernel<MQ, MP, TH, TW>), grid, dim3(256), lds, st, P, Q, ws, g);
   return ssbev_launch_status();
@@ -1398,6 +1429,7 @@ WgRingGeom make_wr_geom(const ssbev_conv_dims* d) {
   g.ntiles = g.B * g.D * g.nth * g.ntw;
   const bool narrow = g.Cq <= 32 && g.Cp <= 32;
   g.ncqt = narrow ? 1 : (g.Cq + 31) / 32;
+  g.xcd_order = 0;
   const long types = narrow ? 1 : (long)g.ncqt * ((g.Cp + 127) / 128) * 3;
   // ~1024 workgroups in all (two resident per CU, two rounds), at least 4 tiles per chunk, partial slabs bounded to 256 MB
   long want = std::max(1L, 1024 / types);
@@ -1411,14 +1443,19 @@ WgRingGeom make_wr_geom(const ssbev_conv_dims* d) {
   return g;
 }
 
-int launch_wg_ring(const bf16_t* P, const bf16_t* Q, float* ws, const WgRingGeom& g, hipStream_t st) {
+int launch_wg_ring(const bf16_t* P, const bf16_t* Q, float* ws, WgRingGeom g, hipStream_t st) {
   const bool narrow = g.Cq <= 32 && g.Cp <= 32;
   if (narrow) {
     const size_t lds = 3 * kWrQPlaneB + kWrRows * 16 * 64;
     hipLaunchKernelGGL(wgrad_ring16_kernel<true>, dim3(g.nchunks), dim3(256), lds, st, P, Q, ws, g);
   } else {
     const size_t lds = kWrQPlaneB + kWrRows * 16 * 256;
-    hipLaunchKernelGGL(wgrad_ring16_kernel<false>, dim3(g.nchunks, g.ncqt * ((g.Cp + 127) / 128), 3), dim3(256), lds, st, P, Q, ws, g);
+    static const int xcd_order = getenv("SSBEV_WGRAD_RING_XCD") ? atoi(getenv("SSBEV_WGRAD_RING_XCD")) : 1;
+    g.xcd_order = xcd_order;
+    if (xcd_order)
+      hipLaunchKernelGGL(wgrad_ring16_kernel<false>, dim3(g.nchunks * g.ncqt * ((g.Cp + 127) / 128) * 3), dim3(256), lds, st, P, Q, ws, g);
+    else
+      hipLaunchKernelGGL(wgrad_ring16_kernel<false>, dim3(g.nchunks, g.ncqt * ((g.Cp + 127) / 128), 3), dim3(256), lds, st, P, Q, ws, g);
   }
   return ssbev_launch_status();
 }
