@@ -429,7 +429,7 @@ class CA3D(nn.Module):
         if data.shape[0] == 1:
             y = F.conv3d(data, c2.weight * gate.view(1, -1, 1, 1, 1), c2.bias, c2.stride, c2.padding, c2.dilation)
         else:
-            y = c2(gate[..., None, None, None] * data)
+            y = c2(gate.to(data.dtype)[..., None, None, None] * data)      # (bf16 storage: the gate joins the chain's dtype, no fp32 pass)
         gamma, beta = (gn2.weight, gn2.bias) if alpha is None else (alpha * gn2.weight, alpha * gn2.bias)
         return F.group_norm(y, gn2.num_groups, gamma, beta, gn2.eps, residual=residual, pre_act="gelu")
 

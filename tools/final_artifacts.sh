@@ -2,7 +2,7 @@
 # Regenerate the judged artifacts of a round from ONE tree on the GPU box: usage (inside gpurun) bash tools/final_artifacts.sh r3z
 # Writes gpurun_out/<tag>/*; copy what is to be judged into profiles/<tag>_*.  Every step runs under `timeout`.
 set -u
-tag=${1:-r4z}
+tag=${1:-r5z}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -2,7 +2,7 @@
 # SQ wait / issue / LDS-conflict counters per kernel over the serial fp32 step (separate --pmc passes, no tracing):
 # usage (inside gpurun) bash tools/sq_counters.sh <tag>  ->  gpurun_out/<tag>/sq_counters.txt
 set -u
-tag=${1:-r4z}
+tag=${1:-r5z}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
