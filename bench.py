@@ -285,6 +285,12 @@ def main():
     assert local < torch.cuda.device_count(), f"rank {rank}: local rank {local} but {torch.cuda.device_count()} GPUs visible"
     torch.cuda.set_device(local)
     import torch.distributed as dist
+    # stdout carries the ONE JSON record and nothing else: RCCL prints a version banner through C stdio when a process group
+    # comes up (block-buffered on a pipe, i.e. flushed at exit, AFTER the record).  File descriptor 1 is pointed at stderr for the
+    # life of the process; the record is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     rccl_world1 = None
     if distributed:
@@ -563,7 +569,9 @@ def main():
         if exch is not None:
             out["gradient_exchange"] = exch
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample if world == 1 else "none", cfg)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if distributed:
         dist.destroy_process_group()
 

@@ -112,7 +112,7 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         g = x.mean(dim=(2, 3), dtype=torch.float32)                  # AdaptiveAvgPool2d((1,1)); fp32 also for bf16 activations
-        g = TF.linear(g, self.global_avg_pool[1].weight.flatten(1))  # 1x1 conv on a 1x1 map
+        g = F.small_linear(g, self.global_avg_pool[1].weight.flatten(1))   # 1x1 conv on a 1x1 map (own GEMM kernels)
         g = torch.relu(self.global_avg_pool[2](g))[..., None, None]
         g = g.expand(-1, -1, x.shape[2], x.shape[3])                 # bilinear(align_corners) of a 1x1 map
         branches = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)
