@@ -321,9 +321,17 @@ def test_full_size_step_fwd_bwd_vs_oracle(cfg_name, ac):
     rows = _l2_table(grads, ograds)
     worst = max((v, k) for k, v in rows.items())
     print(f"{cfg_name} ac={ac} step: {len(rows)} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
-    # measured 9.2e-3 on dres0.2.1.weight (profiles/r2_grad_gates.txt); test_gradient_gate_vs_oracle_noise_floor shows where
-    # that figure comes from (the oracle moves by as much under a one-ulp change of its input); every other tensor < 5e-3
-    assert len(rows) > 150 and worst[0] < 2e-2, worst
+    # The gate is set against the ORACLE'S OWN response to a one-ulp perturbation of its inputs (x * (1 + 2^-23)), tensor by tensor:
+    # the camera-aware MLP / SE parameters of the stereo branch and the dres* layers behind them sit at a floor of 0.5-2e-2 at this
+    # size (ReLU / max sign flips: tools/grad_gate_floor.py, profiles/r5_grad_gate_floor.txt: ours 2.16e-2 at a floor of 2.08e-2 on
+    # depth_mlp.fc1.bias), everything else at 1e-5..1e-3.  A tensor may be at most three times its floor (+ 2e-3) away from the
+    # oracle -- the criterion of test_gradient_gate_vs_oracle_noise_floor (one perturbation is ONE sample of the floor).
+    _, _, pgrads = _oracle_step(cfg_name, ac, sd0, trainable, smp, model.img_view_transformer.D, perturb=1)
+    floor = _l2_table(pgrads, ograds)
+    over = sorted(((rows[k] / (3.0 * floor[k] + 2e-3), k, rows[k], floor[k]) for k in rows), reverse=True)
+    print(f"{cfg_name} ac={ac} worst distance / (3 floor + 2e-3): {over[0][0]:.2f} ({over[0][1]}: ours {over[0][2]:.3e}, floor {over[0][3]:.3e})")
+    assert len(rows) > 150 and worst[0] < 5e-2, worst
+    assert over[0][0] < 1.0, over[:3]
 
 
 def test_gradient_gate_vs_oracle_noise_floor():
