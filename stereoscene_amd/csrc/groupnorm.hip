@@ -565,12 +565,31 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
   if (lane == 0) { dbeta[c] = (float)tb; dgamma[c] = (float)ts; }
 }
 
+// Sample index of lane-vector i along a grid-stride walk: one 64-bit division per THREAD instead of one per step (round 5: the
+// division was ~60 VALU instructions in front of every 8 / 16 bytes -- the bf16 apply passes, with twice the elements per byte,
+// were VALU-bound on it: 42 / 60 us where the fp32 passes take 29 / 36 us for the same bytes).
+struct SampleWalk {
+  long per, rem;
+  int b;
+  __device__ __forceinline__ SampleWalk() : per(1), rem(0), b(0) {}
+  __device__ __forceinline__ SampleWalk(long i, long per_) : per(per_) { b = (int)(i / per_); rem = i - (long)b * per_; }
+  __device__ __forceinline__ void step(long stride) {
+    rem += stride;
+    while (rem >= per) { rem -= per; ++b; }
+  }
+};
+
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
-template <bool PRE, typename T = float, int VW = 4>
+// U = lane-vectors a thread has in flight per step of its grid-stride walk (i and i + stride: the SAME channels, so the per-channel
+// constants are shared); U = 2 is an A/B hook (SSBEV_GN_APPLY_U=2), measured slower than U = 1 on both dtypes.
+template <bool PRE, typename T = float, int VW = 4, int U = 1>
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const T* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
                     T* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long totalv) {
+  // bf16 tensors: the per-channel constants are folded to one fma per element (the stored result is rounded to 8 bits of
+  // mantissa anyway); fp32 tensors keep the reference's operation order (x - mean) * rstd * gamma + beta
+  constexpr bool FOLD = sizeof(T) == 2;
   const int q = g.C / VW, cpg = g.C / g.G;
   const long stride = (long)gridDim.x * NT;
   const bool fixed = stride % q == 0;            // see gn_apply_bwd_kernel
@@ -579,47 +598,68 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
   float gam[VW], bet[VW], mu[VW], rs[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
-  for (; i < totalv; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
-    if (!fixed) {
-      c = (int)(i % q) * VW;
+  const long per = (long)q * g.S;
+  SampleWalk sw[U];
 #pragma unroll
-      for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
+  for (int u = 0; u < U; ++u) sw[u] = SampleWalk(i + u * stride, per);
+  for (; i < totalv; i += U * stride) {
+    long iu[U];
+    float v[U][VW], rr[U][VW];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      iu[u] = i + u * stride;
+      ldn<VW>(x + (size_t)VW * (iu[u] < totalv ? iu[u] : i), v[u]);          // (past the end: a harmless re-read of vector 0)
     }
-    if (!fixed || b != bcur) {
-      bcur = b;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < VW; ++k) rr[u][k] = 0.0f;
+    if (res) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ldn<VW>(res + (size_t)VW * (iu[u] < totalv ? iu[u] : i), rr[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long ii = iu[u];
+      const int b = sw[u].b;
+      sw[u].step(U * stride);
+      if (u > 0 && ii >= totalv) break;
+      if (!fixed) {
+        c = (int)(ii % q) * VW;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
+      }
+      if (!fixed || b != bcur) {
+        bcur = b;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+          const int grp = b * g.G + (c + k) / cpg;
+          mu[k] = mean[grp]; rs[k] = rstd[grp];
+          if (FOLD) { rs[k] *= gam[k]; mu[k] = bet[k] - mu[k] * rs[k]; }       // y = rs' x + mu'
+        }
+      }
+      if (PRE) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) v[u][k] = gelu_f(v[u][k]);
+      }
 #pragma unroll
       for (int k = 0; k < VW; ++k) {
-        const int grp = b * g.G + (c + k) / cpg;
-        mu[k] = mean[grp]; rs[k] = rstd[grp];
+        float o = FOLD ? fmaf(v[u][k], rs[k], mu[k]) + rr[u][k] : (v[u][k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[u][k];
+        v[u][k] = g.relu ? fmaxf(o, 0.0f) : o;
       }
-    }
-    float v[VW], rr[VW];
-    ldn<VW>(x + (size_t)VW * i, v);
-    if (PRE) {
+      if (mask) {
+        // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
+        // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
+        // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
 #pragma unroll
-      for (int k = 0; k < VW; ++k) v[k] = gelu_f(v[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < VW; ++k) rr[k] = 0.0f;
-    if (res) ldn<VW>(res + (size_t)VW * i, rr);
-#pragma unroll
-    for (int k = 0; k < VW; ++k) {
-      float o = (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
-      v[k] = g.relu ? fmaxf(o, 0.0f) : o;
-    }
-    if (mask) {
-      // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
-      // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
-      // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
-#pragma unroll
-      for (int k = 0; k < VW; ++k) {
-        const unsigned long long bal = __ballot(v[k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
+        for (int k = 0; k < VW; ++k) {
+          const unsigned long long bal = __ballot(v[u][k] > 0.0f);
+          if ((threadIdx.x & 63) == 0) mask[(ii >> 6) * VW + k] = bal;
+        }
       }
+      if (g.ldy == g.C) stn<VW>(y + (size_t)VW * ii, v[u]);
+      else stn<VW>(y + (ii / q) * g.ldy + (ii % q) * VW, v[u]);
     }
-    if (g.ldy == g.C) stn<VW>(y + (size_t)VW * i, v);
-    else stn<VW>(y + (i / q) * g.ldy + (i % q) * VW, v);
   }
 }
 
@@ -694,14 +734,25 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
   const long stride = (long)gridDim.x * NT;
   // the launch makes `stride` a multiple of q whenever it can: a thread then always owns the same channels and
   // the per-channel / per-group constants leave the streaming loop
+  constexpr bool FOLD = sizeof(T) == 2;          // bf16 tensors: folded constants, see gn_apply_fwd_kernel
   const bool fixed = stride % q == 0;
   long i = (long)blockIdx.x * NT + threadIdx.x;
   int c = (int)(i % q) * VW, bcur = -1;
   float gam[VW], mu[VW], rs[VW], c0[VW], c1[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; mu[k] = 0.f; rs[k] = 0.f; c0[k] = 0.f; c1[k] = 0.f; }
-  for (; i < totalv; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  constexpr bool PF = sizeof(T) == 2;            // prefetch one step ahead (bf16 tensors), see gn_apply_fwd_kernel
+  float nx[VW], ng[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) { nx[k] = 0.0f; ng[k] = 0.0f; }
+  if (PF && i < totalv) {
+    ldn<VW>(x + (size_t)VW * i, nx);
+    if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, ng);
+    else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, ng);
+  }
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < totalv; i += stride, sw.step(stride)) {
+    const int b = sw.b;
     if (!fixed) {
       c = (int)(i % q) * VW;
 #pragma unroll
@@ -713,12 +764,24 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
       for (int k = 0; k < VW; ++k) {
         const int grp = b * g.G + (c + k) / cpg;
         mu[k] = mean[grp]; rs[k] = rstd[grp]; c0[k] = coef[grp * 2]; c1[k] = coef[grp * 2 + 1];
+        if (FOLD) { c0[k] = -rs[k] * rs[k] * c0[k]; c1[k] = -c1[k] * rs[k]; rs[k] *= gam[k]; }   // gx = rs' g + c0' (u - mu) + c1'
       }
     }
     float xs[VW], gs[VW];
-    ldn<VW>(x + (size_t)VW * i, xs);
-    if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, gs);
-    else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
+    if (PF) {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) { xs[k] = nx[k]; gs[k] = ng[k]; }
+      const long in = i + stride;
+      if (in < totalv) {
+        ldn<VW>(x + (size_t)VW * in, nx);
+        if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * in, ng);
+        else ldn<VW>(gy + (in / q) * g.ldg + (in % q) * VW, ng);
+      }
+    } else {
+      ldn<VW>(x + (size_t)VW * i, xs);
+      if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, gs);
+      else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
+    }
     if (g.relu && mask) {
       const unsigned long long* mw = mask + (i >> 6) * VW;
       const int sh = (int)(i & 63);
@@ -735,8 +798,13 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
     for (int k = 0; k < VW; ++k) {
       float u = xs[k], du = 1.0f;
       if (PRE) gelu_both(xs[k], u, du);
-      const float xh = (u - mu[k]) * rs[k];
-      o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
+      if (FOLD) {
+        const float t = fmaf(rs[k], gs[k], fmaf(c0[k], u - mu[k], c1[k]));
+        o[k] = PRE ? t * du : t;
+      } else {
+        const float xh = (u - mu[k]) * rs[k];
+        o[k] = (gam[k] * gs[k] - xh * c0[k] - c1[k]) * rs[k] * du;
+      }
     }
     stn<VW>(gx + (size_t)VW * i, o);
     if (gres) stn<VW>(gres + (size_t)VW * i, gs);
@@ -777,8 +845,9 @@ gn_apply_fwd16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ga
 #pragma unroll
   for (int k = 0; k < VW; ++k) { sc[k] = 0.f; sh[k] = 0.f; }
   const long total4 = 2 * total8;
-  for (; i < total8; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < total8; i += stride, sw.step(stride)) {
+    const int b = sw.b;
     if (!fixed) c = (int)(i % q) * VW;
     if (!fixed || b != bcur) {
       bcur = b;
@@ -831,8 +900,9 @@ gn_apply_bwd16_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ 
   float ka[VW], kb[VW], kc[VW], mu[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { ka[k] = 0.f; kb[k] = 0.f; kc[k] = 0.f; mu[k] = 0.f; }
-  for (; i < total8; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < total8; i += stride, sw.step(stride)) {
+    const int b = sw.b;
     if (!fixed) c = (int)(i % q) * VW;
     if (!fixed || b != bcur) {
       bcur = b;
@@ -972,8 +1042,9 @@ gn2_apply_fwd_kernel(const T* __restrict__ xa, const float* __restrict__ gamma_a
   float ga[VW], ba[VW], gb[VW], bb[VW], mua[VW], rsa[VW], mub[VW], rsb[VW], d0[VW], d1[VW], d2[VW], d3[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; ba[k] = beta_a[c + k]; gb[k] = gamma_b[c + k]; bb[k] = beta_b[c + k]; }
-  for (; i < totalv; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < totalv; i += stride, sw.step(stride)) {
+    const int b = sw.b;
     if (!fixed) {
       c = (int)(i % q) * VW;
 #pragma unroll
@@ -1086,8 +1157,9 @@ gn2_apply_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restr
   float ga[VW], gb[VW], mua[VW], rsa[VW], mub[VW], rsb[VW], c0a[VW], c1a[VW], c0b[VW], c1b[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { ga[k] = gamma_a[c + k]; gb[k] = gamma_b[c + k]; }
-  for (; i < totalv; i += stride) {
-    const int b = (int)(i / ((long)q * g.S));
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < totalv; i += stride, sw.step(stride)) {
+    const int b = sw.b;
     if (!fixed) {
       c = (int)(i % q) * VW;
 #pragma unroll
@@ -1242,8 +1314,14 @@ static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, co
   }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
+  // two vectors in flight per thread: measured SLOWER on the 189 MB activation (fp32 66.7 -> 76.8 us, bf16 96.2 -> 103.4 us): the
+  // passes are not latency-bound -- the bf16 ones are instruction-issue-bound (~90 wave instructions per 512 B in, 512 B out)
+  static const int apply_u = getenv("SSBEV_GN_APPLY_U") ? atoi(getenv("SSBEV_GN_APPLY_U")) : 1;
   if (g.pre)
     hipLaunchKernelGGL((gn_apply_fwd_kernel<true, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
+                       d->relu ? mask : nullptr, g, totalv);
+  else if (apply_u == 2)
+    hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T, 4, 2>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
                        d->relu ? mask : nullptr, g, totalv);
   else
     hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
