@@ -62,7 +62,7 @@ for mode in ("full", "stereo_only", "bev_only"):
 print(json.dumps({"_doc": "BASELINE configs[4]: fp32, kitti_d192, B = 1, fwd + bwd, one MI355X; step_roofline as in bench.py", "modes": res}, indent=1))
 PYEOF
 for cfgline in "--config kitti_d112" "--batch 2" "--ablation stereo_only" "--ablation bev_only"; do
-  echo "$cfgline: $(timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample none --skip-forward-extra --skip-serial-replay $cfgline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), 'ms/step', round(d['value']/1e6,2), 'M voxels/s')")" >> $out/other_configs.txt
+  echo "$cfgline: $(timeout 300 python bench.py --steps 8 --warmup 3 --cpu-sample none --skip-forward-extra --skip-serial-replay $cfgline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), 'ms/step', round(d['value']/1e6,2), 'M voxels/s')")" >> $out/other_configs.txt
 done
 timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $out/pytest_gpu.txt
 tail -3 $out/pytest_gpu.txt; head -14 $out/summary.txt; cat $out/other_configs.txt; python -c "
