@@ -344,6 +344,7 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __
           // the mask is laid out per channel QUAD (word (quad / 64) * 4 + component, bit quad % 64) whatever VW is: an
           // 8-channel lane reads two neighbouring bits (its first quad index is even) of the same four words
           const int sh = (int)((it.off >> 2) & 63);
+          // (two 16-byte loads for the four words + one shift per word were measured: 115 -> 123 us on the bf16 pass; not kept)
 #pragma unroll
           for (int k = 0; k < VW; ++k) gs[k] = ((it.mw[k & 3] >> (sh + (k >> 2))) & 1ull) ? gs[k] : 0.0f;
         } else if (RM == 2) {
@@ -565,6 +566,49 @@ bn_finalize_bwd_flat_kernel(const float* __restrict__ partial, const float* __re
   if (lane == 0) { dbeta[c] = (float)tb; dgamma[c] = (float)ts; }
 }
 
+// ---- ReLU bit mask of the streaming apply kernels (VW = 4 lanes) ------------------------------------------------------------------
+// Word (i / 64) * 4 + k holds bit (i % 64) = [component k of lane-vector i > 0]; the 64 lanes of a wave own 64 consecutive,
+// 64-aligned vectors (block offsets and the grid stride are multiples of 256), so a mask word is exactly a wave's LANE MASK of one
+// component.  Round 5: the writer stores the four ballots of a step as ONE 8-byte store from lanes 0..3 (was: four predicated
+// stores from lane 0 behind four branches): forward apply on the 189 MB activation (tools/gn_dtype_probe.py) bf16 94.6 -> 82.4 us,
+// fp32 65.8 -> 60.5 us (without any mask: 75.0 / 58.3).
+__device__ __forceinline__ void relu_mask_store4(unsigned long long* __restrict__ mask, long i, const float (&v)[4]) {
+  unsigned long long bal[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bal[k] = __ballot(v[k] > 0.0f);
+  const int ln = threadIdx.x & 63;
+  const unsigned long long act = __ballot(1);
+  if (act == ~0ull || __popcll(act) >= 4) {          // lanes 0..3 are active (a partial wave is a prefix of lanes)
+    if (ln < 4) {
+      unsigned long long w = bal[0];
+      w = ln == 1 ? bal[1] : w; w = ln == 2 ? bal[2] : w; w = ln == 3 ? bal[3] : w;
+      mask[(i >> 6) * 4 + ln] = w;
+    }
+  } else if (ln == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mask[(i >> 6) * 4 + k] = bal[k];
+  }
+}
+// Reader: the word index is made wave-uniform with v_readfirstlane on the INDEX (no memory wait), so the four words of a step
+// come through the scalar cache (s_load, no vector-memory instruction: the bf16 passes issue twice the VMEM instructions of the
+// fp32 ones for the same bytes) straight into SGPR pairs, and each is the select mask of ONE v_cndmask_b32.
+__device__ __forceinline__ float lane_select(unsigned long long wave_mask, float v) {     // wave_mask: wave-uniform (SGPR pair)
+  float o;
+  asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(wave_mask));
+  return o;
+}
+__device__ __forceinline__ void relu_mask_apply4(const unsigned long long* __restrict__ mask, long i, float (&gs)[4]) {
+  const long wq = i >> 6;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)wq), hi = __builtin_amdgcn_readfirstlane((unsigned)(wq >> 32));
+  const unsigned long long* mw = mask + ((((unsigned long long)hi << 32) | lo) << 2);
+  const unsigned long long w0 = mw[0], w1 = mw[1], w2 = mw[2], w3 = mw[3];      // one s_load_dwordx8, one wait
+  gs[0] = lane_select(w0, gs[0]); gs[1] = lane_select(w1, gs[1]); gs[2] = lane_select(w2, gs[2]); gs[3] = lane_select(w3, gs[3]);
+}
+
+// (The reader side was tried the same way -- each word into an SGPR pair through v_readfirstlane, applied as the select mask of one
+// v_cndmask_b32 -- and LOSES: bf16 backward apply 129.7 -> 165 us, fp32 92.7 -> 101.5: the readfirstlanes wait for the mask loads in
+// front of everything else.  The shift / and / select form stays.)
+
 // Sample index of lane-vector i along a grid-stride walk: one 64-bit division per THREAD instead of one per step (round 5: the
 // division was ~60 VALU instructions in front of every 8 / 16 bytes -- the bf16 apply passes, with twice the elements per byte,
 // were VALU-bound on it: 42 / 60 us where the fp32 passes take 29 / 36 us for the same bytes).
@@ -651,10 +695,13 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
         // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
         // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
         // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
+        if constexpr (VW == 4) relu_mask_store4(mask, ii, v[u]);
+        else {
 #pragma unroll
-        for (int k = 0; k < VW; ++k) {
-          const unsigned long long bal = __ballot(v[u][k] > 0.0f);
-          if ((threadIdx.x & 63) == 0) mask[(ii >> 6) * VW + k] = bal;
+          for (int k = 0; k < VW; ++k) {
+            const unsigned long long bal = __ballot(v[u][k] > 0.0f);
+            if ((threadIdx.x & 63) == 0) mask[(ii >> 6) * VW + k] = bal;
+          }
         }
       }
       if (g.ldy == g.C) stn<VW>(y + (size_t)VW * ii, v[u]);
@@ -783,10 +830,13 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
       else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
     }
     if (g.relu && mask) {
-      const unsigned long long* mw = mask + (i >> 6) * VW;
-      const int sh = (int)(i & 63);
+      if constexpr (VW == 4) relu_mask_apply4(mask, i, gs);
+      else {
+        const unsigned long long* mw = mask + (i >> 6) * VW;
+        const int sh = (int)(i & 63);
 #pragma unroll
-      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+        for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      }
     } else if (g.relu) {
       float yv[VW];
       ldn<VW>(y + (size_t)VW * i, yv);
@@ -1064,10 +1114,13 @@ gn2_apply_fwd_kernel(const T* __restrict__ xa, const float* __restrict__ gamma_a
       v[k] = g.relu ? fmaxf(o, 0.0f) : o;
     }
     if (mask) {
+      if constexpr (VW == 4) relu_mask_store4(mask, i, v);
+      else {
 #pragma unroll
-      for (int k = 0; k < VW; ++k) {
-        const unsigned long long bal = __ballot(v[k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
+        for (int k = 0; k < VW; ++k) {
+          const unsigned long long bal = __ballot(v[k] > 0.0f);
+          if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
+        }
       }
     }
     stn<VW>(y + (size_t)VW * i, v);
@@ -1174,10 +1227,13 @@ gn2_apply_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restr
     ldn<VW>(xa + (size_t)VW * i, as);
     ldn<VW>(xb + (size_t)VW * i, bs);
     if (g.relu) {
-      const unsigned long long* mw = mask + (i >> 6) * VW;
-      const int sh = (int)(i & 63);
+      if constexpr (VW == 4) relu_mask_apply4(mask, i, gs);
+      else {
+        const unsigned long long* mw = mask + (i >> 6) * VW;
+        const int sh = (int)(i & 63);
 #pragma unroll
-      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+        for (int k = 0; k < VW; ++k) gs[k] = ((mw[k] >> sh) & 1ull) ? gs[k] : 0.0f;
+      }
     }
     float oa[VW], ob[VW];
 #pragma unroll
