@@ -166,8 +166,20 @@ def _act(t, what):
     return t, 0
 
 
+_WS_NONE = {}
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    """Caller-owned workspace of an entry point.  Most calls need none (size 0: the kernels never touch the pointer); those share
+    one 16-byte buffer per device instead of an allocator round trip each (~600 per step: tools/host_profile.py)."""
+    n = int(nbytes)
+    if n == 0:
+        key = (device.type, device.index) if isinstance(device, torch.device) else device
+        t = _WS_NONE.get(key)
+        if t is None:
+            t = _WS_NONE[key] = torch.empty(16, dtype=torch.uint8, device=device)
+        return t
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
 
 
 # -------------------------------------------------------------------------------------------------
