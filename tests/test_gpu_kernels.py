@@ -487,7 +487,10 @@ def test_conv2d_incl_dilation(Cin, Cout, k, p, dil, bias):
 
 # ------------------------------------------------------------------------------------ normalisation
 @pytest.mark.parametrize("B,C,G,sp", [(1, 32, 2, (6, 8, 10)), (2, 128, 32, (4, 4, 4)), (1, 192, 32, (3, 5, 7)),
-                                       (2, 32, 1, (4, 6, 6)), (1, 640, 2, (1, 12, 40)), (1, 512, 32, (2, 2, 1))])
+                                       (2, 32, 1, (4, 6, 6)), (1, 640, 2, (1, 12, 40)), (1, 512, 32, (2, 2, 1)),
+                                       # last wave of the apply passes with 1 / 2 / 1 active lanes: the ReLU bit mask's
+                                       # four-lane store falls back to lane 0 (relu_mask_store4, round 5)
+                                       (1, 4, 2, (5, 13, 1)), (1, 8, 2, (1, 33, 1)), (1, 12, 3, (1, 43, 1))])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
 def test_group_norm_fused_fwd_bwd(B, C, G, sp, relu, res):
     x = S.hash_normal("gn/x", (B, C) + sp) * 1.5 + 0.3
