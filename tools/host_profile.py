@@ -29,4 +29,4 @@ with torch.autograd.set_multithreading_enabled(False):      # backward on this t
 prof.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(prof)
-st.sort_stats("tottime").print_stats(int(os.environ.get("ROWS", "40")))
+st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(os.environ.get("FILTER", ""), int(os.environ.get("ROWS", "40")))
