@@ -68,6 +68,104 @@ SINGLE_KERNEL_FAMILIES = {
     "wgrad_ring16": ("wgrad_ring16_kernel", "mfma"),
 }
 
+# ---- the stdout record --------------------------------------------------------------------------------------------------
+# The driver captures ONE JSON line from stdout; r5's line had grown to 20 kB and was not parsed (BENCH_r05.json: parsed = null).
+# stdout carries the compact record below (< 6000 characters, tests/test_bench_record.py); everything else -- the other timed
+# kernels, the serial replay, the per-group floor table, the prose notes -- goes to `bench_detail.json` (SSBEV_BENCH_DETAIL
+# overrides the path).
+FLOP_CONVENTIONS = {
+    "executed": "achieved/frac = multiply-adds the kernel EXECUTES (frac <= 1 = matrix-pipe utilisation); operator_* = "
+                "direct-convolution FLOPs 2*voxels*Cin*Cout*27 (SURVEY 8(d))",
+}
+RECORD_LIMIT = 6000
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "operator_tflops", "operator_frac", "launches_per_step",
+              "avg_launch_us", "executed_gflop_per_launch", "algorithmic_gflop_per_launch", "algorithmic_bytes_per_launch",
+              "ms_per_step_in_kernel", "traffic", "traffic_source", "traffic_matches_tree")
+_TIE_KEYS = ("kernel", "achieved", "frac", "operator_frac", "avg_launch_us", "launches_per_step", "ms_per_step_in_kernel", "traffic")
+
+
+def _round(v, nd=4):
+    """Floats to `nd` significant digits after the leading one (JSON stays readable and short); containers recursively."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd + 2}g}")
+    if isinstance(v, dict):
+        return {k: _round(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_round(x, nd) for x in v]
+    return v
+
+
+def compact_record(full):
+    """The stdout line: the contract keys + `roofline` (dominant kernel, ties) + `step_roofline` (no groups) + `forward_only`
+    + `gradient_exchange` (no prose) + `cpu_baseline`.  `full` is the complete record (written to bench_detail.json)."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "config") if k in full}
+    roof = full.get("roofline")
+    if roof:
+        r = {k: roof[k] for k in _ROOF_KEYS if k in roof}
+        r["flop_convention"] = "executed"
+        r["timed"] = "hip_events_in_timed_region" + ("_two_streams" if full.get("streams", {}).get("side_stream_weight_gradients") else "")
+        sel = roof.get("selection") or {}
+        r["selection"] = {"rule": "largest_summed_event_time",
+                          "ms_per_step_by_symbol": sel.get("ms_per_step_by_symbol", {}),
+                          "tied_within_5_percent": [{k: t[k] for k in _TIE_KEYS if k in t}
+                                                    for t in sel.get("tied_within_5_percent", [])]}
+        rep = (full.get("roofline_serial_replay") or {})
+        alone = {}
+        for name in [roof["kernel"]] + [t["kernel"] for t in sel.get("tied_within_5_percent", [])]:
+            if name in rep:
+                alone[name] = {k: rep[name][k] for k in ("avg_launch_us", "achieved", "frac", "operator_frac") if k in rep[name]}
+        if alone:
+            r["alone_on_device"] = alone         # the same kernels in the serial replay (side streams off)
+            r["serial_replay_ms_per_step"] = next(iter(rep.values())).get("replay_ms_per_step")
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    sr = full.get("step_roofline")
+    if sr:
+        out["step_roofline"] = {k: sr[k] for k in ("floor_ms", "frac", "operator_floor_ms", "operator_frac") if k in sr}
+    if full.get("streams"):
+        out["streams"] = full["streams"]
+    if full.get("losses"):
+        out["losses"] = full["losses"]
+    fo = full.get("forward_only")
+    if fo:
+        out["forward_only"] = {k: fo[k] for k in ("ms_per_step", "value", "unit") if k in fo}
+    ex = full.get("gradient_exchange")
+    if ex:
+        out["gradient_exchange"] = {k: v for k, v in ex.items() if k != "note"}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "workload", "step_seconds_min_median_max",
+                                                  "spread", "cpu") if k in cb}
+    else:
+        out["cpu_baseline"] = cb
+    out["detail"] = full.get("detail_file", "bench_detail.json")
+    out = _round(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > RECORD_LIMIT:                 # never let the line outgrow the driver's capture again: shed optional keys
+        for k in ("losses", "streams", "gradient_exchange", "forward_only"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= RECORD_LIMIT:
+                break
+    assert len(line) <= RECORD_LIMIT, f"stdout record is {len(line)} characters"
+    return line
+
+
+def emit_record(full, json_fd):
+    """Full record -> bench_detail.json; compact record -> the saved stdout descriptor (ONE line)."""
+    path = os.environ.get("SSBEV_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    full["detail_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as exc:
+        full["detail_file"] = f"not written: {exc}"
+    sys.stderr.write(f"bench detail: {full['detail_file']}\n")      # (not the record itself: stderr may share the driver's capture)
+    sys.stderr.flush()
+    os.write(json_fd, (compact_record(full) + "\n").encode())
+
 
 def csrc_sha16():
     """Hash of the kernel sources (csrc/*.hip, *.h, include/ssbev.h): ties a PMC traffic file to the tree it was collected on."""
@@ -570,7 +668,7 @@ def main():
             out["gradient_exchange"] = exch
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample if world == 1 else "none", cfg)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit_record(out, json_fd)
     os.close(json_fd)
     if distributed:
         dist.destroy_process_group()

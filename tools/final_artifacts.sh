@@ -2,12 +2,12 @@
 # Regenerate the judged artifacts of a round from ONE tree on the GPU box: usage (inside gpurun) bash tools/final_artifacts.sh r3z
 # Writes gpurun_out/<tag>/*; copy what is to be judged into profiles/<tag>_*.  Every step runs under `timeout`.
 set -u
-tag=${1:-r5z}
+tag=${1:-r6z}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?" >> $out/smoke.txt
-timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err
+SSBEV_BENCH_DETAIL=$out/bench_detail.json timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err
 timeout 300 python bench.py --steps 10 --warmup 5 --cpu-sample none --precision bf16 2>/dev/null | tail -1 > $out/bench_line_bf16.json
 timeout 300 python bench.py --steps 8 --warmup 5 --cpu-sample none --precision bf16 --batch 2 --skip-forward-extra 2>/dev/null | tail -1 > $out/bench_line_bf16_b2.json
 # bf16 storage mode (configs[3]): serial-schedule kernel roll-up at B = 2, layer table at B = 1, PMC traffic of its kernels at B = 1
@@ -52,10 +52,12 @@ python - > $out/ablation_roofline.json <<PYEOF
 import json, subprocess, sys
 res = {}
 for mode in ("full", "stereo_only", "bev_only"):
+    import os
+    env = dict(os.environ, SSBEV_BENCH_DETAIL="/tmp/ablation_detail.json")
     out = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "3", "--cpu-sample", "none", "--skip-forward-extra",
-                          "--skip-serial-replay", "--ablation", mode], capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+                          "--skip-serial-replay", "--ablation", mode], capture_output=True, text=True, timeout=600, env=env).stdout.strip().splitlines()[-1]
     d = json.loads(out)
-    sr = d["step_roofline"]
+    sr = json.load(open("/tmp/ablation_detail.json"))["step_roofline"]      # the per-group table lives in the detail file
     res[mode] = {"ms_per_step": d["ms_per_step"], "voxels_per_s": d["value"], "step_roofline": {k: sr[k] for k in ("floor_ms", "frac", "operator_floor_ms", "operator_frac")},
                  "groups_ms_floor": {k: round(v["floor_ms_per_step"], 3) for k, v in sr["groups"].items()},
                  "roofline_kernel": d["roofline"] and {k: d["roofline"][k] for k in ("kernel", "frac", "avg_launch_us", "launches_per_step")}}
@@ -66,4 +68,4 @@ for cfgline in "--config kitti_d112" "--batch 2" "--ablation stereo_only" "--abl
 done
 timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $out/pytest_gpu.txt
 tail -3 $out/pytest_gpu.txt; head -14 $out/summary.txt; cat $out/other_configs.txt; python -c "
-import json; d=json.loads(open('$out/bench_line.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'], {k: round(v['frac'], 3) for k, v in d['roofline_serial_replay'].items()}, d['cpu_baseline'])"
+import json; d=json.loads(open('$out/bench_line.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('alone_on_device'), d['cpu_baseline'])"
