@@ -42,6 +42,10 @@ typedef void* ssbev_stream_t; /* hipStream_t */
 /* library / device identification */
 int ssbev_version(void);                 /* 10000*major + 100*minor + patch */
 const char* ssbev_build_arch(void);      /* "gfx950" */
+/* The library reads its SSBEV_* environment switches once per process (first use) and answers from a table afterwards: no
+ * getenv on the launch path.  A host that changes a switch later (tests do) calls this to have it read again; not to be called
+ * while other threads are inside the library. */
+void ssbev_env_refresh(void);
 
 /* ------------------------------------------------------------------------------------------
  * Frustum -> voxel scatter  (replaces VT:432-476 `voxel_pooling` + mmdet3d.ops.bev_pool, VT:473)
@@ -289,21 +293,14 @@ int ssbev_groupnorm_bwd_mask(const float* gy, const float* x, const uint64_t* re
                              const float* mean, const float* rstd, float* gx, float* gresidual, float* ggamma, float* gbeta,
                              const ssbev_norm_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
-/* Round 5: statistics + finalize in ONE launch, and the BatchNorm running-statistics update inside it.
- * The statistics of a normalisation were three launches (chunk partials, a latency-bound finalize kernel, apply); with a
- * caller-provided synchronisation word the finalize runs in the tail of the statistics kernel: its last-arriving workgroup
- * reduces the chunk records (double precision, fixed order: run-to-run identical, independent of which workgroup is last).
- *   sync          SSBEV_NORM_SYNC_WORDS 32-bit words of device memory that are ALL ZERO when the call is enqueued; the library
- *                 leaves them zero when the call's kernels have run, so one buffer zeroed once serves every later call ON THE
- *                 SAME STREAM (calls that may overlap on different streams need different buffers).  The library keeps no
- *                 state of its own.  NULL = the finalize kernels run as separate launches (the round 1-4 behaviour).
+/* BatchNorm running statistics inside the statistics finalize (round 5).
  *   running_mean / running_var (BatchNorm, G == C with the batch folded into S; NULL = none): the momentum update
  *                 r = (1 - momentum) r + momentum {mean, var * n / (n - 1)} of nn.BatchNorm in training mode, done by the
- *                 same tail (ssbev_bn_update_running as a launch of its own otherwise); n = samples per channel.
+ *                 finalize kernel (ssbev_bn_update_running as a launch of its own otherwise); n = samples per channel.
  * _fwd_ext / _bwd_ext are ssbev_groupnorm_fwd_mask / _bwd_mask (relu_mask may be NULL when relu = 0; _bwd_ext takes y OR
- * relu_mask for a fused ReLU) with `ext` (may be NULL). */
-#define SSBEV_NORM_SYNC_WORDS 16
-typedef struct { uint32_t* sync; float* running_mean; float* running_var; float momentum; int64_t n; } ssbev_norm_ext;
+ * relu_mask for a fused ReLU) with `ext` (may be NULL).
+ * (Round 5 also carried a `sync` word here for a finalize-in-the-statistics-tail variant; measured slower, removed in round 6.) */
+typedef struct { float* running_mean; float* running_var; float momentum; int64_t n; } ssbev_norm_ext;
 int ssbev_groupnorm_fwd_ext(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                             float* mean, float* rstd, uint64_t* relu_mask, const ssbev_norm_dims* d,
                             const ssbev_norm_ext* ext, void* ws, size_t ws_bytes, ssbev_stream_t stream);
@@ -328,8 +325,8 @@ int ssbev_groupnorm2_bwd(const float* gy, const uint64_t* relu_mask, const float
                          float* gxa, float* gxb, float* ggamma_a, float* gbeta_a, float* ggamma_b, float* gbeta_b,
                          const ssbev_norm2_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
-/* as ssbev_norm_ext for the two-norm operator (sync shared by both sides; running statistics per side, n = B * S) */
-typedef struct { uint32_t* sync; float* running_mean_a; float* running_var_a; float momentum_a;
+/* as ssbev_norm_ext for the two-norm operator (running statistics per side, n = B * S) */
+typedef struct { float* running_mean_a; float* running_var_a; float momentum_a;
                  float* running_mean_b; float* running_var_b; float momentum_b; } ssbev_norm2_ext;
 int ssbev_groupnorm2_fwd_ext(const float* xa, const float* gamma_a, const float* beta_a, float* mean_a, float* rstd_a,
                              const float* xb, const float* gamma_b, const float* beta_b, float* mean_b, float* rstd_b, float* y,

@@ -61,16 +61,13 @@ class Gemm16Dims(C.Structure):
 
 
 class NormExt(C.Structure):
-    _fields_ = [("sync", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
+    _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
                 ("n", C.c_int64)]
 
 
 class Norm2Ext(C.Structure):
-    _fields_ = [("sync", C.c_void_p), ("running_mean_a", C.c_void_p), ("running_var_a", C.c_void_p), ("momentum_a", C.c_float),
+    _fields_ = [("running_mean_a", C.c_void_p), ("running_var_a", C.c_void_p), ("momentum_a", C.c_float),
                 ("running_mean_b", C.c_void_p), ("running_var_b", C.c_void_p), ("momentum_b", C.c_float)]
-
-
-NORM_SYNC_WORDS = 16
 
 
 class DcnDims(C.Structure):
@@ -112,6 +109,7 @@ _P = C.c_void_p
 SIGNATURES = {
     "ssbev_version": (C.c_int, []),
     "ssbev_build_arch": (C.c_char_p, []),
+    "ssbev_env_refresh": (None, []),
     "ssbev_voxel_index": (C.c_int, [_P, _P, _P, C.POINTER(PoolDims), _P]),
     "ssbev_coords_to_vox": (C.c_int, [_P, C.c_int, _P, C.POINTER(PoolDims), _P]),
     "ssbev_pool_prepare_workspace": (C.c_size_t, [C.c_int, C.POINTER(PoolDims)]),

@@ -15,6 +15,12 @@ static inline hipStream_t as_stream(ssbev_stream_t s) { return reinterpret_cast<
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Environment switches of the library (SSBEV_*): each name is looked up in the process environment ONCE (first use, under a
+// mutex) and answered from a table afterwards -- no getenv per launch (the launch helpers run hundreds of times per step, from
+// the host thread and from autograd's) and no race with setenv on the host-language side.  A process that changes a switch after
+// the library has read it calls ssbev_env_refresh() (include/ssbev.h).  Returns nullptr when the variable is unset.  capi.hip.
+const char* ssbev_env(const char* name);
+
 // 64-lane butterfly sum (all lanes receive the total).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

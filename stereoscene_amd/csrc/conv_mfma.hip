@@ -654,7 +654,7 @@ wgrad_reduce_stage_kernel(float* __restrict__ ws, int nchunks, int per, long tot
 void launch_wgrad_reduce(float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
   const long total = (long)taps * Cq * Cp;
   long cstride = total;
-  static const int two_stage = getenv("SSBEV_WGRAD_REDUCE2") ? atoi(getenv("SSBEV_WGRAD_REDUCE2")) : 1;
+  static const int two_stage = ssbev_env("SSBEV_WGRAD_REDUCE2") ? atoi(ssbev_env("SSBEV_WGRAD_REDUCE2")) : 1;
   if (two_stage && nchunks >= 64 && total % 4 == 0) {
     const long total4 = total / 4, bx = cdiv(total4, 256);
     int nsl = (int)std::min<long>(std::max<long>(cdiv(2048, bx), 1), nchunks / 8);
@@ -1038,7 +1038,7 @@ conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
 // chosen before dispatch_gather is reached): fp32 gathers whose source
 // has a multiple of 32 channels, more than one tap or stride, <= 8 taps per axis, and enough rows to fill tiles
 bool conv_igemm_applicable(const ConvGeom& g) {
-  const char* env = getenv("SSBEV_IGEMM");                        // (read per call: the tests switch it inside one process)
+  const char* env = ssbev_env("SSBEV_IGEMM");                        // (read per call: the tests switch it inside one process)
   const int mode = env ? atoi(env) : 2;
   if (mode == 0 || g.bf16 || g.hint) return false;
   if (g.Cin % 32 != 0 || g.Cout % 4 != 0 || g.Cout < 64) return false;
@@ -1080,7 +1080,7 @@ int launch_igemm(const float* x, const float* wp, const float* bias, float* y, c
   // the largest tile that still leaves enough workgroups: 512 for the plain form, 1024 for the parity-class form (its classes walk
   // 1 .. 8 taps: the heavy ones must fill the chip on their own).  Measured (tools/igemm_probe.py, profiles/r5_igemm_probe.txt):
   // 64 -> 128 s2 at 23 040 output voxels: 128x128 = 180 workgroups 134 us, 64x64 = 720 workgroups 113 us.
-  const int force = getenv("SSBEV_IGEMM_TILE") ? atoi(getenv("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
+  const int force = ssbev_env("SSBEV_IGEMM_TILE") ? atoi(ssbev_env("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
   const bool wide = g.CoutPad % 128 == 0;
   const long need = g.form == 1 ? 1024 : 512;
   const int cand[3][2] = {{128, wide ? 128 : 64}, {64, wide ? 128 : 64}, {64, 64}};
@@ -1853,7 +1853,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   for (int pass = 0; pass < 2 && !p.ok; ++pass)
   for (int Wseg = 4 * p.ksplit; Wseg <= g.Wp && Wseg <= 80; Wseg += 4 * p.ksplit) {
     if (g.Wp % Wseg) continue;
-    if (const char* e = getenv("SSBEV_WGL_WSEG")) { if (atoi(e) > 0 && atoi(e) != Wseg) continue; }   // tuning hook
+    if (const char* e = ssbev_env("SSBEV_WGL_WSEG")) { if (atoi(e) > 0 && atoi(e) != Wseg) continue; }   // tuning hook
     const int ncol = S * Wseg + 2;
     // rows per step: aim at >= 16 MFMA k-steps per wave and barrier, within the staging lists and LDS
     int RG = 1;
@@ -1893,7 +1893,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
       }
     }
   }
-  if (getenv("SSBEV_WGL_DEBUG") && p.ok)
+  if (ssbev_env("SSBEV_WGL_DEBUG") && p.ok)
     fprintf(stderr, "wgrad_lds plan: cfg %d Cq %d Cp %d grid %dx%dx%d -> Wseg %d RG %d nslot %d gpc %d nranges %d nchunks %d lds %zu\n",
             p.cfg, g.Cq, g.Cp, g.Dp, g.Hp, g.Wp, g.Wseg, g.RG, g.nslot, g.gpc, g.nranges, p.nchunks, p.lds_bytes);
   return p;
@@ -3774,7 +3774,7 @@ int launch_conv_thin(const float* x, const float* wt, const float* bias, float* 
 // transposed) with k3 s2 p1 (output_padding 1: source = 2 x destination), K <= 32 source channels, 33..64 destination channels.
 // tile_hint 8 keeps the generic gather kernel, 5 forces this one on small problems (tests).
 bool conv_tap2_applicable(const ssbev_conv_dims* d, int mode) {
-  static const bool enabled = !(getenv("SSBEV_TAP2") && atoi(getenv("SSBEV_TAP2")) == 0);          // A/B hook
+  static const bool enabled = !(ssbev_env("SSBEV_TAP2") && atoi(ssbev_env("SSBEV_TAP2")) == 0);          // A/B hook
   if (!enabled && d->tile_hint != 5) return false;
   if (!((mode == 0 && !d->transposed) || (mode == 1 && d->transposed))) return false;
   if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
@@ -3815,7 +3815,7 @@ int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* 
     const double cost = rounds * (c + 1.0 + 0.5 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = getenv("SSBEV_TAP2_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_env("SSBEV_TAP2_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kT2LdsBytes) != hipSuccess)
@@ -3827,7 +3827,7 @@ int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* 
 // Stride-2 "up" gather on conv_tap2up_kernel: transposed-conv forward (mode 0, transposed) or conv data gradient (mode 1,
 // !transposed) with k3 s2 p1, fine grid = 2 x coarse grid, 33..64 source channels, <= 32 destination channels (multiple of 8).
 bool conv_tap2up_applicable(const ssbev_conv_dims* d, int mode) {
-  static const bool enabled = !(getenv("SSBEV_TAP2UP") && atoi(getenv("SSBEV_TAP2UP")) == 0);      // A/B hook
+  static const bool enabled = !(ssbev_env("SSBEV_TAP2UP") && atoi(ssbev_env("SSBEV_TAP2UP")) == 0);      // A/B hook
   if (!enabled && d->tile_hint != 5) return false;
   if (!((mode == 0 && d->transposed) || (mode == 1 && !d->transposed))) return false;
   if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
@@ -3866,7 +3866,7 @@ int launch_conv_tap2up(const float* x, const float* wp, const float* bias, float
     const double cost = rounds * (c + 1.0 + 0.5 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = getenv("SSBEV_TAP2UP_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_env("SSBEV_TAP2UP_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kUpLdsBytes) != hipSuccess)
@@ -3897,7 +3897,7 @@ bool conv_taph_applicable(const ssbev_conv_dims* d, int mode) {
 
 // 1x1x1 stride-1 layers with <= 32 channels on both sides on conv_pw32_kernel (tile_hint 8 keeps the generic gather kernel)
 bool conv_pw32_applicable(const ssbev_conv_dims* d, int mode) {
-  static const int off = getenv("SSBEV_PW32") ? atoi(getenv("SSBEV_PW32")) == 0 : 0;
+  static const int off = ssbev_env("SSBEV_PW32") ? atoi(ssbev_env("SSBEV_PW32")) == 0 : 0;
   if (off || d->transposed || d->precision != 0 || d->tile_hint == 8) return false;
   if (d->kd != 1 || d->kh != 1 || d->kw != 1 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pd != 0 || d->ph != 0 || d->pw != 0) return false;
@@ -3928,7 +3928,7 @@ int launch_conv_pw32(const float* x, const float* wp, const float* bias, float* 
 
 // F(2,3) along d and h: even D as well.  tile_hint 4 keeps the h-only kernel (A/B timing, tests)
 bool conv_tapdh_applicable(const ssbev_conv_dims* d, int mode) {
-  static const int off = getenv("SSBEV_TAPDH") ? atoi(getenv("SSBEV_TAPDH")) == 0 : 0;
+  static const int off = ssbev_env("SSBEV_TAPDH") ? atoi(ssbev_env("SSBEV_TAPDH")) == 0 : 0;
   return !off && conv_taph_applicable(d, mode) && d->Do % 2 == 0 && d->tile_hint != 4;
 }
 
@@ -3955,12 +3955,12 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
     const double cost = rounds * (c + 0.5 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = getenv("SSBEV_TAPDH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_env("SSBEV_TAPDH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tapdh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kDhLdsBytes) != hipSuccess)
     return SSBEV_ELAUNCH;
-  static const int times = getenv("SSBEV_TAPDH_TIMES") ? atoi(getenv("SSBEV_TAPDH_TIMES")) : 0;
+  static const int times = ssbev_env("SSBEV_TAPDH_TIMES") ? atoi(ssbev_env("SSBEV_TAPDH_TIMES")) : 0;
   if (times) {      // tuning hook: per-phase shader clocks of every wave (fresh stage / walk / publish + barrier / fold / tail barrier)
     const size_t nwg = (size_t)(nranges * g.nseg), n = nwg * 16 * 8;
     unsigned long long* dev = nullptr;
@@ -3994,7 +3994,7 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
 size_t align256b(size_t x);
 struct WgradDhPlan { bool ok; WgradDhGeom g; int nchunks; };
 WgradDhPlan plan_wgrad_dh(const ssbev_conv_dims* d) {
-  static const int off = getenv("SSBEV_WGRAD_DH") ? atoi(getenv("SSBEV_WGRAD_DH")) == 0 : 0;
+  static const int off = ssbev_env("SSBEV_WGRAD_DH") ? atoi(ssbev_env("SSBEV_WGRAD_DH")) == 0 : 0;
   WgradDhPlan p;
   p.ok = false; p.nchunks = 0;
   if (off || d->transposed || d->precision != 0) return p;
@@ -4022,7 +4022,7 @@ WgradDhPlan plan_wgrad_dh(const ssbev_conv_dims* d) {
     const double cost = rounds * (c + 1.0 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = getenv("SSBEV_WGRAD_DH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_env("SSBEV_WGRAD_DH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   p.nchunks = ((g.NG + g.gpc - 1) / g.gpc) * g.nseg;
   p.ok = true;
   return p;
@@ -4072,7 +4072,7 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
     if (cost < best) { best = cost; g.gpc = c; }
   }
   long nranges;
-  if (const char* e = getenv("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_env("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   // Plane-aligned order (see the kernel) when the planes split evenly over the 8 XCDs.  The cut of a plane into a first and a
   // second chunk is chosen by simulating the dispatch on one XCD's 32 CUs (chunks go to the CU that is free first, in index
   // order; a chunk costs its row pairs + 0.6 of start-up): for 24 planes x 5 segments of 24 pairs, 18 + 6 ends level with
@@ -4081,7 +4081,7 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
   // 572 -> 228 MB for the 189 MB tensor -- but the kernel is not HBM-bound and the workgroups moving in step cost it 8 %
   // (0.533 -> 0.579 ms; every aligned variant, whatever its tail, lands at 0.58-0.60), +0.3 ms on the step
   // (profiles/r3y_taph_plane_aligned.txt)
-  static const int aligned = getenv("SSBEV_TAPH_ALIGNED") ? atoi(getenv("SSBEV_TAPH_ALIGNED")) : 0;
+  static const int aligned = ssbev_env("SSBEV_TAPH_ALIGNED") ? atoi(ssbev_env("SSBEV_TAPH_ALIGNED")) : 0;
   long nblocks = 0;
   if (aligned > 0 && (g.B * g.D) % 8 == 0 && H2 >= 2) {
     g.slab = g.B * g.D / 8;

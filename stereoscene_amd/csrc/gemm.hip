@@ -567,7 +567,7 @@ int tn_chunks_model(const ssbev_gemm_dims* d, int tiles) {
 // a multiple of 160 (16 x [1920 rows -> 640 x 640]: 320 tiles x 4 chunks = 5.0 per CU instead of 400 x 2 = 3.1 -> 4 rounds of
 // twice the rows); SSBEV_GEMM_TN_WIDE=0 keeps the 128 x 128 tiles
 bool tn_wide(const ssbev_gemm_dims* d) {
-  static const bool enabled = !(getenv("SSBEV_GEMM_TN_WIDE") && atoi(getenv("SSBEV_GEMM_TN_WIDE")) == 0);
+  static const bool enabled = !(ssbev_env("SSBEV_GEMM_TN_WIDE") && atoi(ssbev_env("SSBEV_GEMM_TN_WIDE")) == 0);
   return enabled && d->batch >= 8 && d->N % 160 == 0 && d->d2s_kd == 0 && !d->ep_mul;
 }
 
@@ -577,7 +577,7 @@ int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
   // 640 x 640], 4 instead of 8 on the BRI energy product: +2 ... +9 % alone on the device, but +1.3 ms per step next to the side
   // stream's kernels, where many small workgroups fill the gaps better (profiles/r5_gemm_cfg_probe.txt).  SSBEV_GEMM_TN_CHUNKS=model
   // selects it.)
-  static const std::string sel = getenv("SSBEV_GEMM_TN_CHUNKS") ? getenv("SSBEV_GEMM_TN_CHUNKS") : "";
+  static const std::string sel = ssbev_env("SSBEV_GEMM_TN_CHUNKS") ? ssbev_env("SSBEV_GEMM_TN_CHUNKS") : "";
   const bool model = sel == "model" || (sel == "batched" && d->batch >= 8);       // "batched": only the frequency products
   if (!model) return std::min(std::max(1, 1024 / std::max(1, tiles * d->batch)), std::max(1, d->M / 256));
   const int cmax = std::min(16, std::max(1, d->M / 256));
@@ -605,7 +605,7 @@ int nn_chunks(const ssbev_gemm_dims* d, int tiles) {
 // rows of the workgroup tile: 192 when that wastes fewer padded rows than 128 (M = 192: 0 % instead of 25 %)
 int pick_bm(const ssbev_gemm_dims* d, int wn) {
   if (d->d2s_kd > 0 || wn != 2) return 128;
-  static const bool enabled = !(getenv("SSBEV_GEMM_BM192") && atoi(getenv("SSBEV_GEMM_BM192")) == 0);     // A/B hook
+  static const bool enabled = !(ssbev_env("SSBEV_GEMM_BM192") && atoi(ssbev_env("SSBEV_GEMM_BM192")) == 0);     // A/B hook
   if (!enabled) return 128;
   const long p128 = (long)((d->M + 127) / 128) * 128, p192 = (long)((d->M + 191) / 192) * 192;
   return p192 * 8 <= p128 * 7 ? 192 : 128;              // at least 1/8 fewer MFMA rows
@@ -623,7 +623,7 @@ constexpr NnCfg kNnCfgs[] = {
 constexpr int kNnCfgCount = sizeof(kNnCfgs) / sizeof(kNnCfgs[0]);
 
 int nn_forced_cfg() {          // SSBEV_GEMM_CFG=<n>: probing hook (tools/gemm_probe.py)
-  const char* e = getenv("SSBEV_GEMM_CFG");
+  const char* e = ssbev_env("SSBEV_GEMM_CFG");
   if (!e || !*e) return -1;
   const int c = atoi(e);
   return c >= 0 && c < kNnCfgCount ? c : -1;
@@ -653,7 +653,7 @@ int nn_pick_cfg(const ssbev_gemm_dims* d, int* nchunk_out) {
       // rounds 2-4 choice (tiles that pad least), unless the model says another shape is >= 5 % cheaper
       const int wn = pick_wn(d->N, 0);
       cfg = wn == 2 ? (pick_bm(d, wn) == 192 ? 2 : 0) : 1;
-      static const bool wide = !(getenv("SSBEV_GEMM_WIDE_TILES") && atoi(getenv("SSBEV_GEMM_WIDE_TILES")) == 0);     // A/B hook
+      static const bool wide = !(ssbev_env("SSBEV_GEMM_WIDE_TILES") && atoi(ssbev_env("SSBEV_GEMM_WIDE_TILES")) == 0);     // A/B hook
       if (wide) {
         const NnCfg& c0 = kNnCfgs[cfg];
         const int t0 = ((d->M + c0.bm - 1) / c0.bm) * ((d->N + c0.bn - 1) / c0.bn);

@@ -18,7 +18,7 @@ namespace {
 constexpr int NT = 256;
 // The statistics kernels: PNT threads per workgroup, ~kStatBlocks workgroups (three per CU).  Round 5: a workgroup covers a
 // chunk of voxels x a SLAB of kSlabLanes lanes (32 fp32 / 64 bf16 channels), so that every problem, whatever its channel count,
-// leaves the same ~24.6 k (sum, sum-of-squares) records -- what one workgroup can reduce in two round trips (GnTail below).
+// leaves the same ~24.6 k (sum, sum-of-squares) records for the finalize kernels.
 // (One workgroup per CU with 768 threads and 256 chunks was measured and dropped: the streaming passes lost 40-70 %, and a
 // 12-wave workgroup waits for a whole free CU next to the side stream's kernels.)
 constexpr int PNT = 256;
@@ -86,198 +86,13 @@ __device__ __forceinline__ void stn(T* p, const float (&v)[VW]) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Finalize in the tail of the statistics kernel (round 5).  The statistics of a normalisation used to be three launches:
-// chunk partials -> one latency-bound finalize kernel (B * G workgroups; 104 launches of ~7-10 us per step) -> apply.  With a
-// caller-provided, zeroed 32-bit word (ssbev_norm_ext.sync; the C ABI keeps no state) every workgroup of the statistics
-// kernel takes a ticket after publishing its partial record, and the one that draws the last ticket reduces the records of
-// the whole problem -- in double, in a fixed order: run-to-run identical -- writes mean / rstd (forward; plus the BatchNorm
-// running-statistics update that was a launch of its own) or the per-group coefficients and dgamma / dbeta (backward), and
-// puts the word back to zero.  Hand-off = MI355X_MICROARCH "Workgroup dispatch ...", the write-through form: every record is
-// ONE 8-byte agent-scope (sc1) store -> every wave vmcnt(0) -> barrier -> lane 0 takes a relaxed agent-scope ticket; the last
-// arriver reads the records with 8-byte agent-scope (sc1) loads.  Results do not depend on which workgroup is last.
-struct GnTail {
-  unsigned* sync;            // nullptr: no tail (the finalize kernels run as separate launches)
-  unsigned total;            // tickets = workgroups of the launch
-  // forward
-  float* mean; float* rstd;
-  float* rm; float* rv;      // BatchNorm running statistics (G == C), nullptr = none
-  float mom, unbias;
-  // backward
-  const float* gamma; float* coef; float* dgamma; float* dbeta;
-};
-
-constexpr int kTailMaxC = 1024;       // channels the tail handles: everything on the voxel path and DepthNet
-constexpr int kTailRounds = (kTailMaxC + PNT - 1) / PNT;
-
-__host__ __device__ inline size_t gn_tail_lds_bytes(int C) { return (size_t)(2 * PNT + 2 * C) * sizeof(double); }
-
-// A chunk record = (sum, sum of squares) of one channel = ONE aligned 8-byte agent-scope (sc1, write-through) store, read back
-// by 8-byte agent-scope loads: the "8-byte agent atomics on both sides" form of the guide -- no release fence (a buffer_wbl2
-// per workgroup), no acquire.
+// A chunk record = (sum, sum of squares) of one channel = ONE aligned 8-byte store (round 5: whatever its channel count, a problem
+// leaves ~24.6 k records for the finalize kernels, which request all of them at once).
+// (Round 5 also built a finalize-in-the-tail variant -- last-arriving workgroup behind agent-scope tickets folds the records,
+// no finalize launch.  Measured +0.7 ms per step (one workgroup folds 200 KB while the stream's other 255 CUs wait; ~770
+// serialised ticket atomics per problem) and removed in round 6; profiles/r5z_summary*.txt)
 __device__ __forceinline__ void st_record(float* p, float a, float q) {
-  const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(q) << 32);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// true in exactly one workgroup of the launch: the last one to arrive (all threads of the workgroup get the same answer).
-// Two levels of tickets: 768 arrivals on ONE word are a serial chain of ~12 ns each (MI355X_MICROARCH "fanin": 9 us behind the
-// last streaming read), so a workgroup first arrives on one of kTailShards words (workgroup index modulo 8 = its XCD on
-// today's dispatcher; any placement is correct) and only the last arriver of a shard goes on to the top word.
-constexpr unsigned kTailShards = 8;
-__device__ __forceinline__ bool gn_last_arriver(const GnTail& t, int* flag_lds) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its (write-through) record stores
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned shard = lin % kTailShards;
-    const unsigned members = (t.total - shard + kTailShards - 1) / kTailShards;       // workgroups with this residue
-    int last = 0;
-    if (members > 0 && __hip_atomic_fetch_add(t.sync + 1 + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-      __hip_atomic_store(t.sync + 1 + shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next call
-      const unsigned shards = t.total < kTailShards ? t.total : kTailShards;
-      last = __hip_atomic_fetch_add(t.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u;
-    }
-    *flag_lds = last;
-  }
-  __syncthreads();
-  return *flag_lds != 0;
-}
-
-// per-(sample, channel) sums of the chunk records of one sample into dtot[C][2] (double).  PNT threads = CW channels x L
-// lanes; lane j of a channel takes chunks j, j + L, ..., lane 0 adds the L lane sums in lane order.  The records of a lane
-// are requested kTailBatch at a time (64 - 96 registers) before the first add: the tail is a chain of round trips to another CU's data
-// (~1.5 us each), not a bandwidth problem.
-template <bool SHIFT_BACK, typename T>
-__device__ __forceinline__ void gn_tail_channel_sums(const float* partial, const T* x, const GnGeom& g, int b, double* dred,
-                                                     double* dtot) {
-  constexpr int kTailBatch = 48;
-  const int tid = threadIdx.x, C = g.C, CW = C < PNT ? C : PNT, L = PNT / CW;
-  const int ci = tid % CW, j = tid / CW;
-  for (int c0 = 0; c0 < C; c0 += CW) {
-    const int c = c0 + ci;
-    const bool on = j < L && c < C;
-    double a = 0.0, q = 0.0;
-    if (on) {
-      float pf = 0.0f;
-      if (SHIFT_BACK) pf = ld1(x + (size_t)b * g.S * g.C + c);        // the pivot: requested with the first batch of records
-      const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(partial) + ((size_t)b * g.chunks * g.C + c);
-      for (int chunk0 = j; chunk0 < g.chunks; chunk0 += L * kTailBatch) {
-        unsigned long long raw[kTailBatch];
-#pragma unroll
-        for (int u = 0; u < kTailBatch; ++u) {
-          const int chunk = chunk0 + u * L;
-          raw[u] = chunk < g.chunks ? __hip_atomic_load(pp + (size_t)chunk * g.C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < kTailBatch; ++u) {       // (records beyond the last chunk were requested as zeros)
-          a += (double)__uint_as_float((unsigned)raw[u]);
-          q += (double)__uint_as_float((unsigned)(raw[u] >> 32));
-        }
-      }
-      if (SHIFT_BACK) {
-        // shifted partials (pivot p = the channel's value at voxel 0, see gn_partial_kernel): over the n voxels of this lane's
-        // chunks  sum u = sum d + n p,  sum u^2 = sum d^2 + 2 p sum d + n p^2
-        if (g.pre) pf = gelu_f(pf);
-        const double pd = pf;
-        const long k = j < g.chunks ? (g.chunks - 1 - j) / L + 1 : 0;                       // chunks of this lane
-        long nv = k * g.chunk_len;
-        if (k > 0 && (g.chunks - 1 - j) % L == 0) nv -= (long)g.chunks * g.chunk_len - g.S;   // it owns the (shorter) last chunk
-        const double n = (double)nv;
-        q += 2.0 * pd * a + n * pd * pd;
-        a += n * pd;
-      }
-      dred[(j * CW + ci) * 2 + 0] = a;
-      dred[(j * CW + ci) * 2 + 1] = q;
-    }
-    __syncthreads();
-    if (j == 0 && c < C) {
-      double sa = 0.0, sq = 0.0;
-      for (int jj = 0; jj < L; ++jj) { sa += dred[(jj * CW + ci) * 2]; sq += dred[(jj * CW + ci) * 2 + 1]; }
-      dtot[c * 2] = sa; dtot[c * 2 + 1] = sq;
-    }
-    __syncthreads();
-  }
-}
-
-template <typename T>
-__device__ void gn_tail_fwd(const float* partial, const T* x, const GnGeom& g, const GnTail& t, double* dl) {
-  double* dred = dl;
-  double* dtot = dl + 2 * PNT;
-  const int cpg = g.C / g.G;
-  for (int b = 0; b < g.B; ++b) {
-    if (g.G == g.C) {
-      // one channel per group (BatchNorm): the statistics of the SHIFTED values d = u - p directly (mean = p + E[d])
-      gn_tail_channel_sums<false>(partial, x, g, b, dred, dtot);
-      for (int c = threadIdx.x; c < g.C; c += PNT) {
-        float pf = ld1(x + (size_t)b * g.S * g.C + c);
-        if (g.pre) pf = gelu_f(pf);
-        const double n = (double)g.S, md = dtot[c * 2] / n;
-        double var = dtot[c * 2 + 1] / n - md * md;
-        if (var < 0.0) var = 0.0;
-        const float mf = (float)((double)pf + md), rs = (float)(1.0 / sqrt(var + (double)g.eps));
-        t.mean[b * g.C + c] = mf;
-        t.rstd[b * g.C + c] = rs;
-        if (t.rm && b == 0) {                           // (running statistics: B is folded into S for a BatchNorm)
-          const float vf = 1.0f / (rs * rs) - g.eps;    // as bn_update_running_kernel computes it from the stored rstd
-          t.rm[c] = (1.0f - t.mom) * t.rm[c] + t.mom * mf;
-          t.rv[c] = (1.0f - t.mom) * t.rv[c] + t.mom * (vf * t.unbias);
-        }
-      }
-    } else {
-      gn_tail_channel_sums<true>(partial, x, g, b, dred, dtot);
-      for (int grp = threadIdx.x; grp < g.G; grp += PNT) {
-        double sa = 0.0, sq = 0.0;
-        for (int k = 0; k < cpg; ++k) { sa += dtot[(grp * cpg + k) * 2]; sq += dtot[(grp * cpg + k) * 2 + 1]; }
-        const double n = (double)g.S * cpg, m = sa / n;
-        double var = sq / n - m * m;
-        if (var < 0.0) var = 0.0;
-        t.mean[b * g.G + grp] = (float)m;
-        t.rstd[b * g.G + grp] = (float)(1.0 / sqrt(var + (double)g.eps));
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// backward: coef[(b, group)] = (sum_c gamma_c sum(g xhat), sum_c gamma_c sum(g)) / n ; dbeta / dgamma = sums over samples
-__device__ void gn_tail_bwd(const float* partial, const GnGeom& g, const GnTail& t, double* dl) {
-  double* dred = dl;
-  double* dtot = dl + 2 * PNT;
-  const int cpg = g.C / g.G;
-  const int CW = g.C < PNT ? g.C : PNT;
-  const bool owner = (int)threadIdx.x < CW;                  // lane 0 of a channel column
-  double accb[kTailRounds] = {0, 0}, accs[kTailRounds] = {0, 0};
-  for (int b = 0; b < g.B; ++b) {
-    gn_tail_channel_sums<false>(partial, (const float*)nullptr, g, b, dred, dtot);
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < kTailRounds; ++r) {
-        const int c = r * CW + threadIdx.x;
-        if (c < g.C) { accb[r] += dtot[c * 2]; accs[r] += dtot[c * 2 + 1]; }
-      }
-    }
-    for (int grp = threadIdx.x; grp < g.G; grp += PNT) {
-      double s = 0.0, u = 0.0;
-      for (int k = 0; k < cpg; ++k) {
-        const int c = grp * cpg + k;
-        const double gm = t.gamma[c];
-        u += gm * dtot[c * 2];
-        s += gm * dtot[c * 2 + 1];
-      }
-      const double n = (double)g.S * cpg;
-      t.coef[(b * g.G + grp) * 2 + 0] = (float)(s / n);
-      t.coef[(b * g.G + grp) * 2 + 1] = (float)(u / n);
-    }
-    __syncthreads();
-  }
-  if (owner) {
-#pragma unroll
-    for (int r = 0; r < kTailRounds; ++r) {
-      const int c = r * CW + threadIdx.x;
-      if (c < g.C) { t.dbeta[c] = (float)accb[r]; t.dgamma[c] = (float)accs[r]; }
-    }
-  }
+  *reinterpret_cast<float2*>(p) = make_float2(a, q);
 }
 
 // Per-channel partial sums over one chunk of voxels.  MODE 0: (sum x, sum x^2).
@@ -286,8 +101,8 @@ template <int MODE, bool PRE, int RM = 0, typename T = float, int VW = 4>   // R
 __global__ void __launch_bounds__(PNT, 3)
 gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ y,
                   const unsigned long long* __restrict__ mask, const float* __restrict__ mean,
-                  const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g, GnTail tail) {
-  extern __shared__ __align__(16) float lds[];         // [rows][Cs][2]; the finalize tail re-uses it as doubles
+                  const float* __restrict__ rstd, float* __restrict__ partial, GnGeom g) {
+  extern __shared__ __align__(16) float lds[];         // [rows][Cs][2]
   // channel slab of this block (blockIdx.z): g.slab_q lanes of VW channels
   const int q0 = blockIdx.z * g.slab_q;                // first lane of the slab
   const int q = min(g.C / VW - q0, g.slab_q);          // lanes per voxel in this slab
@@ -398,13 +213,6 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ gy, const T* __
     float s0 = 0.0f, s1 = 0.0f;
     for (int rr = 0; rr < rows; ++rr) { s0 += lds[((size_t)rr * Cs + t) * 2]; s1 += lds[((size_t)rr * Cs + t) * 2 + 1]; }
     st_record(partial + ((size_t)(b * g.chunks + chunk) * g.C + q0 * VW + t) * 2, s0, s1);
-  }
-  if (tail.sync) {
-    if (!gn_last_arriver(tail, reinterpret_cast<int*>(lds))) return;
-    __syncthreads();
-    if (MODE == 0) gn_tail_fwd<T>(partial, x, g, tail, reinterpret_cast<double*>(lds));
-    else gn_tail_bwd(partial, g, tail, reinterpret_cast<double*>(lds));
-    if (tid == 0) __hip_atomic_store(tail.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
   }
 }
 
@@ -624,9 +432,7 @@ struct SampleWalk {
 };
 
 // y = (x - mean) * rstd * gamma + beta (+ residual) (ReLU)
-// U = lane-vectors a thread has in flight per step of its grid-stride walk (i and i + stride: the SAME channels, so the per-channel
-// constants are shared); U = 2 is an A/B hook (SSBEV_GN_APPLY_U=2), measured slower than U = 1 on both dtypes.
-template <bool PRE, typename T = float, int VW = 4, int U = 1>
+template <bool PRE, typename T = float, int VW = 4>
 __global__ void __launch_bounds__(NT)
 gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const T* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -642,71 +448,52 @@ gn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, co
   float gam[VW], bet[VW], mu[VW], rs[VW];
 #pragma unroll
   for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; mu[k] = 0.f; rs[k] = 0.f; }
-  const long per = (long)q * g.S;
-  SampleWalk sw[U];
+  SampleWalk sw(i, (long)q * g.S);
+  for (; i < totalv; i += stride, sw.step(stride)) {
+    float v[VW], rr[VW];
+    ldn<VW>(x + (size_t)VW * i, v);
 #pragma unroll
-  for (int u = 0; u < U; ++u) sw[u] = SampleWalk(i + u * stride, per);
-  for (; i < totalv; i += U * stride) {
-    long iu[U];
-    float v[U][VW], rr[U][VW];
+    for (int k = 0; k < VW; ++k) rr[k] = 0.0f;
+    if (res) ldn<VW>(res + (size_t)VW * i, rr);
+    const int b = sw.b;
+    if (!fixed) {
+      c = (int)(i % q) * VW;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      iu[u] = i + u * stride;
-      ldn<VW>(x + (size_t)VW * (iu[u] < totalv ? iu[u] : i), v[u]);          // (past the end: a harmless re-read of vector 0)
+      for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int k = 0; k < VW; ++k) rr[u][k] = 0.0f;
-    if (res) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) ldn<VW>(res + (size_t)VW * (iu[u] < totalv ? iu[u] : i), rr[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long ii = iu[u];
-      const int b = sw[u].b;
-      sw[u].step(U * stride);
-      if (u > 0 && ii >= totalv) break;
-      if (!fixed) {
-        c = (int)(ii % q) * VW;
-#pragma unroll
-        for (int k = 0; k < VW; ++k) { gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
-      }
-      if (!fixed || b != bcur) {
-        bcur = b;
-#pragma unroll
-        for (int k = 0; k < VW; ++k) {
-          const int grp = b * g.G + (c + k) / cpg;
-          mu[k] = mean[grp]; rs[k] = rstd[grp];
-          if (FOLD) { rs[k] *= gam[k]; mu[k] = bet[k] - mu[k] * rs[k]; }       // y = rs' x + mu'
-        }
-      }
-      if (PRE) {
-#pragma unroll
-        for (int k = 0; k < VW; ++k) v[u][k] = gelu_f(v[u][k]);
-      }
+    if (!fixed || b != bcur) {
+      bcur = b;
 #pragma unroll
       for (int k = 0; k < VW; ++k) {
-        float o = FOLD ? fmaf(v[u][k], rs[k], mu[k]) + rr[u][k] : (v[u][k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[u][k];
-        v[u][k] = g.relu ? fmaxf(o, 0.0f) : o;
+        const int grp = b * g.G + (c + k) / cpg;
+        mu[k] = mean[grp]; rs[k] = rstd[grp];
+        if (FOLD) { rs[k] *= gam[k]; mu[k] = bet[k] - mu[k] * rs[k]; }       // y = rs' x + mu'
       }
-      if (mask) {
-        // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
-        // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
-        // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
-        if constexpr (VW == 4) relu_mask_store4(mask, ii, v[u]);
-        else {
+    }
+    if (PRE) {
 #pragma unroll
-          for (int k = 0; k < VW; ++k) {
-            const unsigned long long bal = __ballot(v[u][k] > 0.0f);
-            if ((threadIdx.x & 63) == 0) mask[(ii >> 6) * VW + k] = bal;
-          }
+      for (int k = 0; k < VW; ++k) v[k] = gelu_f(v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float o = FOLD ? fmaf(v[k], rs[k], mu[k]) + rr[k] : (v[k] - mu[k]) * rs[k] * gam[k] + bet[k] + rr[k];
+      v[k] = g.relu ? fmaxf(o, 0.0f) : o;
+    }
+    if (mask) {
+      // ReLU mask for the backward pass: word (i / 64) * VW + k holds bit (i % 64) = [component k of lane-vector i is > 0].
+      // The 64 lanes of a wave own 64 consecutive vectors (block offsets and the grid stride are multiples of 256), so one
+      // ballot per component is exactly one mask word; backward then reads 1 bit per element instead of the 189 MB of y.
+      if constexpr (VW == 4) relu_mask_store4(mask, i, v);
+      else {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+          const unsigned long long bal = __ballot(v[k] > 0.0f);
+          if ((threadIdx.x & 63) == 0) mask[(i >> 6) * VW + k] = bal;
         }
       }
-      if (g.ldy == g.C) stn<VW>(y + (size_t)VW * ii, v[u]);
-      else stn<VW>(y + (ii / q) * g.ldy + (ii % q) * VW, v[u]);
     }
+    if (g.ldy == g.C) stn<VW>(y + (size_t)VW * i, v);
+    else stn<VW>(y + (i / q) * g.ldy + (i % q) * VW, v);
   }
 }
 
@@ -861,130 +648,6 @@ gn_apply_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// bf16 apply passes with 16-byte lanes (round 5).  With 8-byte lanes (VW = 4) the bf16 passes move half the bytes per load
-// instruction of the fp32 ones and run at 60 / 42 us where fp32 takes 36 / 29 us for the same bytes; round 4's 8-channel lanes
-// were slower still because the per-channel constants doubled (gamma, beta, mean, rstd, two coefficients: 48 registers).  Here the
-// constants are FUSED per channel before the loop -- forward y = a x + b with a = rstd gamma, b = beta - mean a (16 registers);
-// backward gx = A g + B (x - mean) + C with A = gamma rstd, B = -rstd^2 c0, C = -c1 rstd (32) -- so an 8-channel lane carries
-// fewer registers than the 4-channel one did.  The ReLU bit mask keeps its per-quad layout: a lane's two quads are neighbouring
-// bits, so a mask word is the bit-interleave of two half ballots.
-// MEASURED (bf16, two samples, kitti_d192): 73.6 ms per step with these kernels against 72.5 ms with the 8-byte lanes -- half the
-// threads carry the same bytes in flight and three times the unpack / pack / ballot work each; OFF unless SSBEV_GN_APPLY16=1.
-__device__ __forceinline__ unsigned long long spread32(unsigned x) {
-  unsigned long long v = x;
-  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  v = (v | (v << 2)) & 0x3333333333333333ull;
-  v = (v | (v << 1)) & 0x5555555555555555ull;
-  return v;
-}
-
-__global__ void __launch_bounds__(NT)
-gn_apply_fwd16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                      const bf16_t* __restrict__ res, const float* __restrict__ mean, const float* __restrict__ rstd,
-                      bf16_t* __restrict__ y, unsigned long long* __restrict__ mask, GnGeom g, long total8) {
-  constexpr int VW = 8;
-  const int q = g.C / VW, cpg = g.C / g.G;
-  const long stride = (long)gridDim.x * NT;
-  const bool fixed = stride % q == 0;
-  long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * VW, bcur = -1;
-  float sc[VW], sh[VW];
-#pragma unroll
-  for (int k = 0; k < VW; ++k) { sc[k] = 0.f; sh[k] = 0.f; }
-  const long total4 = 2 * total8;
-  SampleWalk sw(i, (long)q * g.S);
-  for (; i < total8; i += stride, sw.step(stride)) {
-    const int b = sw.b;
-    if (!fixed) c = (int)(i % q) * VW;
-    if (!fixed || b != bcur) {
-      bcur = b;
-#pragma unroll
-      for (int k = 0; k < VW; ++k) {
-        const int grp = b * g.G + (c + k) / cpg;
-        const float a = rstd[grp] * gamma[c + k];
-        sc[k] = a;
-        sh[k] = beta[c + k] - mean[grp] * a;
-      }
-    }
-    float v[VW], rr[VW];
-    ldn<VW>(x + (size_t)VW * i, v);
-#pragma unroll
-    for (int k = 0; k < VW; ++k) rr[k] = 0.0f;
-    if (res) ldn<VW>(res + (size_t)VW * i, rr);
-#pragma unroll
-    for (int k = 0; k < VW; ++k) {
-      const float o = fmaf(v[k], sc[k], sh[k]) + rr[k];
-      v[k] = g.relu ? fmaxf(o, 0.0f) : o;
-    }
-    if (mask) {
-      // quad Q = 2 i + h of lane-vector i; word (Q / 64) * 4 + k, bit Q % 64: the wave's 64 lanes cover 128 quads = two word sets
-      const long Q0 = 2 * (i - (threadIdx.x & 63));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned long long b0 = __ballot(v[k] > 0.0f), b1 = __ballot(v[4 + k] > 0.0f);
-        if ((threadIdx.x & 63) == 0) {
-          mask[(Q0 >> 6) * 4 + k] = spread32((unsigned)b0) | (spread32((unsigned)b1) << 1);
-          if (Q0 + 64 < total4) mask[((Q0 >> 6) + 1) * 4 + k] = spread32((unsigned)(b0 >> 32)) | (spread32((unsigned)(b1 >> 32)) << 1);
-        }
-      }
-    }
-    if (g.ldy == g.C) stn<VW>(y + (size_t)VW * i, v);
-    else stn<VW>(y + (i / q) * g.ldy + (i % q) * VW, v);
-  }
-}
-
-__global__ void __launch_bounds__(NT)
-gn_apply_bwd16_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
-                      bf16_t* __restrict__ gx, bf16_t* __restrict__ gres, const unsigned long long* __restrict__ mask, GnGeom g,
-                      long total8) {
-  constexpr int VW = 8;
-  const int q = g.C / VW, cpg = g.C / g.G;
-  const long stride = (long)gridDim.x * NT;
-  const bool fixed = stride % q == 0;
-  long i = (long)blockIdx.x * NT + threadIdx.x;
-  int c = (int)(i % q) * VW, bcur = -1;
-  float ka[VW], kb[VW], kc[VW], mu[VW];
-#pragma unroll
-  for (int k = 0; k < VW; ++k) { ka[k] = 0.f; kb[k] = 0.f; kc[k] = 0.f; mu[k] = 0.f; }
-  SampleWalk sw(i, (long)q * g.S);
-  for (; i < total8; i += stride, sw.step(stride)) {
-    const int b = sw.b;
-    if (!fixed) c = (int)(i % q) * VW;
-    if (!fixed || b != bcur) {
-      bcur = b;
-#pragma unroll
-      for (int k = 0; k < VW; ++k) {
-        const int grp = b * g.G + (c + k) / cpg;
-        const float rs = rstd[grp];
-        mu[k] = mean[grp];
-        ka[k] = gamma[c + k] * rs;
-        kb[k] = -rs * rs * coef[grp * 2];
-        kc[k] = -coef[grp * 2 + 1] * rs;
-      }
-    }
-    float xs[VW], gs[VW];
-    ldn<VW>(x + (size_t)VW * i, xs);
-    if (g.ldg == g.C) ldn<VW>(gy + (size_t)VW * i, gs);
-    else ldn<VW>(gy + (i / q) * g.ldg + (i % q) * VW, gs);
-    if (mask) {
-      const long Q = 2 * i;
-      const unsigned long long* mw = mask + (Q >> 6) * 4;
-      const int sb = (int)(Q & 63);
-#pragma unroll
-      for (int k = 0; k < VW; ++k) gs[k] = ((mw[k & 3] >> (sb + (k >> 2))) & 1ull) ? gs[k] : 0.0f;
-    }
-    float o[VW];
-#pragma unroll
-    for (int k = 0; k < VW; ++k) o[k] = fmaf(ka[k], gs[k], fmaf(kb[k], xs[k] - mu[k], kc[k]));
-    stn<VW>(gx + (size_t)VW * i, o);
-    if (gres) stn<VW>(gres + (size_t)VW * i, gs);
-  }
-}
-
 // grid of the streaming apply kernels: <= 16384 workgroups, and (workgroups * NT) a multiple of the float4 count per
 // voxel q so that every thread keeps its channels for the whole grid-stride loop
 unsigned apply_blocks(long total4, int q) {
@@ -1134,8 +797,8 @@ __global__ void __launch_bounds__(PNT, 3)
 gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __restrict__ mask, const T* __restrict__ xa,
                        const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const T* __restrict__ xb,
                        const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float* __restrict__ pa,
-                       float* __restrict__ pb, Gn2Geom g, GnGeom side_a, GnGeom side_b, GnTail tail_a, GnTail tail_b) {
-  extern __shared__ __align__(16) float lds[];         // [rows][C][3]; the finalize tail re-uses it as doubles
+                       float* __restrict__ pb, Gn2Geom g) {
+  extern __shared__ __align__(16) float lds[];         // [rows][C][3]
   const int q = g.C / VW, rows = PNT / q > 0 ? PNT / q : 1;
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
   const long s0 = (long)chunk * g.chunk_len, s1 = min(g.S, s0 + g.chunk_len);
@@ -1184,14 +847,6 @@ gn2_partial_bwd_kernel(const T* __restrict__ gy, const unsigned long long* __res
     const size_t o = ((size_t)(b * g.chunks + chunk) * g.C + t) * 2;
     st_record(pa + o, s0v, s1v);
     st_record(pb + o, s0v, s2v);
-  }
-  if (tail_a.sync) {                                   // both backward finalizes in the last workgroup's tail (see GnTail)
-    if (!gn_last_arriver(tail_a, reinterpret_cast<int*>(lds))) return;
-    __syncthreads();
-    gn_tail_bwd(pa, side_a, tail_a, reinterpret_cast<double*>(lds));
-    __syncthreads();
-    gn_tail_bwd(pb, side_b, tail_b, reinterpret_cast<double*>(lds));
-    if (tid == 0) __hip_atomic_store(tail_a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1309,40 +964,26 @@ size_t ssbev_groupnorm_mask_words(const ssbev_norm_dims* d) {
 }
 
 extern "C++" {
-// statistics of one normalisation: chunk partials + finalize, as ONE launch (finalize in the last workgroup's tail) when the
-// caller provides the zeroed sync word, else as two
+// statistics of one normalisation: chunk partials + finalize
 template <typename T, int VW>
 static int gn_stats_fwd(const T* x, float* mean, float* rstd, const GnGeom& g, float* partial, const ssbev_norm_ext* ext,
                         hipStream_t st) {
-  size_t lds = lds_bytes(g, VW);
+  const size_t lds = lds_bytes(g, VW);
   if (lds > 96 * 1024) return SSBEV_EINVAL;
   const dim3 grid(g.chunks, g.B, gn_slabs(g, VW));
-  GnTail tail = {};
-  const bool fused = ext && ext->sync && g.C <= kTailMaxC;
-  if (fused) {
-    tail.sync = ext->sync; tail.total = grid.x * grid.y * grid.z;
-    tail.mean = mean; tail.rstd = rstd;
-    if (g.G == g.C && ext->running_mean && ext->running_var) {
-      tail.rm = ext->running_mean; tail.rv = ext->running_var; tail.mom = ext->momentum;
-      tail.unbias = (float)((double)ext->n / (double)(ext->n > 1 ? ext->n - 1 : 1));
-    }
-    lds = std::max(lds, gn_tail_lds_bytes(g.C));
-  }
   if (g.pre)
     hipLaunchKernelGGL((gn_partial_kernel<0, true, 0, T, VW>), grid, dim3(PNT), lds, st, x, (const T*)nullptr,
-                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g, tail);
+                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
   else
     hipLaunchKernelGGL((gn_partial_kernel<0, false, 0, T, VW>), grid, dim3(PNT), lds, st, x, (const T*)nullptr,
-                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g, tail);
-  if (!fused) {
-    if (g.G == g.C) {
-      const bool run = ext && ext->running_mean && ext->running_var;       // running statistics: updated by the finalize kernel
-      hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g,
-                         run ? ext->running_mean : nullptr, run ? ext->running_var : nullptr, run ? ext->momentum : 0.0f,
-                         run ? (float)((double)ext->n / (double)(ext->n > 1 ? ext->n - 1 : 1)) : 0.0f);
-    } else {
-      hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
-    }
+                       (const T*)nullptr, nullptr, nullptr, nullptr, partial, g);
+  if (g.G == g.C) {
+    const bool run = ext && ext->running_mean && ext->running_var;       // running statistics: updated by the finalize kernel
+    hipLaunchKernelGGL(bn_finalize_fwd_flat_kernel<T>, dim3(cdiv((size_t)g.B * g.C, 4)), dim3(256), 0, st, partial, x, mean, rstd, g,
+                       run ? ext->running_mean : nullptr, run ? ext->running_var : nullptr, run ? ext->momentum : 0.0f,
+                       run ? (float)((double)ext->n / (double)(ext->n > 1 ? ext->n - 1 : 1)) : 0.0f);
+  } else {
+    hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(g.B * g.G), dim3(FT), 0, st, partial, x, mean, rstd, g);
   }
   return SSBEV_OK;
 }
@@ -1358,26 +999,12 @@ static int groupnorm_fwd_t(const T* x, const float* gamma, const float* beta, co
     const int rc = gn_stats_fwd<T, VW>(x, mean, rstd, g, partial, ext, st);
     if (rc != SSBEV_OK) return rc;
   }
-  if constexpr (VW == 8) {          // bf16 tensors with 16-byte rows: the fused-constant 8-channel apply pass
-    static const bool wide_apply = getenv("SSBEV_GN_APPLY16") && atoi(getenv("SSBEV_GN_APPLY16")) != 0;          // opt-in, see above
-    auto a16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (wide_apply && !g.pre && a16(x) && a16(y) && a16(residual) && g.ldy % 8 == 0) {
-      const long total8 = (long)g.B * g.S * (g.C / 8);
-      hipLaunchKernelGGL(gn_apply_fwd16_kernel, dim3(apply_blocks(total8, g.C / 8)), dim3(NT), 0, st, x, gamma, beta, residual, mean,
-                         rstd, y, d->relu ? mask : nullptr, g, total8);
-      return ssbev_launch_status();
-    }
-  }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
-  // two vectors in flight per thread: measured SLOWER on the 189 MB activation (fp32 66.7 -> 76.8 us, bf16 96.2 -> 103.4 us): the
-  // passes are not latency-bound -- the bf16 ones are instruction-issue-bound (~90 wave instructions per 512 B in, 512 B out)
-  static const int apply_u = getenv("SSBEV_GN_APPLY_U") ? atoi(getenv("SSBEV_GN_APPLY_U")) : 1;
+  // (measured and removed in round 6: two lane-vectors in flight per thread -- fp32 66.7 -> 76.8 us, bf16 96.2 -> 103.4 us on the
+  // 189 MB activation -- and 16-byte bf16 lanes with fused constants -- 73.6 vs 72.5 ms per two-sample step)
   if (g.pre)
     hipLaunchKernelGGL((gn_apply_fwd_kernel<true, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
-                       d->relu ? mask : nullptr, g, totalv);
-  else if (apply_u == 2)
-    hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T, 4, 2>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
                        d->relu ? mask : nullptr, g, totalv);
   else
     hipLaunchKernelGGL((gn_apply_fwd_kernel<false, T, 4>), dim3(blocks), dim3(NT), 0, st, x, gamma, beta, residual, mean, rstd, y,
@@ -1454,39 +1081,21 @@ static int groupnorm_bwd_t(const T* gy, const T* x, const T* y, const unsigned l
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(ws);
   float* coef = partial + (size_t)g.B * g.chunks * g.C * 2;
-  size_t lds = lds_bytes(g, VW);
+  const size_t lds = lds_bytes(g, VW);
   if (lds > 96 * 1024) return SSBEV_EINVAL;
-  GnTail tail = {};
   {
     const dim3 grid(g.chunks, g.B, gn_slabs(g, VW));
-    if (ext && ext->sync && g.C <= kTailMaxC) {
-      tail.sync = ext->sync; tail.total = grid.x * grid.y * grid.z;
-      tail.gamma = gamma; tail.coef = coef; tail.dgamma = ggamma; tail.dbeta = gbeta;
-      lds = std::max(lds, gn_tail_lds_bytes(g.C));
-    }
     const int rm = !g.relu ? 0 : (mask ? 1 : 2);
 #define SSBEV_GNP(PRE_, RM_) \
-    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T, VW>), grid, dim3(PNT), lds, st, x, gy, y, mask, mean, rstd, partial, g, tail)
+    hipLaunchKernelGGL((gn_partial_kernel<1, PRE_, RM_, T, VW>), grid, dim3(PNT), lds, st, x, gy, y, mask, mean, rstd, partial, g)
     if (g.pre) { if (rm == 0) SSBEV_GNP(true, 0); else if (rm == 1) SSBEV_GNP(true, 1); else SSBEV_GNP(true, 2); }
     else { if (rm == 0) SSBEV_GNP(false, 0); else if (rm == 1) SSBEV_GNP(false, 1); else SSBEV_GNP(false, 2); }
 #undef SSBEV_GNP
   }
-  if (tail.sync) {
-    // finalize ran in the statistics kernel's tail
-  } else if (g.G == g.C)
+  if (g.G == g.C)
     hipLaunchKernelGGL(bn_finalize_bwd_flat_kernel, dim3(cdiv((size_t)g.C, 4)), dim3(256), 0, st, partial, gamma, coef, ggamma, gbeta, g);
   else
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(g.B * g.G + g.C), dim3(FT), 0, st, partial, gamma, coef, ggamma, gbeta, g);
-  if constexpr (VW == 8) {
-    static const bool wide_apply = getenv("SSBEV_GN_APPLY16") && atoi(getenv("SSBEV_GN_APPLY16")) != 0;
-    auto a16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (wide_apply && !g.pre && (!g.relu || mask) && a16(gy) && a16(x) && a16(gx) && a16(gresidual) && g.ldg % 8 == 0) {
-      const long total8 = (long)g.B * g.S * (g.C / 8);
-      hipLaunchKernelGGL(gn_apply_bwd16_kernel, dim3(apply_blocks(total8, g.C / 8)), dim3(NT), 0, st, gy, x, gamma, mean, rstd, coef, gx,
-                         gresidual, g.relu ? mask : nullptr, g, total8);
-      return ssbev_launch_status();
-    }
-  }
   const long totalv = (long)g.B * g.S * (g.C / 4);
   const unsigned blocks = apply_blocks(totalv, g.C / 4);
   if (g.pre)
@@ -1575,7 +1184,6 @@ static int groupnorm2_fwd_t(const T* xa, const float* gamma_a, const float* beta
     float* partial = reinterpret_cast<float*>(wsp);
     ssbev_norm_ext e1 = {};
     if (ext) {
-      e1.sync = ext->sync;
       e1.running_mean = side ? ext->running_mean_b : ext->running_mean_a;
       e1.running_var = side ? ext->running_var_b : ext->running_var_a;
       e1.momentum = side ? ext->momentum_b : ext->momentum_a;
@@ -1647,14 +1255,6 @@ static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa,
   const int q = g.C / VW, rows = PNT / q > 0 ? PNT / q : 1;
   size_t lds = (size_t)rows * g.C * 3 * sizeof(float);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(relu_mask);
-  const GnGeom side_a = gn2_bwd_side_geom(g, d, 0), side_b = gn2_bwd_side_geom(g, d, 1);
-  GnTail ta = {}, tb = {};
-  if (ext && ext->sync && g.C <= kTailMaxC) {
-    ta.sync = tb.sync = ext->sync; ta.total = tb.total = (unsigned)(g.chunks * g.B);
-    ta.gamma = gamma_a; ta.coef = coef_a; ta.dgamma = ggamma_a; ta.dbeta = gbeta_a;
-    tb.gamma = gamma_b; tb.coef = coef_b; tb.dgamma = ggamma_b; tb.dbeta = gbeta_b;
-    lds = std::max(lds, gn_tail_lds_bytes(g.C));
-  }
   if (lds > 48 * 1024) {                    // above the default dynamic-LDS limit of a launch: raise it for this instance (once)
     static bool raised = false;
     if (!raised) {
@@ -1665,11 +1265,9 @@ static int groupnorm2_bwd_t(const T* gy, const uint64_t* relu_mask, const T* xa,
     }
   }
   hipLaunchKernelGGL((gn2_partial_bwd_kernel<T, VW>), dim3(g.chunks, g.B), dim3(PNT), lds, st, gy, mk, xa, mean_a, rstd_a, xb, mean_b,
-                     rstd_b, pa, pb, g, side_a, side_b, ta, tb);
-  if (!ta.sync) {
-    gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
-    gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
-  }
+                     rstd_b, pa, pb, g);
+  gn2_finalize_bwd(g, d, 0, pa, gamma_a, coef_a, ggamma_a, gbeta_a, st);
+  gn2_finalize_bwd(g, d, 1, pb, gamma_b, coef_b, ggamma_b, gbeta_b, st);
   const long totalv = (long)g.B * g.S * (g.C / 4);
   hipLaunchKernelGGL((gn2_apply_bwd_kernel<T, 4>), dim3(apply_blocks(totalv, g.C / 4)), dim3(NT), 0, st, gy, mk, xa, gamma_a, mean_a,
                      rstd_a, coef_a, xb, gamma_b, mean_b, rstd_b, coef_b, gxa, gxb, g, totalv);

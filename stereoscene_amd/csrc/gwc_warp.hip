@@ -879,7 +879,7 @@ size_t bwd_lds_bytes(const ssbev_gwc_dims* d) {
 }
 
 int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
+  const char* v = ssbev_env(name);
   return v ? atoi(v) : dflt;
 }
 

@@ -130,7 +130,7 @@ struct CsrPlan {
 
 // SSBEV_POOL_MAX_DIGIT_BITS (2..11, tests only) narrows the level-1 digit so that small inputs exercise the multi-pass path
 int csr_max_digit_bits() {
-  const char* e = getenv("SSBEV_POOL_MAX_DIGIT_BITS");
+  const char* e = ssbev_env("SSBEV_POOL_MAX_DIGIT_BITS");
   const int x = e ? atoi(e) : CSR_MAX_DIGIT_BITS;
   return x < 2 ? 2 : (x > CSR_MAX_DIGIT_BITS ? CSR_MAX_DIGIT_BITS : x);
 }
@@ -435,59 +435,6 @@ csr_bucket_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ 
   }
 }
 
-// ---------------------------------------------------------------- gather-sum kernels
-// FUSED = true : acc += fp32(depth[p] * feat[row(p), c])   (lift + splat)
-// FUSED = false: acc += feats[p, c]                          (bev_pool drop-in)
-template <bool FUSED, int VEC>
-__global__ void __launch_bounds__(256)
-pool_gather_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
-                   const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
-                   float* __restrict__ out, int nv, int C, int P, int vox_per_batch, int N, int D, int HW) {
-  const int lane = threadIdx.x & 63;
-  const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (v >= nv) return;
-  const int s = starts[v], e = starts[v + 1];
-  const int b = v / vox_per_batch;
-  for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    for (int j = s; j < e; ++j) {
-      const int p = order[j];
-      size_t row;
-      float w = 1.0f;
-      if (FUSED) {
-        const int q = p - b * P;              // point index inside the batch element
-        const int n = q / (D * HW);
-        row = (size_t)(b * N + n) * HW + (q % HW);
-        w = depth[p];
-      } else {
-        row = (size_t)p;
-      }
-      const float* src = feat + row * C + c0;
-      float f[VEC];
-      if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        f[0] = t.x; f[1 % VEC] = t.y; f[2 % VEC] = t.z; f[3 % VEC] = t.w;
-      } else if (VEC == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(src);
-        f[0] = t.x; f[1 % VEC] = t.y;
-      } else {
-        f[0] = src[0];
-      }
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = __fadd_rn(acc[k], FUSED ? __fmul_rn(w, f[k]) : f[k]);
-    }
-    float* dst = out + (size_t)v * C + c0;
-    if (VEC == 4) {
-      *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
-    } else if (VEC == 2) {
-      *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1 % VEC]);
-    } else {
-      dst[0] = acc[0];
-    }
-  }
-}
 
 // r2 version of the gather: the same sums in the same order, with the latency chain of a voxel's point list cut from three
 // dependent loads per point (order[j] -> depth[p] / feature row -> add) to ~6 load round trips per 64 points:
@@ -571,78 +518,6 @@ pool_gather2_kernel(const float* __restrict__ depth, const float* __restrict__ f
   }
 }
 
-// Third layout, used when C == 64 * NV4 (the path's C = 128 -> NV4 = 2): FOUR voxels per wave side by side, 16 lanes each,
-// a lane owning 4 * NV4 consecutive channels (a 16-lane group reads one feature row as a contiguous 256 * NV4-byte run).
-// The per-voxel latency chains (bounds -> order[] -> depth[] / rows -> sums) of four voxels overlap inside one wave, which is
-// what the occupancy-limited gather2 (one voxel at a time per wave, 92 us) lacked.  Same sums, same order => bit-exact.
-template <bool FUSED, int NV4>
-__global__ void __launch_bounds__(256)
-pool_gather3_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
-                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
-                    float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
-  constexpr int C = 64 * NV4, U = 8;
-  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;
-  const int v = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
-  const bool vok = v < nv;
-  const int s = vok ? starts[v] : 0, e = vok ? starts[v + 1] : 0;
-  const int b = vok ? v / vox_per_batch : 0;
-  float4 acc[NV4];
-#pragma unroll
-  for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  int p_next = (s + gl < e) ? order[s + gl] : 0;
-  for (int base = s; base < e; base += 16) {            // trip count differs between the four groups of a wave
-    const int cnt = min(16, e - base);
-    const int p = p_next;
-    // the next block's point ids travel while this block's rows are summed (long near-camera lists: the serial chain
-    // per 16 points is the two feature-row batches, not order[] -> rows)
-    p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
-    int row = p;
-    float wgt = 1.0f;
-    if (FUSED) {
-      const int q = p - b * P;
-      const int n = q / (D * HW);
-      row = (b * N + n) * HW + (q % HW);
-      wgt = gl < cnt ? depth[p] : 0.0f;
-    }
-    for (int j0 = 0; j0 < cnt; j0 += U) {
-      float4 f[U][NV4];
-      float ww[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int jj = gbase + min(j0 + u, cnt - 1);     // a lane of this group (all of them are active here)
-        const int r = __shfl(row, jj, 64);
-        ww[u] = __shfl(wgt, jj, 64);
-        const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
-#pragma unroll
-        for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (j0 + u < cnt) {
-#pragma unroll
-          for (int k = 0; k < NV4; ++k) {
-            if (FUSED) {
-              acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
-              acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
-              acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
-              acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
-            } else {
-              acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
-              acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
-              acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
-              acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
-            }
-          }
-        }
-      }
-    }
-  }
-  if (vok) {
-    float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
-#pragma unroll
-    for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
-  }
-}
 
 // Fifth layout = the third one plus a WIDE path for long lists.  What bounds gather3 is not its thousands of short voxels but
 // the handful of near-camera ones: the longest list of the KITTI frustum has 342 points, a 16-lane group keeps 8 feature rows
@@ -1046,95 +921,6 @@ pool_gather7_kernel(const float* __restrict__ depth, const float* __restrict__ f
   }
 }
 
-// Fourth layout = the third one made PERSISTENT and software-pipelined.  gather3 gives a wave four voxels and lets it die: its
-// three dependent loads (segment bounds -> point ids -> depth / feature rows) are exposed once per wave, and with ~4.6 k waves
-// resident the 65 k waves of the KITTI grid take 14 rounds of ~4 us (66 us; the 134 MB output alone would take 24 us).  Here
-// a wave walks groups g, g + nwaves, ...: the bounds of group i+2 and the first block of point ids of group i+1 are loaded
-// while group i is summed, so one latency (the rows) is exposed per group instead of three.  Same sums in the same order.
-template <bool FUSED, int NV4>
-__global__ void __launch_bounds__(256)
-pool_gather4_kernel(const float* __restrict__ depth, const float* __restrict__ feat,
-                    const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
-                    float* __restrict__ out, int nv, int P, int vox_per_batch, int N, int D, int HW) {
-  constexpr int C = 64 * NV4, U = 8;
-  const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48, sub = lane >> 4;
-  const int nwaves = (int)((size_t)gridDim.x * blockDim.x >> 6);
-  const int ngroups = (nv + 3) >> 2;
-  int grp = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  auto bounds = [&](int g, int& s_, int& e_) {
-    const int vv = g * 4 + sub;
-    const bool ok = g < ngroups && vv < nv;
-    s_ = ok ? starts[vv] : 0;
-    e_ = ok ? starts[vv + 1] : 0;
-  };
-  int s, e, s1, e1;
-  bounds(grp, s, e);
-  bounds(grp + nwaves, s1, e1);
-  int p_first = (s + gl < e) ? order[s + gl] : 0;
-  for (; grp < ngroups; grp += nwaves) {
-    int s2, e2;
-    bounds(grp + 2 * nwaves, s2, e2);                               // two groups ahead
-    const int p_first1 = (s1 + gl < e1) ? order[s1 + gl] : 0;       // first id block of the next group
-    const int v = grp * 4 + sub;
-    const bool vok = v < nv;
-    const int b = vok ? v / vox_per_batch : 0;
-    float4 acc[NV4];
-#pragma unroll
-    for (int k = 0; k < NV4; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int p_next = p_first;
-    for (int base = s; base < e; base += 16) {            // trip count differs between the four groups of a wave
-      const int cnt = min(16, e - base);
-      const int p = p_next;
-      p_next = (base + 16 + gl < e) ? order[base + 16 + gl] : 0;
-      int row = p;
-      float wgt = 1.0f;
-      if (FUSED) {
-        const int q = p - b * P;
-        const int n = q / (D * HW);
-        row = (b * N + n) * HW + (q % HW);
-        wgt = gl < cnt ? depth[p] : 0.0f;
-      }
-      for (int j0 = 0; j0 < cnt; j0 += U) {
-        float4 f[U][NV4];
-        float ww[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int jj = gbase + min(j0 + u, cnt - 1);     // a lane of this group (all of them are active here)
-          const int r = __shfl(row, jj, 64);
-          ww[u] = __shfl(wgt, jj, 64);
-          const float4* src = reinterpret_cast<const float4*>(feat + (size_t)r * C) + gl * NV4;
-#pragma unroll
-          for (int k = 0; k < NV4; ++k) f[u][k] = src[k];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (j0 + u < cnt) {
-#pragma unroll
-            for (int k = 0; k < NV4; ++k) {
-              if (FUSED) {
-                acc[k].x = __fadd_rn(acc[k].x, __fmul_rn(ww[u], f[u][k].x));
-                acc[k].y = __fadd_rn(acc[k].y, __fmul_rn(ww[u], f[u][k].y));
-                acc[k].z = __fadd_rn(acc[k].z, __fmul_rn(ww[u], f[u][k].z));
-                acc[k].w = __fadd_rn(acc[k].w, __fmul_rn(ww[u], f[u][k].w));
-              } else {
-                acc[k].x = __fadd_rn(acc[k].x, f[u][k].x);
-                acc[k].y = __fadd_rn(acc[k].y, f[u][k].y);
-                acc[k].z = __fadd_rn(acc[k].z, f[u][k].z);
-                acc[k].w = __fadd_rn(acc[k].w, f[u][k].w);
-              }
-            }
-          }
-        }
-      }
-    }
-    if (vok) {
-      float4* dst = reinterpret_cast<float4*>(out + (size_t)v * C) + gl * NV4;
-#pragma unroll
-      for (int k = 0; k < NV4; ++k) dst[k] = acc[k];
-    }
-    s = s1; e = e1; s1 = s2; e1 = e2; p_first = p_first1;
-  }
-}
 
 // grad_feats[n,:] = grad_out[vox[n],:]
 __global__ void bev_pool_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ vox,
@@ -1296,9 +1082,8 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
                   const ssbev_pool_dims* d, int N, int D, int HW, hipStream_t st, const int32_t* long_list = nullptr) {
   const int nv = d->B * d->nx * d->ny * d->nz;
   const int vpb = d->nx * d->ny * d->nz;
-  static const int split_variant = getenv("SSBEV_POOL_SPLIT") ? atoi(getenv("SSBEV_POOL_SPLIT")) : 7;   // 7 = one launch (C = 128), 6 = two launches
-  if (long_list && d->C == 128 && split_variant == 7) {
-    static const int nlw = getenv("SSBEV_POOL7_LONG_WGS") ? std::max(1, atoi(getenv("SSBEV_POOL7_LONG_WGS"))) : POOL7_LONG_WGS;   // (tuning hook)
+  if (long_list && d->C == 128) {                         // one launch: long-voxel workgroups first, short role behind them
+    static const int nlw = ssbev_env("SSBEV_POOL7_LONG_WGS") ? std::max(1, atoi(ssbev_env("SSBEV_POOL7_LONG_WGS"))) : POOL7_LONG_WGS;   // (tuning hook)
     dim3 g7(nlw + cdiv((size_t)cdiv(nv, 4) * 64, 256));
     hipLaunchKernelGGL((pool_gather7_kernel<FUSED>), g7, dim3(256), 0, st, depth, feat, starts, order, long_list, out, nv, d->P, vpb,
                        N, D, HW, nlw);
@@ -1315,8 +1100,9 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
 #undef SSBEV_GATHER_SPLIT
     return ssbev_launch_status();
   }
-  static const int variant = getenv("SSBEV_POOL_GATHER") ? atoi(getenv("SSBEV_POOL_GATHER")) : 5;   // 1 = r1 kernel, 2 = one voxel per wave at a time, 3 = four side by side, 4 = 3 persistent + pipelined (not faster), 5 = 3 + whole-wave path for long lists
-  if (variant == 5 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+  // (the r1 one-voxel-per-wave kernel, the four-side-by-side one without the whole-wave long-list path and its persistent
+  // variant were superseded in rounds 2-4 and removed in round 6)
+  if (d->C == 64 || d->C == 128 || d->C == 256) {
     dim3 grid5(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block5(256);
     if (d->C == 64)
       hipLaunchKernelGGL((pool_gather5_kernel<FUSED, 1>), grid5, block5, 0, st, depth, feat, starts, order, out, nv, d->P,
@@ -1329,56 +1115,15 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
                          vpb, N, D, HW);
     return ssbev_launch_status();
   }
-  if (variant == 4 && (d->C == 64 || d->C == 128 || d->C == 256)) {
-    static const int wgs_env = getenv("SSBEV_POOL_GATHER_WGS") ? atoi(getenv("SSBEV_POOL_GATHER_WGS")) : 2048;
-    const unsigned need = cdiv((size_t)cdiv(nv, 4) * 64, 256);
-    dim3 grid4(std::min<unsigned>(need, (unsigned)std::max(1, wgs_env))), block4(256);
-    if (d->C == 64)
-      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 1>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    else if (d->C == 128)
-      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 2>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    else
-      hipLaunchKernelGGL((pool_gather4_kernel<FUSED, 4>), grid4, block4, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    return ssbev_launch_status();
-  }
-  if ((variant >= 3) && (d->C == 64 || d->C == 128 || d->C == 256)) {
-    dim3 grid3(cdiv((size_t)cdiv(nv, 4) * 64, 256)), block3(256);
-    if (d->C == 64)
-      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 1>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    else if (d->C == 128)
-      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 2>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    else
-      hipLaunchKernelGGL((pool_gather3_kernel<FUSED, 4>), grid3, block3, 0, st, depth, feat, starts, order, out, nv, d->P,
-                         vpb, N, D, HW);
-    return ssbev_launch_status();
-  }
-  if (variant != 1) {
-    dim3 grid2(cdiv((size_t)cdiv(nv, POOL_VPW) * 64, 256)), block2(256);
-    if (d->C % 256 == 0)
-      hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 4>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
-                         d->P, vpb, N, D, HW);
-    else if (d->C % 2 == 0)
-      hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 2>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
-                         d->P, vpb, N, D, HW);
-    else
-      hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 1>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
-                         d->P, vpb, N, D, HW);
-    return ssbev_launch_status();
-  }
-  dim3 grid(cdiv((size_t)nv * 64, 256)), block(256);
+  dim3 grid2(cdiv((size_t)cdiv(nv, POOL_VPW) * 64, 256)), block2(256);      // any other channel count
   if (d->C % 256 == 0)
-    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 4>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+    hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 4>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
                        d->P, vpb, N, D, HW);
   else if (d->C % 2 == 0)
-    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 2>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+    hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 2>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
                        d->P, vpb, N, D, HW);
   else
-    hipLaunchKernelGGL((pool_gather_kernel<FUSED, 1>), grid, block, 0, st, depth, feat, starts, order, out, nv, d->C,
+    hipLaunchKernelGGL((pool_gather2_kernel<FUSED, 1>), grid2, block2, 0, st, depth, feat, starts, order, out, nv, d->C,
                        d->P, vpb, N, D, HW);
   return ssbev_launch_status();
 }
@@ -1549,8 +1294,7 @@ int ssbev_lift_splat_bwd(const float* grad_out, const float* depth, const float*
   if (l->N <= 0 || l->D <= 0 || l->HW <= 0 || (long)l->N * l->D * l->HW != d->P || d->C % 4 != 0)
     return SSBEV_EINVAL;
   const int rows = d->B * l->N * l->HW;
-  static const int variant = getenv("SSBEV_LIFT_BWD") ? atoi(getenv("SSBEV_LIFT_BWD")) : 2;          // 1 = r1 kernel
-  if (variant != 1 && (d->C == 64 || d->C == 128 || d->C == 256)) {
+  if (d->C == 64 || d->C == 128 || d->C == 256) {
     hipStream_t st = as_stream(stream);
     if (d->C == 64)
       hipLaunchKernelGGL(lift_splat_bwd2_kernel<16>, dim3(rows), dim3(256), 0, st, grad_out, depth, feat, vox, grad_depth,

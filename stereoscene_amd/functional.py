@@ -1713,30 +1713,9 @@ def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
 GN_RELU_MASK = os.environ.get("SSBEV_GN_RELU_MASK", "1") != "0"
 
 
-# Finalize of the statistics in the tail of the statistics kernel (csrc/groupnorm.hip, GnTail): needs SSBEV_NORM_SYNC_WORDS zeroed
-# words that the kernels leave zeroed -- one small buffer per (device, stream), zeroed once when it is created.  OFF by default:
-# measured on MI355X (profiles/r5_gn_tail.txt) the last-arriver tail is a chain of 4-5 dependent round trips to other CUs' data
-# (tickets, two batches of records, write-out: 8-10 us behind the last streaming read) where the separate finalize kernel
-# spreads one batch over many workgroups (~5 us + a 1.7 us kernel boundary): 160 fewer launches, but +0.7 ms per step.
-GN_TAIL = os.environ.get("SSBEV_GN_TAIL", "0") != "0"
-_NORM_SYNC = {}
-
-
-def _norm_sync(device):
-    if not GN_TAIL:
-        return None
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-    t = _NORM_SYNC.get(key)
-    if t is None:
-        t = _NORM_SYNC[key] = torch.zeros(capi.NORM_SYNC_WORDS, dtype=torch.int32, device=device)
-    return t
-
-
 def _norm_ext(device, running=None, n=0):
-    """ssbev_norm_ext: the sync words of this stream + (running_mean, running_var, momentum) of a training-mode BatchNorm."""
-    sync = _norm_sync(device)
-    e = capi.NormExt(sync.data_ptr() if sync is not None else None, None, None, 0.0, int(n))
+    """ssbev_norm_ext: (running_mean, running_var, momentum) of a training-mode BatchNorm, updated inside the statistics finalize."""
+    e = capi.NormExt(None, None, 0.0, int(n))
     if running is not None:
         e.running_mean, e.running_var, e.momentum = running[0].data_ptr(), running[1].data_ptr(), float(running[2])
     return e
@@ -1970,8 +1949,7 @@ class _DualNorm(torch.autograd.Function):
         nd = capi.NormDims(B, Cch, ga, S, float(eps_a), int(relu), 0, 0, 0, 0, io)
         mask = torch.empty(lib.ssbev_groupnorm_mask_words(C.byref(nd)), dtype=torch.int64, device=dev) if relu else None
         wa_, ba_, wb_, bb_ = (t.detach().contiguous() for t in (wa, ba, wb, bb))
-        sync = _norm_sync(dev)
-        ext = capi.Norm2Ext(sync.data_ptr() if sync is not None else None, None, None, 0.0, None, None, 0.0)
+        ext = capi.Norm2Ext(None, None, 0.0, None, None, 0.0)
         if run_a is not None and a_batch:
             ext.running_mean_a, ext.running_var_a, ext.momentum_a = run_a[0].data_ptr(), run_a[1].data_ptr(), float(run_a[2])
         if run_b is not None and b_batch:
@@ -1998,8 +1976,7 @@ class _DualNorm(torch.autograd.Function):
         gga, gba, ggb, gbb = (torch.empty(Cch, dtype=torch.float32, device=dev) for _ in range(4))
         ws = _ws(lib.ssbev_groupnorm2_workspace(C.byref(d)), dev)
         with _span("groupnorm", 0.0, float(acl.element_size()) * acl.numel() * 8, f"bwd   N2 C={Cch} Ga={ctx.meta[2]} Gb={ctx.meta[3]} S={ctx.meta[4]}"):
-            sync = _norm_sync(dev)
-            ext = capi.Norm2Ext(sync.data_ptr() if sync is not None else None, None, None, 0.0, None, None, 0.0)
+            ext = capi.Norm2Ext(None, None, 0.0, None, None, 0.0)
             capi.check(lib.ssbev_groupnorm2_bwd_ext(capi.ptr(gcl), capi.ptr(mask), capi.ptr(acl), capi.ptr(wa_), capi.ptr(mean_a),
                                                     capi.ptr(rstd_a), capi.ptr(bcl), capi.ptr(wb_), capi.ptr(mean_b), capi.ptr(rstd_b),
                                                     capi.ptr(gxa), capi.ptr(gxb), capi.ptr(gga), capi.ptr(gba), capi.ptr(ggb),

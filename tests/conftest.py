@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_library_switches(request):
+    """The HIP library caches its SSBEV_* environment switches (ssbev_env_refresh in include/ssbev.h); GPU tests flip some with
+    monkeypatch.setenv inside one process, so every GPU test starts from -- and leaves behind -- an empty cache."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from stereoscene_amd import capi
+    capi.load().ssbev_env_refresh()
+    yield
+    capi.load().ssbev_env_refresh()
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         return {k: z[k] for k in z.files}

@@ -107,6 +107,6 @@ def test_bf16_storage_entry_points_refuse_a_mismatched_precision_on_host():
             assert lib.ssbev_conv_bwd_weight_bf16(fake, fake, fake, C.byref(c), fake, 1 << 30, None) == capi.EINVAL
     c3 = capi.ConvDims(1, 32, 32, 8, 8, 8, 8, 8, 8, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 3)
     assert lib.ssbev_conv_bwd_weight_bf16(fake, fake, fake, C.byref(c3), fake, 1 << 30, None) == capi.EINVAL   # fp32-result mode has no wgrad
-    # normalisation: sync words and running statistics ride in ssbev_norm_ext; NULL ext is allowed, bad dims are not
+    # normalisation: the BatchNorm running statistics ride in ssbev_norm_ext; NULL ext is allowed, bad dims are not
     n = capi.NormDims(1, 30, 2, 100, 1e-5, 0, 0, 0, 0, 0, 0)          # C % 4 != 0
     assert lib.ssbev_groupnorm_fwd_ext(fake, fake, fake, None, fake, fake, fake, None, C.byref(n), None, fake, 1 << 20, None) == capi.EINVAL

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
+from stereoscene_amd import capi
 from stereoscene_amd import functional as F
 from stereoscene_amd import synthetic as S
 
@@ -215,6 +216,7 @@ def test_conv_igemm16_is_bit_identical_to_the_gather_kernel(case, monkeypatch):
         outs = []
         for mode in ("1", "0"):
             monkeypatch.setenv("SSBEV_IGEMM16", mode)
+            capi.load().ssbev_env_refresh()          # the library caches its switches
             xg = x.detach().requires_grad_(True)
             y = F.conv_transpose3d(xg, w, None, st, 1, st - 1) if kind == "deconv" else F.conv3d(xg, w, None, st, 1, 1)
             go = _r16(S.hash_normal(f"ig16/go{case}", tuple(y.shape))).to(DEV).to(torch.bfloat16)

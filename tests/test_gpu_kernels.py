@@ -6,6 +6,7 @@ import torch.nn.functional as TF
 
 from conftest import load_golden
 from oracle import path_ref as O
+from stereoscene_amd import capi
 from stereoscene_amd import functional as F
 from stereoscene_amd import synthetic as S
 
@@ -121,6 +122,7 @@ def test_pool_prepare_csr_is_a_stable_sort(digit_bits, monkeypatch):
     several-pass level 1 (bucket bounds by binary search) that full-size grids above 2^22 cells would take."""
     if digit_bits is not None:
         monkeypatch.setenv("SSBEV_POOL_MAX_DIGIT_BITS", digit_bits)
+        capi.load().ssbev_env_refresh()          # the library caches its switches
     g = torch.Generator().manual_seed(7)
     for (n, B, nx, ny, nz) in [(100000, 2, 32, 32, 8), (5000, 1, 7, 5, 3), (37, 1, 4, 4, 2), (70000, 1, 128, 128, 16), (1, 1, 1, 1, 1)]:
         nv = B * nx * ny * nz
@@ -292,6 +294,7 @@ def test_conv_igemm_kernel_strided_and_transposed(case, monkeypatch):
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("SSBEV_IGEMM", mode)
+        capi.load().ssbev_env_refresh()          # the library caches its switches
         xg = x.to(DEV).requires_grad_(True)
         if not tr:
             w = S.hash_uniform(f"ig/w{case}", (N, K, 3, 3, 3), -1, 1) * (3.0 / (K * 27)) ** 0.5
@@ -317,6 +320,7 @@ def test_conv_igemm_kernel_strided_and_transposed(case, monkeypatch):
     assert torch.equal(got, outs["0"][0]) and torch.equal(gx, outs["0"][1])
     # accumulating epilogue: the data gradient lands on top of another consumer's gradient (gradient slot)
     monkeypatch.setenv("SSBEV_IGEMM", "1")
+    capi.load().ssbev_env_refresh()          # the library caches its switches
     if not tr:
         xa = x.to(DEV).requires_grad_(True)
         a, b = F.fork(xa)
@@ -627,41 +631,34 @@ def _norm_step(kind, x, w, b, G, r, go, running=None):
 @pytest.mark.parametrize("kind,B,C,G,sp", [("gn", 1, 32, 2, (48, 24, 80)), ("gn", 2, 128, 32, (8, 16, 16)), ("gn", 1, 192, 32, (4, 16, 16)),
                                             ("gn", 3, 640, 2, (1, 12, 40)), ("bn", 2, 64, 64, (6, 12, 20)), ("bn", 1, 640, 640, (1, 48, 160)),
                                             ("gn", 1, 48, 1, (3, 5, 7)), ("bn", 2, 1024, 1024, (1, 4, 8))])
-def test_norm_finalize_in_the_statistics_tail_equals_the_separate_finalize(kind, B, C, G, sp, monkeypatch):
-    """Round 5: mean / rstd (forward) and the group coefficients + dgamma / dbeta (backward) are reduced by the last-arriving
-    workgroup of the statistics kernel (csrc/groupnorm.hip GnTail) instead of by a finalize launch.  Both reductions run in
-    double in a fixed order, so the two paths agree to the last rounding of the fp32 results; the tail path is run-to-run
-    identical; the BatchNorm running statistics it updates in passing match the stand-alone update; and the sync words it
-    borrows are zero again afterwards."""
+def test_norm_statistics_are_run_to_run_identical_and_update_running_stats(kind, B, C, G, sp):
+    """The statistics of a normalisation are chunk records reduced by the finalize kernels in double, in a fixed order: two runs
+    agree bit for bit (forward outputs, statistics, all gradients), and the BatchNorm running statistics the finalize kernel
+    updates in passing (ssbev_norm_ext) match nn.functional.batch_norm's update.  (Round 5's finalize-in-the-statistics-tail
+    variant, which this test used to compare against, was measured slower and removed in round 6.)"""
     x = (S.hash_normal(f"tail/x{C}", (B, C) + sp) * 1.5 + 0.7).to(DEV)
     w = (1 + S.hash_uniform(f"tail/w{C}", (C,), -0.3, 0.3)).to(DEV)
     b = S.hash_uniform(f"tail/b{C}", (C,), -0.2, 0.2).to(DEV)
     r = S.hash_normal(f"tail/r{C}", (B, C) + sp).to(DEV)
     go = S.hash_normal(f"tail/go{C}", (B, C) + sp).to(DEV)
-    n = x.numel() // C
 
-    def run(tail):
-        monkeypatch.setattr(F, "GN_TAIL", tail)
+    def run():
         rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
         outs = _norm_step(kind, x, w, b, G, r, go, running=(rm, rv, 0.1) if kind == "bn" else None)
         return outs + ([rm, rv] if kind == "bn" else [])
 
-    sep, t1, t2 = run(False), run(True), run(True)
+    t1, t2 = run(), run()
     for a, c in zip(t1, t2):
-        assert torch.equal(a, c)                                     # deterministic whichever workgroup arrives last
-    for a, c in zip(t1, sep):
-        assert maxdiff(a, c) <= 2e-6 * max(1.0, c.abs().max().item())
+        assert torch.equal(a, c)
     if kind == "bn":                                                 # running statistics against nn.functional.batch_norm's update
         rm, rv = torch.zeros(C), torch.ones(C)
         TF.batch_norm(x.cpu(), rm, rv, w.cpu(), b.cpu(), True, 0.1, 1e-5)
         assert maxdiff(t1[-2], rm) < 1e-5 and maxdiff(t1[-1], rv) < 1e-5 * max(1.0, rv.abs().max().item())
-    assert all(int(v.abs().sum()) == 0 for v in F._NORM_SYNC.values())
 
 
-def test_norm_tail_on_two_streams_back_to_back(monkeypatch):
-    """The sync words are per (device, stream): normalisations of different shapes issued back to back on two streams at once
-    (the stereo branch and DepthNet's side stream do exactly that) must neither disturb each other nor leave a word non-zero."""
-    monkeypatch.setattr(F, "GN_TAIL", True)
+def test_norm_on_two_streams_back_to_back():
+    """Normalisations of different shapes issued back to back on two streams at once (the stereo branch and DepthNet's side
+    stream do exactly that) must not disturb each other: the operator keeps no state between calls, workspaces are per stream."""
     side = torch.cuda.Stream()
     shapes = [(1, 32, 2, (24, 12, 40)), (2, 64, 2, (6, 12, 20)), (1, 128, 32, (8, 8, 8)), (1, 640, 640, (1, 12, 40))]
     data = []
@@ -684,7 +681,6 @@ def test_norm_tail_on_two_streams_back_to_back(monkeypatch):
         assert maxdiff(y, data[k % 4][4]) < 3e-5
     for k, y in enumerate(got_side):
         assert maxdiff(y, data[3 - k % 4][4]) < 3e-5
-    assert len(F._NORM_SYNC) >= 2 and all(int(v.abs().sum()) == 0 for v in F._NORM_SYNC.values())
 
 
 # ------------------------------------------------------------------------------------ trilinear x2
