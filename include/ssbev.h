@@ -349,23 +349,6 @@ int ssbev_trilinear2x_fwd(const float* x, float* y, const ssbev_upsample_dims* d
 int ssbev_trilinear2x_bwd(const float* gy, float* gx, const ssbev_upsample_dims* d, ssbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * BRI cross attention (replaces ATT:63-81: softmax(Q K) * conf, V A^T) without the T x T matrices.
- *   q, k, v, out and their gradients: [B, Dh, T] fp32, token axis contiguous (= the reference's
- *   [B,1,D,H,W] volumes viewed as [B, D, H*W]);  conf [B, T] key-side weight;  lse [B, T].
- *   out[b,:,i] = sum_j softmax_j(q[b,:,i] . k[b,:,j]) * conf[b,j] * v[b,:,j]
- * Supported head sizes (compile-time specialisations): Dh in {16, 48, 112, 192}, T % 32 == 0.
- * ------------------------------------------------------------------------------------------ */
-typedef struct { int B, T, Dh; } ssbev_attn_dims;
-int ssbev_bri_attention_supported(const ssbev_attn_dims* d);
-size_t ssbev_bri_attention_workspace(const ssbev_attn_dims* d);
-int ssbev_bri_attention_fwd(const float* q, const float* k, const float* v, const float* conf,
-                            float* out, float* lse, const ssbev_attn_dims* d, ssbev_stream_t stream);
-int ssbev_bri_attention_bwd(const float* q, const float* k, const float* v, const float* conf,
-                            const float* out, const float* lse, const float* gout, float* gq,
-                            float* gk, float* gv, float* gconf, const ssbev_attn_dims* d, void* ws,
-                            size_t ws_bytes, ssbev_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------
  * Optimiser step over one flat fp32 parameter buffer: global gradient L2 norm + fused AdamW with
  * clip-by-global-norm (the reference recipe, stereoscene.py:203-209: AdamW lr 1e-4 wd 0.01,
  * grad_clip max_norm 5).  torch.optim.AdamW semantics (decoupled decay, bias correction).

@@ -86,10 +86,6 @@ class UpsampleDims(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int)]
 
 
-class AttnDims(C.Structure):
-    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Dh", C.c_int)]
-
-
 class GemmDims(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64), ("sc", C.c_int64),
@@ -254,10 +250,6 @@ SIGNATURES = {
     "ssbev_grad_norm_workspace": (C.c_size_t, []),
     "ssbev_grad_norm": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),
     "ssbev_adamw_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(AdamWCfg), _P, _P]),
-    "ssbev_bri_attention_supported": (C.c_int, [C.POINTER(AttnDims)]),
-    "ssbev_bri_attention_workspace": (C.c_size_t, [C.POINTER(AttnDims)]),
-    "ssbev_bri_attention_fwd": (C.c_int, [_P] * 6 + [C.POINTER(AttnDims), _P]),
-    "ssbev_bri_attention_bwd": (C.c_int, [_P] * 11 + [C.POINTER(AttnDims), _P, C.c_size_t, _P]),
 }
 
 _lib = None

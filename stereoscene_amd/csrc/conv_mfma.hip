@@ -1952,8 +1952,6 @@ struct ConvTapGeom {
   int accumulate = 0;             // y += result (second consumer of a multi-consumer activation's gradient, see functional.fork)
   int Ds = 0, Hs = 0, Ws = 0;     // conv_tap2_kernel: source grid of the stride-2 gather (D / H / W are the destination grid)
   unsigned long long* dbg = nullptr;   // conv_tapdh_kernel phase clocks (tuning hook, SSBEV_TAPDH_TIMES=1)
-  int slab = 0, cut = 0;          // conv_taph_kernel, plane-aligned chunk order (0 = off): planes per XCD; row pairs of a plane's
-                                  // first chunk (the rest of the plane is a second, shorter chunk dispatched behind all first ones)
 };
 
 constexpr int kTapWseg = 32, kTapCols = kTapWseg + 2, kTapRowF = kTapCols * 32, kTapSlots = 4;
@@ -2251,26 +2249,9 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     chunk_id = base + (L >> 3);
   }
-  int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
+  const int seg = chunk_id % g.nseg, range = chunk_id / g.nseg;
   const int H2 = g.H >> 1;
-  int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
-  if (g.slab) {
-    // plane-aligned order: XCD x owns the planes [x * slab, (x + 1) * slab) and walks them with the PLANE index fastest, so
-    // the workgroups that run at the same time on an XCD are the same (row chunk, w segment) of consecutive depth planes and
-    // move through the rows in step: a plane row staged by the chunk of plane d is found in the XCD's L2 by the chunks of
-    // d - 1 and d + 1 (the linear order re-fetched every plane three times: 599 MB fetched for a 189 MB tensor).  A plane is
-    // cut into a long first chunk and a short second one; all second chunks are dispatched behind all first ones and fill
-    // the idle CUs of the last round (launch_conv_taph picks the cut by simulating the dispatch).
-    const unsigned xcd = blockIdx.x & 7;
-    int i = blockIdx.x >> 3;
-    const int nfirst = g.slab * g.nseg;
-    const bool second = i >= nfirst;
-    if (second) i -= nfirst;
-    const int plane = (int)xcd * g.slab + i % g.slab;
-    seg = i / g.slab;
-    g_begin = plane * H2 + (second ? g.cut : 0);
-    g_end = plane * H2 + (second ? H2 : g.cut);
-  }
+  const int g_begin = range * g.gpc, g_end = min(g.NG, g_begin + g.gpc);
   const int w0 = seg * kTapWseg;
 
   constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 staging entries per (plane, row), see conv_tap_kernel
@@ -4071,43 +4052,15 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
     const double cost = rounds * (c + 0.6 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  long nranges;
   if (const char* e = ssbev_env("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
-  // Plane-aligned order (see the kernel) when the planes split evenly over the 8 XCDs.  The cut of a plane into a first and a
-  // second chunk is chosen by simulating the dispatch on one XCD's 32 CUs (chunks go to the CU that is free first, in index
-  // order; a chunk costs its row pairs + 0.6 of start-up): for 24 planes x 5 segments of 24 pairs, 18 + 6 ends level with
-  // the 5 exact rounds of the linear order (94 against 93 pair-times), whole planes leave a quarter of the last round idle
-  // OPT-IN (SSBEV_TAPH_ALIGNED=1): it does what it is built for -- 4.47 M -> 1.78 M 128-byte HBM read requests per launch,
-  // 572 -> 228 MB for the 189 MB tensor -- but the kernel is not HBM-bound and the workgroups moving in step cost it 8 %
-  // (0.533 -> 0.579 ms; every aligned variant, whatever its tail, lands at 0.58-0.60), +0.3 ms on the step
-  // (profiles/r3y_taph_plane_aligned.txt)
-  static const int aligned = ssbev_env("SSBEV_TAPH_ALIGNED") ? atoi(ssbev_env("SSBEV_TAPH_ALIGNED")) : 0;
-  long nblocks = 0;
-  if (aligned > 0 && (g.B * g.D) % 8 == 0 && H2 >= 2) {
-    g.slab = g.B * g.D / 8;
-    const int nfirst = g.slab * g.nseg;
-    double best_t = 1e30;
-    for (int cut = (H2 + 1) / 2; cut <= H2; ++cut) {
-      double cu[32];
-      for (double& t : cu) t = 0.0;
-      const int n = cut < H2 ? 2 * nfirst : nfirst;
-      for (int i = 0; i < n; ++i) {
-        int m = 0;
-        for (int c = 1; c < 32; ++c) if (cu[c] < cu[m]) m = c;
-        cu[m] += (i < nfirst ? cut : H2 - cut) + 0.6;
-      }
-      double t = 0.0;
-      for (double v : cu) t = std::max(t, v);
-      if (t < best_t - 1e-9) { best_t = t; g.cut = cut; }
-    }
-    if (aligned > 1 && aligned <= H2) g.cut = aligned;               // tuning hook: force the cut
-    nblocks = 8L * (g.cut < H2 ? 2 * nfirst : nfirst);
-  }
-  nranges = (g.NG + g.gpc - 1) / g.gpc;
+  // (Round 3 built a plane-aligned chunk order -- XCD x owns 24 consecutive planes, plane index fastest, so that the chunks of
+  // d - 1, d, d + 1 meet in one L2: 572 -> 228 MB of HBM reads per launch, but the workgroups moving in step cost the kernel
+  // 8 % (0.533 -> 0.579 ms, profiles/r3y_taph_plane_aligned.txt).  The kernel is not HBM-bound; removed in round 6.)
+  const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_taph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kTwLdsBytes) != hipSuccess)
     return SSBEV_ELAUNCH;
-  hipLaunchKernelGGL(conv_taph_kernel, dim3((unsigned)(g.slab ? nblocks : nranges * g.nseg)), dim3(512), kTwLdsBytes, st, x, wp,
+  hipLaunchKernelGGL(conv_taph_kernel, dim3((unsigned)(nranges * g.nseg)), dim3(512), kTwLdsBytes, st, x, wp,
                      bias, y, g);
   return ssbev_launch_status();
 }

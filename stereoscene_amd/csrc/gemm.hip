@@ -575,21 +575,8 @@ int tn_chunks(const ssbev_gemm_dims* d, int tiles) {
   // TN: M = reduction rows.  Enough workgroups for ~2 rounds of the 512 slots, at least 256 rows per chunk.
   // (Round 5 tried the chunk count that minimises the rows the busiest CU walks -- 3 chunks instead of 2 on 16 x [1920 rows ->
   // 640 x 640], 4 instead of 8 on the BRI energy product: +2 ... +9 % alone on the device, but +1.3 ms per step next to the side
-  // stream's kernels, where many small workgroups fill the gaps better (profiles/r5_gemm_cfg_probe.txt).  SSBEV_GEMM_TN_CHUNKS=model
-  // selects it.)
-  static const std::string sel = ssbev_env("SSBEV_GEMM_TN_CHUNKS") ? ssbev_env("SSBEV_GEMM_TN_CHUNKS") : "";
-  const bool model = sel == "model" || (sel == "batched" && d->batch >= 8);       // "batched": only the frequency products
-  if (!model) return std::min(std::max(1, 1024 / std::max(1, tiles * d->batch)), std::max(1, d->M / 256));
-  const int cmax = std::min(16, std::max(1, d->M / 256));
-  int best = 1;
-  double best_cost = 1e300;
-  for (int c = 1; c <= cmax; ++c) {
-    const long per_cu = std::max(2L, ((long)tiles * d->batch * c + 255) / 256);      // (a CU needs two workgroups to run at full rate)
-    const double rows = (double)((d->M + c - 1) / c) + 64.0;
-    const double cost = per_cu * rows + (c > 1 ? 12.0 * (c + 1) : 0.0);        // (the sum pass reads c and writes 1 result-sized buffers)
-    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
-  }
-  return best;
+  // stream's kernels, where many small workgroups fill the gaps better (profiles/r5_gemm_cfg_probe.txt); removed in round 6.)
+  return std::min(std::max(1, 1024 / std::max(1, tiles * d->batch)), std::max(1, d->M / 256));
 }
 
 // split-K: when the output tiles alone leave the 512 workgroup slots under-filled and K is deep (BRI's 192 x 7680 products,

@@ -2112,56 +2112,6 @@ def upsample_trilinear(x, size):
 
 
 # -------------------------------------------------------------------------------------------------
-# BRI cross attention
-# -------------------------------------------------------------------------------------------------
-
-
-def bri_attention_supported(B, T, Dh):
-    return bool(capi.load().ssbev_bri_attention_supported(C.byref(capi.AttnDims(int(B), int(T), int(Dh)))))
-
-
-class _BriAttention(torch.autograd.Function):
-    """out[b,:,i] = sum_j softmax_j(q[b,:,i].k[b,:,j]) * conf[b,j] * v[b,:,j] for [B, Dh, T] operands."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, conf):
-        lib = capi.load()
-        q, k, v = (_f32(t, "bri_attention").contiguous() for t in (q, k, v))
-        conf = conf.contiguous()
-        B, Dh, T = q.shape
-        d = capi.AttnDims(B, T, Dh)
-        out = torch.empty_like(q)
-        lse = torch.empty(B, T, dtype=torch.float32, device=q.device)
-        with _span("bri_flash", 4.0 * B * T * T * Dh, 16.0 * q.numel(), f"fwd   bri T={T} Dh={Dh}"):
-            capi.check(lib.ssbev_bri_attention_fwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
-                                                   capi.ptr(lse), C.byref(d), capi.stream()), "ssbev_bri_attention_fwd")
-        ctx.save_for_backward(q, k, v, conf, out, lse)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        lib = capi.load()
-        q, k, v, conf, out, lse = ctx.saved_tensors
-        B, Dh, T = q.shape
-        d = capi.AttnDims(B, T, Dh)
-        g = gout.contiguous()
-        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        gc = torch.empty_like(conf)
-        ws = _ws(lib.ssbev_bri_attention_workspace(C.byref(d)), q.device)
-        # operator FLOPs of the backward: dV, dP, dQ, dK products (4 x 2*T*T*Dh); the flash kernels recompute S twice more
-        with _span("bri_flash", 8.0 * B * T * T * Dh, 32.0 * q.numel(), f"bwd   bri T={T} Dh={Dh}", 14.0 * B * T * T * Dh):
-            capi.check(lib.ssbev_bri_attention_bwd(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(conf), capi.ptr(out),
-                                                   capi.ptr(lse), capi.ptr(g), capi.ptr(gq), capi.ptr(gk), capi.ptr(gv),
-                                                   capi.ptr(gc), C.byref(d), capi.ptr(ws), ws.numel(), capi.stream()),
-                       "ssbev_bri_attention_bwd")
-        return gq, gk, gv, gc
-
-
-def bri_attention(q, k, v, conf):
-    return _BriAttention.apply(q, k, v, conf)
-
-
-# -------------------------------------------------------------------------------------------------
 # fused occupancy-head epilogue
 # -------------------------------------------------------------------------------------------------
 

@@ -267,20 +267,16 @@ class attention(nn.Module):
         hw = H * W
         conf = F.softmax(q, dim=2).amax(dim=2).view(B, hw)                # [B,HW]
         if (BRI_SHELL and kv.is_cuda and C == 1 and q.dtype == kv.dtype == torch.float32 and F.own_gemm_site("bri")
-                and os.environ.get("SSBEV_BRI", "gemm") != "flash" and hw % 4 == 0 and hw <= 8192):
+                and hw % 4 == 0 and hw <= 8192):
             qc, kc, vc = self.query_conv, self.key_conv, self.value_conv
             return _BriBlock.apply(q, kv, conf, qc.weight, qc.bias, kc.weight, kc.bias, vc.weight, vc.bias, self.gamma)
         Q = self._affine(self.query_conv, q).view(B, D, hw)                   # [B,D,HW] (tokens contiguous)
         K = self._affine(self.key_conv, kv).view(B, D, hw)
         V = self._affine(self.value_conv, kv).view(B, D, hw)
-        # Two realisations of the same operator.  Default: six plain NN GEMMs (rocBLAS fp32 MFMA, 75-123 TF/s on these
-        # 7680 x 7680 x 192 shapes) around the materialised T x T attention matrix (236 MB per direction -- nothing on a
-        # 288 GB part).  SSBEV_BRI=flash selects the hand-written flash-style kernels (no T x T matrix, 0.7 GB less saved
-        # state per sample) which currently run at ~45 TF/s: 8 ms/step slower at D=192 (profiles/r1k_bri_paths.txt).
-        if os.environ.get("SSBEV_BRI", "gemm") == "flash" and F.bri_attention_supported(B, hw, D):
-            out = F.bri_attention(Q, K, V, conf).view(B, C, D, H, W)
-        else:
-            out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
+        # Six plain NN GEMMs around the materialised T x T attention matrix (236 MB per direction at T = 7680).  (Rounds 1-5 also
+        # carried hand-written flash-style kernels -- no T x T matrix, ~45 TF/s, 8 ms per step slower at D = 192,
+        # profiles/r1k_bri_paths.txt -- removed in round 6.)
+        out = _BriCore.apply(Q, K, V, conf).view(B, C, D, H, W)
         return self.gamma * out + kv
 
 

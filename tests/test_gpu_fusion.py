@@ -154,11 +154,12 @@ def test_hourglass_module_vs_reference_forward_and_gradients():
         assert maxdiff(m(torch.from_numpy(g["x"]).to(DEV)), torch.from_numpy(g["y_eval"])) < 2e-5
 
 
-@pytest.mark.parametrize("path", ["gemm", "flash"])
-def test_attention_module_gradients_vs_reference(path, monkeypatch):
+@pytest.mark.parametrize("shell", [True, False])
+def test_attention_module_gradients_vs_reference(shell, monkeypatch):
     from conftest import load_golden
+    from stereoscene_amd.plugin import view_transformer as vtm
     from stereoscene_amd.plugin.view_transformer import attention
-    monkeypatch.setenv("SSBEV_BRI", path)
+    monkeypatch.setattr(vtm, "BRI_SHELL", shell)          # the fused block / the tensor-expression form around the same products
     g = load_golden("attention_grad")
     att = attention(1).to(DEV)
     att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})

@@ -700,26 +700,6 @@ def test_trilinear2x_fwd_bwd(B, C, sp):
 
 
 # ------------------------------------------------------------------------------------ BRI attention
-@pytest.mark.parametrize("B,Dh,T", [(2, 16, 96), (1, 48, 480), (1, 112, 256), (1, 192, 320)])
-def test_bri_attention_fwd_bwd_vs_dense(B, Dh, T):
-    q = torch.softmax(S.hash_normal("bri/q", (B, Dh, T), 2.0), 1) * 3.0 + 0.1
-    k = torch.softmax(S.hash_normal("bri/k", (B, Dh, T), 2.0), 1) * 5.0 - 0.2
-    v = S.hash_normal("bri/v", (B, Dh, T))
-    conf = S.hash_uniform("bri/c", (B, T), 0.1, 1.0)
-    cs = [t.clone().requires_grad_(True) for t in (q, k, v, conf)]
-    att = torch.softmax(torch.bmm(cs[0].transpose(1, 2) * 40.0, cs[1]), -1) * cs[3].unsqueeze(1)   # sharp softmax
-    want = torch.bmm(cs[2], att.transpose(1, 2))
-    gs = [t.to(DEV).requires_grad_(True) for t in (q, k, v, conf)]
-    assert F.bri_attention_supported(B, T, Dh)
-    got = F.bri_attention(gs[0] * 40.0, gs[1], gs[2], gs[3])
-    assert maxdiff(got, want) < 2e-5 * max(1.0, want.abs().max().item())
-    go = S.hash_normal("bri/go", tuple(want.shape))
-    want.backward(go)
-    got.backward(go.to(DEV))
-    for a, c in zip(gs, cs):
-        assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
-
-
 @pytest.mark.parametrize("rows,C", [(5, 120), (33, 4096), (7, 7680), (3, 8192), (64, 4)])
 def test_softmax_rows_inplace_fwd_bwd(rows, C):
     """Innermost-axis row softmax (BRI attention matrix): in-place forward and in-place backward vs ATen."""
@@ -760,11 +740,13 @@ def test_bri_core_gemm_realisation_fwd_bwd_vs_dense(own, monkeypatch):
         assert maxdiff(a.grad, c.grad) < 1e-4 * max(1.0, c.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("path", ["gemm", "flash"])
-def test_bri_attention_golden_module(path, monkeypatch):
-    """The attention module (scalar affine q/k/v + gamma) against the reference fixture, both realisations."""
+@pytest.mark.parametrize("shell", [True, False])
+def test_bri_attention_golden_module(shell, monkeypatch):
+    """The attention module (scalar affine q/k/v + gamma) against the reference fixture: the fused block (csrc/bri_shell.hip
+    around the six products) and the tensor-expression form around the same products."""
+    from stereoscene_amd.plugin import view_transformer as vtm
     from stereoscene_amd.plugin.view_transformer import attention
-    monkeypatch.setenv("SSBEV_BRI", path)
+    monkeypatch.setattr(vtm, "BRI_SHELL", shell)
     g = load_golden("attention")
     att = attention(1).to(DEV)
     att.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")})
