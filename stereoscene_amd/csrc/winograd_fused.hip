@@ -552,7 +552,11 @@ static void df_instance(const ssbev_wino_dims* d, int N, int& mt, int& nw) {
   const int ncolgrp = (ntile + nw - 1) / nw;
   // 64-row workgroup tiles unless that leaves the chip's 512 workgroup slots (2 per CU) less than four times covered
   mt = 2;
-  if ((long)36 * d->B * ND * ((Thw + 63) / 64) * ncolgrp < 2048) mt = 1;      // (r4: 256 -> 256 at 64 x 64 x 8, 1152 workgroups of 64 rows: 0.249 -> 0.235 ms with 32-row tiles)
+  if ((long)36 * d->B * ND * ((Thw + 63) / 64) * ncolgrp < 2048) mt = 1;      // (r4: 256 -> 256 at 8 x 64 x 64, 1152 workgroups of 64 rows: 0.249 -> 0.235 ms with 32-row tiles)
+  // round 6: never pad a plane's hw-tiles by more than 10 %.  The voxel encoder's 256 -> 256 layers run on the 64 x 64 x 8 grid
+  // with the SHORT axis last: Thw = 16 x 2 = 32 row tiles per plane, and 64-row workgroup tiles spent half of their MFMAs on
+  // rows that do not exist (0.32 ms per launch at "0.38 of the pipe" -- the pipe was busy, with zeros)
+  if (((Thw + 63) / 64) * 64 * 10 > ((Thw + 31) / 32) * 32 * 11) mt = 1;
   // three-wave workgroups: two 64 KiB workgroups per CU put 6 waves on 4 SIMDs (2, 2, 1, 1); four 32 KiB ones are balanced
   // (384 -> 192 head conv: 1.98 -> 1.72 ms)
   if (nw == 3) mt = 1;

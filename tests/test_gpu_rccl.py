@@ -128,3 +128,44 @@ def test_rccl_world1_collectives_on_a_bucket_sized_buffer(rccl_world1):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     assert float(t) == 3.0
+
+
+# ------------------------------------------------------------------------------------------------ two ranks, two GPUs
+def _launch_two_ranks(script_args, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), *script_args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node (xGMI peers)")
+
+
+@needs_two_gpus
+def test_rccl_world2_exchange_averages_the_two_ranks_gradients():
+    """the first exchange WITH a peer.  Self-skips on a one-GPU box; see tests/rccl_world2_worker.py."""
+    out = _launch_two_ranks([os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world2_worker.py")])
+    assert out.returncode == 0 and "RCCL_WORLD2_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@needs_two_gpus
+def test_bench_two_ranks_prints_one_record_with_bus_bandwidth():
+    """bench.py exactly as the driver launches it at N = 2 (torch.distributed.run, one rank per GPU over RCCL), small config."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _launch_two_ranks([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "small_d48",
+                             "--cpu-sample", "none", "--skip-serial-replay"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["scaling"] == "weak"
+    ex = rec["gradient_exchange"]
+    assert ex["world"] == 2 and ex["backend"] == "nccl" and ex["rs_ag"]["bus_GBps"] > 0

@@ -9,7 +9,9 @@ import torch  # noqa: E402
 from stereoscene_amd import functional as F  # noqa: E402
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-LAYERS = [(128, 128, 16, 128, 128), (384, 192, 16, 128, 128), (256, 256, 8, 64, 64), (64, 64, 96, 24, 80), (128, 128, 48, 12, 40)]
+# (cin, cout, D, H, W) as the MODEL runs them: the occupancy grid is [X, Y, Z] = (D, H, W) with the SHORT axis last (rounds 2-5 probed
+# the encoder layers as 16 x 128 x 128 / 8 x 64 x 64 -- the transposed geometry, Thw = 1024 / 256 hw-tiles per plane instead of 128 / 32)
+LAYERS = [(128, 128, 128, 128, 16), (384, 192, 128, 128, 16), (256, 256, 64, 64, 8), (64, 64, 96, 24, 80), (128, 128, 48, 12, 40)]
 
 
 def timed(fn):
