@@ -178,14 +178,15 @@ def test_full_size_forward_batch2_vs_oracle():
     assert (logits[0] - logits[1]).abs().max().item() > 1e-2          # the two samples really differ
 
 
+@pytest.mark.parametrize("cfg_name", ["kitti_d112", "kitti_d192"])
 @pytest.mark.parametrize("mode", ["bev_only", "stereo_only"])
-def test_full_size_ablation_modes_vs_oracle(mode):
+def test_full_size_ablation_modes_vs_oracle(mode, cfg_name):
     """BASELINE configs[4] at the KITTI size (the ablation modes were compared with the oracle only at the tiny
-    config): kitti_d112, eval mode.  The reference has no ablation switch, so the expected lifted volume is composed from the
+    config; VERDICT r5: at kitti_d112 only -- kitti_d192 is the BASELINE frustum): eval mode.  The reference has no ablation switch, so the expected lifted volume is composed from the
     oracle's own pieces -- its monocular (bev_only) / stereo (stereo_only) depth distribution pushed through its lift + splat;
     gates as for the full path: depth distribution 1e-4, BEV volume 1e-3 of its scale."""
     import torch
-    cfg = S.CONFIGS["kitti_d112"]
+    cfg = S.CONFIGS[cfg_name]
     model = model_zoo.build_detector(cfg).eval()
     vt = model.img_view_transformer
     smp = S.synthetic_sample(cfg, B=1, tag="fsabl")
@@ -210,7 +211,7 @@ def test_full_size_ablation_modes_vs_oracle(mode):
     e_d = (dp.cpu() - dist_ref).abs().max().item()
     e_b = (bev.cpu() - bev_ref).abs().max().item()
     scale = bev_ref.abs().max().item()
-    print(f"kitti_d112 ablation {mode}: depth distribution max-abs {e_d:.2e}, BEV volume max-abs {e_b:.2e} (scale {scale:.2f})")
+    print(f"{cfg_name} ablation {mode}: depth distribution max-abs {e_d:.2e}, BEV volume max-abs {e_b:.2e} (scale {scale:.2f})")
     assert bev.shape == bev_ref.shape and e_d < 1e-4 and e_b < 1e-3 * max(1.0, scale)
 
 
@@ -250,6 +251,7 @@ def test_full_size_bf16_mode_vs_oracle(cfg_name, B):
 
 
 _ORACLE_STEP = {}
+_FLOOR = {}
 
 
 def _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=0):
@@ -274,7 +276,8 @@ def _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=0):
         torch.set_num_threads(nt)
     out = ({k: float(v.detach()) for k, v in want.items()}, {"logits": aux["logits"].detach()},
            {k: v.grad for k, v in sd.items() if k in trainable and v.grad is not None})
-    _ORACLE_STEP[key] = out
+    if not perturb:                       # (perturbed runs are reduced to a small table by _floor_table: 360 MB of gradients each)
+        _ORACLE_STEP[key] = out
     return out
 
 
@@ -321,17 +324,42 @@ def test_full_size_step_fwd_bwd_vs_oracle(cfg_name, ac):
     rows = _l2_table(grads, ograds)
     worst = max((v, k) for k, v in rows.items())
     print(f"{cfg_name} ac={ac} step: {len(rows)} parameter gradients, worst L2-relative error {worst[0]:.3e} ({worst[1]})")
-    # The gate is set against the ORACLE'S OWN response to a one-ulp perturbation of its inputs (x * (1 + 2^-23)), tensor by tensor:
-    # the camera-aware MLP / SE parameters of the stereo branch and the dres* layers behind them sit at a floor of 0.5-2e-2 at this
-    # size (ReLU / max sign flips: tools/grad_gate_floor.py, profiles/r5_grad_gate_floor.txt: ours 2.16e-2 at a floor of 2.08e-2 on
-    # depth_mlp.fc1.bias), everything else at 1e-5..1e-3.  A tensor may be at most three times its floor (+ 2e-3) away from the
-    # oracle -- the criterion of test_gradient_gate_vs_oracle_noise_floor (one perturbation is ONE sample of the floor).
-    _, _, pgrads = _oracle_step(cfg_name, ac, sd0, trainable, smp, model.img_view_transformer.D, perturb=1)
-    floor = _l2_table(pgrads, ograds)
+    # The gate is set against the ORACLE'S OWN response to perturbations of its inputs at rounding level, tensor by tensor: the
+    # camera-aware MLP / SE parameters of the stereo branch and the dres* layers behind them sit at a floor of 0.5-2e-2 at this size
+    # (ReLU / max sign flips), everything else at 1e-5..1e-3.  VERDICT / ADVICE r5: ONE perturbation is one noisy sample of that
+    # floor -- it is now the MEAN response over four (x * (1 +- 2^-23), x * (1 +- 2^-22); table: tools/grad_gate_floor.py ->
+    # profiles/r6_grad_gate_floor.txt).  A tensor may be at most three times its floor (+ 2e-3) away from the oracle; nothing may
+    # be further than 3e-2; and only the tensors of GRAD_FLOOR_EXEMPT (the stereo branch, whose floor is above 1e-3) may be
+    # further than the old absolute gate of 2e-2.
+    floor = _floor_table(cfg_name, ac, sd0, trainable, smp, model.img_view_transformer.D, ograds)
     over = sorted(((rows[k] / (3.0 * floor[k] + 2e-3), k, rows[k], floor[k]) for k in rows), reverse=True)
     print(f"{cfg_name} ac={ac} worst distance / (3 floor + 2e-3): {over[0][0]:.2f} ({over[0][1]}: ours {over[0][2]:.3e}, floor {over[0][3]:.3e})")
-    assert len(rows) > 150 and worst[0] < 5e-2, worst
+    assert len(rows) > 150 and worst[0] < 3e-2, worst
     assert over[0][0] < 1.0, over[:3]
+    above_old_gate = [k for k, v in rows.items() if v >= 2e-2]
+    assert all(k.startswith(GRAD_FLOOR_EXEMPT) and floor[k] > 1e-3 for k in above_old_gate), above_old_gate
+
+
+# tensors allowed above the absolute 2e-2 gradient gate (never above 3e-2), because the ORACLE itself moves by that much on them under a
+# perturbation at rounding level: the camera-aware gate of the stereo feature net (VT:32-65) and the 3-D aggregation behind it
+GRAD_FLOOR_EXEMPT = ("img_view_transformer.stereo_volume_net.feature_withcam.", "img_view_transformer.stereo_volume_net.dres")
+FLOOR_PERTURBATIONS = (1, -1, 2, -2)           # input scaled by (1 + k * 2^-23)
+
+
+def _floor_table(cfg_name, ac, sd0, trainable, smp, D, ograds, per_sample=None):
+    """Mean L2-relative response of the oracle's parameter gradients to FLOOR_PERTURBATIONS of its inputs."""
+    if per_sample is None and (cfg_name, ac) in _FLOOR:
+        return _FLOOR[(cfg_name, ac)]
+    acc = {}
+    for k in FLOOR_PERTURBATIONS:
+        _, _, pg = _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=k)
+        t = _l2_table(pg, ograds)
+        if per_sample is not None:
+            per_sample[k] = t
+        for name, v in t.items():
+            acc[name] = acc.get(name, 0.0) + v / len(FLOOR_PERTURBATIONS)
+    _FLOOR[(cfg_name, ac)] = acc
+    return acc
 
 
 def test_gradient_gate_vs_oracle_noise_floor():
@@ -343,8 +371,7 @@ def test_gradient_gate_vs_oracle_noise_floor():
     model, smp, sd0, trainable, _losses, _logits, grads = _gpu_step(cfg_name, ac)
     D = model.img_view_transformer.D
     _, _, g0 = _oracle_step(cfg_name, ac, sd0, trainable, smp, D)
-    _, _, g1 = _oracle_step(cfg_name, ac, sd0, trainable, smp, D, perturb=1)
-    floor = _l2_table(g1, g0)               # oracle(x (1 + ulp)) vs oracle(x)
+    floor = _floor_table(cfg_name, ac, sd0, trainable, smp, D, g0)      # mean of oracle(x (1 + k ulp)) vs oracle(x), k = +-1, +-2
     ours = _l2_table(grads, g0)             # GPU path vs oracle(x)
     names = sorted(ours, key=lambda k: -ours[k])
     lines = [f"{ours[k]:.3e}  floor {floor.get(k, float('nan')):.3e}  {k}" for k in names[:12]]
