@@ -429,12 +429,15 @@ int ssbev_softmax_rows_bwd(const float* y, const float* gy, float* gx, int64_t r
  * mmcv/ops/csrc deform_conv: deformable_im2col / deformable_col2im / deformable_col2im_coord).  stride 1,
  * deform_groups 1.  x [B,H,W,C], offset [B,H,W,2*k*k] (channel 2t = dy, 2t+1 = dx of tap t),
  * cols / gcols [G][B*H*W][k*k*(C/G)]: slab g is a channels-last [B, k*k*C/G, H, W] tensor, so the grouped
- * contraction is ssbev_conv_fwd with a 1x1 kernel per group.  col2im overwrites gx (atomic corner adds) and goffset.
+ * contraction is ssbev_conv_fwd with a 1x1 kernel per group.  col2im overwrites gx and goffset; both are run-to-run identical
+ * (round 6: the x gradient is a gather over the samples sorted by target pixel with ssbev_pool_prepare, summed in ascending
+ * (pixel, tap, corner) order -- mmcv's col2im scatters with atomics).  ws: ssbev_dcn_col2im_workspace bytes.
  * ------------------------------------------------------------------------------------------ */
 typedef struct { int B, C, H, W, G, k, pad, dil; } ssbev_dcn_dims;
 int ssbev_dcn_im2col(const float* x, const float* offset, float* cols, const ssbev_dcn_dims* d, ssbev_stream_t stream);
+size_t ssbev_dcn_col2im_workspace(const ssbev_dcn_dims* d);
 int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, float* gx, float* goffset,
-                     const ssbev_dcn_dims* d, ssbev_stream_t stream);
+                     const ssbev_dcn_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Data side: CreateDepthFromLiDAR (datasets/pipelines/occ_to_depth.py:216-303), the producer of the

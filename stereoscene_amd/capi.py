@@ -157,7 +157,8 @@ SIGNATURES = {
     "ssbev_trilinear2x_fwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_trilinear2x_bwd": (C.c_int, [_P, _P, C.POINTER(UpsampleDims), _P]),
     "ssbev_dcn_im2col": (C.c_int, [_P, _P, _P, C.POINTER(DcnDims), _P]),
-    "ssbev_dcn_col2im": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(DcnDims), _P]),
+    "ssbev_dcn_col2im_workspace": (C.c_size_t, [C.POINTER(DcnDims)]),
+    "ssbev_dcn_col2im": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(DcnDims), _P, C.c_size_t, _P]),
     "ssbev_bn_update_running": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int64, _P]),
     "ssbev_resize_pil_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "ssbev_crop_normalize_u8": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),

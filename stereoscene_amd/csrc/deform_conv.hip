@@ -6,8 +6,11 @@
 // cols [G][B*H*W][K*Cg] -- i.e. group g's slab IS a channels-last [B, K*Cg, H, W] tensor, so the grouped
 // contraction is one dense 1x1 convolution per group.  One workgroup per output pixel; a thread owns float4s of
 // channels (consecutive threads -> consecutive 16 bytes of one pixel: coalesced gathers).
-// The x gradient uses hardware fp32 atomics like mmcv's col2im (unordered sums); the offset gradient is a
-// deterministic workgroup reduction.
+// The x gradient is a GATHER (round 6): the (output pixel, tap, corner) samples are sorted by the input pixel they touch with the
+// library's own stable counting sort (ssbev_pool_prepare, the CSR build of the voxel scatter), and one workgroup per input pixel
+// adds its list in ascending sample order -- run-to-run identical, no atomics, no memset.  (mmcv's col2im, and rounds 1-5 here,
+// scatter with fp32 atomics: unordered sums, reproducible to rounding only.)  The offset gradient is a deterministic workgroup
+// reduction.
 #include "common.h"
 
 namespace {
@@ -70,13 +73,6 @@ dcn_im2col_kernel(const float* __restrict__ x, const float* __restrict__ off, fl
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-__device__ __forceinline__ void atomic_add4(float* p, float w, const float4& gval) {
-  unsafeAtomicAdd(p + 0, w * gval.x);
-  unsafeAtomicAdd(p + 1, w * gval.y);
-  unsafeAtomicAdd(p + 2, w * gval.z);
-  unsafeAtomicAdd(p + 3, w * gval.w);
-}
-
 // Offset gradient: one workgroup per output pixel, deterministic reduction over the channels.
 __global__ void __launch_bounds__(256)
 dcn_coord_grad_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ gcols,
@@ -118,93 +114,69 @@ dcn_coord_grad_kernel(const float* __restrict__ x, const float* __restrict__ off
   }
 }
 
-// Input gradient.  Every sample adds to four corner pixels (unordered fp32 atomics in mmcv).  Sent straight to L2 that is
-// 4 x 9 atomics per output pixel and channel (177 M per DepthNet step: 2.2 ms).  A workgroup therefore owns a TH x TW tile
-// of output pixels and a 32-channel slice and accumulates into an LDS window that covers the tile plus a reach of R
-// pixels (samples that land outside the window -- offsets larger than R -- go to global memory directly); the window
-// is flushed with one global atomic per touched element (~9x fewer L2 atomics).
-// LDS float atomics are NOT used for the window: ds_add_f32 retires ~0.4 lanes per clock on gfx950 (PMC: 155 LDS-busy
-// cycles per wave instruction, 0.85 ms for this kernel).  Instead every (tap, corner) phase is made collision-free by a
-// claim round: the threads of a pixel store their pixel id into an owner map (plain ds_write), and after a barrier
-// only the pixels that still own their target add with plain 16-byte read-modify-writes; losers (two pixels of the tile
-// whose offsets send the same corner to the same window position -- rare, offsets vary smoothly) retry.  36 phases of a
-// few LDS instructions and barriers each.
-constexpr int kDcnTH = 4, kDcnTW = 16, kDcnR = 3, kDcnCC = 32;
-constexpr int kDcnWH = kDcnTH + 2 * kDcnR + 1, kDcnWW = kDcnTW + 2 * kDcnR + 1, kDcnPitch = kDcnCC + 4;
-
+// ---- input gradient, gather form -------------------------------------------------------------------------------------------
+// sample id = ((pix * K + tap) * 4 + corner); key = the input pixel (b * H + h) * W + w the corner lands on, or -1 (outside the
+// map / zero-padded corner); wts[id] = the bilinear weight of that corner.
 __global__ void __launch_bounds__(256)
-dcn_input_grad_kernel(const float* __restrict__ off, const float* __restrict__ gcols, float* __restrict__ gx, DcnGeom g) {
-  __shared__ __align__(16) float win[kDcnWH * kDcnWW * kDcnPitch];
-  __shared__ int owner[kDcnWH * kDcnWW];
-  const int tiles_w = (g.W + kDcnTW - 1) / kDcnTW;
-  const int th = blockIdx.x / tiles_w, tw = blockIdx.x % tiles_w;
-  const int c0 = blockIdx.y * kDcnCC;
-  const long b = blockIdx.z;
-  const int h_lo = th * kDcnTH - kDcnR, w_lo = tw * kDcnTW - kDcnR;
-  const int K = g.k * g.k, Cg = g.C / g.G;
-  const long BHW = (long)g.B * g.H * g.W;
-  for (int i = threadIdx.x; i < kDcnWH * kDcnWW * kDcnPitch; i += 256) win[i] = 0.0f;
-  __syncthreads();
-  float* gxb = gx + b * (long)g.H * g.W * g.C;
-  const int px = threadIdx.x >> 2, qsub = threadIdx.x & 3;            // 64 pixels x 4 threads, 8 channels each
-  const int oh = th * kDcnTH + px / kDcnTW, ow = tw * kDcnTW + px % kDcnTW;
-  const int c = c0 + qsub * 8;
-  const bool live = oh < g.H && ow < g.W && c < g.C;
-  const long pix = live ? (b * g.H + oh) * g.W + ow : 0;
-  const int grp = live ? c / Cg : 0, cg = c - grp * Cg;
-  for (int tap = 0; tap < K; ++tap) {
-    Sample s;
-    s.inside = false;
-    float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) {
-      s = make_sample(off, pix, oh, ow, tap, g);
-      if (s.inside) {
-        const float* gp = gcols + (((long)grp * BHW + pix) * K + tap) * Cg + cg;
-        const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
-        gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gb.x; gv[5] = gb.y; gv[6] = gb.z; gv[7] = gb.w;
-      }
-    }
-    const bool use = live && s.inside;
-    const float wgt[4] = {(1.f - s.lh) * (1.f - s.lw), (1.f - s.lh) * s.lw, s.lh * (1.f - s.lw), s.lh * s.lw};
-    const bool okc[4] = {s.ok00, s.ok01, s.ok10, s.ok11};
+dcn_corner_keys_kernel(const float* __restrict__ off, int32_t* __restrict__ keys, float* __restrict__ wts, DcnGeom g, long n_samples) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // (pix, tap)
+  if (i >= n_samples) return;
+  const int K = g.k * g.k;
+  const long pix = i / K;
+  const int tap = (int)(i - pix * K);
+  const int ow = (int)(pix % g.W), oh = (int)((pix / g.W) % g.H);
+  const long b = pix / ((long)g.W * g.H);
+  const Sample s = make_sample(off, pix, oh, ow, tap, g);
+  const bool okc[4] = {s.ok00, s.ok01, s.ok10, s.ok11};
+  const float wgt[4] = {(1.f - s.lh) * (1.f - s.lw), (1.f - s.lh) * s.lw, s.lh * (1.f - s.lw), s.lh * s.lw};
+  int4 k4;
+  int* kk = reinterpret_cast<int*>(&k4);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      int pos = -1;
-      if (use && okc[k4]) {
-        const int hc = s.h0 + (k4 >> 1), wc = s.w0 + (k4 & 1);
-        const int wh = hc - h_lo, wwc = wc - w_lo;
-        if (wh >= 0 && wh < kDcnWH && wwc >= 0 && wwc < kDcnWW) {
-          pos = wh * kDcnWW + wwc;
-        } else {                                           // beyond the reach of the window: straight to L2
-          float* dst = gxb + ((long)hc * g.W + wc) * g.C + c;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dst + e, wgt[k4] * gv[e]);
-        }
-      }
-      bool pending = pos >= 0;
-      while (__syncthreads_or(pending ? 1 : 0)) {
-        if (pending) owner[pos] = px;
-        __syncthreads();
-        if (pending && owner[pos] == px) {
-          float4* d = reinterpret_cast<float4*>(win + pos * kDcnPitch + qsub * 8);
-          float4 a0 = d[0], a1 = d[1];
-          const float w = wgt[k4];
-          a0.x += w * gv[0]; a0.y += w * gv[1]; a0.z += w * gv[2]; a0.w += w * gv[3];
-          a1.x += w * gv[4]; a1.y += w * gv[5]; a1.z += w * gv[6]; a1.w += w * gv[7];
-          d[0] = a0; d[1] = a1;
-          pending = false;
-        }
-        __syncthreads();
-      }
-    }
+  for (int c = 0; c < 4; ++c) {
+    const int hc = s.h0 + (c >> 1), wc = s.w0 + (c & 1);
+    kk[c] = okc[c] ? (int)((b * g.H + hc) * g.W + wc) : -1;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kDcnWH * kDcnWW * kDcnCC; i += 256) {
-    const int e = i % kDcnCC, wp = i / kDcnCC;
-    const int hc = h_lo + wp / kDcnWW, wc = w_lo + wp % kDcnWW;
-    const float v = win[wp * kDcnPitch + e];
-    if (v != 0.0f && hc >= 0 && hc < g.H && wc >= 0 && wc < g.W && c0 + e < g.C)
-      unsafeAtomicAdd(gxb + ((long)hc * g.W + wc) * g.C + c0 + e, v);
+  *reinterpret_cast<int4*>(keys + i * 4) = k4;
+  *reinterpret_cast<float4*>(wts + i * 4) = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+}
+
+// One workgroup per INPUT pixel; thread t owns the float4 of channels 4t.. (C / 4 <= 256 lanes per pass).  The list of a pixel
+// (~4 k^2 samples when the offsets are small) is walked in ascending sample id = the canonical summation order.
+__global__ void __launch_bounds__(256)
+dcn_input_grad_gather_kernel(const float* __restrict__ gcols, const int32_t* __restrict__ starts, const int32_t* __restrict__ order,
+                             const float* __restrict__ wts, float* __restrict__ gx, DcnGeom g) {
+  const long ipix = blockIdx.x;
+  const int K = g.k * g.k, q = g.C >> 2, Cg = g.C / g.G;
+  const long BHW = (long)g.B * g.H * g.W;
+  const int e0 = starts[ipix], e1 = starts[ipix + 1];
+  for (int cq = threadIdx.x; cq < q; cq += 256) {
+    const int c = cq * 4, grp = c / Cg, cg = c - grp * Cg;
+    const float* gbase = gcols + (long)grp * BHW * K * Cg + cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {                 // four list entries in flight; the adds stay in list order
+      int id[4];
+      float w[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) id[u] = order[e + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        w[u] = wts[id[u]];
+        v[u] = *reinterpret_cast<const float4*>(gbase + (long)(id[u] >> 2) * Cg);      // (pix * K + tap) * Cg
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w;
+      }
+    }
+    for (; e < e1; ++e) {
+      const int id = order[e];
+      const float w = wts[id];
+      const float4 v = *reinterpret_cast<const float4*>(gbase + (long)(id >> 2) * Cg);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+    *reinterpret_cast<float4*>(gx + ipix * g.C + c) = acc;
   }
 }
 
@@ -226,16 +198,44 @@ int ssbev_dcn_im2col(const float* x, const float* offset, float* cols, const ssb
   return ssbev_launch_status();
 }
 
+static ssbev_pool_dims dcn_sort_dims(const ssbev_dcn_dims* d) {
+  ssbev_pool_dims p = {};
+  p.B = d->B; p.nx = d->H; p.ny = d->W; p.nz = 1; p.C = 4; p.P = d->H * d->W * d->k * d->k * 4;
+  p.dx[0] = p.dx[1] = p.dx[2] = 1.0f;
+  return p;
+}
+
+// workspace of ssbev_dcn_col2im: keys[n] + weights[n] + order[n] + starts[B*H*W + 1] + the counting sort's own, n = 4 k^2 B H W
+size_t ssbev_dcn_col2im_workspace(const ssbev_dcn_dims* d) {
+  if (!dcn_ok(d)) return 0;
+  const size_t n = (size_t)d->B * d->H * d->W * d->k * d->k * 4;
+  const size_t nv = (size_t)d->B * d->H * d->W;
+  if (n >= (1ull << 31)) return 0;
+  const ssbev_pool_dims p = dcn_sort_dims(d);
+  return 3 * n * 4 + ((nv + 1 + 3) & ~(size_t)3) * 4 + ssbev_pool_prepare_workspace((int)n, &p) + 256;
+}
+
 int ssbev_dcn_col2im(const float* x, const float* offset, const float* gcols, float* gx, float* goffset,
-                     const ssbev_dcn_dims* d, ssbev_stream_t stream) {
-  if (!dcn_ok(d) || !x || !offset || !gcols || !gx || !goffset) return SSBEV_EINVAL;
+                     const ssbev_dcn_dims* d, void* ws, size_t ws_bytes, ssbev_stream_t stream) {
+  if (!dcn_ok(d) || !x || !offset || !gcols || !gx || !goffset || !ws) return SSBEV_EINVAL;
+  const size_t need = ssbev_dcn_col2im_workspace(d);
+  if (need == 0) return SSBEV_EINVAL;
+  if (ws_bytes < need) return SSBEV_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(gx, 0, (size_t)d->B * d->H * d->W * d->C * sizeof(float), st) != hipSuccess) return SSBEV_ELAUNCH;
-  hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3((unsigned)((long)d->B * d->H * d->W)), dim3(256), 0, st, x, offset,
-                     gcols, goffset, to_geom(d));
-  const int tiles = ((d->H + kDcnTH - 1) / kDcnTH) * ((d->W + kDcnTW - 1) / kDcnTW);
-  hipLaunchKernelGGL(dcn_input_grad_kernel, dim3(tiles, (d->C + kDcnCC - 1) / kDcnCC, d->B), dim3(256), 0, st, offset,
-                     gcols, gx, to_geom(d));
+  const DcnGeom g = to_geom(d);
+  const long npix = (long)d->B * d->H * d->W, ns = npix * d->k * d->k, n = ns * 4;
+  hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3((unsigned)npix), dim3(256), 0, st, x, offset, gcols, goffset, g);
+  char* w = static_cast<char*>(ws);
+  int32_t* keys = reinterpret_cast<int32_t*>(w);            w += n * 4;
+  float* wts = reinterpret_cast<float*>(w);                  w += n * 4;
+  int32_t* order = reinterpret_cast<int32_t*>(w);           w += n * 4;
+  int32_t* starts = reinterpret_cast<int32_t*>(w);          w += ((npix + 1 + 3) & ~3L) * 4;
+  w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(w) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(dcn_corner_keys_kernel, dim3(cdiv((size_t)ns, 256)), dim3(256), 0, st, offset, keys, wts, g, ns);
+  const ssbev_pool_dims p = dcn_sort_dims(d);
+  const int rc = ssbev_pool_prepare(keys, (int)n, starts, order, &p, w, ssbev_pool_prepare_workspace((int)n, &p), stream);
+  if (rc != SSBEV_OK) return rc;
+  hipLaunchKernelGGL(dcn_input_grad_gather_kernel, dim3((unsigned)npix), dim3(256), 0, st, gcols, starts, order, wts, gx, g);
   return ssbev_launch_status();
 }
 

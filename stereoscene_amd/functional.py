@@ -1682,9 +1682,11 @@ class _DcnIm2col(torch.autograd.Function):
         lib = capi.load()
         xcl, ocl = ctx.saved_tensors
         gx, goff = torch.empty_like(xcl), torch.empty_like(ocl)
+        ws = _ws(lib.ssbev_dcn_col2im_workspace(C.byref(ctx.d)), xcl.device)
         with _span("dcn_sample", 0.0, 4.0 * (2 * xcl.numel() + 2 * ocl.numel() + gcols.numel()), "bwd   dcn_col2im"):
             capi.check(lib.ssbev_dcn_col2im(capi.ptr(xcl), capi.ptr(ocl), capi.ptr(gcols.contiguous()), capi.ptr(gx),
-                                            capi.ptr(goff), C.byref(ctx.d), capi.stream()), "ssbev_dcn_col2im")
+                                            capi.ptr(goff), C.byref(ctx.d), capi.ptr(ws), ws.numel(), capi.stream()),
+                       "ssbev_dcn_col2im")
         return from_cl(gx), from_cl(goff), None, None, None, None
 
 
