@@ -233,188 +233,11 @@ wino_df_kernel(const float* __restrict__ P, const float* __restrict__ Wp, float*
 #endif
 }
 
-// ---- persistent variant (round 6) ----------------------------------------------------------------------------------------------
-// Same tile, same k-stage body, same sums in the same order as wino_df_kernel -- bit-identical output -- but a workgroup walks a
-// LIST of tiles: the grid is what the chip holds at once (occupancy x 256), XCD x keeps its contiguous range of the task list
-// and its resident workgroups take the range round-robin (neighbours in time = neighbours in the list, as with the hardware's
-// dispatch order).  What it removes per tile: the prologue (first A slab + first weight fragments from L2 / HBM with the matrix
-// pipe idle: 7.1 k clocks against 4 stages of 16.2 k on the 128 -> 128 layers) and the workgroup turn-over on the CU -- the first
-// slab and the first weight fragments of tile n + 1 are requested inside the LAST k-stage of tile n, through the very code path
-// that requests stage st + 1 inside stage st.  The epilogue stages its two output tiles through the buffer the last stage read,
-// one after the other (8 KiB per wave), so that the other buffer is free for the next tile's slab; its stores are drained by ONE
-// vmcnt(0) at the top of the next tile (stores and loads retire out of order with respect to each other: the counted waits of the
-// stage body are only valid with no store in flight).
-template <int MT, int NW>
-__global__ void __launch_bounds__(64 * NW, 2)
-wino_df_pkernel(const float* __restrict__ P, const float* __restrict__ Wp, float* __restrict__ Mo, DfGeom g, int ntasks) {
-  constexpr int BM = 32 * MT;
-  constexpr int PLANE = BM * DF_BK;
-  constexpr int STAGE = 4 * PLANE;
-  constexpr int NI = 4 * BM / 8;
-  constexpr int IPP = BM / 8;
-  constexpr int GL = NI / NW;
-  extern __shared__ __align__(16) float lds[];      // [2 stages][4 planes][BM rows][32 k]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lk = lane >> 5;
-  // ---- this workgroup's task list: XCD-local range [xbase, xbase + xcnt), every `xstep`-th task starting at `slot`
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int xstep = ((int)gridDim.x - xcd + 7) >> 3;               // workgroups of this launch on this XCD
-  const int xq = ntasks >> 3, xr = ntasks & 7;
-  const int xbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-  const int xcnt = xq + (xcd < xr ? 1 : 0);
-  if (slot >= xcnt) return;                                         // (more workgroups than tasks: before any barrier)
-  const long R = (long)g.B * g.D * g.Thw;
-  const int nst = g.K / DF_BK;
-  const int Q = g.K >> 3;
-  const size_t fstride = (size_t)Q * 2 * g.NPad * 4;
-  const size_t qstride = (size_t)2 * g.NPad * 4;
-
-  struct Task {
-    const float* Px;      // P of this task's (h, w) frequency
-    const float* wl;      // this lane's first weight fragment
-    int i, b, t0, n0, xhw;
-    bool col_active;
-  };
-  auto decode = [&](int local) {
-    const int logical = xbase + local;
-    Task t;
-    const int cg = logical % g.ncolgrp, u = (logical / g.ncolgrp) % g.NU;
-    t.xhw = logical / (g.ncolgrp * g.NU);
-    t.i = u % g.ND;
-    const int tg = (u / g.ND) % g.nrowgrp;
-    t.b = u / (g.ND * g.nrowgrp);
-    t.t0 = tg * BM;
-    t.n0 = (cg * NW + wave) * 32;
-    t.col_active = t.n0 < g.NPad;
-    t.Px = P + (long)t.xhw * R * g.K;
-    t.wl = Wp + (size_t)t.xhw * 4 * fstride + ((size_t)lk * g.NPad + (t.col_active ? t.n0 : 0) + li) * 4;
-    return t;
-  };
-  // A staging of (task, k-stage st) into buffer buf; live = false requests zeros (the request behind the very last stage of the
-  // list: the stage body stays one straight-line code path with the same number of loads in flight).  A wave instruction copies 8
-  // rows of ONE plane: its source is a wave-uniform base (plane, first row of the tile, stage) plus a 32-bit lane offset -- no
-  // 64-bit per-lane pointers kept across the tile loop.  Rows past the end of the plane (last row group of a plane whose tile count
-  // is not a multiple of BM) re-read the plane's last row: their products are never stored; planes outside the volume read zeros.
-  auto issue = [&](const Task& t, int st, int buf, bool live) {
-    const int rmax = g.Thw - 1 - t.t0;                               // last valid row of this tile (>= 0)
-#pragma unroll
-    for (int e = 0; e < (NI + NW - 1) / NW; ++e) {
-      const int j = wave + NW * e;
-      if (NI % NW != 0 && j >= NI) break;
-      const int a = j / IPP, jj = j % IPP;
-      const int row = jj * 8 + (lane >> 3), slot8 = lane & 7;
-      const int d = 2 * t.i - 1 + a;
-      const bool plane_ok = live && d >= 0 && d < g.D;               // wave-uniform
-      // branch-free selects (a branch here would be a control-flow join with the weight-fragment loads in flight, see below)
-      const long long m = -(long long)plane_ok;
-      const long long pa = (long long)(size_t)(t.Px + (((long)t.b * g.D + min(max(d, 0), g.D - 1)) * g.Thw + t.t0) * g.K + st * DF_BK);
-      const float* sbase = reinterpret_cast<const float*>((size_t)((pa & m) | ((long long)(size_t)kDfZeros & ~m)));
-      const unsigned voff = (unsigned)(min(row, rmax) * g.K + ((slot8 ^ ((row >> 1) & 7)) << 2)) & (unsigned)m;
-      const float* src = sbase + voff;
-      __builtin_amdgcn_global_load_lds(src, lds + buf * STAGE + a * PLANE + jj * 256, 16, 0, 0);
-    }
-  };
-  auto load_b = [&](const float* wl, int q, v4f (&bv)[4]) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) df_load_b(bv[f], wl + (size_t)f * fstride + (size_t)q * qstride);
-  };
-
-  wf32x16 acc[4][MT];
-  v4f bb[2][4];
-  // One k-stage of `cur`.  `nt` / `nst_` / `nlive`: the (task, stage) whose slab is requested in k-step 1 and whose first weight
-  // fragments are requested in k-step 3 -- stage st + 1 of the same task, or stage 0 of the next one.
-  auto stage = [&](const Task& cur, int st, int buf, const Task& nt, int nstg, bool nlive) {
-    __builtin_amdgcn_s_barrier();
-    const float* ab = lds + buf * STAGE;
-#pragma unroll
-    for (int qq = 0; qq < DF_BK / 8; ++qq) {
-      const int q = st * (DF_BK / 8) + qq;
-      v4f (&bc)[4] = bb[qq & 1];
-      v4f (&bn)[4] = bb[(qq + 1) & 1];
-      if (qq < DF_BK / 8 - 1) load_b(cur.wl, q + 1, bn);
-      else load_b(nt.wl, nstg * (DF_BK / 8), bn);            // (behind the last stage of the list: task 0's fragments again, unused)
-      if (qq == 1) issue(nt, nstg, buf ^ 1, nlive);
-      if (qq == 1 || qq == 2) df_wait_b<4 + GL>(bc);
-      else df_wait_b<4>(bc);
-      v4f v[4][MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int row = mt * 32 + li;
-        const int off = row * DF_BK + (((2 * qq + lk) ^ ((row >> 1) & 7)) << 2);
-        const v4f p0 = *reinterpret_cast<const v4f*>(ab + 0 * PLANE + off);
-        const v4f p1 = *reinterpret_cast<const v4f*>(ab + 1 * PLANE + off);
-        const v4f p2 = *reinterpret_cast<const v4f*>(ab + 2 * PLANE + off);
-        const v4f p3 = *reinterpret_cast<const v4f*>(ab + 3 * PLANE + off);
-        v[0][mt] = p0 - p2;
-        v[1][mt] = p1 + p2;
-        v[2][mt] = p2 - p1;
-        v[3][mt] = p1 - p3;
-      }
-#define SSBEV_DF_COMP(COMP)                                                                              \
-      _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                      \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
-        acc[f][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f][mt].COMP, bc[f].COMP, acc[f][mt], 0, 0, 0);
-      SSBEV_DF_COMP(x) SSBEV_DF_COMP(y) SSBEV_DF_COMP(z) SSBEV_DF_COMP(w)
-#undef SSBEV_DF_COMP
-    }
-    df_wait_b<0>(bb[0]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-
-  Task cur = decode(slot);
-  int buf = 0;
-  load_b(cur.wl, 0, bb[0]);
-  issue(cur, 0, 0, true);
-  for (int local = slot; local < xcnt; local += xstep) {
-    const bool has_next = local + xstep < xcnt;
-    df_wait_b<0>(bb[0]);                               // first fragments / first slab landed; the previous tile's stores retired
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc[f][mt][rr] = 0.0f;
-    for (int st = 0; st + 1 < nst; ++st, buf ^= 1) stage(cur, st, buf, cur, st + 1, true);
-    const Task nxt = decode(has_next ? local + xstep : slot);
-    stage(cur, nst - 1, buf, nxt, 0, has_next);
-    // ---- epilogue: depth output transform, the two output tiles one after the other through this wave's 1 / NW of `buf`
-    __builtin_amdgcn_s_barrier();                      // every wave has finished reading `buf`
-    if (cur.col_active && cur.n0 < g.N) {
-      float* wb = lds + buf * STAGE + wave * (BM * 32);             // [BM rows][32 columns]
-      float* Mx = Mo + (long)cur.xhw * R * g.N;
-      const int cq = lane & 7, r8 = lane >> 3;
-      const bool cok = cur.n0 + 4 * cq < g.N;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = mt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lk;
-            const float m0 = acc[0][mt][rr], m1 = acc[1][mt][rr], m2 = acc[2][mt][rr], m3 = acc[3][mt][rr];
-            wb[row * 32 + li] = j == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float* oj = Mx + (((long)cur.b * g.D + 2 * cur.i + j) * g.Thw + cur.t0) * g.N + cur.n0 + 4 * cq;
-#pragma unroll
-        for (int it0 = 0; it0 < BM / 8; it0 += 4) {
-          v4f rowv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) rowv[u] = *reinterpret_cast<const v4f*>(wb + ((it0 + u) * 8 + r8) * 32 + 4 * cq);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are back before tile j + 1 overwrites the region
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int row = (it0 + u) * 8 + r8;
-            if (cok && cur.t0 + row < g.Thw) *reinterpret_cast<v4f*>(oj + (long)row * g.N) = rowv[u];
-          }
-        }
-      }
-    }
-    buf ^= 1;                                          // the next tile's first slab went to the other buffer
-    cur = nxt;
-  }
-}
-
+// (Round 6 built a persistent variant -- resident workgroups walking a tile list, the next tile's first slab and weight fragments
+// requested inside the last k-stage, bit-identical output -- on the hypothesis that the 7.1 k-clock prologue per tile is what keeps
+// the kernel at 0.6-0.7 of the pipe.  Measured SLOWER: 128 -> 128 0.590 -> 0.636 ms, 384 -> 192 1.92 -> 2.37 ms (its 200 registers
+// cost the MT = 1 instances a wave per SIMD), step 70.8 -> 72.9 ms; resident workgroups run in phase, the dispatcher staggers
+// one-tile workgroups.  Removed; profiles/r6d_wino_df_persistent_refuted.txt.)
 // ---- packed weights ----------------------------------------------------------------------------------------------------
 // Wp[xi_hw = e * 6 + f][fd][q][kh][n][t] = U[fd][e][f][k = 8q + 4kh + t][n],  U = G_d (x) G43_h (x) G43_w applied to
 //   mode 0: w[n][k][kd][kh][kw]           (forward: K = Cin, N = Cout)
@@ -703,16 +526,6 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-int df_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, c = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
-    n = c;
-  }
-  return n;
-}
-
 }  // namespace
 
 extern "C" {
@@ -805,27 +618,8 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
 #define DF_CLOCKS_BEGIN(NW_)
 #define DF_CLOCKS_END(NW_)
 #endif
-  // persistent form (wino_df_pkernel) by default; SSBEV_DF_PERSIST=0 = one workgroup per tile (A/B timing, bit-identical)
-  const bool persist = env_int("SSBEV_DF_PERSIST", 1) != 0;          // (answered from the switch table: no getenv per launch)
 #define SSBEV_DF_LAUNCH(MT_, NW_)                                                                                          \
   do {                                                                                                                     \
-    if (persist && nwg < (1L << 30)) {                                                                                     \
-      auto pk = wino_df_pkernel<MT_, NW_>;                                                                                 \
-      static int occ = 0;                                                                                                  \
-      if (occ == 0) {                                                                                                      \
-        if (lds > 64 * 1024 - 1 &&                                                                                         \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != \
-                hipSuccess)                                                                                                \
-          return SSBEV_ELAUNCH;                                                                                            \
-        int o = 0;                                                                                                         \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, pk, 64 * NW_, lds) != hipSuccess || o < 1) o = 1;             \
-        occ = o;                                                                                                           \
-      }                                                                                                                    \
-      const long want = (long)occ * df_cu_count();                                                                         \
-      const long grid = std::min(want, (nwg + 7) / 8 * 8);                                                                 \
-      hipLaunchKernelGGL(pk, dim3((unsigned)grid), dim3(64 * NW_), lds, st, P, Wp, Mo, g, (int)nwg);                       \
-      break;                                                                                                               \
-    }                                                                                                                      \
     auto kern = wino_df_kernel<MT_, NW_>;                                                                                  \
     if (lds > 64 * 1024 - 1 &&                                                                                             \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \

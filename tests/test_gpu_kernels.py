@@ -1097,32 +1097,6 @@ def test_winograd_depth_fused_f43(case, monkeypatch):
         assert rel_max < 2e-4 and rel_l2 < 1e-4, (name, rel_max, rel_l2)
 
 
-@pytest.mark.parametrize("case", [(2, 128, 96, 6, 4, 4), (1, 384, 192, 2, 4, 8), (1, 64, 64, 6, 8, 8), (1, 128, 128, 48, 12, 40),
-                                  (1, 256, 256, 64, 64, 8), (1, 128, 128, 32, 128, 16), (1, 192, 384, 2, 36, 40), (1, 32, 64, 4, 20, 16)])
-def test_winograd_depth_fused_persistent_kernel_is_bit_identical(case, monkeypatch):
-    """Round 6: wino_df_pkernel (a resident workgroup walks a list of tiles and requests tile n + 1's first slab inside tile n's last
-    k-stage) runs the same stage body as wino_df_kernel -- forward output and data gradient must agree bit for bit.  Cases: every
-    <MT, NW> instance, ragged row groups (Thw = 1, 30, 90: rows past the plane's end re-read its last row and are never stored),
-    one k-stage (K = 32: the buffer parity flips per tile), more workgroups than tiles, the encoder's own shapes."""
-    B, Cin, Cout, D, H, W = case
-    monkeypatch.setattr(F, "WINO_DF", True)
-    monkeypatch.setattr(F, "WINO_DF_MIN_ROWS", 0)
-    assert F._wino_df_applicable(B, D, H, W, Cin, Cout)
-    x = S.hash_normal(f"wdfp/x{case}", (B, Cin, D, H, W)).to(DEV)
-    w = (S.hash_uniform(f"wdfp/w{case}", (Cout, Cin, 3, 3, 3), -1, 1) * (3.0 / (Cin * 27)) ** 0.5).to(DEV)
-    go = S.hash_normal(f"wdfp/go{case}", (B, Cout, D, H, W)).to(DEV)
-    outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("SSBEV_DF_PERSIST", mode)
-        capi.load().ssbev_env_refresh()          # the library caches its switches
-        xg = x.clone().requires_grad_(True)
-        y = F.conv3d(xg, w, None, 1, 1)
-        (gx,) = torch.autograd.grad(y, xg, go)
-        outs[mode] = (y.detach().clone(), gx.detach().clone())
-    assert torch.isfinite(outs["1"][0]).all() and torch.isfinite(outs["1"][1]).all()
-    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
-
-
 def test_winograd_depth_fused_falls_back_when_unsupported(monkeypatch):
     monkeypatch.setattr(F, "WINO_DF_MIN_ROWS", 0)
     assert not F._wino_df_applicable(1, 4, 8, 8, 100, 128)       # K % 32 != 0
