@@ -542,8 +542,8 @@ def main():
             exec_tf = k["executed"] / n / avg_s / 1e12
             oper_tf = k["flops"] / n / avg_s / 1e12
             traffic, traffic_src, traffic_fresh = None, None, None
-            cands = (["r5_pmc_traffic_bf16.json", "r4_pmc_traffic_bf16.json"] if args.precision != "fp32"
-                     else ["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"])
+            cands = (["r6_pmc_traffic_bf16.json", "r5_pmc_traffic_bf16.json", "r4_pmc_traffic_bf16.json"] if args.precision != "fp32"
+                     else ["r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"])
             tfile = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
             if tfile and args.config == "kitti_d192" and args.batch == 1:
                 # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command (PMC collection cannot run

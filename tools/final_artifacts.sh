@@ -44,6 +44,8 @@ timeout 300 python tools/wgrad_dh_probe.py 2>&1 | grep -v amdgpu > $out/wgrad_dh
 timeout 300 python tools/pool_prepare_probe.py 2>&1 | grep -v amdgpu > $out/pool_prepare_probe.txt
 timeout 300 python tools/gather_split_probe.py 2>&1 | grep -v amdgpu > $out/gather_split_probe.txt
 timeout 300 python tools/pw32_probe.py 2>&1 | grep -v amdgpu > $out/pw32_probe.txt
+timeout 300 python tools/wino_df_probe.py 20 2>&1 | grep -v amdgpu > $out/wino_df_probe.txt
+timeout 300 python tools/host_time_probe.py 2>&1 | grep -v amdgpu > $out/host_time.txt
 bash tools/sq_counters.sh $tag > /dev/null 2>&1
 SSBEV_WGRAD_STREAM=0 SSBEV_VT_STREAMS=0 timeout 600 python tools/layer_table.py kitti_d192 3 2>&1 | grep -v amdgpu > $out/layer_table.txt
 timeout 600 python tools/bucket_timeline.py 64 300 2>&1 | grep -v amdgpu > $out/bucket_timeline.txt
