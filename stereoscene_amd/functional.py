@@ -2256,7 +2256,8 @@ def same_padding(size, k, stride):
 
 def linear_cl(x, weight, bias=None):
     """1x1 / stride-1 convolution of a channels-last map as the plain GEMM it is -- [pixels, Cin] x [Cin, Cout] on the
-    channels-last buffer, no layout change -- on rocBLAS (forward, data and weight gradient through autograd's mm).
+    channels-last buffer, no layout change -- on the own GEMM kernels (csrc/gemm.hip: forward, data and weight gradient) whenever
+    Cout % 4 == 0, else on the library through autograd's mm.
     Used by the image branch, whose pointwise convs range from 2 rows (SE gates) to 245 k rows x 32..3840 channels."""
     xcl = to_cl(_f32(x, "linear_cl"))
     shp = xcl.shape
@@ -2277,13 +2278,17 @@ def small_linear(x2, weight2, bias=None):
     """nn.functional.linear for the few-row products of the path (camera MLPs, squeeze-excite gates, CA3D's channel MLP:
     [B, K] x [N, K]^T): on the own GEMM kernels (N a multiple of 4; K is zero-padded to one), so that no rocBLAS kernel is launched
     for them either."""
-    if (x2.is_cuda and x2.dim() == 2 and own_gemm_site("linear") and x2.dtype == torch.float32
-            and weight2.shape[0] % 4 == 0 and weight2.shape[1] == x2.shape[1]):
+    if x2.is_cuda and x2.dtype != torch.float32:
+        x2 = x2.float()              # (a bf16 pooled vector in the storage mode: the few-row products stay fp32, like their weights)
+    if (x2.is_cuda and x2.dim() == 2 and own_gemm_site("linear") and weight2.shape[0] % 4 == 0
+            and weight2.shape[1] == x2.shape[1]):
         pad = -x2.shape[1] % 4
         if pad:                      # (the 27-feature camera vector: zero columns on both operands, 16-byte rows)
             x2, weight2 = torch.nn.functional.pad(x2, (0, pad)), torch.nn.functional.pad(weight2, (0, pad))
         return _LinearCL.apply(x2.contiguous(), weight2.contiguous(), bias)
-    return torch.nn.functional.linear(x2, weight2, bias)
+    fl = 2.0 * x2.shape[0] * x2.shape[-1] * weight2.shape[0]
+    with _span("gemm_lib", fl, 4.0 * (x2.numel() + weight2.numel()), f"fwd   linear (library) {x2.shape[-1]}->{weight2.shape[0]} rows={x2.shape[0]}"):
+        return torch.nn.functional.linear(x2, weight2, bias)
 
 
 class _DwConv2d(torch.autograd.Function):
