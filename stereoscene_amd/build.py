@@ -29,7 +29,9 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
+    """tuning=True (`--tuning`): -DSSBEV_TUNING, the ~50 kernel tuning hooks of csrc/ (ssbev_tune in common.h) answer the environment;
+    the product build compiles them out.  Switching between the two needs --force."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -40,7 +42,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+            cmd = [hipcc, *FLAGS, *(["-DSSBEV_TUNING"] if tuning else []), *PER_FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -56,5 +58,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv or "--tuning" in sys.argv, tuning="--tuning" in sys.argv)
     print(LIB)

@@ -20,6 +20,15 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 // the host thread and from autograd's) and no race with setenv on the host-language side.  A process that changes a switch after
 // the library has read it calls ssbev_env_refresh() (include/ssbev.h).  Returns nullptr when the variable is unset.  capi.hip.
 const char* ssbev_env(const char* name);
+// Tuning hooks (forced tile shapes, grid sizes, kernel-family A/B switches, phase-clock dumps: ~50 names) exist only in a tuning
+// build (`python -m stereoscene_amd.build --tuning` = -DSSBEV_TUNING); in the product build the lookup is a null constant and
+// the branches behind it fold away.  What stays switchable at run time is what the parity tests flip (SSBEV_IGEMM, SSBEV_IGEMM16,
+// SSBEV_POOL_MAX_DIGIT_BITS); everything a USER chooses (precision, ablation, DP exchange, streams) is host-side.
+#ifdef SSBEV_TUNING
+static inline const char* ssbev_tune(const char* name) { return ssbev_env(name); }
+#else
+static inline const char* ssbev_tune(const char*) { return nullptr; }
+#endif
 
 // 64-lane butterfly sum (all lanes receive the total).
 __device__ __forceinline__ float wave_sum(float v) {

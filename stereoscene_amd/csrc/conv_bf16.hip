@@ -928,7 +928,7 @@ bool basic_ok(const ssbev_conv_dims* d) {
 }
 
 bool tap16_applicable(const ssbev_conv_dims* d, int mode) {
-  static const bool enabled = !(ssbev_env("SSBEV_TAP16") && atoi(ssbev_env("SSBEV_TAP16")) == 0);       // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_TAP16") && atoi(ssbev_tune("SSBEV_TAP16")) == 0);       // A/B hook
   if (!enabled && d->tile_hint != 9) return false;
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
@@ -941,7 +941,7 @@ bool tap16_applicable(const ssbev_conv_dims* d, int mode) {
 }
 
 int wide16_ntl(const ssbev_conv_dims* d, int mode) {        // 0 = not applicable, else 32-channel column tiles per wave
-  static const bool enabled = !(ssbev_env("SSBEV_WIDE16") && atoi(ssbev_env("SSBEV_WIDE16")) == 0);      // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_WIDE16") && atoi(ssbev_tune("SSBEV_WIDE16")) == 0);      // A/B hook
   if (!enabled && d->tile_hint != 7) return 0;
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return 0;
   if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return 0;
@@ -1249,7 +1249,7 @@ conv_igemm16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
 bool conv_igemm16_applicable(const Geom16& g, int hint) {
   const char* env = ssbev_env("SSBEV_IGEMM16");
   if ((env && atoi(env) == 0) || hint) return false;
-  const char* mc = ssbev_env("SSBEV_IGEMM16_MIN_COUT");             // A/B hook: 32 = also the layers with 32 destination channels
+  const char* mc = ssbev_tune("SSBEV_IGEMM16_MIN_COUT");             // A/B hook: 32 = also the layers with 32 destination channels
   const int min_cout = mc ? atoi(mc) : 64;
   if (g.Cin % 32 != 0 || g.Cout < min_cout || g.Cout % 8 != 0) return false;
   if (g.kd > 8 || g.kh > 8 || g.kw > 8) return false;
@@ -1285,7 +1285,7 @@ int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, 
     classes = (long)g.sd * g.sh * g.sw;
     Mtot = (long)g.B * ((g.Do + g.sd - 1) / g.sd) * ((g.Ho + g.sh - 1) / g.sh) * ((g.Wo + g.sw - 1) / g.sw);
   }
-  const int force = ssbev_env("SSBEV_IGEMM_TILE") ? atoi(ssbev_env("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
+  const int force = ssbev_tune("SSBEV_IGEMM_TILE") ? atoi(ssbev_tune("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
   const bool wide = g.CoutPad % 128 == 0;
   const long need = g.form == 1 ? 1024 : 512;
   const int cand[3][2] = {{128, wide ? 128 : 64}, {64, wide ? 128 : 64}, {64, 64}};
@@ -1296,7 +1296,7 @@ int launch_igemm16(const bf16_t* x, const bf16_t* wp, const float* bias, YT* y, 
   }
   if (g.CoutPad == 32) { bm = 256; bn = 32; }          // 32 destination channels: four waves stacked along M, 64 rows each
   if (force) { bm = force / 1000; bn = force % 1000; }
-  static const int bkc_force = ssbev_env("SSBEV_IGEMM16_BKC") ? atoi(ssbev_env("SSBEV_IGEMM16_BKC")) : 0;    // probing: 32 = 32-channel stages
+  static const int bkc_force = ssbev_tune("SSBEV_IGEMM16_BKC") ? atoi(ssbev_tune("SSBEV_IGEMM16_BKC")) : 0;    // probing: 32 = 32-channel stages
   const bool k64 = g.Cin % 64 == 0 && bkc_force != 32;
 #define SSBEV_IG16(WN_, MW_) (k64 ? launch_igemm16_t<WN_, MW_, 2, 64, YT>(x, wp, bias, y, g, st, nbatch) \
                                   : launch_igemm16_t<WN_, MW_, 2, 32, YT>(x, wp, bias, y, g, st, nbatch))
@@ -1354,7 +1354,7 @@ int launch_tap16(const bf16_t* x, const float* wp, const float* bias, YT* y, con
     const long nr = (768 * rounds) / g.nseg;
     if (nr >= 1 && (g.NG + nr - 1) / nr >= 24) { nranges = nr; break; }
   }
-  if (const char* e = ssbev_env("SSBEV_TAP16_RANGES")) { const long v = atol(e); if (v > 0) nranges = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_TAP16_RANGES")) { const long v = atol(e); if (v > 0) nranges = v; }   // tuning hook
   if (nranges < 1) nranges = 1;
   g.gpc = (int)((g.NG + nranges - 1) / nranges);
   nranges = (g.NG + g.gpc - 1) / g.gpc;
@@ -1389,7 +1389,7 @@ Wg16Geom make_wg_geom(const ssbev_conv_dims* d) {
   const long tiles = (long)cdiv(g.Cp, 32 * c.MP) * cdiv(g.Cq, 32 * c.MQ) * g.kd * cdiv(g.kh, c.TH) * cdiv(g.kw, c.TW);
   // ~4096 wave-tasks in total (2 waves per SIMD x 2 rounds), chunks of at least 256 voxels, partial slabs bounded to 256 MB
   long want = std::max(1L, 4096 / std::max(1L, tiles));
-  if (const char* e = ssbev_env("SSBEV_WG16_WAVES")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / std::max(1L, tiles)); }
+  if (const char* e = ssbev_tune("SSBEV_WG16_WAVES")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / std::max(1L, tiles)); }
   const long slab = (long)g.kd * g.kh * g.kw * g.Cp * g.Cq * 4;
   want = std::min(want, std::max(1L, (256L << 20) / slab));
   long chunk = (Mtot + want - 1) / want;
@@ -1397,7 +1397,7 @@ Wg16Geom make_wg_geom(const ssbev_conv_dims* d) {
   chunk = (chunk + 15) & ~15L;
   g.chunk = (int)chunk;
   g.nchunks = (int)((Mtot + chunk - 1) / chunk);
-  static const int xcd_order = ssbev_env("SSBEV_WGRAD16_XCD") ? atoi(ssbev_env("SSBEV_WGRAD16_XCD")) : 1;
+  static const int xcd_order = ssbev_tune("SSBEV_WGRAD16_XCD") ? atoi(ssbev_tune("SSBEV_WGRAD16_XCD")) : 1;
   g.xcd_order = xcd_order;
   return g;
 }
@@ -1412,7 +1412,7 @@ int launch_wg16(const bf16_t* P, const bf16_t* Q, float* ws, const Wg16Geom& g, 
 }
 
 bool wg_ring_applicable(const ssbev_conv_dims* d) {
-  static const bool enabled = !(ssbev_env("SSBEV_WGRING16") && atoi(ssbev_env("SSBEV_WGRING16")) == 0);    // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_WGRING16") && atoi(ssbev_tune("SSBEV_WGRING16")) == 0);    // A/B hook
   if (!enabled && d->tile_hint != 7 && d->tile_hint != 9) return false;
   if (d->transposed || d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pd != 1 || d->ph != 1 || d->pw != 1 || d->dd != 1 || d->dh != 1 || d->dw != 1) return false;
@@ -1433,7 +1433,7 @@ WgRingGeom make_wr_geom(const ssbev_conv_dims* d) {
   const long types = narrow ? 1 : (long)g.ncqt * ((g.Cp + 127) / 128) * 3;
   // ~1024 workgroups in all (two resident per CU, two rounds), at least 4 tiles per chunk, partial slabs bounded to 256 MB
   long want = std::max(1L, 1024 / types);
-  if (const char* e = ssbev_env("SSBEV_WGRING16_WGS")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / types); }
+  if (const char* e = ssbev_tune("SSBEV_WGRING16_WGS")) { const long v = atol(e); if (v > 0) want = std::max(1L, v / types); }
   const long slab = 27L * g.Cq * g.Cp * 4;
   want = std::min(want, std::max(1L, (256L << 20) / slab));
   long tpc = (g.ntiles + want - 1) / want;
@@ -1450,7 +1450,7 @@ int launch_wg_ring(const bf16_t* P, const bf16_t* Q, float* ws, WgRingGeom g, hi
     hipLaunchKernelGGL(wgrad_ring16_kernel<true>, dim3(g.nchunks), dim3(256), lds, st, P, Q, ws, g);
   } else {
     const size_t lds = kWrQPlaneB + kWrRows * 16 * 256;
-    static const int xcd_order = ssbev_env("SSBEV_WGRAD_RING_XCD") ? atoi(ssbev_env("SSBEV_WGRAD_RING_XCD")) : 1;
+    static const int xcd_order = ssbev_tune("SSBEV_WGRAD_RING_XCD") ? atoi(ssbev_tune("SSBEV_WGRAD_RING_XCD")) : 1;
     g.xcd_order = xcd_order;
     if (xcd_order)
       hipLaunchKernelGGL(wgrad_ring16_kernel<false>, dim3(g.nchunks * g.ncqt * ((g.Cp + 127) / 128) * 3), dim3(256), lds, st, P, Q, ws, g);
@@ -1737,7 +1737,7 @@ bool gemm16_tn_ok(const ssbev_gemm16_dims* d) {
 
 // slices of the m axis: enough workgroups for two per CU, never thinner than 256 rows
 static int gemm16_tn_splits(const ssbev_gemm16_dims* d) {
-  static const int forced = ssbev_env("SSBEV_GEMM16_TN_SPLITS") ? atoi(ssbev_env("SSBEV_GEMM16_TN_SPLITS")) : 0;
+  static const int forced = ssbev_tune("SSBEV_GEMM16_TN_SPLITS") ? atoi(ssbev_tune("SSBEV_GEMM16_TN_SPLITS")) : 0;
   const long tiles = (long)cdiv(d->K, 128) * cdiv(d->N, 128) * d->batch;
   long s = forced > 0 ? forced : cdiv(512, tiles);
   s = std::min<long>(s, std::max<long>(1, d->M / 256));
@@ -1761,7 +1761,7 @@ int gemm16_tn(const bf16_t* A, const bf16_t* Bm, float* Cm, const ssbev_gemm16_d
   const long blocks = (long)ktiles * ntiles * nsl * d->batch;
   if (blocks >= (1L << 31)) return SSBEV_EINVAL;
   dim3 grid((unsigned)blocks);
-  static const int nbuf = ssbev_env("SSBEV_GEMM16_TN_NBUF") ? atoi(ssbev_env("SSBEV_GEMM16_TN_NBUF")) : 2;
+  static const int nbuf = ssbev_tune("SSBEV_GEMM16_TN_NBUF") ? atoi(ssbev_tune("SSBEV_GEMM16_TN_NBUF")) : 2;
   float* out = nsl > 1 ? ws : Cm;
   if (nbuf == 4)
     hipLaunchKernelGGL(gemm16_tn_kernel<4>, grid, dim3(256), 4 * 16384, st, A, Bm, out, d->M, d->K, d->N, chunk, ktiles, ntiles, nsl, (long)total);

@@ -654,7 +654,7 @@ wgrad_reduce_stage_kernel(float* __restrict__ ws, int nchunks, int per, long tot
 void launch_wgrad_reduce(float* partial, float* gw, int nchunks, int taps, int Cq, int Cp, hipStream_t st) {
   const long total = (long)taps * Cq * Cp;
   long cstride = total;
-  static const int two_stage = ssbev_env("SSBEV_WGRAD_REDUCE2") ? atoi(ssbev_env("SSBEV_WGRAD_REDUCE2")) : 1;
+  static const int two_stage = ssbev_tune("SSBEV_WGRAD_REDUCE2") ? atoi(ssbev_tune("SSBEV_WGRAD_REDUCE2")) : 1;
   if (two_stage && nchunks >= 64 && total % 4 == 0) {
     const long total4 = total / 4, bx = cdiv(total4, 256);
     int nsl = (int)std::min<long>(std::max<long>(cdiv(2048, bx), 1), nchunks / 8);
@@ -1080,7 +1080,7 @@ int launch_igemm(const float* x, const float* wp, const float* bias, float* y, c
   // the largest tile that still leaves enough workgroups: 512 for the plain form, 1024 for the parity-class form (its classes walk
   // 1 .. 8 taps: the heavy ones must fill the chip on their own).  Measured (tools/igemm_probe.py, profiles/r5_igemm_probe.txt):
   // 64 -> 128 s2 at 23 040 output voxels: 128x128 = 180 workgroups 134 us, 64x64 = 720 workgroups 113 us.
-  const int force = ssbev_env("SSBEV_IGEMM_TILE") ? atoi(ssbev_env("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
+  const int force = ssbev_tune("SSBEV_IGEMM_TILE") ? atoi(ssbev_tune("SSBEV_IGEMM_TILE")) : 0;             // probing: bm * 1000 + bn
   const bool wide = g.CoutPad % 128 == 0;
   const long need = g.form == 1 ? 1024 : 512;
   const int cand[3][2] = {{128, wide ? 128 : 64}, {64, wide ? 128 : 64}, {64, 64}};
@@ -1853,7 +1853,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
   for (int pass = 0; pass < 2 && !p.ok; ++pass)
   for (int Wseg = 4 * p.ksplit; Wseg <= g.Wp && Wseg <= 80; Wseg += 4 * p.ksplit) {
     if (g.Wp % Wseg) continue;
-    if (const char* e = ssbev_env("SSBEV_WGL_WSEG")) { if (atoi(e) > 0 && atoi(e) != Wseg) continue; }   // tuning hook
+    if (const char* e = ssbev_tune("SSBEV_WGL_WSEG")) { if (atoi(e) > 0 && atoi(e) != Wseg) continue; }   // tuning hook
     const int ncol = S * Wseg + 2;
     // rows per step: aim at >= 16 MFMA k-steps per wave and barrier, within the staging lists and LDS
     int RG = 1;
@@ -1893,7 +1893,7 @@ WgradLdsPlan plan_wgrad_lds_uncached(const ssbev_conv_dims* d) {
       }
     }
   }
-  if (ssbev_env("SSBEV_WGL_DEBUG") && p.ok)
+  if (ssbev_tune("SSBEV_WGL_DEBUG") && p.ok)
     fprintf(stderr, "wgrad_lds plan: cfg %d Cq %d Cp %d grid %dx%dx%d -> Wseg %d RG %d nslot %d gpc %d nranges %d nchunks %d lds %zu\n",
             p.cfg, g.Cq, g.Cp, g.Dp, g.Hp, g.Wp, g.Wseg, g.RG, g.nslot, g.gpc, g.nranges, p.nchunks, p.lds_bytes);
   return p;
@@ -3755,7 +3755,7 @@ int launch_conv_thin(const float* x, const float* wt, const float* bias, float* 
 // transposed) with k3 s2 p1 (output_padding 1: source = 2 x destination), K <= 32 source channels, 33..64 destination channels.
 // tile_hint 8 keeps the generic gather kernel, 5 forces this one on small problems (tests).
 bool conv_tap2_applicable(const ssbev_conv_dims* d, int mode) {
-  static const bool enabled = !(ssbev_env("SSBEV_TAP2") && atoi(ssbev_env("SSBEV_TAP2")) == 0);          // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_TAP2") && atoi(ssbev_tune("SSBEV_TAP2")) == 0);          // A/B hook
   if (!enabled && d->tile_hint != 5) return false;
   if (!((mode == 0 && !d->transposed) || (mode == 1 && d->transposed))) return false;
   if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
@@ -3796,7 +3796,7 @@ int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* 
     const double cost = rounds * (c + 1.0 + 0.5 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = ssbev_env("SSBEV_TAP2_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_TAP2_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kT2LdsBytes) != hipSuccess)
@@ -3808,7 +3808,7 @@ int launch_conv_tap2(const float* x, const float* wp, const float* bias, float* 
 // Stride-2 "up" gather on conv_tap2up_kernel: transposed-conv forward (mode 0, transposed) or conv data gradient (mode 1,
 // !transposed) with k3 s2 p1, fine grid = 2 x coarse grid, 33..64 source channels, <= 32 destination channels (multiple of 8).
 bool conv_tap2up_applicable(const ssbev_conv_dims* d, int mode) {
-  static const bool enabled = !(ssbev_env("SSBEV_TAP2UP") && atoi(ssbev_env("SSBEV_TAP2UP")) == 0);      // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_TAP2UP") && atoi(ssbev_tune("SSBEV_TAP2UP")) == 0);      // A/B hook
   if (!enabled && d->tile_hint != 5) return false;
   if (!((mode == 0 && d->transposed) || (mode == 1 && !d->transposed))) return false;
   if (d->kd != 3 || d->kh != 3 || d->kw != 3 || d->sd != 2 || d->sh != 2 || d->sw != 2) return false;
@@ -3847,7 +3847,7 @@ int launch_conv_tap2up(const float* x, const float* wp, const float* bias, float
     const double cost = rounds * (c + 1.0 + 0.5 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = ssbev_env("SSBEV_TAP2UP_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_TAP2UP_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap2up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kUpLdsBytes) != hipSuccess)
@@ -3878,7 +3878,7 @@ bool conv_taph_applicable(const ssbev_conv_dims* d, int mode) {
 
 // 1x1x1 stride-1 layers with <= 32 channels on both sides on conv_pw32_kernel (tile_hint 8 keeps the generic gather kernel)
 bool conv_pw32_applicable(const ssbev_conv_dims* d, int mode) {
-  static const int off = ssbev_env("SSBEV_PW32") ? atoi(ssbev_env("SSBEV_PW32")) == 0 : 0;
+  static const int off = ssbev_tune("SSBEV_PW32") ? atoi(ssbev_tune("SSBEV_PW32")) == 0 : 0;
   if (off || d->transposed || d->precision != 0 || d->tile_hint == 8) return false;
   if (d->kd != 1 || d->kh != 1 || d->kw != 1 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pd != 0 || d->ph != 0 || d->pw != 0) return false;
@@ -3909,7 +3909,7 @@ int launch_conv_pw32(const float* x, const float* wp, const float* bias, float* 
 
 // F(2,3) along d and h: even D as well.  tile_hint 4 keeps the h-only kernel (A/B timing, tests)
 bool conv_tapdh_applicable(const ssbev_conv_dims* d, int mode) {
-  static const int off = ssbev_env("SSBEV_TAPDH") ? atoi(ssbev_env("SSBEV_TAPDH")) == 0 : 0;
+  static const int off = ssbev_tune("SSBEV_TAPDH") ? atoi(ssbev_tune("SSBEV_TAPDH")) == 0 : 0;
   return !off && conv_taph_applicable(d, mode) && d->Do % 2 == 0 && d->tile_hint != 4;
 }
 
@@ -3936,12 +3936,12 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
     const double cost = rounds * (c + 0.5 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = ssbev_env("SSBEV_TAPDH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_TAPDH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   const long nranges = (g.NG + g.gpc - 1) / g.gpc;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tapdh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kDhLdsBytes) != hipSuccess)
     return SSBEV_ELAUNCH;
-  static const int times = ssbev_env("SSBEV_TAPDH_TIMES") ? atoi(ssbev_env("SSBEV_TAPDH_TIMES")) : 0;
+  static const int times = ssbev_tune("SSBEV_TAPDH_TIMES") ? atoi(ssbev_tune("SSBEV_TAPDH_TIMES")) : 0;
   if (times) {      // tuning hook: per-phase shader clocks of every wave (fresh stage / walk / publish + barrier / fold / tail barrier)
     const size_t nwg = (size_t)(nranges * g.nseg), n = nwg * 16 * 8;
     unsigned long long* dev = nullptr;
@@ -3975,7 +3975,7 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
 size_t align256b(size_t x);
 struct WgradDhPlan { bool ok; WgradDhGeom g; int nchunks; };
 WgradDhPlan plan_wgrad_dh(const ssbev_conv_dims* d) {
-  static const int off = ssbev_env("SSBEV_WGRAD_DH") ? atoi(ssbev_env("SSBEV_WGRAD_DH")) == 0 : 0;
+  static const int off = ssbev_tune("SSBEV_WGRAD_DH") ? atoi(ssbev_tune("SSBEV_WGRAD_DH")) == 0 : 0;
   WgradDhPlan p;
   p.ok = false; p.nchunks = 0;
   if (off || d->transposed || d->precision != 0) return p;
@@ -4003,7 +4003,7 @@ WgradDhPlan plan_wgrad_dh(const ssbev_conv_dims* d) {
     const double cost = rounds * (c + 1.0 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = ssbev_env("SSBEV_WGRAD_DH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_WGRAD_DH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   p.nchunks = ((g.NG + g.gpc - 1) / g.gpc) * g.nseg;
   p.ok = true;
   return p;
@@ -4052,7 +4052,7 @@ int launch_conv_taph(const float* x, const float* wp, const float* bias, float* 
     const double cost = rounds * (c + 0.6 + 0.3 * crossings);
     if (cost < best) { best = cost; g.gpc = c; }
   }
-  if (const char* e = ssbev_env("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
+  if (const char* e = ssbev_tune("SSBEV_TAPH_GPC")) { const int v = atoi(e); if (v > 0) g.gpc = v; }   // tuning hook
   // (Round 3 built a plane-aligned chunk order -- XCD x owns 24 consecutive planes, plane index fastest, so that the chunks of
   // d - 1, d, d + 1 meet in one L2: 572 -> 228 MB of HBM reads per launch, but the workgroups moving in step cost the kernel
   // 8 % (0.533 -> 0.579 ms, profiles/r3y_taph_plane_aligned.txt).  The kernel is not HBM-bound; removed in round 6.)

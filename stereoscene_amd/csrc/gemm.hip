@@ -567,7 +567,7 @@ int tn_chunks_model(const ssbev_gemm_dims* d, int tiles) {
 // a multiple of 160 (16 x [1920 rows -> 640 x 640]: 320 tiles x 4 chunks = 5.0 per CU instead of 400 x 2 = 3.1 -> 4 rounds of
 // twice the rows); SSBEV_GEMM_TN_WIDE=0 keeps the 128 x 128 tiles
 bool tn_wide(const ssbev_gemm_dims* d) {
-  static const bool enabled = !(ssbev_env("SSBEV_GEMM_TN_WIDE") && atoi(ssbev_env("SSBEV_GEMM_TN_WIDE")) == 0);
+  static const bool enabled = !(ssbev_tune("SSBEV_GEMM_TN_WIDE") && atoi(ssbev_tune("SSBEV_GEMM_TN_WIDE")) == 0);
   return enabled && d->batch >= 8 && d->N % 160 == 0 && d->d2s_kd == 0 && !d->ep_mul;
 }
 
@@ -592,7 +592,7 @@ int nn_chunks(const ssbev_gemm_dims* d, int tiles) {
 // rows of the workgroup tile: 192 when that wastes fewer padded rows than 128 (M = 192: 0 % instead of 25 %)
 int pick_bm(const ssbev_gemm_dims* d, int wn) {
   if (d->d2s_kd > 0 || wn != 2) return 128;
-  static const bool enabled = !(ssbev_env("SSBEV_GEMM_BM192") && atoi(ssbev_env("SSBEV_GEMM_BM192")) == 0);     // A/B hook
+  static const bool enabled = !(ssbev_tune("SSBEV_GEMM_BM192") && atoi(ssbev_tune("SSBEV_GEMM_BM192")) == 0);     // A/B hook
   if (!enabled) return 128;
   const long p128 = (long)((d->M + 127) / 128) * 128, p192 = (long)((d->M + 191) / 192) * 192;
   return p192 * 8 <= p128 * 7 ? 192 : 128;              // at least 1/8 fewer MFMA rows
@@ -610,7 +610,7 @@ constexpr NnCfg kNnCfgs[] = {
 constexpr int kNnCfgCount = sizeof(kNnCfgs) / sizeof(kNnCfgs[0]);
 
 int nn_forced_cfg() {          // SSBEV_GEMM_CFG=<n>: probing hook (tools/gemm_probe.py)
-  const char* e = ssbev_env("SSBEV_GEMM_CFG");
+  const char* e = ssbev_tune("SSBEV_GEMM_CFG");
   if (!e || !*e) return -1;
   const int c = atoi(e);
   return c >= 0 && c < kNnCfgCount ? c : -1;
@@ -640,7 +640,7 @@ int nn_pick_cfg(const ssbev_gemm_dims* d, int* nchunk_out) {
       // rounds 2-4 choice (tiles that pad least), unless the model says another shape is >= 5 % cheaper
       const int wn = pick_wn(d->N, 0);
       cfg = wn == 2 ? (pick_bm(d, wn) == 192 ? 2 : 0) : 1;
-      static const bool wide = !(ssbev_env("SSBEV_GEMM_WIDE_TILES") && atoi(ssbev_env("SSBEV_GEMM_WIDE_TILES")) == 0);     // A/B hook
+      static const bool wide = !(ssbev_tune("SSBEV_GEMM_WIDE_TILES") && atoi(ssbev_tune("SSBEV_GEMM_WIDE_TILES")) == 0);     // A/B hook
       if (wide) {
         const NnCfg& c0 = kNnCfgs[cfg];
         const int t0 = ((d->M + c0.bm - 1) / c0.bm) * ((d->N + c0.bn - 1) / c0.bn);

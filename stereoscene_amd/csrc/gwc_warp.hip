@@ -879,7 +879,7 @@ size_t bwd_lds_bytes(const ssbev_gwc_dims* d) {
 }
 
 int env_int(const char* name, int dflt) {
-  const char* v = ssbev_env(name);
+  const char* v = ssbev_tune(name);          // tuning hooks only (common.h)
   return v ? atoi(v) : dflt;
 }
 

@@ -1083,7 +1083,7 @@ int launch_gather(const float* depth, const float* feat, const int32_t* starts, 
   const int nv = d->B * d->nx * d->ny * d->nz;
   const int vpb = d->nx * d->ny * d->nz;
   if (long_list && d->C == 128) {                         // one launch: long-voxel workgroups first, short role behind them
-    static const int nlw = ssbev_env("SSBEV_POOL7_LONG_WGS") ? std::max(1, atoi(ssbev_env("SSBEV_POOL7_LONG_WGS"))) : POOL7_LONG_WGS;   // (tuning hook)
+    static const int nlw = ssbev_tune("SSBEV_POOL7_LONG_WGS") ? std::max(1, atoi(ssbev_tune("SSBEV_POOL7_LONG_WGS"))) : POOL7_LONG_WGS;   // (tuning hook)
     dim3 g7(nlw + cdiv((size_t)cdiv(nv, 4) * 64, 256));
     hipLaunchKernelGGL((pool_gather7_kernel<FUSED>), g7, dim3(256), 0, st, depth, feat, starts, order, long_list, out, nv, d->P, vpb,
                        N, D, HW, nlw);

@@ -1050,7 +1050,7 @@ int ssbev_wino_dgemm(const float* P, const float* Wp, float* Mo, const ssbev_win
   if (!wino_ok(d) || !P || !Wp || !Mo || N <= 0 || d->C % 4 != 0) return SSBEV_EINVAL;
   const WinoGemmGeom g{d->B, d->D, (d->H / 2) * (d->W / 2), d->C, N, (N + 31) & ~31};
   // tiling: env SSBEV_WINO_TILE = MT*10 + NT (tuning), default <1,2> (two to three waves per SIMD)
-  static const int forced = [] { const char* e = ssbev_env("SSBEV_WINO_TILE"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = ssbev_tune("SSBEV_WINO_TILE"); return e ? atoi(e) : 0; }();
   int mt = 1, nt = 2;
   if (forced) { mt = forced / 10; nt = forced % 10; }
   const int tgroups = (g.Thw + 32 * mt - 1) / (32 * mt), tg4 = (tgroups + 3) >> 2;

@@ -522,7 +522,7 @@ bool df_dims_ok(const ssbev_wino_dims* d, int N) {
 }
 
 int env_int(const char* name, int dflt) {
-  const char* v = ssbev_env(name);
+  const char* v = ssbev_tune(name);          // tuning hooks only (common.h)
   return v ? atoi(v) : dflt;
 }
 
@@ -601,7 +601,7 @@ int ssbev_wino43_df_gemm(const float* P, const float* Wp, float* Mo, const ssbev
 #ifdef SSBEV_DF_CLOCKS
 #define DF_CLOCKS_BEGIN(NW_)                                                                                               \
   unsigned long long* dbg_dev = nullptr;                                                                                   \
-  const bool dbg_on = ssbev_env("SSBEV_DF_TIMES") != nullptr;                                                                \
+  const bool dbg_on = ssbev_tune("SSBEV_DF_TIMES") != nullptr;                                                                \
   if (dbg_on) { if (hipMalloc(&dbg_dev, (size_t)nwg * NW_ * 32) != hipSuccess) return SSBEV_ELAUNCH; g.dbg = dbg_dev; }
 #define DF_CLOCKS_END(NW_)                                                                                                 \
   if (dbg_on) {                                                                                                            \
