@@ -1126,6 +1126,11 @@ GEMM_MIN_CIN = int(os.environ.get("SSBEV_GEMM_MIN_CIN", "512"))       # pointwis
 
 
 def _deconv_k_eq_s_gemm(x, weight, bias, k):
+    if tuple(k) == (1, 1, 1) and own_gemm_site("deconv") and own_gemm_site("linear") and weight.shape[1] % 4 == 0:
+        # k = s = 1 (SECONDFPN3D's first branch, FPN:53-69) is a pointwise layer: the plain NT / NN / skinny-TN products of linear_cl.
+        # Through the depth-to-space table of the general k == s path its weight gradient ran at 26 TF/s (0.33 ms for 8.6 GF:
+        # profiles/r6c layer table) where the skinny TN kernel needs 0.12 ms for the same product.
+        return linear_cl(x, weight.reshape(weight.shape[0], weight.shape[1]).t(), bias)
     xcl = to_cl(_f32(x, "deconv_gemm"))
     B, D, H, W, Ci = xcl.shape
     Co = weight.shape[1]
