@@ -1701,14 +1701,69 @@ def deform_conv2d(x, offset, weight, groups=1, padding=1, dilation=1):
     B, _, H, W = x.shape
     cols = _DcnIm2col.apply(x, offset, int(groups), int(k), int(padding), int(dilation))
     Cog = Cout // groups
+    Kc = k * k * Cg
+    if (x.is_cuda and own_gemm_site("linear") and _gemm_supported(cols) and PRECISION == "fp32" and Cog % 4 == 0 and Kc % 4 == 0):
+        # the grouped contraction as ONE batched product per direction, written straight into / read straight out of the
+        # channels-last [pixels, Cout] map through the kernels' row and batch strides: no concatenation forward, no 177 MB
+        # stack of the column gradients backward (round 6; rounds 2-5: four products + cat / unbind per direction)
+        w3 = weight.view(groups, Cog, Cg, k, k).permute(0, 1, 3, 4, 2).reshape(groups, Cog, Kc)
+        y2 = _GroupedLinearCL.apply(cols, w3)                              # [B*H*W, Cout]
+        return from_cl(y2.view(B, H, W, Cout))
     outs = []
     # unbind, not cols[g]: the backward of four selects is four zero-filled [groups, ...] tensors plus three accumulation adds
     # (0.4 ms per step on the 177 MB column tensor); the backward of unbind is one stack
     for g, cg in enumerate(cols.unbind(0)):
-        colg = cg.view(B, H, W, k * k * Cg).permute(0, 3, 1, 2)                 # channels-last [B, K*Cg, H, W]
-        wg = weight[g * Cog:(g + 1) * Cog].permute(0, 2, 3, 1).reshape(Cog, k * k * Cg, 1, 1)
+        colg = cg.view(B, H, W, Kc).permute(0, 3, 1, 2)                 # channels-last [B, K*Cg, H, W]
+        wg = weight[g * Cog:(g + 1) * Cog].permute(0, 2, 3, 1).reshape(Cog, Kc, 1, 1)
         outs.append(conv2d(colg, wg, None, 1, 0, 1))
     return torch.cat(outs, dim=1) if groups > 1 else outs[0]
+
+
+class _GroupedLinearCL(torch.autograd.Function):
+    """y[r, g * N + n] = sum_k cols[g, r, k] * w[g, n, k]: the group contraction of a grouped pointwise layer (DepthNet's DCN,
+    BD:490-498, groups = 4) on the own GEMM kernels, batch element = group.  The group's [R, N] block is a column slice of the
+    channels-last [R, G * N] map: leading dimension G * N, batch stride N -- the operand strides of ssbev_gemm_* do the
+    concatenation (forward, C side) and the split (backward, A side)."""
+
+    @staticmethod
+    def forward(ctx, cols, w3):
+        lib = capi.load()
+        cols, w3 = cols.contiguous(), w3.contiguous()
+        G, R, K = cols.shape
+        N = w3.shape[1]
+        y = torch.empty(R, G * N, dtype=torch.float32, device=cols.device)
+        g = _gdims(R, N, K, G, K, K, G * N, R * K, N * K, N)
+        ws = _ws(lib.ssbev_gemm_nt_workspace(C.byref(g)), cols.device)
+        with _span("gemm_own", 2.0 * G * R * N * K, 4.0 * (cols.numel() + w3.numel() + y.numel()), f"linear fwd grouped {G}x[{K}->{N}] rows={R}"):
+            capi.check(lib.ssbev_gemm_nt(capi.ptr(cols), capi.ptr(w3), None, capi.ptr(y), C.byref(g), capi.ptr(ws), ws.numel(),
+                                         capi.stream()), "ssbev_gemm_nt")
+        ctx.save_for_backward(cols, w3)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = capi.load()
+        cols, w3 = ctx.saved_tensors
+        G, R, K = cols.shape
+        N = w3.shape[1]
+        gy = gy.contiguous()
+        gcols = gw = None
+        fl = 2.0 * G * R * N * K
+        if ctx.needs_input_grad[0]:      # gcols[g] [R, K] = gy[:, g N : (g + 1) N] [R, N] @ w3[g] [N, K]            (NN)
+            gcols = torch.empty_like(cols)
+            g = _gdims(R, K, N, G, G * N, K, K, N, N * K, R * K)
+            ws = _ws(lib.ssbev_gemm_nn_workspace(C.byref(g)), gy.device)
+            with _span("gemm_own", fl, 4.0 * (gy.numel() + w3.numel() + gcols.numel()), f"linear dgrad grouped {G}x[{K}->{N}] rows={R}"):
+                capi.check(lib.ssbev_gemm_nn(capi.ptr(gy), capi.ptr(w3), None, capi.ptr(gcols), C.byref(g), capi.ptr(ws), ws.numel(),
+                                             capi.stream()), "ssbev_gemm_nn")
+        if ctx.needs_input_grad[1]:      # gw[g] [N, K] = gy[:, g N : (g + 1) N]^T [N, R] @ cols[g] [R, K]               (TN)
+            gw = torch.empty_like(w3)
+            g = _gdims(R, K, N, G, G * N, K, K, N, R * K, N * K)
+            ws = _ws(lib.ssbev_gemm_tn_workspace(C.byref(g)), gy.device)
+            with _span("gemm_own", fl, 4.0 * (gy.numel() + cols.numel() + gw.numel()), f"linear wgrad grouped {G}x[{K}->{N}] rows={R}"):
+                capi.check(lib.ssbev_gemm_tn(capi.ptr(gy), capi.ptr(cols), capi.ptr(gw), C.byref(g), capi.ptr(ws), ws.numel(),
+                                             capi.stream()), "ssbev_gemm_tn")
+        return gcols, gw
 
 
 # -------------------------------------------------------------------------------------------------

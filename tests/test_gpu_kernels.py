@@ -1279,6 +1279,27 @@ def test_deconv_k_eq_s_own_gemm_vs_aten(case, monkeypatch):
         assert maxdiff(a, b_) < 3e-5 * max(1.0, b_.abs().max().item()), name
 
 
+@pytest.mark.parametrize("G,R,K,N", [(4, 7680, 1440, 160), (2, 333, 72, 20), (3, 4100, 36, 8), (1, 64, 16, 4)])
+def test_grouped_linear_writes_channel_slices_in_place(G, R, K, N, monkeypatch):
+    """The group contraction of DepthNet's DCN (BD:490-498) as one batched product per direction whose C (forward) / A (backward)
+    operand is a column slice of the channels-last [R, G N] map -- leading dimension G N, batch stride N: forward, column and weight
+    gradient vs the per-group tensor expression, at the KITTI shape and at ragged ones (split-K partials must honour the strides)."""
+    monkeypatch.setattr(F, "OWN_GEMM", True)
+    cols = S.hash_normal(f"gl/c{G}{R}", (G, R, K))
+    w3 = S.hash_uniform(f"gl/w{G}{R}", (G, N, K), -1, 1) * (1.0 / K) ** 0.5
+    go = S.hash_normal(f"gl/g{G}{R}", (R, G * N))
+    cc, wc = cols.clone().requires_grad_(True), w3.clone().requires_grad_(True)
+    want = torch.cat([cc[g].double() @ wc[g].double().t() for g in range(G)], dim=1)
+    want.backward(go.double())
+    cg, wg = cols.to(DEV).requires_grad_(True), w3.to(DEV).requires_grad_(True)
+    got = F._GroupedLinearCL.apply(cg, wg)
+    got.backward(go.to(DEV))
+    scale = K ** 0.5
+    assert maxdiff(got, want.float()) < 2e-5 * scale
+    assert maxdiff(cg.grad, cc.grad) < 2e-5 * max(1.0, cc.grad.abs().max().item()) * N ** 0.5
+    assert maxdiff(wg.grad, wc.grad) < 3e-5 * max(1.0, wc.grad.abs().max().item()) * R ** 0.5
+
+
 def test_linear_cl_own_gemm_vs_aten(monkeypatch):
     monkeypatch.setattr(F, "OWN_GEMM", True)
     x = S.hash_normal("lcl/x", (2, 3200, 12, 20))
