@@ -512,14 +512,21 @@ gemm_sum_wide_kernel(const float* __restrict__ part, float* __restrict__ out, si
 // out[i] = sum over chunks (ascending: deterministic) of part[c][i] (+ bias[i % N], ReLU)
 __global__ void __launch_bounds__(256)
 gemm_sum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nchunk, const float* __restrict__ bias,
-                int N, int relu) {
+                int N, int relu, long MN = 0, long ldc = 0, long sc = 0) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float a = part[i];
   for (int c = 1; c < nchunk; ++c) a += part[(size_t)c * n + i];
   if (bias) a += bias[i % N];
   if (relu) a = fmaxf(a, 0.0f);
-  out[i] = a;
+  // MN > 0: the result is a [batch][M][N] block structure inside a wider buffer (leading dimension ldc, batch stride sc):
+  // round 6, the channel-slice outputs of a grouped pointwise layer
+  if (MN > 0) {
+    const size_t b = i / MN, r = i - b * MN;
+    out[b * sc + (r / N) * ldc + r % N] = a;
+  } else {
+    out[i] = a;
+  }
 }
 
 bool gemm_ok(const ssbev_gemm_dims* d) {
@@ -714,9 +721,10 @@ int launch_nn(const float* A, const float* B, const float* bias, float* Cm, cons
   }
 #undef SSBEV_GEMM_LAUNCH
   if (g.nchunk > 1) {
-    if (d->ldc != d->N || (d->batch > 1 && d->sc != (long)d->M * d->N)) return SSBEV_EINVAL;     // split-K needs a dense C
     const size_t n = (size_t)g.batch * d->M * d->N;
-    hipLaunchKernelGGL(gemm_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, Cm, n, g.nchunk, bias, d->N, d->relu);
+    const bool dense = d->ldc == d->N && (d->batch == 1 || d->sc == (long)d->M * d->N);
+    hipLaunchKernelGGL(gemm_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, Cm, n, g.nchunk, bias, d->N, d->relu,
+                       dense ? 0L : (long)d->M * d->N, (long)d->ldc, (long)d->sc);
   }
   return ssbev_launch_status();
 }
