@@ -110,3 +110,26 @@ def test_bf16_storage_entry_points_refuse_a_mismatched_precision_on_host():
     # normalisation: the BatchNorm running statistics ride in ssbev_norm_ext; NULL ext is allowed, bad dims are not
     n = capi.NormDims(1, 30, 2, 100, 1e-5, 0, 0, 0, 0, 0, 0)          # C % 4 != 0
     assert lib.ssbev_groupnorm_fwd_ext(fake, fake, fake, None, fake, fake, fake, None, C.byref(n), None, fake, 1 << 20, None) == capi.EINVAL
+
+
+def test_only_the_switch_table_reads_the_environment():
+    """no getenv on the launch path.  Every SSBEV_* switch of csrc/ goes through ssbev_env (capi.hip: one lookup
+    per name per process, a table afterwards; ssbev_env_refresh in the C ABI) or, for tuning hooks, through ssbev_tune, which the
+    product build compiles to a null constant -- so `getenv` may be an undefined symbol of capi.o only, and no source but capi.hip
+    may name it."""
+    import glob
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "stereoscene_amd", "csrc")
+    for src in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(src).read()
+        hits = re.findall(r"(?<![A-Za-z_:])getenv\(", text)
+        assert not hits or os.path.basename(src) == "capi.hip", (src, len(hits))
+    objs = glob.glob(os.path.join(ROOT, "stereoscene_amd", "_lib", "*.o"))
+    assert objs, "in-tree build expected (python -m stereoscene_amd.build)"
+    for o in objs:
+        und = subprocess.run(["nm", "-u", o], capture_output=True, text=True).stdout
+        if re.search(r"\bgetenv\b", und):
+            assert os.path.basename(o) == "capi.o", o
+    lib = capi.load()
+    lib.ssbev_env_refresh()          # callable without a GPU; returns nothing
