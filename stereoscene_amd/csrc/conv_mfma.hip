@@ -2421,13 +2421,19 @@ conv_taph_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
 // transforms only (no F(4,3) constants: the rounding behaviour of taph).  Sixteen waves (1024 threads, four per SIMD at
 // <= 128 VGPRs, so a wave's LDS reads and its three add/subs per operand hide behind the other waves' MFMAs): wave =
 // frequency (fd, fh) keeps its three 32 x 32 U slices (kw) in 48 VGPRs, reads FOUR ring rows per operand quad (2 planes x 2
-// rows) and owns one 32 x 32 accumulator.  The ring holds 5 row slots x 4 planes (rows h0 .. h0+3 in use, h0+4 in flight
-// during the walk, h0+5 requested behind the walk into the slot of h0 and landing during the fold); the sixteen partial
-// tiles meet in LDS (64 KB), where the output transform is a signed sum of nine tiles per output.  A workgroup stages 4
-// planes for 2 output planes: every input plane is fetched twice instead of taph's three times.
-constexpr int kDhSlots = 5, kDhPlaneF = kDhSlots * kTapRowF, kDhRingF = 4 * kDhPlaneF;
-constexpr int kDhRedF = 16 * 16 * 64;
-constexpr size_t kDhLdsBytes = (size_t)(kDhRingF + kDhRedF) * sizeof(float);
+// rows) and owns one 32 x 32 accumulator.  The ring holds 6 row slots x 4 planes: rows h0 .. h0+3 in use, h0+4 AND h0+5 in
+// flight during the walk (round 6: with 5 slots the second new row could only be requested behind the walk and its HBM
+// latency stood between the fold and the next walk).  The sixteen partial tiles meet in LDS, where the output transform is a
+// signed sum of nine tiles per output: eight tiles in a 32 KB fold buffer, the other eight in the ring slots of rows h0 and
+// h0+1 of the four planes, which are dead from the end of the walk until the next block's rows are requested into them
+// (ring 102 KB + fold 32 KB + 16 KB for the old values of an accumulating launch = 150 KB; a separate 64 KB fold buffer
+// beside six slots does not fit the CU's 160 KB).  A
+// workgroup stages 4 planes for 2 output planes: every input plane is fetched twice instead of taph's three times.
+constexpr int kDhSlots = 6, kDhPlaneF = kDhSlots * kTapRowF, kDhRingF = 4 * kDhPlaneF;
+constexpr int kDhRedTiles = 8, kDhRedF = kDhRedTiles * 16 * 64;
+static_assert(kTapRowF >= 16 * 64, "conv_tapdh_kernel: a partial tile must fit a dead ring row");
+constexpr int kDhOldF = 16 * 64 * 4;         // `accumulate`: the old values of a block's outputs, one float4 per thread
+constexpr size_t kDhLdsBytes = (size_t)(kDhRingF + kDhRedF + 32 + kDhOldF) * sizeof(float);       // + bias row + old values
 constexpr int kDhPackedElems = 16 * 3 * 16 * 64;
 static_assert(kDhLdsBytes <= 160 * 1024, "conv_tapdh_kernel: ring + fold buffer must fit the CU's LDS");
 
@@ -2468,8 +2474,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
 conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, const float* __restrict__ bias,
                   float* __restrict__ Y, ConvTapGeom g) {     // g.NG / g.gpc count 2 x 2 (plane, row) blocks
   extern __shared__ __align__(16) float tl[];
-  float* ring = tl;                          // [4 planes][5 slots][34 voxels][32 channels], 16-byte swizzled
-  float* red = tl + kDhRingF;                // [16 waves][16 rows][64 lanes]
+  float* ring = tl;                          // [4 planes][6 slots][34 voxels][32 channels], 16-byte swizzled
+  // partial tile t ([4 register quads][64 lanes][4]) of a block whose first row sits in slot s0: tiles 0-7 in the fold buffer behind the
+  // ring, tiles 8-15 in the ring rows (plane (t - 8) & 3, row h0 + ((t - 8) >> 2)) that the finished walk has left dead
+  auto tile_off = [](int t, int s0) {
+    const int sl = s0 + ((t - kDhRedTiles) >> 2);             // s0 is even, < kDhSlots: no wrap
+    return t < kDhRedTiles ? kDhRingF + t * 1024 : ((t - kDhRedTiles) & 3) * kDhPlaneF + sl * kTapRowF;
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
@@ -2495,7 +2506,8 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
 
   constexpr int nxc = (kTapCols * 8 + 63) / 64;                 // 5 staging entries per (plane, row), see conv_tap_kernel
   int xoff[2], xmeta[2];                                        // 4 planes x 5 entries = 20 per row: waves 0-3 take two
-  const int plane_g = g.H * g.W * g.K;
+  const int plane_g = g.H * g.W * g.K;                          // (the per-lane offsets stay in registers: recomputing them per
+                                                                //  request measured 800 clocks of VALU per row and SIMD)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int q = wave + n * 16;
@@ -2512,7 +2524,7 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
     xoff[n] = off;
     xmeta[n] = __builtin_amdgcn_readfirstlane(meta);
   }
-  // padded row hp (= input row hp - 1) of the planes 2 d2 - 1 .. 2 d2 + 2 -> slot hp % 5
+  // padded row hp (= input row hp - 1) of the planes 2 d2 - 1 .. 2 d2 + 2 -> slot hp % 6
   auto stage_row = [&](int b, int d2, int hp) {
     const float* base = X + ((long)(b * g.D + 2 * d2 - 1) * g.H + (hp - 1)) * (long)(g.W * g.K);
     const int h = hp - 1;
@@ -2537,12 +2549,18 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
   const int offPA = pa * kDhPlaneF, offPB = pb * kDhPlaneF;
   // store phase: wave = (output plane jd, output row jh, channel group rg)
   const int jd = wave >> 3, jh = (wave >> 2) & 1, rg = wave & 3;
-  const int nb = 8 * rg + 4 * lk;            // first of the 4 output channels this lane stores
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (g.has_bias) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = nb + i < g.N ? bias[nb + i] : 0.0f;
-  }
+  // Register discipline (round 6): the walk owns the file -- 48 weight registers, the accumulator, two operand quads and the
+  // eight ring reads behind them -- and a spill reload anywhere between the row requests and the end of the walk is a
+  // `s_waitcnt vmcnt(0)`, i.e. a wait for the rows (vmcnt counts the LDS-DMA too).  So nothing per-lane that only the fold needs
+  // lives across the walk: it derives its lane constants from a lane id the compiler cannot see through (no hoisting out of
+  // the block loop), the bias sits in LDS, the store address is formed behind the walk, old values travel by LDS-DMA.
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  float* biasl = tl + kDhRingF + kDhRedF;
+  if (tid < 32) biasl[tid] = (g.has_bias && tid < g.N) ? bias[tid] : 0.0f;      // read behind the first block's barriers
+  // accumulate: the old output values travel global -> LDS beside the rows (no registers across the walk, and no load the
+  // compiler would have to wait for in front of it)
+  float* oldl = biasl + 32 + wave * 256;
+  const bool acc4 = g.accumulate && (g.N & 3) == 0;
   // A^T of F(2,3): output j sums the frequencies j, j + 1, j + 2 with signs (+, +, +) for j = 0 and (+, -, -) for j = 1
   const float s1 = 1.0f - 2.0f * jh, t1 = 1.0f - 2.0f * jd;     // sign of the 2nd and 3rd term along h / d
 
@@ -2561,6 +2579,28 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
     const int bd = g_begin / H2;
     b = bd / D2; d2 = bd % D2;
   }
+  // the four (plane, row) ring offsets of a block whose first row sits in slot s0, as opaque scalars: left to itself the compiler
+  // adds the loop-invariant plane offsets into the twelve per-lane column bases ahead of the loop and keeps 24 address registers
+  // across the walk
+  int oAA = 0, oAB = 0, oBA = 0, oBB = 0;
+  auto block_offsets = [&](int s0) {
+    const int offA = ((s0 + ra) % kDhSlots) * kTapRowF, offB = ((s0 + rb) % kDhSlots) * kTapRowF;
+    oAA = offPA + offA; oAB = offPA + offB; oBA = offPB + offA; oBB = offPB + offB;
+    asm volatile("" : "+s"(oAA), "+s"(oAB), "+s"(oBA), "+s"(oBB));
+  };
+  // operand quad (kw = c, channel quad q): four ring reads, B^T of F(2,3) on both axes
+  auto fetch = [&](int c, int q, float4& v) {
+    const int u = li + c;
+    const float* colp = ring + u * 32 + ((((2 * q + lk) ^ ((u >> 1) & 7))) << 2);
+    const float4 aa = *reinterpret_cast<const float4*>(colp + oAA);
+    const float4 ab = *reinterpret_cast<const float4*>(colp + oAB);
+    const float4 ba = *reinterpret_cast<const float4*>(colp + oBA);
+    const float4 bb = *reinterpret_cast<const float4*>(colp + oBB);
+    const float4 pa4 = make_float4(fmaf(sh, ab.x, aa.x), fmaf(sh, ab.y, aa.y), fmaf(sh, ab.z, aa.z), fmaf(sh, ab.w, aa.w));
+    const float4 pb4 = make_float4(fmaf(sh, bb.x, ba.x), fmaf(sh, bb.y, ba.y), fmaf(sh, bb.z, ba.z), fmaf(sh, bb.w, ba.w));
+    v = make_float4(fmaf(sd, pb4.x, pa4.x), fmaf(sd, pb4.y, pa4.y), fmaf(sd, pb4.z, pa4.z), fmaf(sd, pb4.w, pa4.w));
+  };
+  float4 va, vb;
   for (int G = g_begin; G < g_end; ++G) {
     const int h0 = 2 * h2;
     if (fresh) {
@@ -2570,32 +2610,36 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
     }
     TAPDH_TICK(0)
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
-    if (same_plane) stage_row(b, d2, h0 + 4);                   // slot of h0 - 1: free since the previous walk
-
-    const int offA = ((h0 + ra) % kDhSlots) * kTapRowF, offB = ((h0 + rb) % kDhSlots) * kTapRowF;
-    const bool okst = w0 + li < g.W && nb < g.N;
-    float* dst = Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0 + li) * g.N + nb;
-    float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.accumulate && (g.N & 3) == 0 && okst) told = *reinterpret_cast<const float4*>(dst);
+    const int s0 = h0 % kDhSlots;
+    if (acc4) {
+      const int ln = opaque(lane), sl = ln & 31, nb = 8 * rg + 4 * (ln >> 5);
+      const float* src = (w0 + sl < g.W && nb < g.N)
+          ? Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0) * g.N + (sl * g.N + nb) : kWgZeros;
+      glds16(src, oldl);
+    }
+    block_offsets(s0);
+    fetch(0, 0, va);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    auto fetch = [&](int c, int q, float4& v) {
-      const int u = li + c;
-      const float* colp = ring + u * 32 + ((((2 * q + lk) ^ ((u >> 1) & 7))) << 2);
-      const float4 aa = *reinterpret_cast<const float4*>(colp + offPA + offA);
-      const float4 ab = *reinterpret_cast<const float4*>(colp + offPA + offB);
-      const float4 ba = *reinterpret_cast<const float4*>(colp + offPB + offA);
-      const float4 bb = *reinterpret_cast<const float4*>(colp + offPB + offB);
-      const float4 pa4 = make_float4(fmaf(sh, ab.x, aa.x), fmaf(sh, ab.y, aa.y), fmaf(sh, ab.z, aa.z), fmaf(sh, ab.w, aa.w));
-      const float4 pb4 = make_float4(fmaf(sh, bb.x, ba.x), fmaf(sh, bb.y, ba.y), fmaf(sh, bb.z, ba.z), fmaf(sh, bb.w, ba.w));
-      v = make_float4(fmaf(sd, pb4.x, pa4.x), fmaf(sd, pb4.y, pa4.y), fmaf(sd, pb4.z, pa4.z), fmaf(sd, pb4.w, pa4.w));
-    };
-    float4 va, vb;
-    fetch(0, 0, va);
 #pragma unroll
     for (int s = 0; s < 12; s += 2) {          // step s = (kw = s / 4, channel quad = s % 4): 4 MFMAs each
+      // rows h0 + 4, h0 + 5 are requested INSIDE the walk, into the slots of rows h0 - 2, h0 - 1 (the previous block's fold has
+      // read its tiles there): measured, requests at the head of the walk cost it 400 clocks per row, after the first third
+      // they cost nothing (steps 2 .. 10 measure alike) and land long before the publish phase waits for them
+      if (s == 4 && same_plane) {
+        stage_row(b, d2, h0 + 4);
+        stage_row(b, d2, h0 + 5);
+      }
+      // issue priority falls as a wave advances (2, 1, 0 over the twelve steps; 3 outside the walk): the arbiter serves the
+      // OLDEST ready wave first, which left alone makes the four waves of a SIMD finish their walks 2 k clocks apart (measured
+      // per wave slot: 8.5 / 10.3 / 12.6 / 16 k clocks after the block's start) -- the youngest one runs its last third alone,
+      // at a single wave's latency-bound rate, with fifteen waves parked at the barrier.  With the priorities the four finish
+      // within 1.2 k clocks of each other and the block takes 18.7 k clocks instead of 20.0 k
+      if (s == 0) __builtin_amdgcn_s_setprio(2);
+      if (s == 4) __builtin_amdgcn_s_setprio(1);
+      if (s == 8) __builtin_amdgcn_s_setprio(0);
       fetch((s + 1) >> 2, (s + 1) & 3, vb);
       {
         const int c = s >> 2, q = s & 3;
@@ -2614,23 +2658,67 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
       }
     }
     TAPDH_TICK(1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-    wait_vm0();            // row h0 + 4 has landed (and the previous block's stores)
-    __syncthreads();                                            // every wave is done with rows h0, h0 + 1 and has published
-    TAPDH_TICK(2)
-    if (same_plane) stage_row(b, d2, h0 + 5);                   // slot of h0; lands during the fold
+    __builtin_amdgcn_s_setprio(3);                            // publish, fold and stores ahead of the other waves' walks
+    // store phase: lane = (voxel sl, channel half sk); nb = first of the 4 output channels this lane stores
+    const int sln = opaque(lane), sl = sln & 31, nb = 8 * rg + 4 * (sln >> 5);
+    float* dst = Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0) * g.N + (sl * g.N + nb);
     {
-      // all 36 partial values of this lane's output quad are requested before the first add (a wait per tile made this
-      // phase 3.4 k clocks of LDS latency)
-      const float* rp = red + ((jd * 4 + jh) * 16 + 4 * rg) * 64 + lane;         // tile (fd = jd, fh = jh), row 4 rg
+      float* pub = tl + tile_off(wave, s0) + 4 * sln;              // tile = [register quad][lane][4]: 16-byte LDS accesses
+      if (wave < kDhRedTiles) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4)
+          *reinterpret_cast<float4*>(pub + r * 64) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+      }
+      barrier_lds();                                            // every wave is done with rows h0, h0 + 1: their slots take tiles
+      if (wave >= kDhRedTiles) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4)
+          *reinterpret_cast<float4*>(pub + r * 64) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+      }
+    }
+    wait_vm0();            // rows h0 + 4, h0 + 5 have landed (and the previous block's stores)
+    __syncthreads();                                            // every wave has published
+    TAPDH_TICK(2)
+    {
+      // tile (fd = jd + a, fh = jh + c), register quad rg: two per-lane bases (fold buffer / dead ring rows), everything else is
+      // an immediate offset of the read once the branch on jd (wave-uniform) has fixed which fd lives where.  All nine reads are
+      // requested before the first add (a wait per tile made this phase 3.4 k clocks of LDS latency).
+      const float* redp = tl + kDhRingF + jh * 1024 + 4 * (rg * 64 + sln);
+      const float* deadp = tl + jh * kDhPlaneF + s0 * kTapRowF + 4 * (rg * 64 + sln);
+      const float4 bv4 = *reinterpret_cast<const float4*>(biasl + nb);
+      float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (acc4) told = *reinterpret_cast<const float4*>(oldl + 4 * sln);
+      const float bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+      // nine 16-byte reads by asm: with plain loads the compiler merges the two branches into one sequence of 36 four-byte reads
+      // behind selected addresses
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      f32x4_t mv[3][3];
+      const unsigned redb = (unsigned)(size_t)redp, deadb = (unsigned)(size_t)deadp;
+#define DH_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define DH_RD_RED(a, fd)  DH_RD(mv[a][0], redb, ((fd) * 4 + 0) * 4096); DH_RD(mv[a][1], redb, ((fd) * 4 + 1) * 4096); \
+                          DH_RD(mv[a][2], redb, ((fd) * 4 + 2) * 4096)
+#define DH_RD_DEAD(a, fd) DH_RD(mv[a][0], deadb, ((fd) - 2) * kTapRowF * 4); DH_RD(mv[a][1], deadb, (((fd) - 2) * kTapRowF + kDhPlaneF) * 4); \
+                          DH_RD(mv[a][2], deadb, (((fd) - 2) * kTapRowF + 2 * kDhPlaneF) * 4)
+      if (jd == 0) { DH_RD_RED(0, 0); DH_RD_RED(1, 1); DH_RD_DEAD(2, 2); }
+      else         { DH_RD_RED(0, 1); DH_RD_DEAD(1, 2); DH_RD_DEAD(2, 3); }
+#undef DH_RD_DEAD
+#undef DH_RD_RED
+#undef DH_RD
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // the tiles are read: their slots take the next rows (requested inside the next walk), the fold buffer the next tiles.
+      // The output transform and the stores run behind this barrier, each wave at its own pace.  (Requesting the next block's
+      // first operand quad here as well -- a software pipeline across blocks -- needs four more registers than the file has:
+      // ten spill slots, with reloads inside the walk.)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      TAPDH_TICK(3)
       float m[3][3][4];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) m[a][c][i] = rp[(a * 4 + c) * 1024 + i * 64];
+          for (int i = 0; i < 4; ++i) m[a][c][i] = mv[a][c][i];
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -2640,11 +2728,7 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
         o[i] = ((t[0] + t1 * t[1]) + t1 * t[2]) + bv[i];
         if (g.relu) o[i] = fmaxf(o[i], 0.0f);
       }
-      TAPDH_TICK(3)
-      // row h0 + 5 must have landed before the next walk; waited for BEFORE this block's stores are issued (vmcnt counts
-      // stores too: behind them the wait would sit out the write acknowledgement, 1.8 k clocks per block)
-      wait_vm0();
-      if (w0 + li < g.W) {
+      if (w0 + sl < g.W) {
         if ((g.N & 3) == 0) {
           if (nb < g.N)
             *reinterpret_cast<float4*>(dst) = make_float4(o[0] + told.x, o[1] + told.y, o[2] + told.z, o[3] + told.w);
@@ -2655,7 +2739,6 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
         }
       }
     }
-    barrier_lds();                                              // the fold buffer is rewritten by the next block; stores stay in flight
     TAPDH_TICK(4)
     fresh = !same_plane;
     if (++h2 == H2) {
@@ -2798,12 +2881,18 @@ wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, fl
     wait_vm0();                               // this block's rows (issued during the previous block, or just above)
     __syncthreads();                          // ... of every wave; and every wave has left the previous walk
     const bool has_next = G + 1 < g_end, same_plane = has_next && h2 + 1 < H2;
-    if (same_plane) stage_x(b, d2, h0 + 4);   // the next block's two new rows -> the slots of h0 - 2, h0 - 1 (free since the barrier)
-    if (has_next) {
-      int nh2 = h2 + 1, nd2 = d2, nb = b;
-      if (nh2 == H2) { nh2 = 0; if (++nd2 == D2) { nd2 = 0; ++nb; } }
-      stage_g(nb, nd2, nh2, cur ^ 1);
-    }
+#ifndef WGDH_VAR
+#define WGDH_VAR 3
+#endif
+    auto stage_next = [&]() {
+      if (same_plane) stage_x(b, d2, h0 + 4);   // the next block's two new rows -> the slots of h0 - 2, h0 - 1 (free since the barrier)
+      if (has_next) {
+        int nh2 = h2 + 1, nd2 = d2, nb = b;
+        if (nh2 == H2) { nh2 = 0; if (++nd2 == D2) { nd2 = 0; ++nb; } }
+        stage_g(nb, nd2, nh2, cur ^ 1);
+      }
+    };
+    if (!(WGDH_VAR & 1)) stage_next();
 
     const float* xA = xr + pa * kWdPlaneF + ((h0 + ra) % kWdSlots) * kTapRowF + lk * 32 + li;
     const float* xB = xr + pa * kWdPlaneF + ((h0 + rb) % kWdSlots) * kTapRowF + lk * 32 + li;
@@ -2824,12 +2913,20 @@ wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, fl
     float vc = vcol(0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {            // voxels 2 s + lk of the segment
+      // requests inside the walk and issue priority falling along it: see conv_tapdh_kernel
+      if ((WGDH_VAR & 1) && s == 5) stage_next();
+      if (WGDH_VAR & 2) {
+        if (s == 0) __builtin_amdgcn_s_setprio(2);
+        if (s == 6) __builtin_amdgcn_s_setprio(1);
+        if (s == 11) __builtin_amdgcn_s_setprio(0);
+      }
       const float v1 = vcol(2 * s + 1), v2 = vcol(2 * s + 2), z = zcol(2 * s);
       acc[0] = mfma32(vc, z, acc[0]);
       acc[1] = mfma32(v1, z, acc[1]);
       acc[2] = mfma32(v2, z, acc[2]);
       vc = v2;
     }
+    if (WGDH_VAR & 2) __builtin_amdgcn_s_setprio(3);
     cur ^= 1;
     fresh = !same_plane;
     if (++h2 == H2) {
@@ -3959,6 +4056,13 @@ int launch_conv_tapdh(const float* x, const float* wp, const float* bias, float*
       life += (double)(h[w * 8 + 6] - h[w * 8 + 5]);
       blocks += (double)h[w * 8 + 7];
       t0 = std::min(t0, h[w * 8 + 5]); t1 = std::max(t1, h[w * 8 + 6]);
+    }
+    if (times > 1) {        // per wave slot: where the sixteen waves stand when their walk ends / their publish phase ends
+      for (int wv = 0; wv < 16; ++wv) {
+        double a[5] = {0, 0, 0, 0, 0}, nb = 0;
+        for (size_t w = wv; w < nwg * 16; w += 16) { for (int i = 0; i < 5; ++i) a[i] += (double)h[w * 8 + i]; nb += (double)h[w * 8 + 7]; }
+        fprintf(stderr, "  wave %2d: stage %.0f walk %.0f publish %.0f fold %.0f tail %.0f\n", wv, a[0] / nb, a[1] / nb, a[2] / nb, a[3] / nb, a[4] / nb);
+      }
     }
     fprintf(stderr, "tapdh clocks per 2x2 block and wave (s_memtime ticks): stage %.0f walk %.0f publish+barrier %.0f fold %.0f tail barrier %.0f"
             " | per chunk: life %.0f for %.1f blocks | kernel span %.0f ticks, %zu workgroups\n",
