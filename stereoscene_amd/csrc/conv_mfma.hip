@@ -2881,9 +2881,6 @@ wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, fl
     wait_vm0();                               // this block's rows (issued during the previous block, or just above)
     __syncthreads();                          // ... of every wave; and every wave has left the previous walk
     const bool has_next = G + 1 < g_end, same_plane = has_next && h2 + 1 < H2;
-#ifndef WGDH_VAR
-#define WGDH_VAR 3
-#endif
     auto stage_next = [&]() {
       if (same_plane) stage_x(b, d2, h0 + 4);   // the next block's two new rows -> the slots of h0 - 2, h0 - 1 (free since the barrier)
       if (has_next) {
@@ -2892,7 +2889,6 @@ wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, fl
         stage_g(nb, nd2, nh2, cur ^ 1);
       }
     };
-    if (!(WGDH_VAR & 1)) stage_next();
 
     const float* xA = xr + pa * kWdPlaneF + ((h0 + ra) % kWdSlots) * kTapRowF + lk * 32 + li;
     const float* xB = xr + pa * kWdPlaneF + ((h0 + rb) % kWdSlots) * kTapRowF + lk * 32 + li;
@@ -2913,20 +2909,19 @@ wgrad_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ GY, fl
     float vc = vcol(0);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {            // voxels 2 s + lk of the segment
-      // requests inside the walk and issue priority falling along it: see conv_tapdh_kernel
-      if ((WGDH_VAR & 1) && s == 5) stage_next();
-      if (WGDH_VAR & 2) {
-        if (s == 0) __builtin_amdgcn_s_setprio(2);
-        if (s == 6) __builtin_amdgcn_s_setprio(1);
-        if (s == 11) __builtin_amdgcn_s_setprio(0);
-      }
+      // requests inside the walk and issue priority falling along it, as in conv_tapdh_kernel (round 6: 406 -> 385 us with the
+      // finish kernels, same bits)
+      if (s == 5) stage_next();
+      if (s == 0) __builtin_amdgcn_s_setprio(2);
+      if (s == 6) __builtin_amdgcn_s_setprio(1);
+      if (s == 11) __builtin_amdgcn_s_setprio(0);
       const float v1 = vcol(2 * s + 1), v2 = vcol(2 * s + 2), z = zcol(2 * s);
       acc[0] = mfma32(vc, z, acc[0]);
       acc[1] = mfma32(v1, z, acc[1]);
       acc[2] = mfma32(v2, z, acc[2]);
       vc = v2;
     }
-    if (WGDH_VAR & 2) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     cur ^= 1;
     fresh = !same_plane;
     if (++h2 == H2) {
@@ -3216,10 +3211,6 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
-    if (same_plane) {
-#pragma unroll
-      for (int r = 5; r < 9; ++r) stage_row(b, d, 2 * h0 + r);
-    }
     const int wv = w0 + vx, hrow = h0 + rw;
     const bool ok = wv < g.W && hrow < g.H && nb < g.N;
     float* dst = Y + (((long)(b * g.D + d) * g.H + hrow) * g.W + wv) * g.N + nb;
@@ -3259,6 +3250,14 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     fetch(0, xa);
 #pragma unroll
     for (int tt = 0; tt < 7; tt += 2) {
+      // row requests inside the walk and issue priority falling along it: see conv_tapdh_kernel (round 6: -2 %, same bits)
+      if (tt == 2 && same_plane) {
+#pragma unroll
+        for (int r = 5; r < 9; ++r) stage_row(b, d, 2 * h0 + r);
+      }
+      if (tt == 0) __builtin_amdgcn_s_setprio(2);
+      if (tt == 2) __builtin_amdgcn_s_setprio(1);
+      if (tt == 4) __builtin_amdgcn_s_setprio(0);
       if (tt < ntap) {
         mm_head(tt, xa);
         __builtin_amdgcn_sched_barrier(0);
@@ -3276,6 +3275,7 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_s_setprio(3);
     // fold the four tap groups of each channel half: every wave publishes its partial tile, then sums rows 4 tg .. 4 tg + 3
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
@@ -3429,7 +3429,6 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
       __syncthreads();
     }
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
-    if (same_plane) { stage_row(b, d, h0 + 3); stage_row(b, d, h0 + 4); }
 
     // ring offsets of the coarse rows h0 + rw (+ 1)
     const int srow0 = ((h0 + rw) % kUpSlots) * kUpRowF, srow1 = ((h0 + rw + 1) % kUpSlots) * kUpRowF;
@@ -3442,6 +3441,11 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
       const int tt = gi >> 1, hq = gi & 1;
+      // row requests inside the walk and issue priority falling along it: see conv_tapdh_kernel (round 6: -2 %, same bits)
+      if (gi == 1 && same_plane) { stage_row(b, d, h0 + 3); stage_row(b, d, h0 + 4); }
+      if (gi == 0) __builtin_amdgcn_s_setprio(2);
+      if (gi == 2) __builtin_amdgcn_s_setprio(1);
+      if (gi == 3) __builtin_amdgcn_s_setprio(0);
       if (tt < ntap) {
         const int u = vx + t_dw[tt];
         const float* rowp = ring + t_pl[tt] + (t_dh[tt] ? srow1 : srow0) + u * 64;
@@ -3459,6 +3463,7 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
         }
       }
     }
+    __builtin_amdgcn_s_setprio(3);
     if (wave < kUpTiles) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];

@@ -1,4 +1,4 @@
-"""GPU A/B of conv_tapdh_kernel between two builds of the library: seeded inputs, median time of 20 launches (forward and
+"""GPU A/B of conv_tapdh_kernel / wgrad_tapdh_kernel between two builds of the library: seeded inputs, median time of 20 launches (forward and
 data gradient of the 32 -> 32 cost-volume layer, 192 x 48 x 160, plus an odd-sized ragged case) and a CRC of the output bytes --
 a schedule change of the kernel must leave every bit of the result alone.
     python tools/tapdh_ab.py [path/to/libssbev_hip.so]"""
@@ -30,12 +30,20 @@ def run(B, C, D, H, W, relu, tag):
         torch.cuda.synchronize()
         dt = sorted(a.elapsed_time(b) for a, b in ev)[10]
     xq = x.clone().requires_grad_(True)
-    yq = F.conv3d(xq, w, bias, 1, 1)
+    wq = w.clone().requires_grad_(True)
+    yq = F.conv3d(xq, wq, bias, 1, 1)
     if relu:
         yq = torch.relu(yq)
     yq.backward(go)
     torch.cuda.synchronize()
-    print(f"{tag}: fwd {dt * 1e3:.1f} us  crc(y) {crc(y):08x}  crc(gx) {crc(xq.grad):08x}", flush=True)
+    yw = F.conv3d(x, wq, None, 1, 1)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in ev:
+        a.record(); torch.autograd.grad(yw, wq, go, retain_graph=True); b.record()
+    torch.cuda.synchronize()
+    dtw = sorted(a.elapsed_time(b) for a, b in ev)[10]
+    print(f"{tag}: fwd {dt * 1e3:.1f} us  wgrad {dtw * 1e3:.1f} us  crc(y) {crc(y):08x}  crc(gx) {crc(xq.grad):08x}  crc(gw) {crc(wq.grad):08x}",
+          flush=True)
 
 
 def run_fork(C, D, H, W, tag):
