@@ -2475,7 +2475,7 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
                   float* __restrict__ Y, ConvTapGeom g) {     // g.NG / g.gpc count 2 x 2 (plane, row) blocks
   extern __shared__ __align__(16) float tl[];
   float* ring = tl;                          // [4 planes][6 slots][34 voxels][32 channels], 16-byte swizzled
-  // partial tile t ([4 register quads][64 lanes][4]) of a block whose first row sits in slot s0: tiles 0-7 in the fold buffer behind the
+  // partial tile t ([32 voxels][8 channel quads][4], see the publish phase) of a block whose first row sits in slot s0: tiles 0-7 in the fold buffer behind the
   // ring, tiles 8-15 in the ring rows (plane (t - 8) & 3, row h0 + ((t - 8) >> 2)) that the finished walk has left dead
   auto tile_off = [](int t, int s0) {
     const int sl = s0 + ((t - kDhRedTiles) >> 2);             // s0 is even, < kDhSlots: no wrap
@@ -2547,8 +2547,10 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
   const int pa = fd == 0 ? 0 : (fd == 2 ? 2 : 1), pb = fd == 3 ? 3 : (fd == 2 ? 1 : 2);
   const float sd = fd == 1 ? 1.0f : -1.0f;
   const int offPA = pa * kDhPlaneF, offPB = pb * kDhPlaneF;
-  // store phase: wave = (output plane jd, output row jh, channel group rg)
-  const int jd = wave >> 3, jh = (wave >> 2) & 1, rg = wave & 3;
+  // store phase: wave = (output plane jd, output row jh, voxel octet vq): lane = (voxel 8 vq + (lane >> 3), channel quad
+  // lane & 7), so that a wave's one 16-byte store per lane covers eight whole 128-byte voxels (round 6; a wave used to own
+  // 8 channels of 32 voxels: sixty-four 32-byte pieces per store instruction, 1 k clocks of address processing per block)
+  const int jd = wave >> 3, jh = (wave >> 2) & 1, vq = wave & 3;
   // Register discipline (round 6): the walk owns the file -- 48 weight registers, the accumulator, two operand quads and the
   // eight ring reads behind them -- and a spill reload anywhere between the row requests and the end of the walk is a
   // `s_waitcnt vmcnt(0)`, i.e. a wait for the rows (vmcnt counts the LDS-DMA too).  So nothing per-lane that only the fold needs
@@ -2612,7 +2614,7 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
     const bool same_plane = G + 1 < g_end && h2 + 1 < H2;
     const int s0 = h0 % kDhSlots;
     if (acc4) {
-      const int ln = opaque(lane), sl = ln & 31, nb = 8 * rg + 4 * (ln >> 5);
+      const int ln = opaque(lane), sl = 8 * vq + (ln >> 3), nb = 4 * (ln & 7);
       const float* src = (w0 + sl < g.W && nb < g.N)
           ? Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0) * g.N + (sl * g.N + nb) : kWgZeros;
       glds16(src, oldl);
@@ -2659,32 +2661,36 @@ conv_tapdh_kernel(const float* __restrict__ X, const float* __restrict__ wp, con
     }
     TAPDH_TICK(1)
     __builtin_amdgcn_s_setprio(3);                            // publish, fold and stores ahead of the other waves' walks
-    // store phase: lane = (voxel sl, channel half sk); nb = first of the 4 output channels this lane stores
-    const int sln = opaque(lane), sl = sln & 31, nb = 8 * rg + 4 * (sln >> 5);
+    // store phase: voxel sl of the segment, nb = first of the 4 output channels this lane stores
+    const int sln = opaque(lane), sl = 8 * vq + (sln >> 3), nb = 4 * (sln & 7);
     float* dst = Y + (((long)(b * g.D + 2 * d2 + jd) * g.H + h0 + jh) * g.W + w0) * g.N + (sl * g.N + nb);
     {
-      float* pub = tl + tile_off(wave, s0) + 4 * sln;              // tile = [register quad][lane][4]: 16-byte LDS accesses
+      // tile = [voxel 32][channel quad 8, XOR-swizzled by (voxel >> 1) & 7][4]: the output's own layout.  The publishing lane
+      // (voxel li, half lk) holds the channel quads 2 r + lk in its registers 4 r .. 4 r + 3
+      const int pli = sln & 31, plk = sln >> 5, psw = (pli >> 1) & 7;
+      float* pub = tl + tile_off(wave, s0) + pli * 32;
       if (wave < kDhRedTiles) {
 #pragma unroll
         for (int r = 0; r < 16; r += 4)
-          *reinterpret_cast<float4*>(pub + r * 64) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+          *reinterpret_cast<float4*>(pub + ((((r >> 1) + plk) ^ psw) << 2)) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
       }
       barrier_lds();                                            // every wave is done with rows h0, h0 + 1: their slots take tiles
       if (wave >= kDhRedTiles) {
 #pragma unroll
         for (int r = 0; r < 16; r += 4)
-          *reinterpret_cast<float4*>(pub + r * 64) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+          *reinterpret_cast<float4*>(pub + ((((r >> 1) + plk) ^ psw) << 2)) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
       }
     }
     wait_vm0();            // rows h0 + 4, h0 + 5 have landed (and the previous block's stores)
     __syncthreads();                                            // every wave has published
     TAPDH_TICK(2)
     {
-      // tile (fd = jd + a, fh = jh + c), register quad rg: two per-lane bases (fold buffer / dead ring rows), everything else is
+      // tile (fd = jd + a, fh = jh + c), this lane's (voxel, channel quad): two per-lane bases (fold buffer / dead ring rows), everything else is
       // an immediate offset of the read once the branch on jd (wave-uniform) has fixed which fd lives where.  All nine reads are
       // requested before the first add (a wait per tile made this phase 3.4 k clocks of LDS latency).
-      const float* redp = tl + kDhRingF + jh * 1024 + 4 * (rg * 64 + sln);
-      const float* deadp = tl + jh * kDhPlaneF + s0 * kTapRowF + 4 * (rg * 64 + sln);
+      const int fo = sl * 32 + (((sln & 7) ^ ((sl >> 1) & 7)) << 2);
+      const float* redp = tl + kDhRingF + jh * 1024 + fo;
+      const float* deadp = tl + jh * kDhPlaneF + s0 * kTapRowF + fo;
       const float4 bv4 = *reinterpret_cast<const float4*>(biasl + nb);
       float4 told = make_float4(0.f, 0.f, 0.f, 0.f);
       if (acc4) told = *reinterpret_cast<const float4*>(oldl + 4 * sln);

@@ -170,6 +170,8 @@ gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ B, const f
     const int buf = (st - st_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // (requesting the next stage's copies behind the first quarter of the MFMAs instead -- what pays in the one-workgroup-per-CU
+    // ring kernels -- measured +2 .. +6 % here: the second workgroup of the CU already fills the head of the stage)
     if (st + 1 < st_end) issue(st + 1, buf ^ 1);
     const float* as = lds + buf * SF;
     const float* bs = as + AF;
@@ -329,7 +331,6 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     const int buf = st & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage st's slabs AND the row offsets of stage st+1
     __builtin_amdgcn_s_barrier();
-    if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_rowoff(st + 2); }
     const float* as = lds + buf * SF;
     const float* bs = as + AF;
     float ac[KT], bc[WN], an[KT], bn[WN];
@@ -345,6 +346,9 @@ gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
     for (int rp = 0; rp < BR / 2; ++rp) {
       if (rp + 1 < BR / 2) fetch(rp + 1, an, bn);
       __builtin_amdgcn_sched_barrier(0);
+      // the next stage's copies (address arithmetic from scratch: a 64-bit multiply per piece) are requested behind the first
+      // quarter of this stage's MFMAs, not between the barrier and the first one (round 6: -1 .. -2 %, same bits)
+      if (rp == 4 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_rowoff(st + 2); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
