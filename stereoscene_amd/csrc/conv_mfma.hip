@@ -3012,14 +3012,10 @@ conv_pw32_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
   float wr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) wr[r] = wp[r * 64 + lane];
-  float bv[4][4];
+  const int cq = lane & 7, nq = 4 * cq;                   // store phase: lane = (voxel lane >> 3 of an octet, channel quad cq)
+  float bv[4];
 #pragma unroll
-  for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = 8 * rq + 4 * lk + i;
-      bv[rq][i] = (g.has_bias && n < g.N) ? bias[n] : 0.0f;
-    }
+  for (int i = 0; i < 4; ++i) bv[i] = (g.has_bias && nq + i < g.N) ? bias[nq + i] : 0.0f;
   const long ntiles = (g.M + 31) >> 5;
   const long t0 = ((long)blockIdx.x * 4 + wave) * g.tpw, t1 = min(ntiles, t0 + g.tpw);
   // staging: instruction e copies the voxels 8 e .. 8 e + 7 of the tile; lane = (voxel u, physical quad p), source quad p ^ key(u)
@@ -3064,27 +3060,48 @@ conv_pw32_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
       acc = mfma32(wr[4 * q + 3], xv.w, acc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile has been read: its buffer is restaged next iteration
-    const long v = t * 32 + li;
-    float* dst = Y + v * g.N + 4 * lk;
-    if (v < g.M) {
-      float4 ov[4];
-      if (g.accumulate) {
+    // round 6: the 32 x 32 output tile goes back through the wave's (consumed) input buffer and leaves as four stores of 1 KiB
+    // of whole voxels each (the direct form stored sixty-four 32-byte pieces per instruction); bias, ReLU and the old values
+    // of an accumulating launch are applied on the way out, in the order of the direct form
+    float* ob = mine + buf * 1024;
+    {
+      const int sw = (li >> 1) & 7;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          ov[rq] = (8 * rq + 4 * lk < g.N) ? *reinterpret_cast<const float4*>(dst + 8 * rq) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<float4*>(ob + li * 32 + (((2 * rq + lk) ^ sw) << 2)) =
+            make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool n4 = (g.N & 3) == 0;
+    float4 ov[4];
+    if (g.accumulate && n4) {                                // every old value is requested before the first store
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[i] = acc[4 * rq + i] + bv[rq][i];
-          if (g.relu) o[i] = fmaxf(o[i], 0.0f);
-        }
-        if (g.accumulate) { o[0] += ov[rq].x; o[1] += ov[rq].y; o[2] += ov[rq].z; o[3] += ov[rq].w; }
-        if (8 * rq + 4 * lk < g.N) *reinterpret_cast<float4*>(dst + 8 * rq) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int it = 0; it < 4; ++it) {
+        const long v = t * 32 + it * 8 + (lane >> 3);
+        ov[it] = (v < g.M && nq < g.N) ? *reinterpret_cast<const float4*>(Y + v * g.N + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int u = it * 8 + (lane >> 3);
+      const long v = t * 32 + u;
+      const float4 a4 = *reinterpret_cast<const float4*>(ob + u * 32 + ((cq ^ ((u >> 1) & 7)) << 2));
+      float o[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+      if (g.relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.0f);
+      }
+      float* dst = Y + v * g.N + nq;
+      if (n4) {
+        if (g.accumulate) { o[0] += ov[it].x; o[1] += ov[it].y; o[2] += ov[it].z; o[3] += ov[it].w; }
+        if (v < g.M && nq < g.N) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      } else if (v < g.M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (nq + i < g.N) dst[i] = g.accumulate ? dst[i] + o[i] : o[i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the buffer is read back before the next iteration restages it
   }
 }
 
@@ -3284,18 +3301,25 @@ conv_tap2_kernel(const float* __restrict__ X, const float* __restrict__ wp, cons
     __builtin_amdgcn_s_setprio(3);
     // fold the four tap groups of each channel half: every wave publishes its partial tile, then sums rows 4 tg .. 4 tg + 3
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc2[0][r] + acc2[1][r];
+    for (int r = 0; r < 16; r += 4)           // tile = [register quad][lane][4]: 16-byte LDS accesses (round 6)
+      *reinterpret_cast<float4*>(red + ((wave * 4 + (r >> 2)) * 64 + lane) * 4) =
+          make_float4(acc2[0][r] + acc2[1][r], acc2[0][r + 1] + acc2[1][r + 1], acc2[0][r + 2] + acc2[1][r + 2], acc2[0][r + 3] + acc2[1][r + 3]);
     wait_vm0();
     __syncthreads();
     {
       float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * tg + i;
-        const float* rp = red + ((nh * 4) * 16 + r) * 64 + lane;
-        o[i] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64] + bv[i];
-        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
+      {
+        const float* rp = red + (((nh * 4) * 4 + tg) * 64 + lane) * 4;
+        const float4 p0 = *reinterpret_cast<const float4*>(rp), p1 = *reinterpret_cast<const float4*>(rp + 1024);
+        const float4 p2 = *reinterpret_cast<const float4*>(rp + 2048), p3 = *reinterpret_cast<const float4*>(rp + 3072);
+        o[0] = ((p0.x + p1.x) + p2.x) + p3.x + bv[0];
+        o[1] = ((p0.y + p1.y) + p2.y) + p3.y + bv[1];
+        o[2] = ((p0.z + p1.z) + p2.z) + p3.z + bv[2];
+        o[3] = ((p0.w + p1.w) + p2.w) + p3.w + bv[3];
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g.relu) o[i] = fmaxf(o[i], 0.0f);
       if (ok) {
         if ((g.N & 3) == 0) {
           *reinterpret_cast<float4*>(dst) = make_float4(o[0] + told.x, o[1] + told.y, o[2] + told.z, o[3] + told.w);
@@ -3472,7 +3496,8 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
     __builtin_amdgcn_s_setprio(3);
     if (wave < kUpTiles) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+      for (int r = 0; r < 16; r += 4)         // tile = [register quad][lane][4]: 16-byte LDS accesses (round 6)
+        *reinterpret_cast<float4*>(red + ((wave * 4 + (r >> 2)) * 64 + lane) * 4) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
     }
     wait_vm0();
     __syncthreads();
@@ -3499,8 +3524,8 @@ conv_tap2up_kernel(const float* __restrict__ X, const float* __restrict__ wp, co
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (t < sntile) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pv[t][i] = red[((stile + t) * 16 + 8 * jp + 4 * jj + i) * 64 + lane];
+            const float4 v = *reinterpret_cast<const float4*>(red + (((stile + t) * 4 + 2 * jp + jj) * 64 + lane) * 4);
+            pv[t][0] = v.x; pv[t][1] = v.y; pv[t][2] = v.z; pv[t][3] = v.w;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pv[t][i] = 0.0f;

@@ -54,7 +54,32 @@ def case(Cf, Cc, D, H, W, bias):
           f"crc {crc(y):08x} {crc(gx):08x} {crc(yu):08x} {crc(gxc):08x}", flush=True)
 
 
+def case_pw(Ci, Co, D, H, W, bias):
+    """1x1x1 convolution (conv_pw32_kernel): forward with bias + ReLU epilogue, data gradient, and a forked input whose second data
+    gradient accumulates into the first one's buffer"""
+    torch.manual_seed(21)
+    x = cl(torch.randn(1, Ci, D, H, W, device="cuda")).requires_grad_(True)
+    w = torch.randn(Co, Ci, 1, 1, 1, device="cuda") * 0.1
+    w2 = torch.randn(Co, Ci, 1, 1, 1, device="cuda") * 0.1
+    b = torch.randn(Co, device="cuda") if bias else None
+    with torch.no_grad():
+        y = F.conv3d(x, w, b, 1, 0)
+        t_f = timed(lambda: F.conv3d(x, w, b, 1, 0))
+    yq = F.conv3d(x, w, b, 1, 0)
+    gq = cl(torch.randn_like(yq))
+    t_d = timed(lambda: torch.autograd.grad(yq, x, gq, retain_graph=True))
+    (gx,) = torch.autograd.grad(yq, x, gq, retain_graph=True)
+    xa, xb = F.fork(x * 1.0, 2)
+    yf = torch.relu(F.conv3d(xa, w, b, 1, 0)) + F.conv3d(xb, w2, None, 1, 0)
+    (gf,) = torch.autograd.grad(yf, x, gq)
+    print(f"1x1x1 {Ci}->{Co} @ {D}x{H}x{W}: fwd {t_f:.1f} us, dgrad {t_d:.1f} | crc {crc(y):08x} {crc(gx):08x} {crc(gf):08x}", flush=True)
+
+
 print("library:", capi.LIB_PATH)
+case_pw(32, 32, 192, 48, 160, True)
+case_pw(32, 32, 192, 48, 160, False)
+case_pw(32, 18, 20, 12, 37, True)
+case_pw(30, 32, 20, 12, 37, False)
 case(32, 64, 192, 48, 160, False)
 case(32, 64, 192, 48, 160, True)
 case(32, 64, 22, 10, 38, True)
